@@ -1,0 +1,319 @@
+"""CPU oracle for the cross-shape-attention (CSA) hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is a CPU restatement (torch fp32/fp64 on the host) of the arithmetic in the
+reference's ``MID-FC/csa_models.py``.  It exists to *check* the HIP path: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it.  Nothing under
+``csn_amd/`` imports it, and the product path raises when the HIP library is missing instead of
+falling back to anything in here.
+
+Parity pinning: every function below is checked in ``tests/test_oracle_golden.py`` against golden
+vectors in ``tests/golden/*.npz`` that were produced by importing the reference module itself
+(``tests/golden/make_golden.py``, run once in the build container; the reference never travels).
+
+All citations are ``MID-FC/csa_models.py:<line>`` (relative to the reference root) unless another
+file is named.  Parameters are passed as a flat ``dict`` keyed by the reference's ``state_dict()``
+names (``attention.w_qs.weight`` ...), so a reference checkpoint can be fed straight in.
+
+Two flavours of the multi-head attention are given:
+
+* ``mha_faithful``   – the reference's own op sequence (python loop over 20 chunks of 500 points,
+                       index gather, growing concatenation).  This is what ``bench.py`` times as the
+                       CPU baseline (``cpu_baseline.kind == "port"``).
+* ``mha_blockdiag``  – the same mathematics in closed form, vectorised over blocks and parametrised
+                       by (block size T, number of blocks); this is the numerical oracle for every
+                       configuration, including the ones the as-shipped reference cannot run
+                       (N != 10000).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+# Reference constants ---------------------------------------------------------------------------
+REF_BLOCK = 500      # csa_models.py:84  (mini_bs = 500; indices arange(i*500,(i+1)*500) :87)
+REF_NBLOCKS = 20     # csa_models.py:83  (iters = 20)
+REF_DK = 256         # csa_models.py:147 (d_k = d_v = 256 whatever n_heads is)
+LN_EPS = 1e-6        # csa_models.py:57
+NORM_EPS = 1e-12     # F.normalize default eps used at :223,:226,:253,:255
+
+
+# ------------------------------------------------------------------------------------------------
+# a1  ScaledDotProductAttention.forward  (csa_models.py:138-144), dropout disabled (eval mode)
+# ------------------------------------------------------------------------------------------------
+def sdpa(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, temperature: float
+         ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """q,k,v: (..., T, d).  The scale divides q *before* the product (:139)."""
+    scores = torch.matmul(q / temperature, k.transpose(-2, -1))
+    prob = F.softmax(scores, dim=-1)                 # :141 (dropout is identity in eval)
+    return torch.matmul(prob, v), prob               # :142
+
+
+def _heads(t: torch.Tensor, n_head: int, d: int) -> torch.Tensor:
+    """(..., T, n_head*d) -> (..., n_head, T, d)   (:103-108 view + transpose)."""
+    *lead, T, _ = t.shape
+    return t.reshape(*lead, T, n_head, d).transpose(-3, -2)
+
+
+def _mha_tail(ctx: torch.Tensor, residual: torch.Tensor, p: Params, prefix: str) -> torch.Tensor:
+    """fc (no bias) -> [dropout = id] -> + residual -> LayerNorm(eps 1e-6)   (:114-118)."""
+    z = F.linear(ctx, p[prefix + "fc.weight"]) + residual
+    C = z.shape[-1]
+    return F.layer_norm(z, (C,), p[prefix + "norm.weight"], p[prefix + "norm.bias"], LN_EPS)
+
+
+# ------------------------------------------------------------------------------------------------
+# a2  MultiHeadAttention.forward  (csa_models.py:81-125) – closed form, any (T, n_blocks)
+# ------------------------------------------------------------------------------------------------
+def mha_blockdiag(xq: torch.Tensor, xk: torch.Tensor, xv: torch.Tensor, p: Params, n_head: int,
+                  d_k: int = REF_DK, d_v: int = REF_DK, block: int = REF_BLOCK,
+                  n_blocks: Optional[int] = REF_NBLOCKS, prefix: str = "attention.",
+                  return_attn: bool = False):
+    """Block-diagonal multi-head attention.
+
+    xq/xk/xv: channels-first ``(B, C, N, 1)`` (or ``(B, C, N)``) as the reference takes them
+    (:88-94).  Query block i attends only to key/value block i (:87-90).  Returns ``(B, nb*T, C)``
+    (and, if asked, the probabilities ``(B, nb, n_head, T, T)``).  ``n_blocks=None`` means
+    ``ceil(N / block)`` with a ragged last block (a generalisation the reference does not have).
+    """
+    def pts_major(x):
+        if x.dim() == 4:
+            x = x.squeeze(-1)
+        return x.permute(0, 2, 1)                                    # (B, N, C)   :92-94
+
+    q_in, k_in, v_in = pts_major(xq), pts_major(xk), pts_major(xv)
+    B, N, C = q_in.shape
+    if n_blocks is None:
+        n_blocks = (N + block - 1) // block
+    need = n_blocks * block
+    ragged = need > N
+    if ragged and n_blocks != (N + block - 1) // block:
+        raise IndexError(f"N={N} points cannot fill {n_blocks} blocks of {block}")   # :88 would raise
+    temperature = float(d_k) ** 0.5                                  # :54
+    outs, attns = [], []
+    if not ragged:
+        qb = q_in[:, :need].reshape(B, n_blocks, block, C)
+        kb = k_in[:, :need].reshape(B, n_blocks, block, C)
+        vb = v_in[:, :need].reshape(B, n_blocks, block, C)
+        q = _heads(F.linear(qb, p[prefix + "w_qs.weight"]), n_head, d_k)   # (B,nb,H,T,dk)  :103
+        k = _heads(F.linear(kb, p[prefix + "w_ks.weight"]), n_head, d_k)   # :104
+        v = _heads(F.linear(vb, p[prefix + "w_vs.weight"]), n_head, d_v)   # :105
+        ctx, prob = sdpa(q, k, v, temperature)                             # :110
+        ctx = ctx.transpose(-3, -2).reshape(B, n_blocks, block, n_head * d_v)  # :114
+        y = _mha_tail(ctx, qb, p, prefix).reshape(B, need, C)
+        return (y, prob) if return_attn else y
+    for i in range(n_blocks):                                       # ragged tail: block by block
+        lo, hi = i * block, min(N, (i + 1) * block)
+        qb, kb, vb = q_in[:, lo:hi], k_in[:, lo:hi], v_in[:, lo:hi]
+        q = _heads(F.linear(qb, p[prefix + "w_qs.weight"]), n_head, d_k)
+        k = _heads(F.linear(kb, p[prefix + "w_ks.weight"]), n_head, d_k)
+        v = _heads(F.linear(vb, p[prefix + "w_vs.weight"]), n_head, d_v)
+        ctx, prob = sdpa(q, k, v, temperature)
+        ctx = ctx.transpose(-3, -2).reshape(B, hi - lo, n_head * d_v)
+        outs.append(_mha_tail(ctx, qb, p, prefix))
+        attns.append(prob)
+    y = torch.cat(outs, dim=1)
+    return (y, attns) if return_attn else y
+
+
+# ------------------------------------------------------------------------------------------------
+# a2 (faithful)  same op sequence as the reference loop – used as the CPU timing baseline
+# ------------------------------------------------------------------------------------------------
+def mha_faithful(xq: torch.Tensor, xk: torch.Tensor, xv: torch.Tensor, p: Params, n_head: int,
+                 d_k: int = REF_DK, d_v: int = REF_DK, prefix: str = "attention.",
+                 p_attn_drop: float = 0.0, p_out_drop: float = 0.0):
+    """Chunk loop exactly as :83-125 runs it: gather by index tensor, per-chunk projections,
+    attention, fc, residual, LayerNorm, and a concatenation that grows by one chunk per iteration.
+    Returns (``(B, 10000, C)``, last chunk's probabilities) like the reference does (:125).
+    ``p_*_drop`` > 0 switches on the two dropouts (:141, :115) for train-mode timing."""
+    acc = None
+    prob = None
+    temperature = float(d_k) ** 0.5
+    for i in range(REF_NBLOCKS):
+        idx = torch.arange(i * REF_BLOCK, (i + 1) * REF_BLOCK)
+        qc = xq[:, :, idx, :].squeeze(-1).permute(0, 2, 1)
+        kc = xk[:, :, idx, :].squeeze(-1).permute(0, 2, 1)
+        vc = xv[:, :, idx, :].squeeze(-1).permute(0, 2, 1)
+        B, Tq, Tk = qc.size(0), qc.size(1), kc.size(1)
+        keep = qc
+        qh = F.linear(qc, p[prefix + "w_qs.weight"]).view(B, Tq, n_head, d_k).transpose(1, 2)
+        kh = F.linear(kc, p[prefix + "w_ks.weight"]).view(B, Tk, n_head, d_k).transpose(1, 2)
+        vh = F.linear(vc, p[prefix + "w_vs.weight"]).view(B, Tk, n_head, d_v).transpose(1, 2)
+        s = torch.matmul(qh / temperature, kh.transpose(2, 3))
+        prob = F.dropout(F.softmax(s, dim=-1), p_attn_drop, training=p_attn_drop > 0)
+        ctx = torch.matmul(prob, vh).transpose(1, 2).contiguous().view(B, Tq, -1)
+        z = F.dropout(F.linear(ctx, p[prefix + "fc.weight"]), p_out_drop, training=p_out_drop > 0)
+        z = z + keep
+        z = F.layer_norm(z, (z.shape[-1],), p[prefix + "norm.weight"], p[prefix + "norm.bias"], LN_EPS)
+        acc = z if acc is None else torch.cat((acc, z), dim=1)
+    return acc, prob
+
+
+# ------------------------------------------------------------------------------------------------
+# a3  MultiHeadAttention.self_attention  (csa_models.py:59-79): unchunked == one block of size N
+# ------------------------------------------------------------------------------------------------
+def mha_full_self(x: torch.Tensor, p: Params, n_head: int, d_k: int, d_v: int,
+                  prefix: str = "attention.", return_attn: bool = False):
+    N = x.shape[2]
+    return mha_blockdiag(x, x, x, p, n_head, d_k, d_v, block=N, n_blocks=1, prefix=prefix,
+                         return_attn=return_attn)
+
+
+# ------------------------------------------------------------------------------------------------
+# a4/a5  CrossShapeAt.get_ssa_feats / get_csa_feats  (csa_models.py:204-242)
+# ------------------------------------------------------------------------------------------------
+def ssa_feats(x: torch.Tensor, p: Params, n_head: int, mha=mha_blockdiag, **kw) -> torch.Tensor:
+    """(B,C,N,1) -> (B,C,N',1) channels-first again (:205-206)."""
+    y = mha(x, x, x, p, n_head, **kw)
+    y = y[0] if isinstance(y, tuple) else y
+    return y.permute(0, 2, 1).unsqueeze(-1)
+
+
+def compatibility(pooled: torch.Tensor, p: Params, layout: str = "reference") -> torch.Tensor:
+    """pooled: (B, K+1, C) mean-over-points SSA descriptors, slot 0 = query shape.
+    Returns softmax_k( <normalize(Wq y_0 + bq), normalize(Wk y_k + bk)> )  -> (B, K+1)   (:222-230).
+
+    ``layout="reference"`` reproduces the reference's row bookkeeping exactly: the key descriptors
+    are concatenated neighbour-major, rows ``k*B + b`` (:213, :220), and then *re-viewed* as
+    ``(B, K+1, C)`` (:227), i.e. read back shape-major.  For B == 1 the two orders coincide; for
+    B > 1 query shape b is scored against rows ``b*(K+1) .. b*(K+1)+K`` of the neighbour-major
+    stack, which belong to other (shape, neighbour) pairs of the same batch.  That is what the
+    reference computes (and trained with), so it is what a drop-in must compute.
+    ``layout="per_shape"`` is the un-scrambled variant (each shape against its own neighbours)."""
+    B, K1, C = pooled.shape
+    u_q = F.normalize(F.linear(pooled[:, 0], p["compatibility_q.weight"], p["compatibility_q.bias"]),
+                      dim=-1, eps=NORM_EPS)
+    if layout == "reference":
+        keys = pooled.transpose(0, 1).reshape(K1 * B, C).view(B, K1, C)
+    elif layout == "per_shape":
+        keys = pooled
+    else:
+        raise ValueError(layout)
+    u_k = F.normalize(F.linear(keys, p["compatibility_k.weight"], p["compatibility_k.bias"]),
+                      dim=-1, eps=NORM_EPS)
+    return F.softmax(torch.einsum("bc,bkc->bk", u_q, u_k), dim=-1)
+
+
+def csa_feats(x: torch.Tensor, x_neighbors: torch.Tensor, p: Params, n_head: int,
+              mha=mha_blockdiag, return_parts: bool = False, compat_layout: str = "reference", **kw):
+    """x: (B,C,N,1); x_neighbors: (B,K+1,C,N,1), slot 0 = x itself (ignored, as :214 starts at 1).
+    out = comp_0 * MHA(x,x,x) + sum_k comp_k * MHA(x, x_k, x_k)              (:232-238)
+    comp from the mean-pooled self-attention features of x and of every x_k   (:210-230)."""
+    def run(a, b):
+        y = mha(a, b, b, p, n_head, **kw)
+        return y[0] if isinstance(y, tuple) else y
+
+    K1 = x_neighbors.shape[1]
+    y_self = run(x, x)                                               # :210
+    pooled = [y_self.mean(dim=1)]                                    # :212
+    for k in range(1, K1):
+        xk = x_neighbors[:, k]
+        pooled.append(run(xk, xk).mean(dim=1))                       # :217-219
+    pooled = torch.stack(pooled, dim=1)                              # (B,K+1,C)
+    comp = compatibility(pooled, p, compat_layout)
+    out = comp[:, 0, None, None] * run(x, x)                         # :232-233 (second self call)
+    for k in range(1, K1):
+        xk = x_neighbors[:, k]
+        out = out + comp[:, k, None, None] * run(x, xk)              # :237-238
+    feats = out.permute(0, 2, 1).unsqueeze(-1)                       # :240
+    return (feats, comp, pooled) if return_parts else feats
+
+
+# ------------------------------------------------------------------------------------------------
+# a6  CrossShapeAt.forward (+ logit 1x1 conv, no bias)  (csa_models.py:182-202, 151, 177-180)
+# ------------------------------------------------------------------------------------------------
+def forward_ssa(x: torch.Tensor, p: Params, n_head: int, **kw) -> torch.Tensor:
+    return F.conv2d(ssa_feats(x, p, n_head, **kw), p["logit.weight"])            # :193-194
+
+
+def forward_csa(x: torch.Tensor, x_neighbors: torch.Tensor, p: Params, n_head: int, **kw) -> torch.Tensor:
+    return F.conv2d(csa_feats(x, x_neighbors, p, n_head, **kw), p["logit.weight"])  # :199-201
+
+
+# ------------------------------------------------------------------------------------------------
+# loss used by the callers (MID-FC/csa_training.py:88-108): CE over points whose label > 0
+# ------------------------------------------------------------------------------------------------
+def masked_ce_loss(logit: torch.Tensor, label: torch.Tensor, mask: int = 0) -> torch.Tensor:
+    """logit (B,n_cls,N,1), label (B,N) ints.  Points with label <= mask are dropped
+    (csa_training.py:101-104), then mean cross-entropy (csa_training.py:88-92)."""
+    n_cls = logit.shape[1]
+    flat = logit.squeeze(-1).permute(0, 2, 1).reshape(-1, n_cls)
+    lab = label.reshape(-1)
+    keep = torch.where(lab > mask)[0]
+    return F.cross_entropy(flat[keep], lab[keep].long())
+
+
+# ------------------------------------------------------------------------------------------------
+# a9  retrieval measure / kNN graph  (csa_models.py:244-280)
+# ------------------------------------------------------------------------------------------------
+def retrieval_measure(f1: torch.Tensor, f2: torch.Tensor) -> torch.Tensor:
+    """f1: (S1,N1,C), f2: (S2,N2,C) SSA features.  r[i,j] = mean_n max_m cos(f1[i,n], f2[j,m])
+    over L2-normalised rows (:253-257).  Pair-at-a-time like the reference (the N x N matrix is
+    never kept across pairs)."""
+    S1, S2 = f1.shape[0], f2.shape[0]
+    out = torch.empty(S1, S2, dtype=f1.dtype)
+    g2 = [F.normalize(f, dim=-1, eps=NORM_EPS) for f in f2]
+    for i in range(S1):
+        a = F.normalize(f1[i], dim=-1, eps=NORM_EPS)
+        for j in range(S2):
+            out[i, j] = torch.matmul(a, g2[j].t()).max(dim=-1)[0].mean()
+    return out
+
+
+def knn_graph(f1: torch.Tensor, f2: torch.Tensor, K: int) -> torch.Tensor:
+    """topk(K+1) candidate indices per query shape, int64 (S1, K+1)  (:277-280)."""
+    return retrieval_measure(f1, f2).topk(K + 1, dim=-1)[1]
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter helpers (shapes as the reference's state_dict, csa_models.py:49-57,147-161)
+# ------------------------------------------------------------------------------------------------
+def make_params(rng, n_head: int, d_model: int = 256, d_k: int = REF_DK, d_v: int = REF_DK,
+                n_cls: int = 39, csa: bool = True, dtype=torch.float32) -> Params:
+    """Deterministic parameters from a ``numpy.random.Generator`` (version-stable stream), scaled
+    like the reference's default initialisers so activations have realistic magnitudes."""
+    import numpy as np
+
+    def uni(shape, bound):
+        return torch.from_numpy(rng.uniform(-bound, bound, size=shape).astype(np.float32)).to(dtype)
+
+    p: Params = {}
+    p["attention.w_qs.weight"] = uni((n_head * d_k, d_model), 1.0 / math.sqrt(d_model))
+    p["attention.w_ks.weight"] = uni((n_head * d_k, d_model), 1.0 / math.sqrt(d_model))
+    p["attention.w_vs.weight"] = uni((n_head * d_v, d_model), 1.0 / math.sqrt(d_model))
+    p["attention.fc.weight"] = uni((d_model, n_head * d_v), 1.0 / math.sqrt(n_head * d_v))
+    p["attention.norm.weight"] = 1.0 + uni((d_model,), 0.25)
+    p["attention.norm.bias"] = uni((d_model,), 0.25)
+    p["logit.weight"] = uni((n_cls, d_model, 1, 1), math.sqrt(6.0 / (d_model + n_cls)))
+    if csa:
+        for nm in ("compatibility_q", "compatibility_k"):
+            p[nm + ".weight"] = uni((d_model, d_model), 1.0 / math.sqrt(d_model))
+            p[nm + ".bias"] = uni((d_model,), 1.0 / math.sqrt(d_model))
+    return p
+
+
+def synth_points(rng, shape: Sequence[int], dtype=torch.float32) -> torch.Tensor:
+    import numpy as np
+    return torch.from_numpy(rng.standard_normal(size=tuple(shape)).astype(np.float32)).to(dtype)
+
+
+def synth_labels(rng, B: int, N: int, n_cls: int, p_unlabeled: float = 0.1) -> torch.Tensor:
+    """Integer part labels in [0, n_cls) with ~10 % forced to 0 (= unlabeled, masked out by the loss,
+    csa_training.py:101)."""
+    import numpy as np
+    lab = rng.integers(0, n_cls, size=(B, N))
+    lab[rng.random(size=(B, N)) < p_unlabeled] = 0
+    return torch.from_numpy(lab.astype(np.int64))
+
+
+def synth_clustered_feats(rng, S: int, N: int, C: int = 256, n_centers: int = 4) -> torch.Tensor:
+    """(S, N, C) point features drawn around a few shared centres, so retrieval scores are well
+    separated and the kNN ranking is not decided by rounding noise."""
+    import numpy as np
+    centers = rng.standard_normal(size=(n_centers, 1, C)).astype(np.float32)
+    pick = rng.integers(0, n_centers, size=S)
+    return torch.from_numpy((centers[pick] * 0.7 + rng.standard_normal(size=(S, N, C))).astype(np.float32))

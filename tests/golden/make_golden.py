@@ -1,0 +1,186 @@
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE module itself.
+
+Run once, in the build container (the only place /root/reference exists):
+
+    python tests/golden/make_golden.py
+
+Inputs and parameters are drawn from ``numpy.random.default_rng(seed)`` (a version-stable stream) through
+``oracle.csa_oracle.make_params`` / ``synth_points`` so the tests can regenerate them bit-for-bit on
+any box; only the reference's OUTPUTS (sub-sampled where large) are stored.  The reference is imported,
+never copied: nothing from it is written anywhere but numbers.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/MID-FC")
+
+import csa_models as ref  # noqa: E402  (the reference)
+from oracle import csa_oracle as orc  # noqa: E402
+
+torch.set_num_threads(8)
+
+ROW_STRIDE = 97
+
+
+def sample_rows(t: torch.Tensor, stride: int = ROW_STRIDE) -> np.ndarray:
+    """(B, N, C) -> every stride-th row along N."""
+    return t.detach()[:, ::stride].contiguous().numpy().astype(np.float32)
+
+
+def stats(t: torch.Tensor) -> np.ndarray:
+    t = t.detach().double()
+    return np.array([t.mean().item(), t.norm().item(), t.abs().max().item()], dtype=np.float64)
+
+
+def load_into(model, p):
+    missing, unexpected = model.load_state_dict(p, strict=False)
+    assert not unexpected, unexpected
+    assert all(k.startswith("fc_1.") for k in missing), missing
+    return model
+
+
+def g1_sdpa(out):
+    for tag, (B, H, T, d), seed in [("a", (1, 1, 500, 256), 101), ("b", (2, 8, 500, 256), 102),
+                                    ("c", (1, 2, 64, 32), 103)]:
+        rng = np.random.default_rng(seed)
+        q, k, v = (orc.synth_points(rng, (B, H, T, d)) for _ in range(3))
+        m = ref.ScaledDotProductAttention(temperature=d ** 0.5).eval()
+        o, pr = m(q, k, v)
+        out[f"g1{tag}_shape"] = np.array([B, H, T, d, seed])
+        out[f"g1{tag}_out"] = o.reshape(B * H, T, d)[:, ::31].numpy()
+        out[f"g1{tag}_prob"] = pr.reshape(B * H, T, T)[:, ::31].numpy()
+        out[f"g1{tag}_out_stats"] = stats(o)
+
+
+def g2_self_attention(out):
+    cases = [(500, 256, 1), (512, 128, 2), (2048, 128, 1), (2048, 96, 2), (512, 256, 2)]
+    for i, (N, C, H) in enumerate(cases):
+        seed = 200 + i
+        rng = np.random.default_rng(seed)
+        p = orc.make_params(rng, H, d_model=C, d_k=C, d_v=C, csa=False)
+        x = orc.synth_points(rng, (1, C, N, 1))
+        m = ref.MultiHeadAttention(H, C, C, C).eval()
+        m.load_state_dict({k[len("attention."):]: v for k, v in p.items() if k.startswith("attention.")})
+        y, _ = m.self_attention(x)
+        out[f"g2_{i}_cfg"] = np.array([N, C, H, seed])
+        out[f"g2_{i}_rows"] = sample_rows(y, 29)
+        out[f"g2_{i}_stats"] = stats(y)
+
+
+def g3_mha_forward(out):
+    for i, H in enumerate([1, 8]):
+        seed = 300 + i
+        rng = np.random.default_rng(seed)
+        p = orc.make_params(rng, H, csa=False)
+        xa = orc.synth_points(rng, (1, 256, 10000, 1))
+        xb = orc.synth_points(rng, (1, 256, 10000, 1))
+        m = ref.MultiHeadAttention(H, 256, 256, 256).eval()
+        m.load_state_dict({k[len("attention."):]: v for k, v in p.items() if k.startswith("attention.")})
+        with torch.no_grad():
+            ys, _ = m(xa, xa, xa, "test")
+            yc, attn_last = m(xa, xb, xb, "test")
+        out[f"g3_{i}_cfg"] = np.array([H, seed])
+        out[f"g3_{i}_self_rows"] = sample_rows(ys)
+        out[f"g3_{i}_cross_rows"] = sample_rows(yc)
+        out[f"g3_{i}_self_stats"] = stats(ys)
+        out[f"g3_{i}_cross_stats"] = stats(yc)
+        out[f"g3_{i}_attn_last_row0"] = attn_last[0, :, 0].numpy()      # (H, 500) last chunk, query 0
+
+
+def grads_pack(model, out, key):
+    for name, prm in model.named_parameters():
+        if prm.grad is None:
+            out[f"{key}_nograd_{name}"] = np.zeros(1)
+            continue
+        g = prm.grad.detach()
+        out[f"{key}_gstats_{name}"] = stats(g)
+        if g.numel() <= 10000:
+            out[f"{key}_grad_{name}"] = g.numpy().astype(np.float32)
+        else:
+            out[f"{key}_grad_{name}"] = g.reshape(g.shape[0], -1)[::17, ::13].contiguous().numpy().astype(np.float32)
+
+
+def labels_for(rng, B, N, n_cls):
+    return orc.synth_labels(rng, B, N, n_cls)       # ~10 % unlabeled -> exercises the mask (csa_training.py:101)
+
+
+def g4_csa(out):
+    n_cls = 39
+    for i, (B, K, H) in enumerate([(1, 2, 1), (2, 3, 1), (1, 2, 8)]):
+        seed = 400 + i
+        rng = np.random.default_rng(seed)
+        p = orc.make_params(rng, H, n_cls=n_cls, csa=True)
+        x = orc.synth_points(rng, (B, 256, 10000, 1))
+        nb = orc.synth_points(rng, (B, K + 1, 256, 10000, 1))
+        nb[:, 0] = x
+        lab = labels_for(rng, B, 10000, n_cls)
+        model = load_into(ref.get_model("csa", n_cls, H, K), p).eval()
+        logits = model(x, "test", nb)
+        loss = orc.masked_ce_loss(logits, lab)
+        loss.backward()
+        with torch.no_grad():
+            feats, comp, pooled = orc.csa_feats(x, nb, p, H, return_parts=True)   # oracle's comp, cross-checked below
+            ref_feats = model.get_csa_feats(x, nb, "test")
+        assert (feats - ref_feats).abs().max().item() < 2e-5
+        out[f"g4_{i}_cfg"] = np.array([B, K, H, n_cls, seed])
+        out[f"g4_{i}_logit_rows"] = logits.detach().squeeze(-1).permute(0, 2, 1)[:, ::ROW_STRIDE].contiguous().numpy()
+        out[f"g4_{i}_feat_rows"] = ref_feats.squeeze(-1).permute(0, 2, 1)[:, ::ROW_STRIDE].contiguous().numpy()
+        out[f"g4_{i}_feat_stats"] = stats(ref_feats)
+        out[f"g4_{i}_loss"] = np.array([loss.item()], dtype=np.float64)
+        out[f"g4_{i}_comp_oracle"] = comp.numpy()
+        grads_pack(model, out, f"g4_{i}")
+
+
+def g5_ssa(out):
+    n_cls = 39
+    for i, (B, H) in enumerate([(2, 1), (1, 8)]):
+        seed = 500 + i
+        rng = np.random.default_rng(seed)
+        p = orc.make_params(rng, H, n_cls=n_cls, csa=False)
+        x = orc.synth_points(rng, (B, 256, 10000, 1))
+        lab = labels_for(rng, B, 10000, n_cls)
+        model = load_into(ref.get_model("ssa", n_cls, H), p).eval()
+        logits = model(x, "train")
+        loss = orc.masked_ce_loss(logits, lab)
+        loss.backward()
+        out[f"g5_{i}_cfg"] = np.array([B, H, n_cls, seed])
+        out[f"g5_{i}_logit_rows"] = logits.detach().squeeze(-1).permute(0, 2, 1)[:, ::ROW_STRIDE].contiguous().numpy()
+        out[f"g5_{i}_loss"] = np.array([loss.item()], dtype=np.float64)
+        grads_pack(model, out, f"g5_{i}")
+
+
+def g6_retrieval(out):
+    model = ref.get_model("ssa", 4, 1).eval()
+    for i, (S, N, K) in enumerate([(6, 300, 2), (16, 1000, 3)]):
+        seed = 600 + i
+        rng = np.random.default_rng(seed)
+        # clustered features so the ranking is not a coin toss between near-equal scores
+        f = orc.synth_clustered_feats(rng, S, N)
+        with torch.no_grad():
+            r = model.get_retrieval_measure(f, f)
+            g = model.get_knn_graph(f, f, K)
+        out[f"g6_{i}_cfg"] = np.array([S, N, K, seed])
+        out[f"g6_{i}_measure"] = r.numpy()
+        out[f"g6_{i}_graph"] = g.numpy().astype(np.int64)
+
+
+def main():
+    for name, fn in [("g1_sdpa", g1_sdpa), ("g2_self_attention", g2_self_attention),
+                     ("g3_mha_forward", g3_mha_forward), ("g4_csa", g4_csa), ("g5_ssa", g5_ssa),
+                     ("g6_retrieval", g6_retrieval)]:
+        out = {}
+        fn(out)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(name, "->", path, f"{os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,178 @@
+"""Pins oracle/csa_oracle.py to the golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only; inputs are regenerated from the recorded seeds."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import csa_oracle as orc
+
+ROW_STRIDE = 97
+TOL = 2e-5          # reference (MKL, 8 threads) vs oracle (different blocking): fp32 rounding only
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _stats(t):
+    t = t.detach().double()
+    return np.array([t.mean().item(), t.norm().item(), t.abs().max().item()])
+
+
+def _close(a, b, tol=TOL):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max()
+    assert err <= tol * max(1.0, np.abs(b).max()), err
+
+
+def test_g1_sdpa(golden_dir):
+    g = _load(golden_dir, "g1_sdpa")
+    for tag in "abc":
+        B, H, T, d, seed = g[f"g1{tag}_shape"]
+        rng = np.random.default_rng(int(seed))
+        q, k, v = (orc.synth_points(rng, (B, H, T, d)) for _ in range(3))
+        o, pr = orc.sdpa(q, k, v, float(d) ** 0.5)
+        _close(o.reshape(B * H, T, d)[:, ::31].numpy(), g[f"g1{tag}_out"])
+        _close(pr.reshape(B * H, T, T)[:, ::31].numpy(), g[f"g1{tag}_prob"], 1e-6)
+        _close(_stats(o), g[f"g1{tag}_out_stats"], 1e-5)
+
+
+def test_g2_self_attention(golden_dir):
+    g = _load(golden_dir, "g2_self_attention")
+    i = 0
+    while f"g2_{i}_cfg" in g:
+        N, C, H, seed = (int(v) for v in g[f"g2_{i}_cfg"])
+        rng = np.random.default_rng(seed)
+        p = orc.make_params(rng, H, d_model=C, d_k=C, d_v=C, csa=False)
+        x = orc.synth_points(rng, (1, C, N, 1))
+        y = orc.mha_full_self(x, p, H, C, C)
+        _close(y[:, ::29].numpy(), g[f"g2_{i}_rows"])
+        _close(_stats(y), g[f"g2_{i}_stats"], 1e-5)
+        i += 1
+    assert i == 5
+
+
+@pytest.mark.parametrize("flavour", ["blockdiag", "faithful"])
+def test_g3_mha_forward(golden_dir, flavour):
+    g = _load(golden_dir, "g3_mha_forward")
+    for i in range(2):
+        H, seed = (int(v) for v in g[f"g3_{i}_cfg"])
+        if flavour == "faithful" and H == 8:
+            continue                                  # slow; blockdiag covers H=8
+        rng = np.random.default_rng(seed)
+        p = orc.make_params(rng, H, csa=False)
+        xa = orc.synth_points(rng, (1, 256, 10000, 1))
+        xb = orc.synth_points(rng, (1, 256, 10000, 1))
+        with torch.no_grad():
+            if flavour == "blockdiag":
+                ys = orc.mha_blockdiag(xa, xa, xa, p, H)
+                yc, attn = orc.mha_blockdiag(xa, xb, xb, p, H, return_attn=True)
+                last_row0 = attn[0, -1, :, 0]
+            else:
+                ys, _ = orc.mha_faithful(xa, xa, xa, p, H)
+                yc, attn = orc.mha_faithful(xa, xb, xb, p, H)
+                last_row0 = attn[0, :, 0]
+        _close(ys[:, ::ROW_STRIDE].numpy(), g[f"g3_{i}_self_rows"])
+        _close(yc[:, ::ROW_STRIDE].numpy(), g[f"g3_{i}_cross_rows"])
+        _close(_stats(ys), g[f"g3_{i}_self_stats"], 1e-5)
+        _close(_stats(yc), g[f"g3_{i}_cross_stats"], 1e-5)
+        _close(last_row0.numpy(), g[f"g3_{i}_attn_last_row0"], 1e-6)
+
+
+def _check_grads(g, key, grads):
+    seen = 0
+    for name, gr in grads.items():
+        if f"{key}_nograd_{name}" in g:
+            assert gr is None or float(gr.abs().max()) == 0.0
+            continue
+        ref = g[f"{key}_grad_{name}"]
+        got = gr.numpy() if gr.numel() <= 10000 else gr.reshape(gr.shape[0], -1)[::17, ::13].contiguous().numpy()
+        scale = max(np.abs(ref).max(), 1e-30)
+        assert np.abs(got - ref).max() <= 1e-4 * scale + 1e-9, (name, np.abs(got - ref).max(), scale)
+        st = g[f"{key}_gstats_{name}"]
+        assert abs(gr.double().norm().item() - st[1]) <= 1e-4 * st[1] + 1e-12, name
+        seen += 1
+    return seen
+
+
+def _run_model(p, fwd, lab):
+    p = {k: v.clone().requires_grad_(not k.startswith("fc_1")) for k, v in p.items()}
+    logits = fwd(p)
+    loss = orc.masked_ce_loss(logits, lab)
+    loss.backward()
+    return logits.detach(), loss.item(), {k: v.grad for k, v in p.items()}
+
+
+def test_g4_csa(golden_dir):
+    g = _load(golden_dir, "g4_csa")
+    for i in range(3):
+        B, K, H, n_cls, seed = (int(v) for v in g[f"g4_{i}_cfg"])
+        if H == 8 and os.environ.get("CSN_SLOW", "0") != "1":
+            continue                                   # ~1 min of CPU; run with CSN_SLOW=1
+        rng = np.random.default_rng(seed)
+        p = orc.make_params(rng, H, n_cls=n_cls, csa=True)
+        x = orc.synth_points(rng, (B, 256, 10000, 1))
+        nb = orc.synth_points(rng, (B, K + 1, 256, 10000, 1))
+        nb[:, 0] = x
+        lab = orc.synth_labels(rng, B, 10000, n_cls)
+        logits, loss, grads = _run_model(p, lambda q: orc.forward_csa(x, nb, q, H), lab)
+        _close(logits.squeeze(-1).permute(0, 2, 1)[:, ::ROW_STRIDE].numpy(), g[f"g4_{i}_logit_rows"])
+        assert abs(loss - g[f"g4_{i}_loss"][0]) < 1e-5
+        with torch.no_grad():
+            feats, comp, _ = orc.csa_feats(x, nb, p, H, return_parts=True)
+        _close(feats.squeeze(-1).permute(0, 2, 1)[:, ::ROW_STRIDE].numpy(), g[f"g4_{i}_feat_rows"])
+        _close(comp.numpy(), g[f"g4_{i}_comp_oracle"], 1e-6)
+        assert _check_grads(g, f"g4_{i}", grads) == 11
+
+
+def test_g5_ssa(golden_dir):
+    g = _load(golden_dir, "g5_ssa")
+    for i in range(2):
+        B, H, n_cls, seed = (int(v) for v in g[f"g5_{i}_cfg"])
+        if H == 8 and os.environ.get("CSN_SLOW", "0") != "1":
+            continue
+        rng = np.random.default_rng(seed)
+        p = orc.make_params(rng, H, n_cls=n_cls, csa=False)
+        x = orc.synth_points(rng, (B, 256, 10000, 1))
+        lab = orc.synth_labels(rng, B, 10000, n_cls)
+        logits, loss, grads = _run_model(p, lambda q: orc.forward_ssa(x, q, H), lab)
+        _close(logits.squeeze(-1).permute(0, 2, 1)[:, ::ROW_STRIDE].numpy(), g[f"g5_{i}_logit_rows"])
+        assert abs(loss - g[f"g5_{i}_loss"][0]) < 1e-5
+        assert _check_grads(g, f"g5_{i}", grads) == 7
+
+
+def test_g6_retrieval_and_knn_indices_bit_exact(golden_dir):
+    g = _load(golden_dir, "g6_retrieval")
+    for i in range(2):
+        S, N, K, seed = (int(v) for v in g[f"g6_{i}_cfg"])
+        rng = np.random.default_rng(seed)
+        f = orc.synth_clustered_feats(rng, S, N)
+        r = orc.retrieval_measure(f, f)
+        _close(r.numpy(), g[f"g6_{i}_measure"], 1e-6)
+        graph = orc.knn_graph(f, f, K)
+        assert graph.dtype == torch.int64
+        assert np.array_equal(graph.numpy(), g[f"g6_{i}_graph"])          # bit-exact index table
+
+
+def test_compat_layout_is_the_reference_one_for_batches():
+    """B > 1: the reference scores shape b against rows b*(K+1).. of the neighbour-major stack
+    (csa_models.py:220,227).  For B == 1 both layouts agree."""
+    rng = np.random.default_rng(7)
+    p = orc.make_params(rng, 1, csa=True)
+    pooled = orc.synth_points(rng, (3, 4, 256))
+    a = orc.compatibility(pooled, p, "reference")
+    b = orc.compatibility(pooled, p, "per_shape")
+    assert not torch.allclose(a, b)
+    assert torch.allclose(orc.compatibility(pooled[:1], p, "reference"),
+                          orc.compatibility(pooled[:1], p, "per_shape"))
+    # explicit statement of the scramble
+    stack = torch.cat([pooled[:, k] for k in range(4)], dim=0)          # rows k*B + b
+    keys = stack.view(3, 4, 256)
+    uq = torch.nn.functional.normalize(torch.nn.functional.linear(pooled[:, 0], p["compatibility_q.weight"], p["compatibility_q.bias"]), dim=-1)
+    uk = torch.nn.functional.normalize(torch.nn.functional.linear(keys, p["compatibility_k.weight"], p["compatibility_k.bias"]), dim=-1)
+    ref = torch.softmax(torch.einsum("bc,bkc->bk", uq, uk), dim=-1)
+    assert torch.allclose(a, ref, atol=1e-7)
