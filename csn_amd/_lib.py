@@ -1,0 +1,104 @@
+"""ctypes binding of libcsn_hip.so (C ABI: include/csn_hip.h) and its in-tree build.
+
+This is the binding a maintainer of the reference would add next to ``MID-FC/csa_models.py``: the
+library knows nothing about torch; tensors are handed over as raw device pointers plus sizes and the
+current HIP stream.  There is NO fallback: if the library cannot be built/loaded, every op raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_void_p
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libcsn_hip.so")
+SOURCES = ["gemm_f32.hip", "attn_f32.hip", "outproj_ln.hip", "retrieval.hip", "csn_capi.hip"]
+HEADERS = ["csn_common.h", "csn_kernels.h", os.path.join("..", "..", "include", "csn_hip.h")]
+ARCH = "gfx950"
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class CsnError(RuntimeError):
+    pass
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(_CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into csn_amd/libcsn_hip.so (in-tree, so it travels to the GPU box)."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH + ".tmp"]
+    cmd += [os.path.join(_CSRC, f) for f in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise CsnError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    global _lib
+    _lib = None
+    return LIB_PATH
+
+
+_SIGNATURES = {
+    "csn_version": (c_int, []),
+    "csn_status_string": (c_char_p, [c_int]),
+    "csn_wgrad_workspace_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
+    "csn_project_f32": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_int, c_int, c_void_p, c_longlong, c_int,
+                                c_int, c_int, c_int, c_float, c_void_p]),
+    "csn_block_attn_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_void_p, c_void_p, c_int,
+                                       c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                       c_int, c_float, c_void_p]),
+    "csn_block_attn_bwd_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong,
+                                       c_longlong, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_int,
+                                       c_int, c_void_p]),
+    "csn_outproj_ln_fwd_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p,
+                                       c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "csn_outproj_ln_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int,
+                                       c_int, c_int, c_void_p]),
+    "csn_project_wgrad_f32": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_longlong, c_int, c_void_p, c_int, c_int,
+                                      c_int, c_int, c_float, c_int, c_void_p, c_longlong, c_void_p]),
+    "csn_retrieval_measure_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                          c_longlong, c_void_p]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded library; raises CsnError if it is missing (build it with csn_amd.build())."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CsnError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU or eager fallback for the CSA kernels)")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        if handle.csn_version() != 1:
+            raise CsnError("libcsn_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = lib().csn_status_string(status).decode()
+        raise CsnError(f"{what or 'csn call'} failed with status {status}: {msg}")

@@ -1,0 +1,333 @@
+"""MI355X-native drop-in for the model surface of ``MID-FC/csa_models.py`` (marios2019/CSN).
+
+Same public names, constructor arguments, ``forward`` signatures, ``state_dict`` keys and results as the
+reference (``from csa_models import *`` in csa_training.py:18 / ssa_training.py:17), but the attention
+path — Q/K/V projections, block-diagonal scaled-dot-product attention, output projection + residual +
+LayerNorm, and all of their gradients — runs in hand-written gfx950 kernels behind the C ABI of
+``include/csn_hip.h``.  Nothing in this file falls back to eager PyTorch for that path: CPU tensors or a
+missing ``libcsn_hip.so`` raise.
+
+Differences a caller can see (all opt-in or strictly more permissive):
+  * ``MultiHeadAttention(..., block=500, n_blocks=20)`` exposes the reference's hard-coded chunking
+    (csa_models.py:83-84) so other point counts can be run; the defaults reproduce the reference,
+    including "points beyond 20*500 are ignored" (N < 10000 raises ``IndexError`` like the reference).
+  * outputs of the attention are views of channel-major buffers (values identical).
+  * the attention probabilities (2nd return value of ``MultiHeadAttention.forward``; every caller in the
+    reference discards it) are only materialised on request (``return_attn=True``), otherwise ``None``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as CF
+from ._lib import CsnError
+
+__all__ = ["ScaledDotProductAttention", "MultiHeadAttention", "CrossShapeAt", "get_model",
+           "backbone_fc_ssa_logit", "backbone_fc_csa_logit", "device"]
+
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")       # csa_models.py:8
+
+
+def _channel_major(x: torch.Tensor, n_points: int) -> torch.Tensor:
+    """(B, C, N, 1) or (B, C, N) -> contiguous (B, C, n_points) on the GPU, fp32."""
+    if x.dim() == 4:
+        x = x.squeeze(-1)
+    if x.shape[-1] < n_points:
+        raise IndexError(f"index {n_points - 1} is out of bounds for dimension 2 with size {x.shape[-1]}")
+    if not x.is_cuda:
+        x = x.to(device, non_blocking=True)
+    return x[..., :n_points].to(torch.float32).contiguous()
+
+
+class ScaledDotProductAttention(nn.Module):
+    """softmax((q / temperature) k^T) v on (B, H, T, d) tensors (csa_models.py:128-144)."""
+
+    def __init__(self, temperature, attn_dropout=0.1):
+        super().__init__()
+        self.temperature = temperature
+        self.dropout = nn.Dropout(attn_dropout)
+
+    def forward(self, q, k, v):
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError("attention dropout is not wired into the HIP path yet; use .eval() or p = 0")
+        from .sdpa import sdpa_block
+        return sdpa_block(q, k, v, float(self.temperature))
+
+
+class MultiHeadAttention(nn.Module):
+    """Block-diagonal multi-head attention (csa_models.py:37-125)."""
+
+    def __init__(self, n_head, d_model, d_k, d_v, dropout=0.1, block=CF.REF_BLOCK, n_blocks=CF.REF_NBLOCKS):
+        super().__init__()
+        if d_k != d_v:
+            raise ValueError("the HIP attention kernels need d_k == d_v (the reference always uses 256/256)")
+        self.n_head, self.d_k, self.d_v = n_head, d_k, d_v
+        self.block, self.n_blocks = block, n_blocks
+        self.w_qs = nn.Linear(d_model, n_head * d_k, bias=False)
+        self.w_ks = nn.Linear(d_model, n_head * d_k, bias=False)
+        self.w_vs = nn.Linear(d_model, n_head * d_v, bias=False)
+        self.fc = nn.Linear(n_head * d_v, d_model, bias=False)
+        self.attention = ScaledDotProductAttention(temperature=d_k ** 0.5)
+        self.dropout = nn.Dropout(dropout)
+        self.norm = nn.LayerNorm(d_model, eps=CF.LN_EPS)
+
+    # -- helpers ------------------------------------------------------------------------------------------
+    def geometry(self, block: Optional[int] = None, n_blocks: Optional[int] = None) -> CF.MHAGeometry:
+        return CF.MHAGeometry(self.n_head, self.d_k, self.block if block is None else block,
+                              self.n_blocks if n_blocks is None else n_blocks)
+
+    def _check_mode(self):
+        if self.training and (self.dropout.p > 0 or self.attention.dropout.p > 0):
+            raise NotImplementedError("dropout is not wired into the HIP path yet; call .eval() or build with dropout=0")
+
+    def evaluate(self, x_all: torch.Tensor, q_slots: torch.Tensor, kv_slots: torch.Tensor,
+                 geo: Optional[CF.MHAGeometry] = None) -> torch.Tensor:
+        """Normalised (pre-affine) outputs (E, C, NP) of a batch of evaluations over shared slots."""
+        self._check_mode()
+        return CF.mha_evals(x_all, self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight,
+                            q_slots, kv_slots, geo or self.geometry())
+
+    def affine(self, xhat: torch.Tensor) -> torch.Tensor:
+        """LayerNorm's gamma/beta on channel-major activations (csa_models.py:118)."""
+        return xhat * self.norm.weight[:, None] + self.norm.bias[:, None]
+
+    def _run(self, Q, K, V, geo):
+        B = Q.shape[0]
+        npts = geo.n_points
+        same_kv = (K is V) or (K.data_ptr() == V.data_ptr() and K.shape == V.shape)
+        if not same_kv:
+            raise NotImplementedError("distinct key and value inputs are not supported (the reference never uses them)")
+        xq = _channel_major(Q, npts)
+        dev = xq.device
+        ar = torch.arange(B, device=dev, dtype=torch.int32)
+        if (Q is K) or (Q.data_ptr() == K.data_ptr() and Q.shape == K.shape):
+            x_all, q_slots, kv_slots = xq, ar, ar
+        else:
+            x_all = torch.cat((xq, _channel_major(K, npts)), dim=0)
+            q_slots, kv_slots = ar, ar + B
+        return self.affine(self.evaluate(x_all, q_slots, kv_slots, geo))          # (B, C, NP)
+
+    # -- reference surface ------------------------------------------------------------------------------
+    def self_attention(self, x):
+        """Unchunked self-attention over all N points (csa_models.py:59-79)."""
+        N = x.shape[2]
+        y = self._run(x, x, x, self.geometry(block=N, n_blocks=1))
+        return y.permute(0, 2, 1), None
+
+    def forward(self, Q, K, V, mode=None, return_attn: bool = False):
+        """(B, C, N, 1) x3 -> ((B, n_blocks*block, C), attn-of-last-block or None)   (csa_models.py:81-125)."""
+        y = self._run(Q, K, V, self.geometry())
+        attn = None
+        if return_attn:
+            from .sdpa import last_block_probabilities
+            attn = last_block_probabilities(self, Q, K)
+        return y.permute(0, 2, 1), attn
+
+
+class CrossShapeAt(nn.Module):
+    """csa_models.py:146-404."""
+
+    def __init__(self, num_classes, d_model, n_heads, K=None, d_k=256, d_v=256, attention_type='ssa',
+                 after_fc=False, device=None):
+        super().__init__()
+        self.fc_1 = self._conv1x1_bn_relu(928, 256)            # never executed when after_fc=True; kept for checkpoints
+        self.logit = self._conv1x1(256, num_classes)
+        self.attention = MultiHeadAttention(n_heads, d_model, d_k, d_v)
+        self.attention_type = attention_type
+        self.after_fc = after_fc
+        self.device = device
+        self.compat_layout = "reference"      # see get_csa_feats
+        if 'csa' in self.attention_type:
+            self.K = K
+            self.compatibility_q = nn.Linear(256, 256)
+            self.compatibility_k = nn.Linear(256, 256)
+
+    @staticmethod
+    def _conv1x1(nin, nout, use_bias=False):
+        layer = nn.Conv2d(nin, nout, kernel_size=1, stride=1, padding='same', bias=use_bias)
+        nn.init.xavier_uniform_(layer.weight)                                  # csa_models.py:179
+        return layer
+
+    @classmethod
+    def _conv1x1_bn_relu(cls, nin, nout):
+        return nn.Sequential(nn.Sequential(cls._conv1x1(nin, nout), nn.BatchNorm2d(nout)), nn.ReLU())
+
+    # -- forward ----------------------------------------------------------------------------------------------
+    def forward(self, x, mode=None, neighbor_feats=None):
+        if self.attention_type == 'ssa':
+            return self.forward_ssa(x, mode)
+        if self.attention_type == 'csa':
+            return self.forward_csa(x, neighbor_feats, mode)
+        return x                                                               # csa_models.py:182-189 falls through
+
+    def _logits(self, feats_cm: torch.Tensor) -> torch.Tensor:
+        """1x1 conv without bias on channel-major features (csa_models.py:151,194,201) -> (B, n_cls, N, 1)."""
+        w = self.logit.weight.view(self.logit.weight.shape[0], -1)
+        return torch.matmul(w, feats_cm).unsqueeze(-1)
+
+    def forward_ssa(self, x, mode=None):
+        if not self.after_fc:
+            raise NotImplementedError("only the after_fc=True models that get_model builds are supported")
+        return self._logits(self._ssa_cm(x))
+
+    def forward_csa(self, x, x_neighbors, mode=None):
+        if not self.after_fc:
+            raise NotImplementedError("only the after_fc=True models that get_model builds are supported")
+        return self._logits(self._csa_cm(x, x_neighbors))
+
+    def _ssa_cm(self, x) -> torch.Tensor:
+        att = self.attention
+        geo = att.geometry()
+        xc = _channel_major(x, geo.n_points)
+        ar = torch.arange(xc.shape[0], device=xc.device, dtype=torch.int32)
+        return att.affine(att.evaluate(xc, ar, ar, geo))
+
+    def get_ssa_feats(self, x, mode=None):
+        """(B, 256, N, 1) -> ((B, 256, N', 1), None)   (csa_models.py:204-207)."""
+        return self._ssa_cm(x).unsqueeze(-1), None
+
+    def _csa_cm(self, x, x_neighbors, return_parts: bool = False):
+        """Cross-shape attention features, channel-major (B, C, NP)   (csa_models.py:209-242).
+
+        Slots: s = b*(K+1) + k holds x_b (k = 0) or its k-th neighbour.  Evaluations, in this order:
+          [b*(K+1) + k]          k = 0: SSA(x_b) = MHA(x_b, x_b, x_b);  k >= 1: MHA(x_b, x_bk, x_bk)   (mixed, :232-238)
+          [B*(K+1) + b*K + k-1]  SSA(x_bk), only its mean over points is used                          (:214-220)
+        In eval mode the reference's two self calls (:210 and :232) are the same numbers; they are computed once.
+        """
+        att = self.attention
+        geo = att.geometry()
+        npts = geo.n_points
+        xc = _channel_major(x, npts)                                           # (B, C, NP)
+        B, C, _ = xc.shape
+        K1 = x_neighbors.shape[1]
+        K = K1 - 1
+        dev = xc.device
+        nb = x_neighbors
+        if nb.dim() == 5:
+            nb = nb.squeeze(-1)
+        x_all = torch.empty((B, K1, C, npts), device=dev, dtype=torch.float32)
+        x_all[:, 0] = xc                                                       # the query shape itself (:210, :232)
+        if K > 0:
+            if nb.shape[-1] < npts:
+                raise IndexError(f"index {npts - 1} is out of bounds for dimension 2 with size {nb.shape[-1]}")
+            x_all[:, 1:] = nb[:, 1:, :, :npts].to(dev, non_blocking=True)      # neighbours may arrive on the CPU (:216)
+        x_all = x_all.view(B * K1, C, npts)
+
+        b_idx = torch.arange(B, device=dev, dtype=torch.int32)
+        k_idx = torch.arange(K1, device=dev, dtype=torch.int32)
+        mix_q = (b_idx[:, None] * K1).expand(B, K1).reshape(-1)                # query slot of (b, k): x_b
+        mix_kv = (b_idx[:, None] * K1 + k_idx[None, :]).reshape(-1)            # key/value slot: x_bk
+        nbr = mix_kv.view(B, K1)[:, 1:].reshape(-1)                            # SSA of the neighbours
+        q_slots = torch.cat((mix_q, nbr)).contiguous()
+        kv_slots = torch.cat((mix_kv, nbr)).contiguous()
+
+        xhat = att.evaluate(x_all, q_slots, kv_slots, geo)                     # (E, C, NP)
+        E1 = B * K1
+        gamma, beta = att.norm.weight, att.norm.bias
+        xh_mix = xhat[:E1].view(B, K1, C, npts)
+        # pooled descriptors y_k = mean_n SSA(x_k)  (:211-212, :218-219); the affine commutes with the mean
+        pooled_hat = torch.cat((xh_mix[:, :1].mean(dim=3), xhat[E1:].view(B, K, C, npts).mean(dim=3)), dim=1)
+        pooled = pooled_hat * gamma + beta                                     # (B, K+1, C)
+        comp = self._compatibility(pooled)                                     # (B, K+1)
+        mix = torch.einsum("bk,bkcn->bcn", comp, xh_mix)
+        feats = mix * gamma[:, None] + beta[:, None] * comp.sum(dim=1)[:, None, None]
+        return (feats, comp, pooled) if return_parts else feats
+
+    def _compatibility(self, pooled: torch.Tensor) -> torch.Tensor:
+        """softmax_k <normalize(Wq y_0 + b), normalize(Wk y_k + b)>   (csa_models.py:222-230).
+
+        ``compat_layout == "reference"`` reproduces the reference's row bookkeeping for B > 1: the key
+        descriptors are concatenated neighbour-major (rows k*B + b, :213,:220) and then re-viewed as
+        (B, K+1, C) (:227).  ``"per_shape"`` scores every shape against its own neighbours."""
+        B, K1, C = pooled.shape
+        u_q = F.normalize(self.compatibility_q(pooled[:, 0]), dim=-1)
+        keys = pooled.transpose(0, 1).reshape(K1 * B, C).view(B, K1, C) if self.compat_layout == "reference" else pooled
+        u_k = F.normalize(self.compatibility_k(keys), dim=-1)
+        return F.softmax(torch.einsum("bc,bkc->bk", u_q, u_k), dim=-1)
+
+    def get_csa_feats(self, x, x_neighbors, mode=None):
+        return self._csa_cm(x, x_neighbors).unsqueeze(-1)
+
+    # -- shape-graph construction (csa_models.py:244-404) -----------------------------------------------
+    def get_retrieval_measure(self, ssa_feats_1, ssa_feats_2):
+        """(S1, N, C), (S2, N, C) point-major SSA features -> (S1, S2) retrieval scores."""
+        f1 = ssa_feats_1.to(device, torch.float32)
+        f2 = ssa_feats_2.to(device, torch.float32)
+        return CF.retrieval_measure(f1, f2)
+
+    def get_knn_graph(self, ssa_feats_1, ssa_feats_2, K):
+        scores, knn_graph = self.get_retrieval_measure(ssa_feats_1, ssa_feats_2).topk(K + 1, -1)
+        return knn_graph
+
+    def get_all_feats(self, logs_dir, train_dataloader, K, mode):
+        chunks = []
+        for feats, label in train_dataloader:
+            feats = torch.squeeze(feats, dim=1)
+            with torch.no_grad():
+                chunks.append(self._ssa_cm(feats).permute(0, 2, 1).cpu())      # point-major, on the host like :295
+        return torch.cat(chunks, dim=0)
+
+    def get_center_shape_indices(self, train_loader):
+        """k-means seeding of the candidate set for big categories (csa_models.py:302-332)."""
+        from sklearn.cluster import KMeans
+        glob = []
+        for feats, label in train_loader:
+            feats = torch.squeeze(feats, dim=1)
+            with torch.no_grad():
+                glob.append(torch.amax(self._ssa_cm(feats), dim=2))            # max over points -> (B, C)
+        glob = torch.cat(glob, dim=0).cpu().numpy()
+        n_centers = len(glob) // 10
+        kmeans = KMeans(n_clusters=n_centers, random_state=0, n_init=10).fit(glob)
+        centers = np.expand_dims(kmeans.cluster_centers_, axis=1)
+        return np.argmin(np.sum((centers - glob) ** 2, axis=-1), axis=-1)
+
+    def get_candidate_ssa_feats(self, data_loader, candidate_shape_indices):
+        out, counter = [], 0
+        for i, (feats, label) in enumerate(data_loader):
+            if i != candidate_shape_indices[counter]:
+                continue
+            feats = torch.squeeze(feats, dim=1)
+            with torch.no_grad():
+                out.append(self._ssa_cm(feats).permute(0, 2, 1))
+            counter += 1
+            if counter == len(candidate_shape_indices):
+                break
+        return torch.cat(out, dim=0)
+
+    def get_retrieval_measure_big(self, query_loader, candidate_loader, candidate_shape_indices):
+        candidate_shape_indices.sort()
+        cand = self.get_candidate_ssa_feats(candidate_loader, candidate_shape_indices).contiguous()
+        rows = []
+        for feats, label in query_loader:
+            feats = torch.squeeze(feats, dim=1)
+            with torch.no_grad():
+                f1 = self._ssa_cm(feats).permute(0, 2, 1).contiguous()
+                rows.append(CF.retrieval_measure(f1, cand))
+        return torch.cat(rows, dim=0)
+
+    def get_knn_graph_big(self, query_loader, candidate_loader, candidate_shape_indices, K):
+        measure = self.get_retrieval_measure_big(query_loader, candidate_loader, candidate_shape_indices)
+        scores, knn_graph = measure.topk(K + 1, -1)
+        return knn_graph
+
+
+def backbone_fc_ssa_logit(num_classes, n_heads):
+    return CrossShapeAt(num_classes, 256, n_heads, attention_type='ssa', after_fc=True)
+
+
+def backbone_fc_csa_logit(num_classes, n_heads, K):
+    return CrossShapeAt(num_classes, 256, n_heads, K, attention_type='csa', after_fc=True)
+
+
+def get_model(attention_type, num_classes, n_heads, K=None):
+    """csa_models.py:426-432."""
+    if attention_type == 'ssa':
+        return backbone_fc_ssa_logit(num_classes, n_heads)
+    if attention_type == 'csa':
+        return backbone_fc_csa_logit(num_classes, n_heads, K)
+    raise AttributeError(f'{attention_type} not supported')

@@ -1,0 +1,236 @@
+// extern "C" surface of libcsn_hip.so (declared in include/csn_hip.h).  Argument checking and the
+// decomposition of each domain-level call into kernel launches live here; no allocation, no sync.
+#include "../../include/csn_hip.h"
+#include "csn_kernels.h"
+
+int csn_launch_retrieval_f32(const float* f1, const float* f2, float* out, int s1, int n1, int s2, int n2, int C,
+                             float* ws, hipStream_t st);
+
+namespace {
+
+inline bool mis16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
+inline bool dim_ok(int d) { return d == 32 || d == 64 || d == 96 || d == 128 || d == 256; }
+
+CsnOperand operand(const float* p, long long s0, long long s1, long long s2, const int* idx2, int ld) {
+  CsnOperand o;
+  o.ptr = const_cast<float*>(p);
+  o.s0 = s0; o.s1 = s1; o.s2 = s2; o.idx2 = idx2; o.ld = ld;
+  return o;
+}
+
+// points contracted per work-group of a split weight gradient
+int wgrad_chunk(int n_maps, int n_points) {
+  long long total = (long long)n_maps * n_points;
+  long long want = (total + 511) / 512;                   // aim at ~512 slabs
+  long long c = ((want + 31) / 32) * 32;
+  if (c < 256) c = 256;
+  if (c > 4096) c = 4096;
+  if (c > n_points) c = ((n_points + 3) / 4) * 4;
+  return (int)c;
+}
+
+// dw[rows][cols] (+)= scale * sum_{z2, n} a[z2][rows][n] * b[z2][cols][n]
+int wgrad(const float* a, long long a_stride, int lda, const float* b, long long b_stride, int ldb, float* dw, int rows,
+          int cols, int n_maps, int n_points, float scale, int accumulate, float* ws, long long ws_floats,
+          hipStream_t st) {
+  const int chunk = wgrad_chunk(n_maps, n_points);
+  const int n_chunks = (n_points + chunk - 1) / chunk;
+  const long long slabs = (long long)n_maps * n_chunks;
+  if (ws_floats < slabs * rows * cols) return CSN_E_WORKSPACE;
+  CsnGemmArgs g;
+  g.A = operand(a, chunk, 0, a_stride, nullptr, lda);
+  g.B = operand(b, chunk, 0, b_stride, nullptr, ldb);
+  g.C = operand(ws, (long long)rows * cols, 0, (long long)n_chunks * rows * cols, nullptr, cols);
+  g.M = rows; g.N = cols; g.K = n_points;
+  g.n0 = n_chunks; g.n1 = 1; g.k_chunk = chunk;
+  g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = 0;
+  int rc = csn_launch_gemm_f32(g, /*b_is_nk=*/1, (int)slabs, st);
+  if (rc) return rc;
+  return csn_launch_slab_reduce(ws, dw, (int)slabs, (long long)rows * cols, scale, accumulate, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int csn_version(void) { return CSN_ABI_VERSION; }
+
+const char* csn_status_string(int status) {
+  switch (status) {
+    case 0: return "ok";
+    case CSN_E_ARG: return "csn: null pointer or non-positive size";
+    case CSN_E_ALIGN: return "csn: a size or leading dimension is not a multiple of 4 floats";
+    case CSN_E_PTR: return "csn: device pointer not 16-byte aligned";
+    case CSN_E_STRIDE: return "csn: a stride is not a multiple of 4 floats";
+    case CSN_E_DIM: return "csn: unsupported head / model dimension (need 32, 64, 96, 128 or 256)";
+    case CSN_E_WORKSPACE: return "csn: workspace too small";
+    default: return status > 0 ? hipGetErrorString((hipError_t)status) : "csn: unknown status";
+  }
+}
+
+long long csn_wgrad_workspace_floats(int rows, int cols, int n_maps, int n_points) {
+  if (rows <= 0 || cols <= 0 || n_maps <= 0 || n_points <= 0) return 0;
+  const int chunk = wgrad_chunk(n_maps, n_points);
+  const long long n_chunks = (n_points + chunk - 1) / chunk;
+  return (long long)n_maps * n_chunks * rows * cols;
+}
+
+int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const float* w, int rows, int channels,
+                    float* out, long long out_shape_stride, int ld_out, int n_shapes, int n_points, int div_rows,
+                    float temperature, void* stream) {
+  if (!x || !w || !out || rows <= 0 || channels <= 0 || n_shapes <= 0 || n_points <= 0) return CSN_E_ARG;
+  if ((ld_x & 3) || (ld_out & 3) || (n_points & 3) || (channels & 3)) return CSN_E_ALIGN;
+  if (mis16(x) || mis16(w) || mis16(out)) return CSN_E_PTR;
+  if ((x_shape_stride & 3) || (out_shape_stride & 3)) return CSN_E_STRIDE;
+  CsnGemmArgs g;
+  g.A = operand(w, 0, 0, 0, nullptr, channels);
+  g.B = operand(x, 0, 0, x_shape_stride, nullptr, ld_x);
+  g.C = operand(out, 0, 0, out_shape_stride, nullptr, ld_out);
+  g.M = rows; g.N = n_points; g.K = channels;
+  g.n0 = 1; g.n1 = 1; g.k_chunk = 0;
+  g.alpha = 1.f; g.div_rows = div_rows; g.div_val = temperature; g.accumulate = 0;
+  return csn_launch_gemm_f32(g, /*b_is_nk=*/0, n_shapes, (hipStream_t)stream);
+}
+
+int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
+                           long long kv_shape_stride, const int* q_index, const int* kv_index, int ld, float* ctx,
+                           long long ctx_eval_stride, float* scores, float* lse, int n_evals, int n_heads,
+                           int d_head, int block, int n_blocks, int score_pitch, float rescale_threshold,
+                           void* stream) {
+  if (!q || !k || !v || !ctx || n_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
+  if (!dim_ok(d_head)) return CSN_E_DIM;
+  if ((ld & 3) || (block & 3) || (score_pitch & 3) || score_pitch < block) return CSN_E_ALIGN;
+  if (mis16(q) || mis16(k) || mis16(v) || mis16(ctx) || mis16(scores)) return CSN_E_PTR;
+  if ((q_shape_stride & 3) || (kv_shape_stride & 3) || (ctx_eval_stride & 3)) return CSN_E_STRIDE;
+  if ((long long)n_blocks * block > ld) return CSN_E_ARG;
+  CsnAttnArgs a;
+  a.q = q; a.k = k; a.v = v;
+  a.q_shape_stride = q_shape_stride; a.kv_shape_stride = kv_shape_stride;
+  a.q_index = q_index; a.kv_index = kv_index; a.ld = ld;
+  a.out = ctx; a.out_eval_stride = ctx_eval_stride;
+  a.scores = scores; a.dscores = nullptr; a.lse = lse; a.delta = nullptr;
+  a.E = n_evals; a.H = n_heads; a.T = block; a.Tp = score_pitch; a.n_blocks = n_blocks;
+  a.rescale_threshold = rescale_threshold;
+  return csn_launch_attn_fwd_f32(a, d_head, (hipStream_t)stream);
+}
+
+int csn_block_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* q,
+                           const float* k, const float* v, long long q_shape_stride, long long kv_shape_stride,
+                           const int* q_index, const int* kv_index, int ld, float* scores, float* dscores,
+                           const float* lse, float* delta, float* dq, float* dk, float* dv,
+                           long long grad_eval_stride, int n_evals, int n_heads, int d_head, int block,
+                           int n_blocks, int score_pitch, void* stream) {
+  if (!dctx || !ctx || !q || !k || !v || !scores || !dscores || !lse || !delta || !dq || !dk || !dv) return CSN_E_ARG;
+  if (n_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
+  if (!dim_ok(d_head)) return CSN_E_DIM;
+  if ((ld & 3) || (block & 3) || (score_pitch & 3) || score_pitch < block) return CSN_E_ALIGN;
+  if (mis16(dctx) || mis16(q) || mis16(k) || mis16(v) || mis16(scores) || mis16(dscores) || mis16(dq) || mis16(dk) ||
+      mis16(dv))
+    return CSN_E_PTR;
+  if ((q_shape_stride & 3) || (kv_shape_stride & 3) || (ctx_eval_stride & 3) || (grad_eval_stride & 3)) return CSN_E_STRIDE;
+  hipStream_t st = (hipStream_t)stream;
+  const int n_points = n_blocks * block;
+  const int D = n_heads * d_head;
+  // delta[e][h][n] = sum_c dctx * ctx   (softmax backward row constant)
+  int rc = csn_launch_rowdot_f32(dctx, ctx, delta, n_evals, n_heads, d_head, ld, n_points, ctx_eval_stride, st);
+  if (rc) return rc;
+  // dP -> dS, P (in place of S), dQs
+  CsnAttnArgs a;
+  a.q = dctx; a.k = k; a.v = v;
+  a.q_shape_stride = ctx_eval_stride; a.kv_shape_stride = kv_shape_stride;
+  a.q_index = nullptr; a.kv_index = kv_index; a.ld = ld;
+  a.out = dq; a.out_eval_stride = grad_eval_stride;
+  a.scores = scores; a.dscores = dscores; a.lse = const_cast<float*>(lse); a.delta = delta;
+  a.E = n_evals; a.H = n_heads; a.T = block; a.Tp = score_pitch; a.n_blocks = n_blocks;
+  a.rescale_threshold = 0.f;
+  rc = csn_launch_attn_bwd_f32(a, d_head, st);
+  if (rc) return rc;
+  // dV^T[c][key] = sum_q dO^T[c][q] P^T[key][q]   and   dK^T[d][key] = sum_q Qs^T[d][q] dS^T[key][q]
+  const long long blk_sc = (long long)block * score_pitch;
+  CsnGemmArgs g;
+  g.M = d_head; g.N = block; g.K = block;
+  g.n0 = n_blocks; g.n1 = n_heads; g.k_chunk = 0;
+  g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = 0;
+  g.A = operand(dctx, block, (long long)d_head * ld, ctx_eval_stride, nullptr, ld);
+  g.B = operand(scores, blk_sc, blk_sc * n_blocks, blk_sc * n_blocks * n_heads, nullptr, score_pitch);
+  g.C = operand(dv, block, (long long)d_head * ld, grad_eval_stride, nullptr, ld);
+  rc = csn_launch_gemm_f32(g, 1, n_blocks * n_heads * n_evals, st);
+  if (rc) return rc;
+  g.A = operand(q, block, (long long)d_head * ld, q_shape_stride, q_index, ld);
+  g.B = operand(dscores, blk_sc, blk_sc * n_blocks, blk_sc * n_blocks * n_heads, nullptr, score_pitch);
+  g.C = operand(dk, block, (long long)d_head * ld, grad_eval_stride, nullptr, ld);
+  (void)D;
+  return csn_launch_gemm_f32(g, 1, n_blocks * n_heads * n_evals, st);
+}
+
+int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const float* wfc, const float* xres,
+                           long long xres_shape_stride, const int* res_index, float* xhat,
+                           long long xhat_eval_stride, float* rstd, int n_evals, int d_model, int d_inner, int ld,
+                           int n_points, float eps, void* stream) {
+  if (!ctx || !wfc || !xres || !xhat || !rstd || n_evals <= 0 || n_points <= 0 || d_inner <= 0) return CSN_E_ARG;
+  if (!dim_ok(d_model)) return CSN_E_DIM;
+  if ((ld & 3) || (d_inner & 3) || (n_points & 3)) return CSN_E_ALIGN;
+  if (mis16(ctx) || mis16(wfc) || mis16(xres) || mis16(xhat)) return CSN_E_PTR;
+  if ((ctx_eval_stride & 3) || (xres_shape_stride & 3) || (xhat_eval_stride & 3)) return CSN_E_STRIDE;
+  CsnOutProjArgs a;
+  a.ctx = ctx; a.ctx_eval_stride = ctx_eval_stride; a.wfc = wfc;
+  a.xres = xres; a.xres_shape_stride = xres_shape_stride; a.res_index = res_index;
+  a.xhat = xhat; a.xhat_eval_stride = xhat_eval_stride; a.rstd = rstd;
+  a.E = n_evals; a.C = d_model; a.D = d_inner; a.ld = ld; a.n_points = n_points; a.eps = eps;
+  return csn_launch_outproj_ln_fwd_f32(a, (hipStream_t)stream);
+}
+
+int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* rstd, long long eval_stride,
+                           const float* ctx, long long ctx_eval_stride, const float* wfc_t, float* dz, float* dctx,
+                           float* dwfc, float* ws, long long ws_floats, int n_evals, int d_model, int d_inner,
+                           int ld, int n_points, int accumulate, void* stream) {
+  if (!dxhat || !xhat || !rstd || !ctx || !wfc_t || !dz || !dctx || !dwfc || !ws) return CSN_E_ARG;
+  if (n_evals <= 0 || n_points <= 0 || d_inner <= 0 || d_model <= 0) return CSN_E_ARG;
+  if ((ld & 3) || (d_inner & 3) || (d_model & 3) || (n_points & 3)) return CSN_E_ALIGN;
+  if (mis16(dxhat) || mis16(xhat) || mis16(ctx) || mis16(wfc_t) || mis16(dz) || mis16(dctx) || mis16(dwfc) || mis16(ws))
+    return CSN_E_PTR;
+  if ((eval_stride & 3) || (ctx_eval_stride & 3)) return CSN_E_STRIDE;
+  hipStream_t st = (hipStream_t)stream;
+  CsnLnBwdArgs l;
+  l.dxhat = dxhat; l.xhat = xhat; l.rstd = rstd; l.dz = dz; l.eval_stride = eval_stride;
+  l.E = n_evals; l.C = d_model; l.ld = ld; l.n_points = n_points;
+  int rc = csn_launch_ln_bwd_f32(l, st);
+  if (rc) return rc;
+  // dctx[e][D][n] = wfc_t[D][c] dz[e][c][n]
+  CsnGemmArgs g;
+  g.A = operand(wfc_t, 0, 0, 0, nullptr, d_model);
+  g.B = operand(dz, 0, 0, eval_stride, nullptr, ld);
+  g.C = operand(dctx, 0, 0, ctx_eval_stride, nullptr, ld);
+  g.M = d_inner; g.N = n_points; g.K = d_model;
+  g.n0 = 1; g.n1 = 1; g.k_chunk = 0;
+  g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = 0;
+  rc = csn_launch_gemm_f32(g, 0, n_evals, st);
+  if (rc) return rc;
+  // dwfc[c][D] (+)= sum_{e,n} dz[e][c][n] ctx[e][D][n]
+  return wgrad(dz, eval_stride, ld, ctx, ctx_eval_stride, ld, dwfc, d_model, d_inner, n_evals, n_points, 1.f,
+               accumulate, ws, ws_floats, st);
+}
+
+int csn_project_wgrad_f32(const float* dout, long long dout_shape_stride, int ld_dout, const float* x,
+                          long long x_shape_stride, int ld_x, float* dw, int rows, int channels, int n_shapes,
+                          int n_points, float scale, int accumulate, float* ws, long long ws_floats,
+                          void* stream) {
+  if (!dout || !x || !dw || !ws || rows <= 0 || channels <= 0 || n_shapes <= 0 || n_points <= 0) return CSN_E_ARG;
+  if ((ld_dout & 3) || (ld_x & 3) || (n_points & 3)) return CSN_E_ALIGN;
+  if (mis16(dout) || mis16(x) || mis16(dw) || mis16(ws)) return CSN_E_PTR;
+  if ((dout_shape_stride & 3) || (x_shape_stride & 3)) return CSN_E_STRIDE;
+  return wgrad(dout, dout_shape_stride, ld_dout, x, x_shape_stride, ld_x, dw, rows, channels, n_shapes, n_points, scale,
+               accumulate, ws, ws_floats, (hipStream_t)stream);
+}
+
+int csn_retrieval_measure_f32(const float* f1, const float* f2, float* out, int s1, int n1, int s2, int n2,
+                              int channels, float* ws, long long ws_floats, void* stream) {
+  if (!f1 || !f2 || !out || !ws || s1 <= 0 || s2 <= 0 || n1 <= 0 || n2 <= 0 || channels <= 0) return CSN_E_ARG;
+  if (channels & 3) return CSN_E_ALIGN;
+  if (mis16(f1) || mis16(f2) || mis16(ws)) return CSN_E_PTR;
+  const long long need = (long long)s1 * n1 + (long long)s2 * n2 + (long long)s1 * s2 * n1;
+  if (ws_floats < need) return CSN_E_WORKSPACE;
+  return csn_launch_retrieval_f32(f1, f2, out, s1, n1, s2, n2, channels, ws, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+// Shared device-side helpers for the CSN cross-shape-attention kernels (gfx950 / CDNA4 only).
+//
+// Conventions used by every kernel in this directory
+//   * All activations are CHANNEL-MAJOR: a tensor of per-point features is stored [channel][point]
+//     exactly like the reference's (B, C, N, 1) input (MID-FC/csa_models.py:88-94 gathers along N).
+//     Lanes always run along the point index, so every global access is a 128-byte row segment.
+//   * Matrix products use the exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32
+//     (D = A(32x2) * B(2x32) + C, fp32 in, fp32 accumulate, bit-identical to an fmaf chain).
+//       A operand : lane l holds A[i = l & 31][k = l >> 5]
+//       B operand : lane l holds B[k = l >> 5][j = l & 31]
+//       C/D       : reg r of lane l is C[i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][j = l & 31]
+//   * The contraction index inside an 8-wide k group is visited in the order k = 4*h + t
+//     (h = lane >> 5, t = 0..3) whenever an operand is fetched from LDS with one 16-byte read per
+//     lane; both operands use the same order, so the sum is simply re-associated.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define CSN_DEVINL __device__ __forceinline__
+
+CSN_DEVINL f32x16 csn_mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// row index inside a 32x32 accumulator tile held by (reg r, lane half h)
+CSN_DEVINL int csn_acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---- buffer (SRD) addressing ---------------------------------------------------------------------
+// Every global access of the hot kernels goes through a wave-uniform buffer descriptor plus a 32-bit
+// per-lane byte offset: out-of-window lanes are dropped by the hardware range check (loads return 0,
+// stores vanish), so ragged tiles need no branches and no 64-bit per-lane address arithmetic.
+// A lane is switched off by giving it CSN_OOB as its offset.  Windows are kept below 2 GiB.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t csn_rsrc_t;
+#define CSN_OOB 0x80000000u
+
+CSN_DEVINL csn_rsrc_t csn_make_rsrc(const void* base, long long bytes) {
+  const unsigned nb = bytes > 0x7fffffffLL ? 0x7fffffffu : (bytes < 0 ? 0u : (unsigned)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, nb, 0x00020000);
+}
+CSN_DEVINL float csn_bload(csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+CSN_DEVINL f32x4 csn_bload4(csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+CSN_DEVINL void csn_bstore(float v, csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
+// Guarded 16-byte load of 4 consecutive floats row[c..c+3]; elements at index >= clim read as 0.
+// row + c must be 16-byte aligned when c + 3 < clim (hosts check ld % 4 == 0 and offsets % 4 == 0).
+CSN_DEVINL f32x4 csn_ldg4(const float* __restrict__ row, int c, int clim, bool row_ok) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (row_ok) {
+    if (c + 3 < clim) {
+      v = *reinterpret_cast<const f32x4*>(row + c);
+    } else {
+      if (c < clim) v.x = row[c];
+      if (c + 1 < clim) v.y = row[c + 1];
+      if (c + 2 < clim) v.z = row[c + 2];
+    }
+  }
+  return v;
+}
+
+// Three-level batched operand: element offset = s0*z0 + s1*z1 + s2*(idx2 ? idx2[z2] : z2)
+struct CsnOperand {
+  float* ptr;
+  long long s0, s1, s2;
+  const int* idx2;
+  int ld;
+};
+
+CSN_DEVINL float* csn_operand_base(const CsnOperand& o, int z0, int z1, int z2) {
+  long long i2 = o.idx2 ? (long long)o.idx2[z2] : (long long)z2;
+  return o.ptr + o.s0 * z0 + o.s1 * z1 + o.s2 * i2;
+}
+
+// sum / max across the two 32-lane halves of a wave (lane l <-> lane l ^ 32)
+CSN_DEVINL float csn_xhalf(float v) { return __shfl_xor(v, 32, 64); }

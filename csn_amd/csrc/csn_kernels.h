@@ -1,0 +1,61 @@
+// Internal launch interface between the kernel translation units and the C-ABI (csn_capi.hip).
+#pragma once
+#include "csn_common.h"
+
+struct CsnGemmArgs {
+  CsnOperand A, B, C;
+  int M, N, K;
+  int n0, n1;        // blockIdx.z = (z2 * n1 + z1) * n0 + z0
+  int k_chunk;       // > 0: this z0 contracts only k in [0, min(k_chunk, K - z0*k_chunk)); the operand
+                     //      strides s0 carry the matching offsets (split-K over the point index)
+  float alpha;
+  int div_rows;      // output rows m < div_rows are divided by div_val (query scaling, csa_models.py:139)
+  float div_val;
+  int accumulate;    // C += result
+};
+
+int csn_launch_gemm_f32(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st);
+int csn_launch_slab_reduce(const float* slab, float* out, int n_slabs, long long n, float alpha, int accumulate,
+                           hipStream_t st);
+
+// ---- fused block attention (attn_f32.hip) -----------------------------------------------------
+struct CsnAttnArgs {
+  // channel-major projected features, one slab of [H*d][ld] per shape
+  const float* q;  const float* k;  const float* v;     // forward: Qs^T, K^T, V^T ; backward: dO^T(=dCtx^T), V^T, K^T
+  long long q_shape_stride, kv_shape_stride;             // elements between consecutive shapes
+  const int* q_index; const int* kv_index;               // evaluation e -> shape slot (nullptr: identity)
+  int ld;                                                // points per row (leading dimension)
+  float* out;        long long out_eval_stride;          // forward: Ctx^T[e][H*d][ld] ; backward: dQs^T[e][H*d][ld]
+  float* scores;                                         // S^T / P^T  [e][h][blk][T][Tp]   (may be null in forward)
+  float* dscores;                                        // backward: dS^T, same geometry
+  float* lse;                                            // [e][h][n_blocks*T]
+  const float* delta;                                    // backward: rowsum(dO*O) [e][h][n_blocks*T]
+  int E, H, T, Tp, n_blocks;
+  float rescale_threshold;
+};
+int csn_launch_attn_fwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
+int csn_launch_attn_bwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
+
+// ---- output projection + residual + LayerNorm (outproj_ln.hip) --------------------------------
+struct CsnOutProjArgs {
+  const float* ctx;   long long ctx_eval_stride;         // Ctx^T[e][D][ld]
+  const float* wfc;                                      // [C][D] row-major (csa_models.py:52)
+  const float* xres;  long long xres_shape_stride; const int* res_index;   // residual x[shape][C][ld] (:99,:116)
+  float* xhat;        long long xhat_eval_stride;        // normalised output [e][C][ld]
+  float* rstd;                                           // [e][n_points]
+  int E, C, D, ld, n_points;
+  float eps;
+};
+int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, hipStream_t st);
+
+struct CsnLnBwdArgs {
+  const float* dxhat; const float* xhat; const float* rstd;   // [e][C][ld], [e][C][ld], [e][n_points]
+  float* dz;                                                   // [e][C][ld]
+  long long eval_stride;
+  int E, C, ld, n_points;
+};
+int csn_launch_ln_bwd_f32(const CsnLnBwdArgs& a, hipStream_t st);
+
+// delta[e][h][n] = sum_{c in head h} a[e][c][n] * b[e][c][n]
+int csn_launch_rowdot_f32(const float* a, const float* b, float* out, int E, int H, int d, int ld, int n_points,
+                          long long eval_stride, hipStream_t st);

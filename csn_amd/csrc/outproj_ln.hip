@@ -1,0 +1,198 @@
+// Output projection + residual + LayerNorm of the CSA multi-head attention, and its backward helpers.
+//
+// Reference arithmetic (MID-FC/csa_models.py:114-118):   q = LayerNorm(fc(ctx) + residual), eps = 1e-6,
+// where the residual is the *un-projected* query input (csa_models.py:99).  The affine part of the
+// LayerNorm (gamma, beta) is applied by the caller; this kernel emits the normalised activations
+// xhat and the reciprocal standard deviation, which is exactly what the backward pass needs.
+//
+// Orientation: Z^T[c][n] = sum_D W_fc[c][D] * Ctx^T[D][n].  The point index n sits on the lanes and
+// ALL channels of a point sit in the registers of one lane pair, so the LayerNorm statistics are an
+// in-register reduction (+ one exchange between the two 32-lane halves), the residual x[c][n] is
+// read in its native channels-first layout with 128-byte row segments, and xhat is written the same way.
+#include "csn_common.h"
+#include "csn_kernels.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;
+constexpr int BN = 128;          // points per work-group (32 per wave)
+
+template <int CT>
+__global__ __launch_bounds__(256, 2) void csn_outproj_ln_fwd_kernel(CsnOutProjArgs p) {
+  constexpr int C = 32 * CT;
+  __shared__ __attribute__((aligned(16))) float As[C * LDK];     // W_fc[c][k0..k0+31]
+  __shared__ __attribute__((aligned(16))) float Bs[BK * BN];     // Ctx^T[k0..k0+31][n0..n0+127]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int e = blockIdx.y, n0 = blockIdx.x * BN;
+  const int D = p.D, ld = p.ld, NP = p.n_points;
+  const long long rs = p.res_index ? p.res_index[e] : e;
+
+  const csn_rsrc_t Wr = csn_make_rsrc(p.wfc, (long long)C * D * 4);
+  const csn_rsrc_t Xr = csn_make_rsrc(p.ctx + (long long)e * p.ctx_eval_stride + n0, ((long long)(D - 1) * ld + (NP - n0)) * 4);
+  const csn_rsrc_t Rr = csn_make_rsrc(p.xres + rs * p.xres_shape_stride + n0, ((long long)(C - 1) * ld + (NP - n0)) * 4);
+  const csn_rsrc_t Hr = csn_make_rsrc(p.xhat + (long long)e * p.xhat_eval_stride + n0, ((long long)(C - 1) * ld + (NP - n0)) * 4);
+
+  f32x16 acc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  const int pr = tid >> 3, pc = (tid & 7) * 4;        // W slab piece: row pr + 32 i, k piece pc
+  const int kr = tid >> 5, kc = (tid & 31) * 4;       // Ctx slab piece: k row kr + 8 i, points kc..kc+3
+  unsigned a_off[CT], b_off[4];
+#pragma unroll
+  for (int i = 0; i < CT; ++i) a_off[i] = (unsigned)((pr + 32 * i) * D + pc) * 4u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b_off[i] = (n0 + kc) < NP ? (unsigned)((kr + 8 * i) * ld + kc) * 4u : CSN_OOB;
+
+  f32x4 ra[CT], rb[4];
+  auto load_slab = [&](int k0) {
+    const unsigned kp = (k0 + pc) < D ? 0u : CSN_OOB;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) ra[i] = csn_bload4(Wr, a_off[i] | kp, (unsigned)k0 * 4u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned kq = (k0 + kr + 8 * i) < D ? 0u : CSN_OOB;
+      rb[i] = csn_bload4(Xr, b_off[i] | kq, (unsigned)k0 * (unsigned)ld * 4u);
+    }
+  };
+  auto store_slab = [&]() {
+#pragma unroll
+    for (int i = 0; i < CT; ++i) *reinterpret_cast<f32x4*>(&As[(pr + 32 * i) * LDK + pc]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&Bs[(kr + 8 * i) * BN + kc]) = rb[i];
+  };
+
+  const int nk = (D + BK - 1) / BK;
+  load_slab(0);
+  store_slab();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_slab((kt + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 8) {
+      float bf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bf[t] = Bs[(kk + 4 * h + t) * BN + 32 * wave + l31];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const f32x4 af = *reinterpret_cast<const f32x4*>(&As[(c * 32 + l31) * LDK + kk + 4 * h]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[c] = csn_mfma(af[t], bf[t], acc[c]);
+      }
+    }
+    __syncthreads();
+    if (kt + 1 < nk) { store_slab(); __syncthreads(); }
+  }
+
+  // ---- + residual, LayerNorm over the C channels of each point (csa_models.py:116-118) -----------
+  const int nl = 32 * wave + l31;
+  const bool n_ok = (n0 + nl) < NP;
+  const unsigned n_off = n_ok ? (unsigned)(4 * h * ld + nl) * 4u : CSN_OOB;
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[c][r] += csn_bload(Rr, n_off, (unsigned)(c * 32 + csn_acc_row(r, 0)) * (unsigned)ld * 4u);
+      sum += acc[c][r];
+    }
+  sum += csn_xhalf(sum);
+  const float mean = sum * (1.f / C);
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float dlt = acc[c][r] - mean;
+      sq += dlt * dlt;
+    }
+  sq += csn_xhalf(sq);
+  const float rstd = 1.f / sqrtf(sq * (1.f / C) + p.eps);
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      csn_bstore((acc[c][r] - mean) * rstd, Hr, n_off, (unsigned)(c * 32 + csn_acc_row(r, 0)) * (unsigned)ld * 4u);
+  if (n_ok && h == 0) p.rstd[(long long)e * NP + n0 + nl] = rstd;
+}
+
+// LayerNorm backward without the affine part:  dz = rstd * (dx - mean_c(dx) - xhat * mean_c(dx * xhat)).
+// One thread per point, lanes along n: both sweeps over the channels are 256-byte coalesced rows.
+__global__ __launch_bounds__(256) void csn_ln_bwd_kernel(CsnLnBwdArgs p) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.y;
+  if (n >= p.n_points) return;
+  const float* __restrict__ dx = p.dxhat + (long long)e * p.eval_stride + n;
+  const float* __restrict__ xh = p.xhat + (long long)e * p.eval_stride + n;
+  float* __restrict__ dz = p.dz + (long long)e * p.eval_stride + n;
+  const int C = p.C;
+  const long long ld = p.ld;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float g = dx[c * ld], x = xh[c * ld];
+    s1 += g;
+    s2 += g * x;
+  }
+  const float rstd = p.rstd[(long long)e * p.n_points + n];
+  const float m1 = s1 / C, m2 = s2 / C;
+  for (int c = 0; c < C; ++c) {
+    const float g = dx[c * ld], x = xh[c * ld];
+    dz[c * ld] = rstd * (g - m1 - x * m2);
+  }
+}
+
+// out[e][h][n] = sum_{c < d} a[e][h*d + c][n] * b[e][h*d + c][n]    (delta = rowsum(dO * O) of the softmax backward)
+__global__ __launch_bounds__(256) void csn_rowdot_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ out, int H, int d, int ld, int n_points,
+                                                         long long eval_stride) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  const int hd = blockIdx.y % H, e = blockIdx.y / H;
+  if (n >= n_points) return;
+  const long long base = (long long)e * eval_stride + (long long)hd * d * ld + n;
+  float s = 0.f;
+  for (int c = 0; c < d; ++c) s += a[base + (long long)c * ld] * b[base + (long long)c * ld];
+  out[((long long)e * H + hd) * n_points + n] = s;
+}
+
+template <int CT>
+int launch_fwd(const CsnOutProjArgs& a, hipStream_t st) {
+  dim3 grid((a.n_points + BN - 1) / BN, a.E);
+  hipLaunchKernelGGL((csn_outproj_ln_fwd_kernel<CT>), grid, dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, hipStream_t st) {
+  if (a.E <= 0 || a.n_points <= 0) return 0;
+  if ((a.ld & 3) || (a.D & 3) || (a.n_points & 3)) return -2;
+  if ((a.ctx_eval_stride & 3) || (a.xres_shape_stride & 3) || (a.xhat_eval_stride & 3)) return -4;
+  switch (a.C) {
+    case 32: return launch_fwd<1>(a, st);
+    case 64: return launch_fwd<2>(a, st);
+    case 96: return launch_fwd<3>(a, st);
+    case 128: return launch_fwd<4>(a, st);
+    case 256: return launch_fwd<8>(a, st);
+    default: return -5;
+  }
+}
+
+int csn_launch_ln_bwd_f32(const CsnLnBwdArgs& a, hipStream_t st) {
+  if (a.E <= 0 || a.n_points <= 0) return 0;
+  dim3 grid((a.n_points + 255) / 256, a.E);
+  hipLaunchKernelGGL(csn_ln_bwd_kernel, grid, dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+int csn_launch_rowdot_f32(const float* a, const float* b, float* out, int E, int H, int d, int ld, int n_points,
+                          long long eval_stride, hipStream_t st) {
+  if (E <= 0 || n_points <= 0) return 0;
+  dim3 grid((n_points + 255) / 256, E * H);
+  hipLaunchKernelGGL(csn_rowdot_kernel, grid, dim3(256), 0, st, a, b, out, H, d, ld, n_points, eval_stride);
+  return (int)hipGetLastError();
+}

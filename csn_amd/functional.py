@@ -1,0 +1,221 @@
+"""Autograd wrappers over the C ABI (include/csn_hip.h) for the cross-shape-attention hot path.
+
+torch is plumbing here: it owns device memory, the stream and the autograd tape.  All arithmetic of
+the attention path runs in libcsn_hip.so; there is no eager fallback (missing library / CPU tensors
+raise).
+
+Vocabulary: a *slot* is one shape's channel-major feature map ``[C][N]``; an *evaluation* is one
+``MultiHeadAttention.forward(x_q, x_kv, x_kv)`` of the reference (MID-FC/csa_models.py:81-125), given
+as a (query slot, key/value slot) pair.  One CSA forward of a query shape with K neighbours is 2K+1
+evaluations over K+1 slots (csa_models.py:209-242); each slot is projected to Q/K/V exactly once.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+REF_BLOCK = 500       # MID-FC/csa_models.py:84
+REF_NBLOCKS = 20      # MID-FC/csa_models.py:83
+LN_EPS = 1e-6         # MID-FC/csa_models.py:57
+RESCALE_THRESHOLD = 8.0
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.CsnError("csn_amd ops need tensors on the MI355X (cuda) device; there is no CPU path")
+        if t is not None and t.dtype != torch.float32 and t.dtype != torch.int32:
+            raise _lib.CsnError(f"csn_amd ops are fp32 (got {t.dtype})")
+
+
+@dataclass(frozen=True)
+class MHAGeometry:
+    n_head: int
+    d_head: int            # d_k == d_v (csa_models.py:147 fixes both to 256)
+    block: int             # points per attention block (csa_models.py:84)
+    n_blocks: int          # csa_models.py:83
+
+    @property
+    def n_points(self) -> int:
+        return self.block * self.n_blocks
+
+    @property
+    def d_inner(self) -> int:
+        return self.n_head * self.d_head
+
+    @property
+    def score_pitch(self) -> int:
+        return (self.block + 31) // 32 * 32
+
+
+# ------------------------------------------------------------------------------------------------------
+# raw (non-differentiable) calls — thin, typed views of the C ABI
+# ------------------------------------------------------------------------------------------------------
+def project(x: torch.Tensor, w: torch.Tensor, div_rows: int = 0, temperature: float = 1.0,
+            n_points: Optional[int] = None) -> torch.Tensor:
+    """x (S, C, N), w (R, C)  ->  (S, R, n_points) = w @ x[s]; rows < div_rows divided by temperature."""
+    _need_cuda(x, w)
+    S, C, N = x.shape
+    R = w.shape[0]
+    npts = N if n_points is None else n_points
+    assert x.stride(2) == 1 and x.stride(1) == N and w.is_contiguous()
+    out = torch.empty((S, R, npts), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().csn_project_f32(_ptr(x), x.stride(0), N, _ptr(w), R, C, _ptr(out), R * npts, npts, S, npts,
+                                          div_rows, float(temperature), _stream()), "csn_project_f32")
+    return out
+
+
+def project_wgrad(dout: torch.Tensor, x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """dout (S, R, NP), x (S, C, N>=NP) -> dw (R, C) = scale * sum_s dout[s] @ x[s][:, :NP]^T."""
+    _need_cuda(dout, x)
+    S, R, NP = dout.shape
+    C, N = x.shape[1], x.shape[2]
+    assert dout.is_contiguous() and x.stride(2) == 1 and x.stride(1) == N
+    dw = torch.empty((R, C), device=x.device, dtype=torch.float32)
+    ws_n = _lib.lib().csn_wgrad_workspace_floats(R, C, S, NP)
+    ws = torch.empty((ws_n,), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().csn_project_wgrad_f32(_ptr(dout), R * NP, NP, _ptr(x), x.stride(0), N, _ptr(dw), R, C, S, NP,
+                                                float(scale), 0, _ptr(ws), ws_n, _stream()), "csn_project_wgrad_f32")
+    return dw
+
+
+def retrieval_measure(f1: torch.Tensor, f2: torch.Tensor) -> torch.Tensor:
+    """f1 (S1, N1, C), f2 (S2, N2, C) point-major SSA features -> (S1, S2) mean-of-max cosine
+    (get_retrieval_measure, MID-FC/csa_models.py:244-267)."""
+    _need_cuda(f1, f2)
+    f1 = f1.contiguous()
+    f2 = f2.contiguous()
+    S1, N1, C = f1.shape
+    S2, N2, _ = f2.shape
+    out = torch.empty((S1, S2), device=f1.device, dtype=torch.float32)
+    ws_n = S1 * N1 + S2 * N2 + S1 * S2 * N1
+    ws = torch.empty((ws_n,), device=f1.device, dtype=torch.float32)
+    _lib.check(_lib.lib().csn_retrieval_measure_f32(_ptr(f1), _ptr(f2), _ptr(out), S1, N1, S2, N2, C, _ptr(ws), ws_n,
+                                                    _stream()), "csn_retrieval_measure_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------
+# the differentiable unit: a batch of MHA evaluations over shared, once-projected slots
+# ------------------------------------------------------------------------------------------------------
+class _MHAEvals(torch.autograd.Function):
+    """xhat[e] = LayerNorm_noaffine( fc( BlockAttn(Wq x[q_e] / sqrt(d), Wk x[kv_e], Wv x[kv_e]) ) + x[q_e] ).
+
+    Inputs : x_all (S, C, NP) channel-major slots, w_qs/w_ks/w_vs (H*d, C), fc (C, H*d),
+             q_slots / kv_slots int32 (E,) on the device.
+    Output : xhat (E, C, NP).  The LayerNorm affine is applied by the caller (it is plain elementwise torch,
+             and the backward needs the un-affined activations anyway).
+    """
+
+    @staticmethod
+    def forward(ctx, x_all, w_qs, w_ks, w_vs, w_fc, q_slots, kv_slots, geo: MHAGeometry, keep_scores: bool):
+        _need_cuda(x_all, w_qs, w_ks, w_vs, w_fc, q_slots, kv_slots)
+        L = _lib.lib()
+        S, C, NP = x_all.shape
+        H, d, D = geo.n_head, geo.d_head, geo.d_inner
+        assert NP == geo.n_points and x_all.is_contiguous()
+        E = q_slots.numel()
+        T, nb, Tp = geo.block, geo.n_blocks, geo.score_pitch
+        dev = x_all.device
+        temperature = float(d) ** 0.5                                  # csa_models.py:54
+        w_qkv = torch.cat((w_qs, w_ks, w_vs), dim=0).contiguous()      # (3D, C)
+        qkv = project(x_all, w_qkv, div_rows=D, temperature=temperature)   # (S, 3D, NP); Q rows pre-scaled
+        att = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
+        lse = torch.empty((E, H, NP), device=dev, dtype=torch.float32)
+        scores = torch.empty((E, H, nb, T, Tp), device=dev, dtype=torch.float32) if keep_scores else None
+        slot_stride = 3 * D * NP
+        base = qkv.data_ptr()
+        _lib.check(L.csn_block_attn_fwd_f32(base, base + 4 * D * NP, base + 8 * D * NP, slot_stride, slot_stride,
+                                            _ptr(q_slots), _ptr(kv_slots), NP, _ptr(att), D * NP, _ptr(scores),
+                                            _ptr(lse), E, H, d, T, nb, Tp, RESCALE_THRESHOLD, _stream()),
+                   "csn_block_attn_fwd_f32")
+        xhat = torch.empty((E, C, NP), device=dev, dtype=torch.float32)
+        rstd = torch.empty((E, NP), device=dev, dtype=torch.float32)
+        w_fc = w_fc.contiguous()
+        _lib.check(L.csn_outproj_ln_fwd_f32(_ptr(att), D * NP, _ptr(w_fc), _ptr(x_all), C * NP, _ptr(q_slots),
+                                            _ptr(xhat), C * NP, _ptr(rstd), E, C, D, NP, NP, LN_EPS, _stream()),
+                   "csn_outproj_ln_fwd_f32")
+        if keep_scores:
+            ctx.save_for_backward(x_all, w_qkv, w_fc, q_slots, kv_slots, qkv, att, lse, scores, xhat, rstd)
+            ctx.geo = geo
+        return xhat
+
+    @staticmethod
+    def backward(ctx, dxhat):
+        x_all, w_qkv, w_fc, q_slots, kv_slots, qkv, att, lse, scores, xhat, rstd = ctx.saved_tensors
+        geo: MHAGeometry = ctx.geo
+        L = _lib.lib()
+        S, C, NP = x_all.shape
+        H, d, D = geo.n_head, geo.d_head, geo.d_inner
+        E = q_slots.numel()
+        T, nb, Tp = geo.block, geo.n_blocks, geo.score_pitch
+        dev = x_all.device
+        dxhat = dxhat.contiguous()
+        temperature = float(d) ** 0.5
+
+        # ---- LayerNorm + fc backward -------------------------------------------------------------------
+        dz = torch.empty((E, C, NP), device=dev, dtype=torch.float32)
+        datt = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
+        dw_fc = torch.empty((C, D), device=dev, dtype=torch.float32)
+        ws_n = L.csn_wgrad_workspace_floats(C, D, E, NP)
+        ws = torch.empty((ws_n,), device=dev, dtype=torch.float32)
+        w_fc_t = w_fc.t().contiguous()
+        _lib.check(L.csn_outproj_ln_bwd_f32(_ptr(dxhat), _ptr(xhat), _ptr(rstd), C * NP, _ptr(att), D * NP,
+                                            _ptr(w_fc_t), _ptr(dz), _ptr(datt), _ptr(dw_fc), _ptr(ws), ws_n, E, C, D,
+                                            NP, NP, 0, _stream()), "csn_outproj_ln_bwd_f32")
+        del ws
+
+        # ---- attention backward ----------------------------------------------------------------------------
+        dscores = torch.empty_like(scores)
+        delta = torch.empty((E, H, NP), device=dev, dtype=torch.float32)
+        dq = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
+        dk = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
+        dv = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
+        slot_stride = 3 * D * NP
+        base = qkv.data_ptr()
+        _lib.check(L.csn_block_attn_bwd_f32(_ptr(datt), _ptr(att), D * NP, base, base + 4 * D * NP, base + 8 * D * NP,
+                                            slot_stride, slot_stride, _ptr(q_slots), _ptr(kv_slots), NP, _ptr(scores),
+                                            _ptr(dscores), _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk), _ptr(dv),
+                                            D * NP, E, H, d, T, nb, Tp, _stream()), "csn_block_attn_bwd_f32")
+        del dscores, delta, datt
+
+        # ---- evaluations that share a slot add up (Q of the query shape, K/V of each neighbour) -------------
+        dqkv = torch.zeros((S, 3, D * NP), device=dev, dtype=torch.float32)
+        qi, ki = q_slots.long(), kv_slots.long()
+        dqkv[:, 0].index_add_(0, qi, dq.view(E, D * NP))
+        dqkv[:, 1].index_add_(0, ki, dk.view(E, D * NP))
+        dqkv[:, 2].index_add_(0, ki, dv.view(E, D * NP))
+        del dq, dk, dv
+        dqkv = dqkv.view(S, 3 * D, NP)
+
+        # ---- projection weight gradients ------------------------------------------------------------------
+        dw_qkv = project_wgrad(dqkv, x_all)
+        dw_q = dw_qkv[:D] / temperature               # Qs = (x Wq^T) / sqrt(d)  (csa_models.py:139)
+        dw_k, dw_v = dw_qkv[D:2 * D], dw_qkv[2 * D:]
+
+        dx_all = None
+        if ctx.needs_input_grad[0]:
+            # residual path + the three projections (not needed by the reference's training: inputs are constants)
+            dqkv[:, :D] /= temperature
+            dx_all = project(dqkv, w_qkv.t().contiguous())
+            dx_all.index_add_(0, qi, dz)
+        return dx_all, dw_q, dw_k, dw_v, dw_fc, None, None, None, None
+
+
+def mha_evals(x_all: torch.Tensor, w_qs: torch.Tensor, w_ks: torch.Tensor, w_vs: torch.Tensor, w_fc: torch.Tensor,
+              q_slots: torch.Tensor, kv_slots: torch.Tensor, geo: MHAGeometry) -> torch.Tensor:
+    keep = torch.is_grad_enabled() and any(t.requires_grad for t in (x_all, w_qs, w_ks, w_vs, w_fc))
+    return _MHAEvals.apply(x_all, w_qs, w_ks, w_vs, w_fc, q_slots, kv_slots, geo, keep)

@@ -1,0 +1,124 @@
+/* csn_hip.h — C ABI of libcsn_hip.so: the MI355X (gfx950) implementation of CSN's cross-shape-attention
+ * hot path.  Plain pointers and sizes only; every pointer is a DEVICE pointer unless stated otherwise;
+ * `stream` is a hipStream_t passed as void*.  All functions return 0 on success, a negative CSN_E_* code
+ * on a rejected argument, or a positive hipError_t from the launch.  Nothing here allocates, synchronises
+ * or touches the host: every entry point only enqueues kernels on `stream` (graph-capture safe).
+ *
+ * The reference (marios2019/CSN) has no native layer at all: its hot path is the PyTorch op sequence in
+ * MID-FC/csa_models.py.  Each entry point below names the reference lines whose arithmetic it replaces;
+ * the Python binding that a maintainer of the reference would add is shown in INTEGRATION.md and lives
+ * in csn_amd/_lib.py.
+ *
+ * DATA LAYOUT.  Every activation is CHANNEL-MAJOR fp32: a per-shape feature map is [channels][points]
+ * with leading dimension `ld` (>= points) — exactly the reference's (B, C, N, 1) input
+ * (MID-FC/features_data_loader.py:45-48, csa_models.py:88-94).  "shape slot" = one 3D shape's feature map;
+ * "evaluation" = one multi-head-attention call MHA(x_q; x_kv) of csa_models.py:81-125 (a CSA forward of
+ * one query shape with K neighbours is 2K+1 distinct evaluations, csa_models.py:209-242).
+ * Points are processed in `n_blocks` consecutive blocks of `block` points; query block i attends to
+ * key/value block i only (csa_models.py:83-90: 20 blocks of 500).
+ * Alignment contract (checked, CSN_E_ALIGN): device pointers 16-byte aligned; ld, block, n_points,
+ * channel counts and all strides multiples of 4 floats; head dim in {32,64,96,128,256};
+ * d_model in {32,64,96,128,256}.
+ */
+#ifndef CSN_HIP_H
+#define CSN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSN_ABI_VERSION 1
+
+#define CSN_E_ARG (-1)     /* null pointer / non-positive size            */
+#define CSN_E_ALIGN (-2)   /* a size or leading dimension is not % 4      */
+#define CSN_E_PTR (-3)     /* pointer not 16-byte aligned                  */
+#define CSN_E_STRIDE (-4)  /* a stride is not % 4                          */
+#define CSN_E_DIM (-5)     /* unsupported head / model dimension           */
+#define CSN_E_WORKSPACE (-6) /* workspace too small                        */
+
+/* ABI version of the loaded library (== CSN_ABI_VERSION). */
+int csn_version(void);
+/* Human-readable text for a status code returned by any function below. Host pointer, static storage. */
+const char* csn_status_string(int status);
+
+/* ---- (1) pre-attention projections ------------------------------------------------------------------
+ * out[s][r][n] = sum_c w[r][c] * x[s][c][n],  r < rows, n < n_points; rows r < div_rows are then divided
+ * by `temperature`.   Replaces w_qs / w_ks / w_vs (nn.Linear, no bias; csa_models.py:49-51,103-105) and the
+ * `q / temperature` of csa_models.py:139 (stack W_q|W_k|W_v along rows and pass div_rows = n_head*d_k to
+ * project a shape once for all of its evaluations). */
+int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const float* w, int rows, int channels,
+                    float* out, long long out_shape_stride, int ld_out, int n_shapes, int n_points, int div_rows,
+                    float temperature, void* stream);
+
+/* ---- (2) block-diagonal scaled-dot-product attention, forward ----------------------------------------
+ * For evaluation e, head h, block b:  P = softmax(Qs K^T) over the block's keys, ctx = P V
+ * (ScaledDotProductAttention.forward, csa_models.py:138-144, eval mode; Qs is already divided by the
+ * temperature by csn_project_f32).  q/k/v point at row 0 of the projected [n_heads*d_head][ld] maps of
+ * slot 0; evaluation e reads slot q_index[e] (queries) and kv_index[e] (keys, values); NULL = identity.
+ *   ctx    [n_evals][n_heads*d_head][ld]   (eval stride given)         — csa_models.py:114 before `fc`
+ *   lse    [n_evals][n_heads][n_blocks*block]   log-sum-exp of every score row (for the backward)
+ *   scores [n_evals][n_heads][n_blocks][block][score_pitch]  raw scores S^T[key][query]; may be NULL
+ *          (inference).  score_pitch >= block, % 4.
+ * rescale_threshold: the running softmax maximum is only re-based when it grows by more than this
+ * (0 = re-base on every key tile); results agree to fp32 rounding for any value <= ~40. */
+int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
+                           long long kv_shape_stride, const int* q_index, const int* kv_index, int ld, float* ctx,
+                           long long ctx_eval_stride, float* scores, float* lse, int n_evals, int n_heads,
+                           int d_head, int block, int n_blocks, int score_pitch, float rescale_threshold,
+                           void* stream);
+
+/* ---- (3) block attention, backward (autograd of csa_models.py:139-142) -------------------------------
+ * In:  dctx (gradient of ctx), ctx, q/k/v as in forward, scores (S^T from forward), lse.
+ * Out: scores is overwritten with P^T, dscores receives dS^T (same geometry), delta is a
+ *      [n_evals][n_heads][n_blocks*block] scratch (rowsum(dctx*ctx)),
+ *      dq/dk/dv [n_evals][n_heads*d_head][ld] per-evaluation gradients w.r.t. Qs, K, V
+ *      (the caller sums evaluations that share a slot). */
+int csn_block_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* q,
+                           const float* k, const float* v, long long q_shape_stride, long long kv_shape_stride,
+                           const int* q_index, const int* kv_index, int ld, float* scores, float* dscores,
+                           const float* lse, float* delta, float* dq, float* dk, float* dv,
+                           long long grad_eval_stride, int n_evals, int n_heads, int d_head, int block,
+                           int n_blocks, int score_pitch, void* stream);
+
+/* ---- (4) output projection + residual + LayerNorm, forward -------------------------------------------
+ * z[c][n] = sum_D wfc[c][D] ctx[e][D][n] + xres[res_index[e]][c][n];  xhat = (z - mean_c z) * rstd,
+ * rstd = 1/sqrt(var_c z + eps).   Replaces fc + residual + LayerNorm (csa_models.py:52,57,114-118) up to the
+ * LayerNorm's affine (gamma, beta), which the caller applies (it is needed un-applied by the backward).
+ *   xhat [n_evals][d_model][ld],  rstd [n_evals][n_points]. */
+int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const float* wfc, const float* xres,
+                           long long xres_shape_stride, const int* res_index, float* xhat,
+                           long long xhat_eval_stride, float* rstd, int n_evals, int d_model, int d_inner, int ld,
+                           int n_points, float eps, void* stream);
+
+/* ---- (5) output projection + LayerNorm, backward -------------------------------------------------------
+ * dz   = LayerNorm-backward(dxhat; xhat, rstd)            [n_evals][d_model][ld]  (also = d residual)
+ * dctx = wfc^T dz                                          [n_evals][d_inner][ld]
+ * dwfc (+)= sum_{e,n} dz[e][:,n] ctx[e][:,n]^T             [d_model][d_inner]
+ * wfc_t is wfc transposed, [d_inner][d_model] row-major.  `ws` is scratch of at least
+ * csn_wgrad_workspace_floats(d_model, d_inner, n_evals, n_points) floats.  accumulate != 0 adds into dwfc. */
+int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* rstd, long long eval_stride,
+                           const float* ctx, long long ctx_eval_stride, const float* wfc_t, float* dz, float* dctx,
+                           float* dwfc, float* ws, long long ws_floats, int n_evals, int d_model, int d_inner,
+                           int ld, int n_points, int accumulate, void* stream);
+
+/* ---- (6) projection weight gradient ----------------------------------------------------------------------
+ * dw[r][c] (+)= scale * sum_{s,n} dout[s][r][n] * x[s][c][n]        (autograd of csa_models.py:103-105) */
+int csn_project_wgrad_f32(const float* dout, long long dout_shape_stride, int ld_dout, const float* x,
+                          long long x_shape_stride, int ld_x, float* dw, int rows, int channels, int n_shapes,
+                          int n_points, float scale, int accumulate, float* ws, long long ws_floats,
+                          void* stream);
+
+/* Scratch floats needed by (5)/(6) for a [rows][cols] gradient reduced over n_maps maps of n_points points. */
+long long csn_wgrad_workspace_floats(int rows, int cols, int n_maps, int n_points);
+
+/* ---- (7) retrieval measure for the shape kNN graph (csa_models.py:244-267) ------------------------------
+ * r[i][j] = mean_n max_m cos(f1[i][n][:], f2[j][m][:]) over L2-normalised rows (eps 1e-12), for
+ * POINT-MAJOR features f1 [s1][n1][channels], f2 [s2][n2][channels] as get_all_feats returns them
+ * (csa_models.py:299).  ws: at least (s1*n1 + s2*n2) floats (inverse row norms) + s1*s2*n1 floats. */
+int csn_retrieval_measure_f32(const float* f1, const float* f2, float* out, int s1, int n1, int s2, int n2,
+                              int channels, float* ws, long long ws_floats, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSN_HIP_H */

@@ -1,0 +1,254 @@
+"""Per-entry-point parity tests of libcsn_hip.so on the MI355X: every C-ABI function against a float64 torch
+restatement of the same arithmetic on the host (tolerances are fp32 rounding, far inside the 1e-4 contract)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from csn_amd import _lib
+    _lib.build()
+    return _lib
+
+
+def _rand(rng, *shape):
+    return torch.from_numpy(rng.standard_normal(size=shape).astype(np.float32))
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _maxerr(got, ref):
+    ref = ref.double()
+    return ((got.detach().cpu().double() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S,C,N,R,div_rows", [(2, 256, 1000, 768, 256), (3, 96, 500, 96, 0), (1, 128, 2048, 384, 128),
+                                              (1, 32, 36, 32, 0)])
+def test_project(L, S, C, N, R, div_rows):
+    from csn_amd import functional as CF
+    rng = np.random.default_rng(1)
+    x, w = _rand(rng, S, C, N), _rand(rng, R, C) / math.sqrt(C)
+    out = CF.project(x.cuda(), w.cuda(), div_rows=div_rows, temperature=16.0)
+    ref = torch.einsum("rc,scn->srn", w.double(), x.double())
+    ref[:, :div_rows] /= 16.0
+    assert _maxerr(out, ref) < 2e-6
+
+
+def test_project_wgrad(L):
+    from csn_amd import functional as CF
+    rng = np.random.default_rng(2)
+    for (S, R, C, N, NP) in [(3, 768, 256, 1000, 1000), (2, 96, 96, 5000, 4800), (1, 256, 128, 260, 260)]:
+        dout, x = _rand(rng, S, R, NP), _rand(rng, S, C, N)
+        dw = CF.project_wgrad(dout.cuda(), x.cuda(), scale=0.5)
+        ref = 0.5 * torch.einsum("srn,scn->rc", dout.double(), x[:, :, :NP].double())
+        assert _maxerr(dw, ref) < 5e-6, (S, R, C, N)
+
+
+# ---------------------------------------------------------------------------------------------------------
+def _attn_reference(q, k, v, q_idx, kv_idx, H, d, T, nb):
+    """q,k,v: (S, H*d, N) float64 channel-major (q already scaled). Returns ctx (E,H*d,NP), lse (E,H,NP), scores^T."""
+    E = len(q_idx)
+    NP = T * nb
+    ctx = torch.zeros(E, H * d, NP, dtype=torch.float64)
+    lse = torch.zeros(E, H, NP, dtype=torch.float64)
+    sc = torch.zeros(E, H, nb, T, T, dtype=torch.float64)
+    for e in range(E):
+        for h in range(H):
+            for b in range(nb):
+                sl = slice(b * T, (b + 1) * T)
+                qq = q[q_idx[e], h * d:(h + 1) * d, sl]          # (d, T)
+                kk = k[kv_idx[e], h * d:(h + 1) * d, sl]
+                vv = v[kv_idx[e], h * d:(h + 1) * d, sl]
+                s = qq.t() @ kk                                   # (Tq, Tk)
+                p = torch.softmax(s, dim=-1)
+                ctx[e, h * d:(h + 1) * d, sl] = (p @ vv.t()).t()
+                lse[e, h, sl] = torch.logsumexp(s, dim=-1)
+                sc[e, h, b] = s.t()                               # [key][query]
+    return ctx, lse, sc
+
+
+ATTN_CASES = [
+    # S, E, H, d, T, nb
+    (3, 5, 2, 64, 100, 3),
+    (2, 3, 1, 256, 500, 2),
+    (2, 2, 1, 128, 512, 1),
+    (1, 1, 2, 96, 36, 2),
+    (2, 2, 1, 32, 132, 1),
+]
+
+
+def _attn_inputs(rng, S, E, H, d, T, nb, extra_ld=0):
+    N = T * nb + extra_ld
+    q = _rand(rng, S, H * d, N) / math.sqrt(math.sqrt(d))
+    k = _rand(rng, S, H * d, N) / math.sqrt(math.sqrt(d))
+    v = _rand(rng, S, H * d, N)
+    q_idx = rng.integers(0, S, size=E).astype(np.int32)
+    kv_idx = rng.integers(0, S, size=E).astype(np.int32)
+    return q, k, v, q_idx, kv_idx
+
+
+def _run_attn_fwd(L, q, k, v, q_idx, kv_idx, H, d, T, nb, thr=8.0, keep=True):
+    S, D, N = q.shape
+    E = len(q_idx)
+    Tp = (T + 31) // 32 * 32
+    dev = "cuda"
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    qi, ki = torch.from_numpy(q_idx).cuda(), torch.from_numpy(kv_idx).cuda()
+    ctx = torch.full((E, D, N), float("nan"), device=dev)
+    lse = torch.zeros((E, H, T * nb), device=dev)
+    scores = torch.full((E, H, nb, T, Tp), float("nan"), device=dev) if keep else None
+    rc = L.lib().csn_block_attn_fwd_f32(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), D * N, D * N, qi.data_ptr(),
+                                        ki.data_ptr(), N, ctx.data_ptr(), D * N, scores.data_ptr() if keep else None,
+                                        lse.data_ptr(), E, H, d, T, nb, Tp, thr, _stream())
+    L.check(rc, "attn fwd")
+    torch.cuda.synchronize()
+    return ctx, lse, scores, (qd, kd, vd, qi, ki)
+
+
+@pytest.mark.parametrize("S,E,H,d,T,nb", ATTN_CASES)
+def test_block_attn_fwd(L, S, E, H, d, T, nb):
+    rng = np.random.default_rng(3)
+    q, k, v, q_idx, kv_idx = _attn_inputs(rng, S, E, H, d, T, nb, extra_ld=8)
+    ctx, lse, scores, _ = _run_attn_fwd(L, q, k, v, q_idx, kv_idx, H, d, T, nb)
+    NP = T * nb
+    rctx, rlse, rsc = _attn_reference(q.double(), k.double(), v.double(), q_idx, kv_idx, H, d, T, nb)
+    assert _maxerr(ctx[:, :, :NP], rctx) < 5e-6
+    assert torch.isnan(ctx[:, :, NP:]).all()                    # columns past n_blocks*block are never written
+    assert (lse.cpu().double() - rlse).abs().max().item() < 1e-5
+    assert (scores[..., :T].cpu().double() - rsc).abs().max().item() < 1e-5
+    assert torch.isnan(scores[..., T:]).all()                   # padding of the score rows is never written
+
+
+def test_block_attn_fwd_rescale_branch(L):
+    """The lazy softmax re-basing (threshold 8) must agree with re-basing on every tile (threshold 0), also when one
+    late key dominates a query row by far (forces the rare branch: cdna guide rule 26)."""
+    rng = np.random.default_rng(4)
+    S, E, H, d, T, nb = 1, 1, 1, 64, 200, 1
+    q, k, v, q_idx, kv_idx = _attn_inputs(rng, S, E, H, d, T, nb)
+    q_idx[:] = 0
+    kv_idx[:] = 0
+    k[0, :, 150] = q[0, :, 17] * 40.0          # key 150 (5th key tile) spikes for query 17
+    k[0, :, 3] = q[0, :, 90] * 25.0            # key 3 (first tile) spikes for query 90
+    outs = [_run_attn_fwd(L, q, k, v, q_idx, kv_idx, H, d, T, nb, thr=t)[:2] for t in (0.0, 8.0, 30.0)]
+    rctx, rlse, _ = _attn_reference(q.double(), k.double(), v.double(), q_idx, kv_idx, H, d, T, nb)
+    for ctx, lse in outs:
+        assert _maxerr(ctx, rctx) < 5e-6
+        assert (lse.cpu().double() - rlse).abs().max().item() < 2e-5 * rlse.abs().max().item()
+
+
+@pytest.mark.parametrize("S,E,H,d,T,nb", ATTN_CASES)
+def test_block_attn_bwd(L, S, E, H, d, T, nb):
+    rng = np.random.default_rng(5)
+    q, k, v, q_idx, kv_idx = _attn_inputs(rng, S, E, H, d, T, nb)
+    ctx, lse, scores, (qd, kd, vd, qi, ki) = _run_attn_fwd(L, q, k, v, q_idx, kv_idx, H, d, T, nb)
+    D, N = H * d, T * nb
+    Tp = scores.shape[-1]
+    dctx = _rand(rng, E, D, N)
+    dd = dctx.cuda()
+    dscores = torch.full_like(scores, float("nan"))
+    delta = torch.empty((E, H, N), device="cuda")
+    dq, dk, dv = (torch.full((E, D, N), float("nan"), device="cuda") for _ in range(3))
+    rc = L.lib().csn_block_attn_bwd_f32(dd.data_ptr(), ctx.data_ptr(), D * N, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(),
+                                        D * N, D * N, qi.data_ptr(), ki.data_ptr(), N, scores.data_ptr(),
+                                        dscores.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                        dv.data_ptr(), D * N, E, H, d, T, nb, Tp, _stream())
+    L.check(rc, "attn bwd")
+    torch.cuda.synchronize()
+    # float64 autograd reference, per evaluation (no sharing: the ABI returns per-evaluation gradients)
+    q64 = q.double()[q_idx].clone().requires_grad_(True)
+    k64 = k.double()[kv_idx].clone().requires_grad_(True)
+    v64 = v.double()[kv_idx].clone().requires_grad_(True)
+    ident = np.arange(E)
+    rctx, _, _ = _attn_reference_autograd(q64, k64, v64, H, d, T, nb)
+    rctx.backward(dctx.double())
+    assert _maxerr(dq, q64.grad) < 2e-5
+    assert _maxerr(dk, k64.grad) < 2e-5
+    assert _maxerr(dv, v64.grad) < 2e-5
+    # scores now hold P^T
+    p_ref = torch.softmax(_attn_reference(q.double(), k.double(), v.double(), q_idx, kv_idx, H, d, T, nb)[2].transpose(-1, -2), dim=-1)
+    assert (scores[..., :T].cpu().double().transpose(-1, -2) - p_ref).abs().max().item() < 2e-6
+
+
+def _attn_reference_autograd(q, k, v, H, d, T, nb):
+    E = q.shape[0]
+    qb = q.view(E, H, d, nb, T).permute(0, 1, 3, 4, 2)          # (E,H,nb,T,d)
+    kb = k.view(E, H, d, nb, T).permute(0, 1, 3, 4, 2)
+    vb = v.view(E, H, d, nb, T).permute(0, 1, 3, 4, 2)
+    p = torch.softmax(qb @ kb.transpose(-1, -2), dim=-1)
+    o = p @ vb                                                  # (E,H,nb,T,d)
+    return o.permute(0, 1, 4, 2, 3).reshape(E, H * d, nb * T), None, None
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S,E,C,D,NP", [(2, 3, 256, 256, 1000), (1, 2, 96, 192, 500), (2, 2, 128, 128, 2048), (1, 1, 32, 64, 36)])
+def test_outproj_ln_fwd_bwd(L, S, E, C, D, NP):
+    rng = np.random.default_rng(6)
+    att = _rand(rng, E, D, NP)
+    wfc = _rand(rng, C, D) / math.sqrt(D)
+    x = _rand(rng, S, C, NP)
+    ridx = rng.integers(0, S, size=E).astype(np.int32)
+    dxhat = _rand(rng, E, C, NP)
+    dev = "cuda"
+    attd, wd, xd, rid = att.cuda(), wfc.cuda(), x.cuda(), torch.from_numpy(ridx).cuda()
+    xhat = torch.empty((E, C, NP), device=dev)
+    rstd = torch.empty((E, NP), device=dev)
+    L.check(L.lib().csn_outproj_ln_fwd_f32(attd.data_ptr(), D * NP, wd.data_ptr(), xd.data_ptr(), C * NP, rid.data_ptr(),
+                                           xhat.data_ptr(), C * NP, rstd.data_ptr(), E, C, D, NP, NP, 1e-6, _stream()))
+    a64 = att.double().requires_grad_(True)
+    w64 = wfc.double().requires_grad_(True)
+    z = torch.einsum("cd,edn->ecn", w64, a64) + x.double()[ridx]
+    mean = z.mean(dim=1, keepdim=True)
+    var = z.var(dim=1, unbiased=False, keepdim=True)
+    ref = (z - mean) / torch.sqrt(var + 1e-6)
+    assert _maxerr(xhat, ref) < 5e-6
+    assert _maxerr(rstd, (1 / torch.sqrt(var + 1e-6)).squeeze(1)) < 5e-6
+
+    dz = torch.empty((E, C, NP), device=dev)
+    datt = torch.empty((E, D, NP), device=dev)
+    dw = torch.empty((C, D), device=dev)
+    ws_n = L.lib().csn_wgrad_workspace_floats(C, D, E, NP)
+    ws = torch.empty((ws_n,), device=dev)
+    wt = wd.t().contiguous()
+    dxd = dxhat.cuda()
+    L.check(L.lib().csn_outproj_ln_bwd_f32(dxd.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), C * NP, attd.data_ptr(), D * NP,
+                                           wt.data_ptr(), dz.data_ptr(), datt.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws_n,
+                                           E, C, D, NP, NP, 0, _stream()))
+    ref.backward(dxhat.double())
+    assert _maxerr(datt, a64.grad) < 2e-5
+    assert _maxerr(dw, w64.grad) < 2e-5
+
+
+# ---------------------------------------------------------------------------------------------------------
+def test_retrieval_measure_against_oracle(L):
+    from csn_amd import functional as CF
+    from oracle import csa_oracle as orc
+    rng = np.random.default_rng(7)
+    f1 = orc.synth_clustered_feats(rng, 3, 200)
+    f2 = orc.synth_clustered_feats(rng, 5, 333)
+    got = CF.retrieval_measure(f1.cuda(), f2.cuda()).cpu()
+    ref = orc.retrieval_measure(f1, f2)
+    assert (got - ref).abs().max().item() < 2e-6
+
+
+def test_abi_rejects_bad_arguments(L):
+    lib = L.lib()
+    x = torch.zeros(1, 32, 36, device="cuda")
+    w = torch.zeros(32, 32, device="cuda")
+    out = torch.zeros(1, 32, 36, device="cuda")
+    # leading dimension not a multiple of 4
+    rc = lib.csn_project_f32(x.data_ptr(), 32 * 35, 35, w.data_ptr(), 32, 32, out.data_ptr(), 32 * 36, 36, 1, 35, 0, 1.0, _stream())
+    assert rc == -2
+    assert b"multiple of 4" in lib.csn_status_string(rc)
+    rc = lib.csn_project_f32(None, 0, 36, w.data_ptr(), 32, 32, out.data_ptr(), 32 * 36, 36, 1, 36, 0, 1.0, _stream())
+    assert rc == -1
+    rc = lib.csn_block_attn_fwd_f32(x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, 0, None, None, 36, out.data_ptr(), 0, None,
+                                    None, 1, 1, 48, 36, 1, 64, 8.0, _stream())
+    assert rc == -5

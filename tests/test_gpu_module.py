@@ -1,0 +1,211 @@
+"""Module-level parity on the MI355X: the drop-in classes of csn_amd.csa_models against (a) the CPU oracle on the
+same seeded inputs and (b) the committed golden vectors that the reference itself produced
+(tests/golden/make_golden.py).  Tolerance: the 1e-4 fp32 contract of BASELINE.json's north_star
+(absolute on the O(1) LayerNorm-ed outputs / logits, relative on gradients)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import csa_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROW_STRIDE = 97
+ATOL = 1e-4
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+def _model(kind, p, H, n_cls, K=None):
+    from csn_amd.csa_models import get_model
+    m = get_model(kind, n_cls, H, K)
+    missing, unexpected = m.load_state_dict(p, strict=False)
+    assert not unexpected and all(k.startswith("fc_1.") for k in missing)
+    return m.cuda().eval()
+
+
+def test_state_dict_keys_match_reference_contract():
+    from csn_amd.csa_models import get_model
+    m = get_model("csa", 39, 8, 3)
+    keys = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    want = {
+        "fc_1.0.0.weight": (256, 928, 1, 1), "fc_1.0.1.weight": (256,), "fc_1.0.1.bias": (256,),
+        "fc_1.0.1.running_mean": (256,), "fc_1.0.1.running_var": (256,), "fc_1.0.1.num_batches_tracked": (),
+        "logit.weight": (39, 256, 1, 1), "attention.w_qs.weight": (2048, 256), "attention.w_ks.weight": (2048, 256),
+        "attention.w_vs.weight": (2048, 256), "attention.fc.weight": (256, 2048), "attention.norm.weight": (256,),
+        "attention.norm.bias": (256,), "compatibility_q.weight": (256, 256), "compatibility_q.bias": (256,),
+        "compatibility_k.weight": (256, 256), "compatibility_k.bias": (256,),
+    }
+    assert keys == want
+    ssa = get_model("ssa", 4, 1)
+    assert set(ssa.state_dict()) == {k for k in want if not k.startswith("compatibility")}
+    with pytest.raises(AttributeError):
+        get_model("nope", 4, 1)
+
+
+def test_g2_self_attention_config1_shapes(golden_dir):
+    """BASELINE config 1 family: unchunked self-attention at N in {500, 512, 2048}, C in {256, 128, 96}."""
+    from csn_amd.csa_models import MultiHeadAttention
+    g = _load(golden_dir, "g2_self_attention")
+    for i in range(5):
+        N, C, H, seed = (int(v) for v in g[f"g2_{i}_cfg"])
+        rng = np.random.default_rng(seed)
+        p = orc.make_params(rng, H, d_model=C, d_k=C, d_v=C, csa=False)
+        x = orc.synth_points(rng, (1, C, N, 1))
+        m = MultiHeadAttention(H, C, C, C).cuda().eval()
+        m.load_state_dict({k[len("attention."):]: v for k, v in p.items() if k.startswith("attention.")})
+        with torch.no_grad():
+            y, _ = m.self_attention(x.cuda())
+        y = y.cpu()
+        assert y.shape == (1, N, C)
+        assert np.abs(y[:, ::29].numpy() - g[f"g2_{i}_rows"]).max() < ATOL
+        ref = orc.mha_full_self(x, p, H, C, C)
+        assert (y - ref).abs().max().item() < ATOL
+
+
+def test_g3_mha_forward_self_and_cross(golden_dir):
+    from csn_amd.csa_models import MultiHeadAttention
+    g = _load(golden_dir, "g3_mha_forward")
+    for i in range(2):
+        H, seed = (int(v) for v in g[f"g3_{i}_cfg"])
+        rng = np.random.default_rng(seed)
+        p = orc.make_params(rng, H, csa=False)
+        xa = orc.synth_points(rng, (1, 256, 10000, 1))
+        xb = orc.synth_points(rng, (1, 256, 10000, 1))
+        m = MultiHeadAttention(H, 256, 256, 256).cuda().eval()
+        m.load_state_dict({k[len("attention."):]: v for k, v in p.items() if k.startswith("attention.")})
+        with torch.no_grad():
+            xa_d, xb_d = xa.cuda(), xb.cuda()
+            ys, _ = m(xa_d, xa_d, xa_d, "test")
+            yc, attn = m(xa_d, xb_d, xb_d, "test", return_attn=True)
+        assert ys.shape == (1, 10000, 256)
+        assert np.abs(ys.cpu()[:, ::ROW_STRIDE].numpy() - g[f"g3_{i}_self_rows"]).max() < ATOL
+        assert np.abs(yc.cpu()[:, ::ROW_STRIDE].numpy() - g[f"g3_{i}_cross_rows"]).max() < ATOL
+        assert np.abs(attn.cpu()[0, :, 0].numpy() - g[f"g3_{i}_attn_last_row0"]).max() < 1e-6
+
+
+def test_points_beyond_block_grid_are_ignored_and_short_inputs_raise():
+    """csa_models.py:83-90: 20 blocks of 500 — N = 12000 yields 10000 rows, N = 2048 raises IndexError."""
+    from csn_amd.csa_models import MultiHeadAttention
+    rng = np.random.default_rng(5)
+    p = orc.make_params(rng, 1, csa=False)
+    m = MultiHeadAttention(1, 256, 256, 256).cuda().eval()
+    m.load_state_dict({k[len("attention."):]: v for k, v in p.items() if k.startswith("attention.")})
+    x = orc.synth_points(rng, (1, 256, 12000, 1))
+    with torch.no_grad():
+        y, _ = m(x.cuda(), x.cuda(), x.cuda(), "test")
+    assert y.shape == (1, 10000, 256)
+    ref = orc.mha_blockdiag(x, x, x, p, 1)
+    assert (y.cpu() - ref).abs().max().item() < ATOL
+    with pytest.raises(IndexError):
+        m(x[:, :, :2048].cuda(), x[:, :, :2048].cuda(), x[:, :, :2048].cuda(), "test")
+
+
+def _grad_check(model, g, key, expect):
+    seen = 0
+    for name, prm in model.named_parameters():
+        if f"{key}_nograd_{name}" in g:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, name
+            continue
+        ref = g[f"{key}_grad_{name}"]
+        gr = prm.grad.detach().cpu()
+        got = gr.numpy() if gr.numel() <= 10000 else gr.reshape(gr.shape[0], -1)[::17, ::13].contiguous().numpy()
+        scale = np.abs(ref).max()
+        assert np.abs(got - ref).max() <= 1e-4 * scale, (name, np.abs(got - ref).max(), scale)
+        st = g[f"{key}_gstats_{name}"]
+        assert abs(gr.double().norm().item() - st[1]) <= 1e-4 * st[1], name
+        seen += 1
+    assert seen == expect
+
+
+def test_g4_csa_forward_backward_against_reference_goldens(golden_dir):
+    g = _load(golden_dir, "g4_csa")
+    for i in range(3):
+        B, K, H, n_cls, seed = (int(v) for v in g[f"g4_{i}_cfg"])
+        rng = np.random.default_rng(seed)
+        p = orc.make_params(rng, H, n_cls=n_cls, csa=True)
+        x = orc.synth_points(rng, (B, 256, 10000, 1))
+        nb = orc.synth_points(rng, (B, K + 1, 256, 10000, 1))
+        nb[:, 0] = x
+        lab = orc.synth_labels(rng, B, 10000, n_cls)
+        model = _model("csa", p, H, n_cls, K)
+        logits = model(x.cuda(), "test", nb)                 # neighbours on the CPU, as csa_training.py:198-202 passes them
+        assert logits.shape == (B, n_cls, 10000, 1)
+        loss = orc.masked_ce_loss(logits, lab.cuda())
+        loss.backward()
+        rows = logits.detach().cpu().squeeze(-1).permute(0, 2, 1)[:, ::ROW_STRIDE].numpy()
+        assert np.abs(rows - g[f"g4_{i}_logit_rows"]).max() < ATOL
+        assert abs(loss.item() - g[f"g4_{i}_loss"][0]) < 1e-5
+        with torch.no_grad():
+            feats, comp, _ = model._csa_cm(x.cuda(), nb.cuda(), return_parts=True)
+        assert np.abs(feats.cpu().permute(0, 2, 1)[:, ::ROW_STRIDE].numpy() - g[f"g4_{i}_feat_rows"]).max() < ATOL
+        assert np.abs(comp.cpu().numpy() - g[f"g4_{i}_comp_oracle"]).max() < 1e-5
+        _grad_check(model, g, f"g4_{i}", 11)
+
+
+def test_g5_ssa_forward_backward_against_reference_goldens(golden_dir):
+    g = _load(golden_dir, "g5_ssa")
+    for i in range(2):
+        B, H, n_cls, seed = (int(v) for v in g[f"g5_{i}_cfg"])
+        rng = np.random.default_rng(seed)
+        p = orc.make_params(rng, H, n_cls=n_cls, csa=False)
+        x = orc.synth_points(rng, (B, 256, 10000, 1))
+        lab = orc.synth_labels(rng, B, 10000, n_cls)
+        model = _model("ssa", p, H, n_cls)
+        logits = model(x.cuda(), "train")
+        loss = orc.masked_ce_loss(logits, lab.cuda())
+        loss.backward()
+        rows = logits.detach().cpu().squeeze(-1).permute(0, 2, 1)[:, ::ROW_STRIDE].numpy()
+        assert np.abs(rows - g[f"g5_{i}_logit_rows"]).max() < ATOL
+        assert abs(loss.item() - g[f"g5_{i}_loss"][0]) < 1e-5
+        _grad_check(model, g, f"g5_{i}", 7)
+
+
+def test_g6_knn_graph_indices_bit_exact(golden_dir):
+    g = _load(golden_dir, "g6_retrieval")
+    from csn_amd.csa_models import get_model
+    model = get_model("ssa", 4, 1).cuda().eval()
+    for i in range(2):
+        S, N, K, seed = (int(v) for v in g[f"g6_{i}_cfg"])
+        rng = np.random.default_rng(seed)
+        f = orc.synth_clustered_feats(rng, S, N)
+        r = model.get_retrieval_measure(f, f).cpu().numpy()
+        assert np.abs(r - g[f"g6_{i}_measure"]).max() < 1e-5
+        graph = model.get_knn_graph(f, f, K).cpu()
+        assert graph.dtype == torch.int64
+        assert np.array_equal(graph.numpy(), g[f"g6_{i}_graph"])
+
+
+def test_input_gradients_when_requested():
+    """The reference's features are constants, but the module is a normal autograd citizen: d loss / d x must match."""
+    from csn_amd.csa_models import MultiHeadAttention
+    rng = np.random.default_rng(9)
+    C, H, N, T = 64, 2, 400, 100
+    p = orc.make_params(rng, H, d_model=C, d_k=32, d_v=32, csa=False)
+    m = MultiHeadAttention(H, C, 32, 32, block=T, n_blocks=4).cuda().eval()
+    m.load_state_dict({k[len("attention."):]: v for k, v in p.items() if k.startswith("attention.")})
+    xa = orc.synth_points(rng, (2, C, N, 1))
+    xb = orc.synth_points(rng, (2, C, N, 1))
+    wgt = orc.synth_points(rng, (2, N, C))
+    xa_d, xb_d = xa.cuda().requires_grad_(True), xb.cuda().requires_grad_(True)
+    y, _ = m(xa_d, xb_d, xb_d, "test")
+    (y * wgt.cuda()).sum().backward()
+    xa_r, xb_r = xa.double().requires_grad_(True), xb.double().requires_grad_(True)
+    p64 = {k: v.double() for k, v in p.items()}
+    yr = orc.mha_blockdiag(xa_r, xb_r, xb_r, p64, H, d_k=32, d_v=32, block=T, n_blocks=4)
+    (yr * wgt.double()).sum().backward()
+    assert (y.detach().cpu().double() - yr.detach()).abs().max().item() < ATOL
+    for got, ref in ((xa_d.grad, xa_r.grad), (xb_d.grad, xb_r.grad)):
+        assert ((got.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 1e-4
+
+
+def test_product_path_has_no_cpu_fallback():
+    from csn_amd.csa_models import MultiHeadAttention
+    from csn_amd import CsnError
+    m = MultiHeadAttention(1, 32, 32, 32, block=36, n_blocks=1).eval()        # parameters left on the CPU
+    x = torch.zeros(1, 32, 36, 1)
+    with pytest.raises((CsnError, RuntimeError)):
+        m(x.cuda(), x.cuda(), x.cuda(), "test")
