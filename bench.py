@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CSA forward + backward query-points/sec (BASELINE.json metric) on N MI355X.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic shapes, exactly what
+MID-FC/csa_training.py:202-211 does per batch: model(x, neighbours) -> masked cross-entropy -> backward
+(no optimizer step, no data loading; features resident in HBM).
+
+Workload at N = 1: BASELINE.json configs[2] — 32 query shapes x 10000 points x 256 channels, K = 3
+neighbour shapes each (independent synthetic maps), n_heads = 1 (csa_training.py:37 default), 39 classes
+(PartNet Chair).  For N > 1 (configs[3]): every rank owns 32 shapes of a 32*N-shape collection (weak
+scaling), neighbours are drawn from the whole collection, the ranks all-gather the point features over
+RCCL/xGMI inside the timed region, and the 11 weight gradients are all-reduced at the end of the step.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the fused block-attention forward kernel
+(csn_attn_f32_kernel<8,false>), timed live with HIP events on the launch stream; `cpu_baseline` is the
+oracle's faithful op-for-op port of the reference timed on the host cores over a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+N_POINTS, C, T, H, D_HEAD, N_CLS = 10000, 256, 500, 1, 256, 39
+
+
+def algorithmic_flops_fwd(B, K, N=N_POINTS, Cc=C, Dd=H * D_HEAD, Tt=T):
+    """unique matmul FLOPs of one forward (projections once per shape, 2K+1 evaluations)."""
+    return B * ((K + 1) * 6 * N * Cc * Dd + (2 * K + 1) * (4 * N * Tt * Dd + 2 * N * Dd * Cc))
+
+
+def attn_fwd_flops(B, K, N=N_POINTS, Dd=H * D_HEAD, Tt=T):
+    """QK^T + PV of the fused attention forward launch: (2K+1) evaluations x 4*N*T*D."""
+    return B * (2 * K + 1) * 4 * N * Tt * Dd
+
+
+def masked_ce(logits, label):
+    """csa_training.py:94-108 restated: CE over points with label > 0."""
+    n_cls = logits.shape[1]
+    flat = logits.squeeze(-1).permute(0, 2, 1).reshape(-1, n_cls)
+    lab = label.reshape(-1)
+    keep = torch.where(lab > 0)[0]
+    return torch.nn.functional.cross_entropy(flat[keep], lab[keep])
+
+
+def cpu_baseline(K, sample_shapes, threads):
+    """Oracle's faithful port (20 x 500 chunk loop, growing cat, 2K+2 MHA calls) on the host, fwd + bwd."""
+    from oracle import csa_oracle as orc
+    torch.set_num_threads(threads)
+    rng = np.random.default_rng(99)
+    p = {k: v.requires_grad_(True) for k, v in orc.make_params(rng, H, n_cls=N_CLS, csa=True).items()}
+    x = orc.synth_points(rng, (sample_shapes, C, N_POINTS, 1))
+    nb = orc.synth_points(rng, (sample_shapes, K + 1, C, N_POINTS, 1))
+    nb[:, 0] = x
+    lab = orc.synth_labels(rng, sample_shapes, N_POINTS, N_CLS)
+
+    def step():
+        for v in p.values():
+            v.grad = None
+        logits = orc.forward_csa(x, nb, p, H, mha=lambda a, b, c, pp, h, **kw: orc.mha_faithful(a, b, c, pp, h))
+        orc.masked_ce_loss(logits, lab).backward()
+
+    step()
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times)[1]
+    return {"value": sample_shapes * N_POINTS / t, "unit": "points/s", "cores": threads, "kind": "port",
+            "sample": f"{sample_shapes} of the 32 query shapes (K={K}, eval-mode arithmetic, fwd+bwd), median of 3 steps after "
+                      f"1 warm-up, {t:.2f} s/step; oracle/csa_oracle.py mha_faithful"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--shapes", type=int, default=32, help="query shapes per GPU")
+    ap.add_argument("--K", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import csn_amd
+    from csn_amd import functional as CF
+    from csn_amd.csa_models import get_model
+    csn_amd.build()
+    csn_amd.lib()
+
+    B, K = args.shapes, args.K
+    S = B * world
+    torch.manual_seed(0)
+    model = get_model("csa", N_CLS, H, K).to(dev).eval()      # eval-mode arithmetic (dropout off), gradients on
+    params = [p for n, p in model.named_parameters() if not n.startswith("fc_1")]
+
+    rng = np.random.default_rng(1234 + 2 + 1000 * rank)
+    feats = torch.from_numpy(rng.standard_normal(size=(B, C, N_POINTS)).astype(np.float32)).to(dev)
+    label = torch.from_numpy(np.where(rng.random(size=(B, N_POINTS)) < 0.1, 0,
+                                      rng.integers(0, N_CLS, size=(B, N_POINTS))).astype(np.int64)).to(dev)
+    if world == 1:
+        # configs[2]: K independent synthetic neighbour maps per query shape, resident in HBM
+        nbr_maps = torch.from_numpy(rng.standard_normal(size=(B, K, C, N_POINTS)).astype(np.float32)).to(dev)
+        graph = None
+    else:
+        # configs[3]: K-regular shape graph over the whole collection (never self), same on every rank
+        grng = np.random.default_rng(4321)
+        graph_np = np.stack([(s + 1 + grng.choice(S - 1, size=K, replace=False)) % S for s in range(S)])
+        graph = torch.from_numpy(graph_np[rank * B:(rank + 1) * B].astype(np.int64)).to(dev)      # (B, K) global ids
+        nbr_maps = None
+        gathered = torch.empty((S, C, N_POINTS), device=dev, dtype=torch.float32)
+
+    attn_events = []
+
+    def step(record=False):
+        for p in params:
+            p.grad = None
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, feats)               # neighbour point features over xGMI
+            nb = gathered[graph]                                       # (B, K, C, N)
+        else:
+            nb = nbr_maps
+        x_nb = torch.cat((feats[:, None], nb), dim=1).unsqueeze(-1)    # (B, K+1, C, N, 1), slot 0 = the shape itself
+        if record:
+            CF.EVENT_SINK = attn_events
+        logits = model(feats.unsqueeze(-1), "train", x_nb)
+        CF.EVENT_SINK = None
+        loss = masked_ce(logits, label)
+        loss.backward()
+        if world > 1:
+            flat = torch.cat([p.grad.reshape(-1) for p in params])      # one 1.6 MB bucket: latency-bound
+            dist.all_reduce(flat)
+            flat /= world
+            off = 0
+            for p in params:
+                p.grad.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(record=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        value = S * N_POINTS * args.steps / elapsed
+        attn_ms = float(np.mean([a.elapsed_time(b) for a, b in attn_events])) if attn_events else float("nan")
+        achieved = attn_fwd_flops(B, K) / (attn_ms * 1e-3) / 1e12
+        out = {
+            "metric": "CSA fwd+bwd points/sec (10k pts x 256 ch, K=3)", "value": value, "unit": "points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"CSA K={K}, {B} query shapes/GPU x {N_POINTS} pts x {C} ch, n_heads={H}, d_k=d_v={D_HEAD}, "
+                                   f"20 blocks of {T}, {N_CLS} classes, fwd + masked CE + bwd, dropout off (eval arithmetic)",
+                       "shapes_total": S, "K": K, "parallelism": f"shape-graph sharded x{world}" if world > 1 else "single GPU",
+                       "loss": float(loss.item()),
+                       "step_tflops_algorithmic": 3 * algorithmic_flops_fwd(S, K) / (elapsed / args.steps) / 1e12},
+            "roofline": {"bound": "mfma", "kernel": "csn_attn_f32_kernel<8,false> (fused block attention forward)",
+                         "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                         "launch_ms": attn_ms, "flops_per_launch": attn_fwd_flops(B, K)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cores = min(len(os.sched_getaffinity(0)), 16)          # the GPU box gives one GPU a 16-core share
+            out["cpu_baseline"] = cpu_baseline(K, 4, cores)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libcsn_hip.so")
-SOURCES = ["gemm_f32.hip", "attn_f32.hip", "outproj_ln.hip", "retrieval.hip", "csn_capi.hip"]
+SOURCES = ["gemm_f32.hip", "attn_f32.hip", "outproj_ln.hip", "retrieval.hip", "combine.hip", "csn_capi.hip"]
 HEADERS = ["csn_common.h", "csn_kernels.h", os.path.join("..", "..", "include", "csn_hip.h")]
 ARCH = "gfx950"
 
@@ -75,6 +75,10 @@ _SIGNATURES = {
                                       c_int, c_int, c_float, c_int, c_void_p, c_longlong, c_void_p]),
     "csn_retrieval_measure_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                           c_longlong, c_void_p]),
+    "csn_rowsum_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_void_p]),
+    "csn_mix_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "csn_mix_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                c_int, c_void_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -86,31 +86,38 @@ class MultiHeadAttention(nn.Module):
             raise NotImplementedError("dropout is not wired into the HIP path yet; call .eval() or build with dropout=0")
 
     def evaluate(self, x_all: torch.Tensor, q_slots: torch.Tensor, kv_slots: torch.Tensor,
-                 geo: Optional[CF.MHAGeometry] = None) -> torch.Tensor:
+                 geo: Optional[CF.MHAGeometry] = None, v_shift: int = 0) -> torch.Tensor:
         """Normalised (pre-affine) outputs (E, C, NP) of a batch of evaluations over shared slots."""
         self._check_mode()
         return CF.mha_evals(x_all, self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight,
-                            q_slots, kv_slots, geo or self.geometry())
+                            q_slots, kv_slots, geo or self.geometry(), v_shift)
 
     def affine(self, xhat: torch.Tensor) -> torch.Tensor:
         """LayerNorm's gamma/beta on channel-major activations (csa_models.py:118)."""
         return xhat * self.norm.weight[:, None] + self.norm.bias[:, None]
 
+    @staticmethod
+    def _same(a: torch.Tensor, b: torch.Tensor) -> bool:
+        return a is b or (a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride())
+
     def _run(self, Q, K, V, geo):
+        """Slots: the distinct inputs among (Q, K, V), each projected once.  The reference only ever calls
+        (x, x, x) and (x, x_k, x_k) (csa_models.py:205,232,237); three distinct inputs work too."""
         B = Q.shape[0]
         npts = geo.n_points
-        same_kv = (K is V) or (K.data_ptr() == V.data_ptr() and K.shape == V.shape)
-        if not same_kv:
-            raise NotImplementedError("distinct key and value inputs are not supported (the reference never uses them)")
         xq = _channel_major(Q, npts)
-        dev = xq.device
-        ar = torch.arange(B, device=dev, dtype=torch.int32)
-        if (Q is K) or (Q.data_ptr() == K.data_ptr() and Q.shape == K.shape):
-            x_all, q_slots, kv_slots = xq, ar, ar
+        ar = torch.arange(B, device=xq.device, dtype=torch.int32)
+        v_shift = 0
+        if self._same(K, V):
+            if self._same(Q, K):
+                x_all, q_slots, kv_slots = xq, ar, ar
+            else:
+                x_all = torch.cat((xq, _channel_major(K, npts)), dim=0)
+                q_slots, kv_slots = ar, ar + B
         else:
-            x_all = torch.cat((xq, _channel_major(K, npts)), dim=0)
-            q_slots, kv_slots = ar, ar + B
-        return self.affine(self.evaluate(x_all, q_slots, kv_slots, geo))          # (B, C, NP)
+            x_all = torch.cat((xq, _channel_major(K, npts), _channel_major(V, npts)), dim=0)
+            q_slots, kv_slots, v_shift = ar, ar + B, B
+        return self.affine(self.evaluate(x_all, q_slots, kv_slots, geo, v_shift))  # (B, C, NP)
 
     # -- reference surface ------------------------------------------------------------------------------
     def self_attention(self, x):
@@ -229,13 +236,12 @@ class CrossShapeAt(nn.Module):
         xhat = att.evaluate(x_all, q_slots, kv_slots, geo)                     # (E, C, NP)
         E1 = B * K1
         gamma, beta = att.norm.weight, att.norm.bias
-        xh_mix = xhat[:E1].view(B, K1, C, npts)
         # pooled descriptors y_k = mean_n SSA(x_k)  (:211-212, :218-219); the affine commutes with the mean
-        pooled_hat = torch.cat((xh_mix[:, :1].mean(dim=3), xhat[E1:].view(B, K, C, npts).mean(dim=3)), dim=1)
+        means = CF.point_mean(xhat)                                            # (E, C), fp64-accumulated on the device
+        pooled_hat = torch.cat((means[:E1].view(B, K1, C)[:, :1], means[E1:].view(B, K, C)), dim=1)
         pooled = pooled_hat * gamma + beta                                     # (B, K+1, C)
         comp = self._compatibility(pooled)                                     # (B, K+1)
-        mix = torch.einsum("bk,bkcn->bcn", comp, xh_mix)
-        feats = mix * gamma[:, None] + beta[:, None] * comp.sum(dim=1)[:, None, None]
+        feats = CF.csa_mix(xhat, comp, gamma, beta, B, K1)                     # sum_k comp_k * affine(xhat_k)  (:233, :238)
         return (feats, comp, pooled) if return_parts else feats
 
     def _compatibility(self, pooled: torch.Tensor) -> torch.Tensor:

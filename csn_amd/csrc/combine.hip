@@ -1,0 +1,109 @@
+// Cross-shape mixing stage of CSA (MID-FC/csa_models.py:211-212, 218-219, 232-240):
+//   pooled descriptors  y_k = mean_n SSA(x_k)                    -> csn_rowsum (fp64 accumulation)
+//   mixed features      out = sum_k comp_k * LayerNormAffine(xhat_k)   -> csn_mix_fwd / csn_mix_bwd
+// These are HBM-bound streaming passes over channel-major rows ([channel][point], 16-byte lanes).
+// The reductions (row sums, <dOut, xhat_k>) feed gradients that are differences of large numbers
+// (d comp is ~1e-7 of its terms), so they accumulate in double: 64-bit adds are free next to HBM.
+#include "csn_common.h"
+#include "csn_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ double block_sum(double v, double* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// out[r] = sum_n x[r*ld + n], n < n  (one work-group per row)
+__global__ __launch_bounds__(256) void csn_rowsum_kernel(const float* __restrict__ x, float* __restrict__ out, int n,
+                                                         long long ld) {
+  __shared__ double red[4];
+  const float* __restrict__ p = x + (long long)blockIdx.x * ld;
+  double s = 0.0;
+  for (int i = threadIdx.x * 4; i < n; i += 1024) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
+    s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = (float)s;
+}
+
+// feats[b][c][n] = gamma[c] * sum_k comp[b][k] xhat[(b*K1+k)][c][n] + beta[c] * sum_k comp[b][k]
+__global__ __launch_bounds__(256) void csn_mix_fwd_kernel(const float* __restrict__ xhat, const float* __restrict__ comp,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ feats, int K1, int C, int NP) {
+  const int c = blockIdx.x % C, b = blockIdx.x / C;
+  float w[8];
+  float csum = 0.f;
+  for (int k = 0; k < K1; ++k) { w[k] = comp[b * K1 + k]; csum += w[k]; }
+  const float g = gamma[c], bb = beta[c] * csum;
+  const float* __restrict__ x0 = xhat + ((long long)b * K1 * C + c) * NP;
+  float* __restrict__ o = feats + ((long long)b * C + c) * NP;
+  for (int i = threadIdx.x * 4; i < NP; i += 1024) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K1; ++k) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x0 + (long long)k * C * NP + i);
+      acc += v * w[k];
+    }
+    *reinterpret_cast<f32x4*>(o + i) = acc * g + bb;
+  }
+}
+
+// dxhat[(b*K1+k)][c][n] = comp[b][k] gamma[c] dfeats[b][c][n]  (+ pool_grad[(b*K1+k)][c] if given, k = 0 only)
+// rowdot[b][k][c] = sum_n dfeats[b][c][n] xhat[(b*K1+k)][c][n],   rowsum[b][c] = sum_n dfeats[b][c][n]
+__global__ __launch_bounds__(256) void csn_mix_bwd_kernel(const float* __restrict__ dfeats, const float* __restrict__ xhat,
+                                                          const float* __restrict__ comp, const float* __restrict__ gamma,
+                                                          float* __restrict__ dxhat, float* __restrict__ rowdot,
+                                                          float* __restrict__ rowsum, int K1, int C, int NP) {
+  __shared__ double red[4];
+  const int c = blockIdx.x % C, b = blockIdx.x / C;
+  float w[8];
+  for (int k = 0; k < K1; ++k) w[k] = comp[b * K1 + k] * gamma[c];
+  const float* __restrict__ d = dfeats + ((long long)b * C + c) * NP;
+  const float* __restrict__ x0 = xhat + ((long long)b * K1 * C + c) * NP;
+  float* __restrict__ o0 = dxhat + ((long long)b * K1 * C + c) * NP;
+  double dot[8];
+  for (int k = 0; k < 8; ++k) dot[k] = 0.0;
+  double sum = 0.0;
+  for (int i = threadIdx.x * 4; i < NP; i += 1024) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(d + i);
+    sum += ((double)g.x + (double)g.y) + ((double)g.z + (double)g.w);
+    for (int k = 0; k < K1; ++k) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x0 + (long long)k * C * NP + i);
+      dot[k] += ((double)g.x * v.x + (double)g.y * v.y) + ((double)g.z * v.z + (double)g.w * v.w);
+      *reinterpret_cast<f32x4*>(o0 + (long long)k * C * NP + i) = g * w[k];
+    }
+  }
+  for (int k = 0; k < K1; ++k) {
+    const double t = block_sum(dot[k], red);
+    if (threadIdx.x == 0) rowdot[((long long)b * K1 + k) * C + c] = (float)t;
+  }
+  const double t = block_sum(sum, red);
+  if (threadIdx.x == 0) rowsum[(long long)b * C + c] = (float)t;
+}
+
+}  // namespace
+
+int csn_launch_rowsum_f32(const float* x, float* out, long long rows, int n, long long ld, hipStream_t st) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(csn_rowsum_kernel, dim3((unsigned)rows), dim3(256), 0, st, x, out, n, ld);
+  return (int)hipGetLastError();
+}
+
+int csn_launch_mix_fwd_f32(const float* xhat, const float* comp, const float* gamma, const float* beta, float* feats, int B,
+                           int K1, int C, int NP, hipStream_t st) {
+  hipLaunchKernelGGL(csn_mix_fwd_kernel, dim3((unsigned)(B * C)), dim3(256), 0, st, xhat, comp, gamma, beta, feats, K1, C, NP);
+  return (int)hipGetLastError();
+}
+
+int csn_launch_mix_bwd_f32(const float* dfeats, const float* xhat, const float* comp, const float* gamma, float* dxhat,
+                           float* rowdot, float* rowsum, int B, int K1, int C, int NP, hipStream_t st) {
+  hipLaunchKernelGGL(csn_mix_bwd_kernel, dim3((unsigned)(B * C)), dim3(256), 0, st, dfeats, xhat, comp, gamma, dxhat, rowdot,
+                     rowsum, K1, C, NP);
+  return (int)hipGetLastError();
+}

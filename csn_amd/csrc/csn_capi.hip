@@ -3,9 +3,6 @@
 #include "../../include/csn_hip.h"
 #include "csn_kernels.h"
 
-int csn_launch_retrieval_f32(const float* f1, const float* f2, float* out, int s1, int n1, int s2, int n2, int C,
-                             float* ws, hipStream_t st);
-
 namespace {
 
 inline bool mis16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
@@ -231,6 +228,32 @@ int csn_retrieval_measure_f32(const float* f1, const float* f2, float* out, int 
   const long long need = (long long)s1 * n1 + (long long)s2 * n2 + (long long)s1 * s2 * n1;
   if (ws_floats < need) return CSN_E_WORKSPACE;
   return csn_launch_retrieval_f32(f1, f2, out, s1, n1, s2, n2, channels, ws, (hipStream_t)stream);
+}
+
+int csn_rowsum_f32(const float* x, float* out, long long rows, int n_points, long long ld, void* stream) {
+  if (!x || !out || rows <= 0 || n_points <= 0) return CSN_E_ARG;
+  if ((n_points & 3) || (ld & 3)) return CSN_E_ALIGN;
+  if (mis16(x)) return CSN_E_PTR;
+  return csn_launch_rowsum_f32(x, out, rows, n_points, ld, (hipStream_t)stream);
+}
+
+int csn_mix_fwd_f32(const float* xhat, const float* comp, const float* gamma, const float* beta, float* feats,
+                    int n_shapes, int k1, int channels, int n_points, void* stream) {
+  if (!xhat || !comp || !gamma || !beta || !feats || n_shapes <= 0 || k1 <= 0 || k1 > 8 || channels <= 0 || n_points <= 0)
+    return CSN_E_ARG;
+  if (n_points & 3) return CSN_E_ALIGN;
+  if (mis16(xhat) || mis16(feats)) return CSN_E_PTR;
+  return csn_launch_mix_fwd_f32(xhat, comp, gamma, beta, feats, n_shapes, k1, channels, n_points, (hipStream_t)stream);
+}
+
+int csn_mix_bwd_f32(const float* dfeats, const float* xhat, const float* comp, const float* gamma, float* dxhat,
+                    float* rowdot, float* rowsum, int n_shapes, int k1, int channels, int n_points, void* stream) {
+  if (!dfeats || !xhat || !comp || !gamma || !dxhat || !rowdot || !rowsum) return CSN_E_ARG;
+  if (n_shapes <= 0 || k1 <= 0 || k1 > 8 || channels <= 0 || n_points <= 0) return CSN_E_ARG;
+  if (n_points & 3) return CSN_E_ALIGN;
+  if (mis16(dfeats) || mis16(xhat) || mis16(dxhat)) return CSN_E_PTR;
+  return csn_launch_mix_bwd_f32(dfeats, xhat, comp, gamma, dxhat, rowdot, rowsum, n_shapes, k1, channels, n_points,
+                                (hipStream_t)stream);
 }
 
 }  // extern "C"

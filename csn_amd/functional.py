@@ -23,6 +23,8 @@ REF_BLOCK = 500       # MID-FC/csa_models.py:84
 REF_NBLOCKS = 20      # MID-FC/csa_models.py:83
 LN_EPS = 1e-6         # MID-FC/csa_models.py:57
 RESCALE_THRESHOLD = 8.0
+# bench.py sets this to a list to collect (start, end) HIP-event pairs around the fused attention forward launch
+EVENT_SINK = None
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -121,7 +123,8 @@ class _MHAEvals(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x_all, w_qs, w_ks, w_vs, w_fc, q_slots, kv_slots, geo: MHAGeometry, keep_scores: bool):
+    def forward(ctx, x_all, w_qs, w_ks, w_vs, w_fc, q_slots, kv_slots, geo: MHAGeometry, keep_scores: bool,
+                v_shift: int = 0):
         _need_cuda(x_all, w_qs, w_ks, w_vs, w_fc, q_slots, kv_slots)
         L = _lib.lib()
         S, C, NP = x_all.shape
@@ -138,10 +141,20 @@ class _MHAEvals(torch.autograd.Function):
         scores = torch.empty((E, H, nb, T, Tp), device=dev, dtype=torch.float32) if keep_scores else None
         slot_stride = 3 * D * NP
         base = qkv.data_ptr()
-        _lib.check(L.csn_block_attn_fwd_f32(base, base + 4 * D * NP, base + 8 * D * NP, slot_stride, slot_stride,
+        # values may come from a different slot than the keys (slot kv + v_shift): only the generic
+        # MultiHeadAttention.forward(Q, K, V) with three distinct inputs uses that
+        v_base = base + 8 * D * NP + 4 * v_shift * slot_stride
+        if EVENT_SINK is not None:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        _lib.check(L.csn_block_attn_fwd_f32(base, base + 4 * D * NP, v_base, slot_stride, slot_stride,
                                             _ptr(q_slots), _ptr(kv_slots), NP, _ptr(att), D * NP, _ptr(scores),
                                             _ptr(lse), E, H, d, T, nb, Tp, RESCALE_THRESHOLD, _stream()),
                    "csn_block_attn_fwd_f32")
+        if EVENT_SINK is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            EVENT_SINK.append((ev0, ev1))
         xhat = torch.empty((E, C, NP), device=dev, dtype=torch.float32)
         rstd = torch.empty((E, NP), device=dev, dtype=torch.float32)
         w_fc = w_fc.contiguous()
@@ -151,6 +164,7 @@ class _MHAEvals(torch.autograd.Function):
         if keep_scores:
             ctx.save_for_backward(x_all, w_qkv, w_fc, q_slots, kv_slots, qkv, att, lse, scores, xhat, rstd)
             ctx.geo = geo
+            ctx.v_shift = v_shift
         return xhat
 
     @staticmethod
@@ -186,7 +200,8 @@ class _MHAEvals(torch.autograd.Function):
         dv = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
         slot_stride = 3 * D * NP
         base = qkv.data_ptr()
-        _lib.check(L.csn_block_attn_bwd_f32(_ptr(datt), _ptr(att), D * NP, base, base + 4 * D * NP, base + 8 * D * NP,
+        v_base = base + 8 * D * NP + 4 * ctx.v_shift * slot_stride
+        _lib.check(L.csn_block_attn_bwd_f32(_ptr(datt), _ptr(att), D * NP, base, base + 4 * D * NP, v_base,
                                             slot_stride, slot_stride, _ptr(q_slots), _ptr(kv_slots), NP, _ptr(scores),
                                             _ptr(dscores), _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk), _ptr(dv),
                                             D * NP, E, H, d, T, nb, Tp, _stream()), "csn_block_attn_bwd_f32")
@@ -197,7 +212,7 @@ class _MHAEvals(torch.autograd.Function):
         qi, ki = q_slots.long(), kv_slots.long()
         dqkv[:, 0].index_add_(0, qi, dq.view(E, D * NP))
         dqkv[:, 1].index_add_(0, ki, dk.view(E, D * NP))
-        dqkv[:, 2].index_add_(0, ki, dv.view(E, D * NP))
+        dqkv[:, 2].index_add_(0, ki + ctx.v_shift, dv.view(E, D * NP))
         del dq, dk, dv
         dqkv = dqkv.view(S, 3 * D, NP)
 
@@ -212,10 +227,77 @@ class _MHAEvals(torch.autograd.Function):
             dqkv[:, :D] /= temperature
             dx_all = project(dqkv, w_qkv.t().contiguous())
             dx_all.index_add_(0, qi, dz)
-        return dx_all, dw_q, dw_k, dw_v, dw_fc, None, None, None, None
+        return dx_all, dw_q, dw_k, dw_v, dw_fc, None, None, None, None, None
 
 
 def mha_evals(x_all: torch.Tensor, w_qs: torch.Tensor, w_ks: torch.Tensor, w_vs: torch.Tensor, w_fc: torch.Tensor,
-              q_slots: torch.Tensor, kv_slots: torch.Tensor, geo: MHAGeometry) -> torch.Tensor:
+              q_slots: torch.Tensor, kv_slots: torch.Tensor, geo: MHAGeometry, v_shift: int = 0) -> torch.Tensor:
     keep = torch.is_grad_enabled() and any(t.requires_grad for t in (x_all, w_qs, w_ks, w_vs, w_fc))
-    return _MHAEvals.apply(x_all, w_qs, w_ks, w_vs, w_fc, q_slots, kv_slots, geo, keep)
+    return _MHAEvals.apply(x_all, w_qs, w_ks, w_vs, w_fc, q_slots, kv_slots, geo, keep, v_shift)
+
+
+# ------------------------------------------------------------------------------------------------------
+# pooled descriptors and the compatibility-weighted mix (csa_models.py:211-212, 218-219, 232-240)
+# ------------------------------------------------------------------------------------------------------
+class _RowSum(torch.autograd.Function):
+    """(E, C, NP) -> (E, C): sum over the points of every channel row, accumulated in fp64 on the device."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        E, C, NP = x.shape
+        assert x.is_contiguous()
+        out = torch.empty((E, C), device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().csn_rowsum_f32(_ptr(x), _ptr(out), E * C, NP, NP, _stream()), "csn_rowsum_f32")
+        ctx.shape = (E, C, NP)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :, None].expand(ctx.shape)
+
+
+def point_mean(x: torch.Tensor) -> torch.Tensor:
+    """mean over points of channel-major maps, (E, C, NP) -> (E, C)  (csa_models.py:212, 219)."""
+    return _RowSum.apply(x) / x.shape[-1]
+
+
+class _CSAMix(torch.autograd.Function):
+    """feats[b] = sum_k comp[b,k] * (gamma * xhat[b*K1+k] + beta)   for the first B*K1 maps of xhat."""
+
+    @staticmethod
+    def forward(ctx, xhat, comp, gamma, beta, B: int, K1: int):
+        _need_cuda(xhat, comp, gamma, beta)
+        E, C, NP = xhat.shape
+        assert xhat.is_contiguous() and E >= B * K1
+        comp = comp.contiguous()
+        feats = torch.empty((B, C, NP), device=xhat.device, dtype=torch.float32)
+        _lib.check(_lib.lib().csn_mix_fwd_f32(_ptr(xhat), _ptr(comp), _ptr(gamma), _ptr(beta), _ptr(feats), B, K1, C, NP,
+                                              _stream()), "csn_mix_fwd_f32")
+        ctx.save_for_backward(xhat, comp, gamma, beta)
+        ctx.dims = (B, K1)
+        return feats
+
+    @staticmethod
+    def backward(ctx, dfeats):
+        xhat, comp, gamma, beta = ctx.saved_tensors
+        B, K1 = ctx.dims
+        E, C, NP = xhat.shape
+        dfeats = dfeats.contiguous()
+        dxhat = torch.empty_like(xhat)
+        if E > B * K1:
+            dxhat[B * K1:].zero_()
+        rowdot = torch.empty((B, K1, C), device=xhat.device, dtype=torch.float32)
+        rowsum = torch.empty((B, C), device=xhat.device, dtype=torch.float32)
+        _lib.check(_lib.lib().csn_mix_bwd_f32(_ptr(dfeats), _ptr(xhat), _ptr(comp), _ptr(gamma), _ptr(dxhat), _ptr(rowdot),
+                                              _ptr(rowsum), B, K1, C, NP, _stream()), "csn_mix_bwd_f32")
+        rd, rs = rowdot.double(), rowsum.double()
+        g64, b64, c64 = gamma.double(), beta.double(), comp.double()
+        dcomp = (rd * g64).sum(dim=2) + (rs * b64).sum(dim=1, keepdim=True)          # (B, K1)
+        dgamma = torch.einsum("bk,bkc->c", c64, rd)
+        dbeta = (c64.sum(dim=1, keepdim=True) * rs).sum(dim=0)
+        return dxhat, dcomp.float(), dgamma.float(), dbeta.float(), None, None
+
+
+def csa_mix(xhat: torch.Tensor, comp: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B: int, K1: int) -> torch.Tensor:
+    return _CSAMix.apply(xhat, comp, gamma, beta, B, K1)

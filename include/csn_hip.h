@@ -118,6 +118,21 @@ long long csn_wgrad_workspace_floats(int rows, int cols, int n_maps, int n_point
 int csn_retrieval_measure_f32(const float* f1, const float* f2, float* out, int s1, int n1, int s2, int n2,
                               int channels, float* ws, long long ws_floats, void* stream);
 
+/* ---- (8) pooled descriptors and the cross-shape mix (csa_models.py:211-212, 218-219, 232-240) --------------
+ * csn_rowsum_f32 : out[r] = sum_{n < n_points} x[r*ld + n]   (fp64 accumulation; the caller divides by n_points to
+ *                  get the mean-over-points SSA descriptor of :212 / :219).
+ * csn_mix_fwd_f32: feats[b][c][n] = gamma[c] * sum_k comp[b][k] * xhat[b*k1 + k][c][n] + beta[c] * sum_k comp[b][k]
+ *                  i.e. sum_k comp_k * LayerNorm-affine(xhat_k): the compatibility-weighted sum of :233 and :238.
+ * csn_mix_bwd_f32: dxhat[b*k1 + k][c][n] = comp[b][k] gamma[c] dfeats[b][c][n];
+ *                  rowdot[b][k][c] = sum_n dfeats[b][c][n] xhat[b*k1+k][c][n];  rowsum[b][c] = sum_n dfeats[b][c][n]
+ *                  (fp64 accumulation) from which d comp, d gamma, d beta follow with O(B*k1*C) host-side math.
+ * All maps dense channel-major [..][channels][n_points], n_points % 4 == 0, k1 <= 8. */
+int csn_rowsum_f32(const float* x, float* out, long long rows, int n_points, long long ld, void* stream);
+int csn_mix_fwd_f32(const float* xhat, const float* comp, const float* gamma, const float* beta, float* feats,
+                    int n_shapes, int k1, int channels, int n_points, void* stream);
+int csn_mix_bwd_f32(const float* dfeats, const float* xhat, const float* comp, const float* gamma, float* dxhat,
+                    float* rowdot, float* rowsum, int n_shapes, int k1, int channels, int n_points, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,12 +96,30 @@ def test_points_beyond_block_grid_are_ignored_and_short_inputs_raise():
     m.load_state_dict({k[len("attention."):]: v for k, v in p.items() if k.startswith("attention.")})
     x = orc.synth_points(rng, (1, 256, 12000, 1))
     with torch.no_grad():
-        y, _ = m(x.cuda(), x.cuda(), x.cuda(), "test")
+        xd = x.cuda()
+        y, _ = m(xd, xd, xd, "test")
     assert y.shape == (1, 10000, 256)
     ref = orc.mha_blockdiag(x, x, x, p, 1)
     assert (y.cpu() - ref).abs().max().item() < ATOL
     with pytest.raises(IndexError):
-        m(x[:, :, :2048].cuda(), x[:, :, :2048].cuda(), x[:, :, :2048].cuda(), "test")
+        xs = x[:, :, :2048].cuda()
+        m(xs, xs, xs, "test")
+
+
+def test_three_distinct_inputs():
+    """MultiHeadAttention.forward(Q, K, V) with three different tensors (the signature allows it, csa_models.py:81)."""
+    from csn_amd.csa_models import MultiHeadAttention
+    rng = np.random.default_rng(15)
+    C, H, N, T = 64, 2, 200, 100
+    p = orc.make_params(rng, H, d_model=C, d_k=32, d_v=32, csa=False)
+    m = MultiHeadAttention(H, C, 32, 32, block=T, n_blocks=2).cuda().eval()
+    m.load_state_dict({k[len("attention."):]: v for k, v in p.items() if k.startswith("attention.")})
+    xq, xk, xv = (orc.synth_points(rng, (2, C, N, 1)) for _ in range(3))
+    for t in (xq, xk, xv):
+        t.requires_grad_(True)
+    y, _ = m(xq.cuda(), xk.cuda(), xv.cuda(), "test")
+    ref = orc.mha_blockdiag(xq, xk, xv, p, H, d_k=32, d_v=32, block=T, n_blocks=2)
+    assert (y.detach().cpu() - ref.detach()).abs().max().item() < ATOL
 
 
 def _grad_check(model, g, key, expect):
@@ -114,9 +132,12 @@ def _grad_check(model, g, key, expect):
         gr = prm.grad.detach().cpu()
         got = gr.numpy() if gr.numel() <= 10000 else gr.reshape(gr.shape[0], -1)[::17, ::13].contiguous().numpy()
         scale = np.abs(ref).max()
-        assert np.abs(got - ref).max() <= 1e-4 * scale, (name, np.abs(got - ref).max(), scale)
+        # 1e-4 relative, plus the reference's own fp32 rounding noise on this tensor (its deviation from the float64
+        # oracle, recorded by make_golden.py): the compatibility-head gradients are ~1e-7 differences of O(1) sums
+        noise = float(g[f"{key}_gnoise_{name}"][0])
+        assert np.abs(got - ref).max() <= 1e-4 * scale + 4.0 * noise, (name, np.abs(got - ref).max(), scale, noise)
         st = g[f"{key}_gstats_{name}"]
-        assert abs(gr.double().norm().item() - st[1]) <= 1e-4 * st[1], name
+        assert abs(gr.double().norm().item() - st[1]) <= 1e-4 * st[1] + 4.0 * noise * np.sqrt(gr.numel()), name
         seen += 1
     assert seen == expect
 

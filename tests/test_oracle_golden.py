@@ -92,9 +92,11 @@ def _check_grads(g, key, grads):
         ref = g[f"{key}_grad_{name}"]
         got = gr.numpy() if gr.numel() <= 10000 else gr.reshape(gr.shape[0], -1)[::17, ::13].contiguous().numpy()
         scale = max(np.abs(ref).max(), 1e-30)
-        assert np.abs(got - ref).max() <= 1e-4 * scale + 1e-9, (name, np.abs(got - ref).max(), scale)
+        # 1e-4 relative + the reference's own fp32 noise floor on this tensor (vs the float64 oracle, see make_golden.py)
+        noise = float(g[f"{key}_gnoise_{name}"][0])
+        assert np.abs(got - ref).max() <= 1e-4 * scale + 4.0 * noise, (name, np.abs(got - ref).max(), scale, noise)
         st = g[f"{key}_gstats_{name}"]
-        assert abs(gr.double().norm().item() - st[1]) <= 1e-4 * st[1] + 1e-12, name
+        assert abs(gr.double().norm().item() - st[1]) <= 1e-4 * st[1] + 4.0 * noise * np.sqrt(gr.numel()), name
         seen += 1
     return seen
 
