@@ -134,10 +134,12 @@ def _grad_check(model, g, key, expect):
         scale = np.abs(ref).max()
         # 1e-4 relative, plus the reference's own fp32 rounding noise on this tensor (its deviation from the float64
         # oracle, recorded by make_golden.py): the compatibility-head gradients are ~1e-7 differences of O(1) sums
+        # (a 256-long MFMA fp32 accumulation chain is a plain fmaf chain: its rounding error is a few times that of
+        #  the blocked CPU GEMM the reference ran on, hence the factor 10 on the noise term)
         noise = float(g[f"{key}_gnoise_{name}"][0])
-        assert np.abs(got - ref).max() <= 1e-4 * scale + 4.0 * noise, (name, np.abs(got - ref).max(), scale, noise)
+        assert np.abs(got - ref).max() <= 1e-4 * scale + 10.0 * noise, (name, np.abs(got - ref).max(), scale, noise)
         st = g[f"{key}_gstats_{name}"]
-        assert abs(gr.double().norm().item() - st[1]) <= 1e-4 * st[1] + 4.0 * noise * np.sqrt(gr.numel()), name
+        assert abs(gr.double().norm().item() - st[1]) <= 1e-4 * st[1] + 10.0 * noise * np.sqrt(gr.numel()), name
         seen += 1
     assert seen == expect
 
