@@ -122,43 +122,33 @@ def main():
     feats = torch.from_numpy(rng.standard_normal(size=(B, C, N_POINTS)).astype(np.float32)).to(dev)
     label = torch.from_numpy(np.where(rng.random(size=(B, N_POINTS)) < 0.1, 0,
                                       rng.integers(0, N_CLS, size=(B, N_POINTS))).astype(np.int64)).to(dev)
+    shard = None
     if world == 1:
         # configs[2]: K independent synthetic neighbour maps per query shape, resident in HBM
         nbr_maps = torch.from_numpy(rng.standard_normal(size=(B, K, C, N_POINTS)).astype(np.float32)).to(dev)
-        graph = None
     else:
         # configs[3]: K-regular shape graph over the whole collection (never self), same on every rank
-        grng = np.random.default_rng(4321)
-        graph_np = np.stack([(s + 1 + grng.choice(S - 1, size=K, replace=False)) % S for s in range(S)])
-        graph = torch.from_numpy(graph_np[rank * B:(rank + 1) * B].astype(np.int64)).to(dev)      # (B, K) global ids
+        from csn_amd.sharding import ShapeGraphShard, regular_graph
+        shard = ShapeGraphShard(regular_graph(S, K), B, rank, world, dev)
         nbr_maps = None
-        gathered = torch.empty((S, C, N_POINTS), device=dev, dtype=torch.float32)
 
     attn_events = []
 
     def step(record=False):
         for p in params:
             p.grad = None
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, feats)               # neighbour point features over xGMI
-            nb = gathered[graph]                                       # (B, K, C, N)
+        if shard is not None:
+            x_nb = shard.neighbour_stack(feats, shard.exchange(feats))   # all-gather of point features over xGMI
         else:
-            nb = nbr_maps
-        x_nb = torch.cat((feats[:, None], nb), dim=1).unsqueeze(-1)    # (B, K+1, C, N, 1), slot 0 = the shape itself
+            x_nb = torch.cat((feats[:, None], nbr_maps), dim=1).unsqueeze(-1)   # (B, K+1, C, N, 1), slot 0 = self
         if record:
             CF.EVENT_SINK = attn_events
         logits = model(feats.unsqueeze(-1), "train", x_nb)
         CF.EVENT_SINK = None
         loss = masked_ce(logits, label)
         loss.backward()
-        if world > 1:
-            flat = torch.cat([p.grad.reshape(-1) for p in params])      # one 1.6 MB bucket: latency-bound
-            dist.all_reduce(flat)
-            flat /= world
-            off = 0
-            for p in params:
-                p.grad.copy_(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
+        if shard is not None:
+            shard.allreduce_grads(params)                                # one 1.6 MB bucket
         return loss
 
     for _ in range(args.warmup):

@@ -1,0 +1,74 @@
+"""Sharding of the K-neighbour shape graph across the GPUs of one node.
+
+The CSA path shards by query shape: rank r owns shapes [r*B, (r+1)*B) of an S = B*world collection and
+computes their cross-shape attention.  The only data-path exchange is the neighbours' point features
+(constants: they carry no gradient, so there is no reverse exchange); the 11 weight gradients are summed
+at the end of the step.  One process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on the
+MI355X node; "gloo" in the CPU tests).
+
+Nothing here touches the attention arithmetic — it is host logic that runs identically on CPU tensors,
+which is how tests/test_sharding_gloo.py covers the N > 1 path without a GPU.
+"""
+from __future__ import annotations
+
+from typing import Iterable, List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def regular_graph(n_shapes: int, K: int, seed: int = 4321) -> np.ndarray:
+    """(S, K) int64: K distinct neighbours per shape drawn from the other S-1 shapes (never self), the same on
+    every rank (seeded).  Stand-in for the kNN graph that get_knn_graph produces (csa_models.py:270-280)."""
+    rng = np.random.default_rng(seed)
+    rows = [(s + 1 + rng.choice(n_shapes - 1, size=K, replace=False)) % n_shapes for s in range(n_shapes)]
+    return np.stack(rows).astype(np.int64)
+
+
+class ShapeGraphShard:
+    """Rank-local view of a shape collection sharded by contiguous ranges of shape ids."""
+
+    def __init__(self, graph: np.ndarray, shapes_per_rank: int, rank: int, world: int, device: torch.device):
+        S, K = graph.shape
+        if S != shapes_per_rank * world:
+            raise ValueError(f"graph has {S} shapes, expected {shapes_per_rank} x {world}")
+        self.rank, self.world, self.B, self.K, self.S = rank, world, shapes_per_rank, K, S
+        self.device = device
+        self.first = rank * shapes_per_rank
+        own = graph[self.first:self.first + shapes_per_rank]
+        if (own == np.arange(self.first, self.first + shapes_per_rank)[:, None]).any():
+            raise ValueError("a shape may not be its own neighbour (slot 0 already is the shape itself)")
+        self.local_graph = torch.from_numpy(own).to(device)                   # (B, K) global shape ids
+        self._gathered: Optional[torch.Tensor] = None
+
+    # -- the one data-path collective ----------------------------------------------------------------------
+    def exchange(self, feats: torch.Tensor) -> torch.Tensor:
+        """feats (B, C, N) of the owned shapes -> (S, C, N) of the whole collection (all-gather)."""
+        if self.world == 1:
+            return feats
+        if self._gathered is None or self._gathered.shape[1:] != feats.shape[1:]:
+            self._gathered = torch.empty((self.S,) + tuple(feats.shape[1:]), device=feats.device, dtype=feats.dtype)
+        dist.all_gather_into_tensor(self._gathered, feats.contiguous())
+        return self._gathered
+
+    def neighbour_stack(self, feats: torch.Tensor, collection: torch.Tensor) -> torch.Tensor:
+        """(B, K+1, C, N, 1) exactly as CSADatasetK hands it to the model (features_data_loader.py:124-140):
+        slot 0 = the shape itself, slots 1..K = its neighbours in graph order."""
+        nb = collection[self.local_graph]                                      # (B, K, C, N)
+        return torch.cat((feats[:, None], nb), dim=1).unsqueeze(-1)
+
+    # -- gradient reduction ------------------------------------------------------------------------------------
+    def allreduce_grads(self, params: Iterable[torch.nn.Parameter], average: bool = True) -> None:
+        """Sum (or average) the weight gradients over ranks in ONE bucket (≈0.4 M parameters: latency-bound)."""
+        if self.world == 1:
+            return
+        plist: List[torch.nn.Parameter] = [p for p in params if p.grad is not None]
+        flat = torch.cat([p.grad.reshape(-1) for p in plist])
+        dist.all_reduce(flat)
+        if average:
+            flat /= self.world
+        off = 0
+        for p in plist:
+            p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
+            off += p.numel()

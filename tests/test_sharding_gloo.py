@@ -1,0 +1,103 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the shape-graph sharding (csn_amd/sharding.py) must reproduce the
+single-process result.  The compute function is the CPU oracle at a tiny size (the HIP kernels cannot run here);
+what is under test is the host logic: ownership ranges, the feature all-gather, neighbour-stack assembly in graph
+order with slot 0 = self, and the one-bucket gradient all-reduce."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import csa_oracle as orc
+
+B_PER_RANK, K, C, N, N_CLS = 2, 2, 256, 32, 5
+KW = dict(d_k=32, d_v=32, block=16, n_blocks=2)
+
+
+def _collection(world):
+    rng = np.random.default_rng(77)
+    S = B_PER_RANK * world
+    p = orc.make_params(rng, 1, d_model=C, d_k=32, d_v=32, n_cls=N_CLS, csa=True)
+    feats = orc.synth_points(rng, (S, C, N))
+    labels = orc.synth_labels(rng, S, N, N_CLS)
+    return p, feats, labels
+
+
+def _loss(p, x_stack, feats, labels):
+    logits = orc.forward_csa(feats.unsqueeze(-1), x_stack, p, 1, **KW)
+    return orc.masked_ce_loss(logits, labels)
+
+
+def _worker(rank, world, port, out_dir):
+    from csn_amd.sharding import ShapeGraphShard, regular_graph
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    p, feats, labels = _collection(world)
+    graph = regular_graph(B_PER_RANK * world, K)
+    shard = ShapeGraphShard(graph, B_PER_RANK, rank, world, torch.device("cpu"))
+    lo, hi = shard.first, shard.first + B_PER_RANK
+    mine = feats[lo:hi].clone()
+    params = {k: torch.nn.Parameter(v.clone()) for k, v in p.items()}
+    gathered = shard.exchange(mine)
+    assert torch.equal(gathered, feats)                                   # every rank sees the whole collection
+    stack = shard.neighbour_stack(mine, gathered)
+    assert stack.shape == (B_PER_RANK, K + 1, C, N, 1)
+    assert torch.equal(stack[:, 0, :, :, 0], mine)                        # slot 0 = the shape itself
+    for b in range(B_PER_RANK):
+        for k in range(K):
+            assert torch.equal(stack[b, k + 1, :, :, 0], feats[graph[lo + b, k]])
+    loss = _loss(params, stack, mine, labels[lo:hi])
+    loss.backward()
+    shard.allreduce_grads(params.values(), average=True)
+    torch.save({"loss": loss.item(), "grads": {k: v.grad for k, v in params.items()}}, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_sharded_step_equals_single_process(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
+    # single process: the same two per-rank losses, averaged
+    from csn_amd.sharding import ShapeGraphShard, regular_graph
+    p, feats, labels = _collection(world)
+    graph = regular_graph(B_PER_RANK * world, K)
+    params = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    total = 0.0
+    for r in range(world):
+        sh = ShapeGraphShard(graph, B_PER_RANK, r, world, torch.device("cpu"))
+        lo, hi = sh.first, sh.first + B_PER_RANK
+        stack = sh.neighbour_stack(feats[lo:hi], feats)
+        loss = _loss(params, stack, feats[lo:hi], labels[lo:hi])
+        assert abs(loss.item() - res[r]["loss"]) < 1e-6
+        total = total + loss / world
+    total.backward()
+    for k, v in params.items():
+        for r in range(world):
+            got = res[r]["grads"][k]
+            assert torch.allclose(got, v.grad, rtol=1e-4, atol=1e-7), k
+        assert torch.equal(res[0]["grads"][k], res[1]["grads"][k])         # ranks agree bit-for-bit after the all-reduce
+
+
+def test_graph_rejects_self_neighbours_and_bad_sizes():
+    from csn_amd.sharding import ShapeGraphShard, regular_graph
+    g = regular_graph(8, 3)
+    assert g.shape == (8, 3) and g.dtype == np.int64
+    assert all(s not in g[s] and len(set(g[s])) == 3 for s in range(8))
+    with pytest.raises(ValueError):
+        ShapeGraphShard(g, 3, 0, 2, torch.device("cpu"))
+    bad = g.copy()
+    bad[1, 0] = 1
+    with pytest.raises(ValueError):
+        ShapeGraphShard(bad, 4, 0, 2, torch.device("cpu"))
