@@ -62,10 +62,12 @@ _SIGNATURES = {
     "csn_block_attn_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_void_p, c_void_p, c_int,
                                        c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                        c_int, c_float, c_void_p]),
-    "csn_block_attn_bwd_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong,
-                                       c_longlong, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                       c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_int,
-                                       c_int, c_void_p]),
+    "csn_block_attn_bwd_dq_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_int,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_int,
+                                          c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "csn_block_attn_bwd_dkv_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                           c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "csn_outproj_ln_fwd_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p,
                                        c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "csn_outproj_ln_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p,

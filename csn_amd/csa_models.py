@@ -85,12 +85,35 @@ class MultiHeadAttention(nn.Module):
         if self.training and (self.dropout.p > 0 or self.attention.dropout.p > 0):
             raise NotImplementedError("dropout is not wired into the HIP path yet; call .eval() or build with dropout=0")
 
-    def evaluate(self, x_all: torch.Tensor, q_slots: torch.Tensor, kv_slots: torch.Tensor,
-                 geo: Optional[CF.MHAGeometry] = None, v_shift: int = 0) -> torch.Tensor:
+    def evaluate(self, x_all: torch.Tensor, plan: CF.EvalPlan, geo: Optional[CF.MHAGeometry] = None) -> torch.Tensor:
         """Normalised (pre-affine) outputs (E, C, NP) of a batch of evaluations over shared slots."""
         self._check_mode()
         return CF.mha_evals(x_all, self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight,
-                            q_slots, kv_slots, geo or self.geometry(), v_shift)
+                            plan, geo or self.geometry())
+
+    def plan(self, kind: str, B: int, K1: int, dev) -> CF.EvalPlan:
+        """Cached evaluation plans (slot maps live on the device; building one costs a few small H2D copies)."""
+        key = (kind, B, K1, str(dev))
+        cache = self.__dict__.setdefault("_plans", {})
+        if key not in cache:
+            ar = np.arange(B)
+            if kind == "self":            # MHA(x, x, x)
+                cache[key] = CF.EvalPlan(ar, ar, B, dev)
+            elif kind == "cross":         # MHA(x, y, y): slots [x_0..x_B-1, y_0..y_B-1]
+                cache[key] = CF.EvalPlan(ar, ar + B, 2 * B, dev)
+            elif kind == "qkv":           # three distinct inputs: values live B slots after the keys
+                cache[key] = CF.EvalPlan(ar, ar + B, 3 * B, dev, v_shift=B)
+            elif kind == "csa":
+                # slots s = b*K1 + k (k = 0: the query shape).  Evaluations:
+                #   [b*K1 + k]            MHA(x_b, x_bk, x_bk)   (k = 0: self attention)   -> mixed   (csa_models.py:232-238)
+                #   [B*K1 + b*(K1-1)+k-1] MHA(x_bk, x_bk, x_bk)  k >= 1: only its mean is used       (csa_models.py:214-220)
+                b, k = np.meshgrid(ar, np.arange(K1), indexing="ij")
+                mix_q, mix_kv = (b * K1).reshape(-1), (b * K1 + k).reshape(-1)
+                nbr = (b * K1 + k)[:, 1:].reshape(-1)
+                cache[key] = CF.EvalPlan(np.concatenate((mix_q, nbr)), np.concatenate((mix_kv, nbr)), B * K1, dev)
+            else:
+                raise ValueError(kind)
+        return cache[key]
 
     def affine(self, xhat: torch.Tensor) -> torch.Tensor:
         """LayerNorm's gamma/beta on channel-major activations (csa_models.py:118)."""
@@ -106,18 +129,16 @@ class MultiHeadAttention(nn.Module):
         B = Q.shape[0]
         npts = geo.n_points
         xq = _channel_major(Q, npts)
-        ar = torch.arange(B, device=xq.device, dtype=torch.int32)
-        v_shift = 0
+        dev = xq.device
         if self._same(K, V):
             if self._same(Q, K):
-                x_all, q_slots, kv_slots = xq, ar, ar
+                x_all, plan = xq, self.plan("self", B, 1, dev)
             else:
-                x_all = torch.cat((xq, _channel_major(K, npts)), dim=0)
-                q_slots, kv_slots = ar, ar + B
+                x_all, plan = torch.cat((xq, _channel_major(K, npts)), dim=0), self.plan("cross", B, 1, dev)
         else:
             x_all = torch.cat((xq, _channel_major(K, npts), _channel_major(V, npts)), dim=0)
-            q_slots, kv_slots, v_shift = ar, ar + B, B
-        return self.affine(self.evaluate(x_all, q_slots, kv_slots, geo, v_shift))  # (B, C, NP)
+            plan = self.plan("qkv", B, 1, dev)
+        return self.affine(self.evaluate(x_all, plan, geo))                        # (B, C, NP)
 
     # -- reference surface ------------------------------------------------------------------------------
     def self_attention(self, x):
@@ -191,8 +212,7 @@ class CrossShapeAt(nn.Module):
         att = self.attention
         geo = att.geometry()
         xc = _channel_major(x, geo.n_points)
-        ar = torch.arange(xc.shape[0], device=xc.device, dtype=torch.int32)
-        return att.affine(att.evaluate(xc, ar, ar, geo))
+        return att.affine(att.evaluate(xc, att.plan("self", xc.shape[0], 1, xc.device), geo))
 
     def get_ssa_feats(self, x, mode=None):
         """(B, 256, N, 1) -> ((B, 256, N', 1), None)   (csa_models.py:204-207)."""
@@ -225,15 +245,7 @@ class CrossShapeAt(nn.Module):
             x_all[:, 1:] = nb[:, 1:, :, :npts].to(dev, non_blocking=True)      # neighbours may arrive on the CPU (:216)
         x_all = x_all.view(B * K1, C, npts)
 
-        b_idx = torch.arange(B, device=dev, dtype=torch.int32)
-        k_idx = torch.arange(K1, device=dev, dtype=torch.int32)
-        mix_q = (b_idx[:, None] * K1).expand(B, K1).reshape(-1)                # query slot of (b, k): x_b
-        mix_kv = (b_idx[:, None] * K1 + k_idx[None, :]).reshape(-1)            # key/value slot: x_bk
-        nbr = mix_kv.view(B, K1)[:, 1:].reshape(-1)                            # SSA of the neighbours
-        q_slots = torch.cat((mix_q, nbr)).contiguous()
-        kv_slots = torch.cat((mix_kv, nbr)).contiguous()
-
-        xhat = att.evaluate(x_all, q_slots, kv_slots, geo)                     # (E, C, NP)
+        xhat = att.evaluate(x_all, att.plan("csa", B, K1, dev), geo)          # (E, C, NP)
         E1 = B * K1
         gamma, beta = att.norm.weight, att.norm.bias
         # pooled descriptors y_k = mean_n SSA(x_k)  (:211-212, :218-219); the affine commutes with the mean

@@ -5,7 +5,7 @@
 //
 // Everything is channel-major, so one skeleton serves forward and backward:
 //
-//   R      [d][q]   per-wave register operand, 32 query points on the lanes   (fwd: Qs^T   bwd: dO^T)
+//   R      [d][q]   per-wave register operand, 16 query points on the lanes   (fwd: Qs^T   bwd: dO^T)
 //   tileA  [d][key] 32 keys of the streamed operand, k-major in LDS           (fwd: K^T    bwd: V^T)
 //   tileB  [d][key] 32 keys, key-contiguous in LDS (16-byte fragment reads)   (fwd: V^T    bwd: K^T)
 //
@@ -14,103 +14,120 @@
 //   phase 2   OUT[d][q] += sum_key tileB[d][key] * T1[key][q]   fwd: O^T += V^T P^T     bwd: dQs^T += K^T dS^T
 //
 // The phase-1 accumulator (key on registers, query on the lane) is *already* the B operand of the
-// phase-2 products, so the 32 x 32 score tile never leaves registers, and all softmax statistics
-// are per-lane scalars (no cross-lane traffic except one exchange between the two 32-lane halves).
+// phase-2 products, so the score tile never leaves registers, and all softmax statistics are per-lane
+// scalars (two lane exchanges, l ^ 16 and l ^ 32, combine the four key quarters of a query).
+//
+// Matrix instruction: v_mfma_f32_16x16x4_f32 (A: lane l = A[l & 15][l >> 4], B: lane l = B[l >> 4][l & 15],
+// C: reg r of lane l = C[4 (l >> 4) + r][l & 15]).  A wave owns 16 queries, which halves the register
+// footprint of R and OUT (64 + 64 registers at d = 256) against the 32x32x2 shape and lets TWO waves share a
+// SIMD: while one wave sits in its softmax / LDS / barrier phases the other keeps the fp32 matrix pipe busy
+// (round-1 profile of the 32-query, one-wave-per-SIMD version: pipe 66 % busy, 25 % of wave time in waits).
 //
 // Forward additionally writes the raw scores S^T to HBM when training: at 64 FLOP/clk/SIMD the fp32
 // matrix pipe makes recomputing S (2*T*T*d flops per block) dearer than the 4*T*T bytes it costs to
 // keep it in the 288 GB of HBM3E.  Backward turns S^T into P^T in place and emits dS^T next to it;
 // dK^T / dV^T are then plain batched GEMMs over those two buffers (gemm_f32.hip).
 //
-// Work-group = 4 waves = 128 query points of one (evaluation, head, block); one wave per SIMD
-// (the wave keeps R and OUT, 2 x d/2 registers per lane, resident for the whole key sweep).
+// Work-group = 8 waves = 128 query points of one (evaluation, head, block).  LDS: two stages of both
+// tiles, un-padded 128-byte rows made conflict-free by XOR swizzles (tileA: key half ^= row parity;
+// tileB: 16-byte chunk ^= (row >> 1) & 7), 128 KB at d = 256.
 #include "csn_common.h"
 #include "csn_kernels.h"
 
 namespace {
 
 constexpr int KT = 32;               // keys per streamed tile
-constexpr int LDB = KT + 4;          // padded row of tileB (conflict-free ds_read_b128)
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+CSN_DEVINL f32x4v mfma16(float a, float b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 template <int DT, bool BWD>
-__global__ __launch_bounds__(256, 1) void csn_attn_f32_kernel(CsnAttnArgs p) {
+__global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
   constexpr int D = 32 * DT;
-  // two stages of each streamed tile: stage (kt & 1) is read while stage ((kt + 1) & 1) is filled
+  constexpr int PIECES = D * 8;                         // 16-byte pieces per streamed tile
+  constexpr int NP_T = (PIECES + 511) / 512;            // pieces per thread per tile
   __shared__ __attribute__((aligned(16))) float tileA[2][D * KT];
-  __shared__ __attribute__((aligned(16))) float tileB[2][D * LDB];
+  __shared__ __attribute__((aligned(16))) float tileB[2][D * KT];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, h = lane >> 5;
-  const int e = blockIdx.z;
+  const int lq = lane & 15, kq = lane >> 4;
+  const int e = p.eval_ids ? p.eval_ids[blockIdx.z] : (int)blockIdx.z;
   const int hd = blockIdx.y % p.H, blk = blockIdx.y / p.H;
   const int T = p.T, Tp = p.Tp, ld = p.ld;
-  const int qrow = blockIdx.x * 128 + wave * 32 + l31;        // query index inside the block
+  const int qrow = blockIdx.x * 128 + wave * 16 + lq;          // query index inside the block
   const bool q_ok = qrow < T;
 
   const long long qs = p.q_index ? p.q_index[e] : e;
   const long long ks = p.kv_index ? p.kv_index[e] : e;
+  const long long os = p.out_index ? p.out_index[e] : e;
   const long long head_off = (long long)hd * D * ld + (long long)blk * T;
   const long long win = ((long long)(D - 1) * ld + T) * 4;     // bytes spanned by a [D][T] window of pitch ld
   const csn_rsrc_t Rr = csn_make_rsrc(p.q + qs * p.q_shape_stride + head_off, win);
   const csn_rsrc_t Ar = csn_make_rsrc((BWD ? p.v : p.k) + ks * p.kv_shape_stride + head_off, win);
   const csn_rsrc_t Br = csn_make_rsrc((BWD ? p.k : p.v) + ks * p.kv_shape_stride + head_off, win);
-  const csn_rsrc_t Or = csn_make_rsrc(p.out + (long long)e * p.out_eval_stride + head_off, win);
+  const csn_rsrc_t Or = csn_make_rsrc(p.out + os * p.out_eval_stride + head_off, win);
   const long long stat_off = ((long long)e * p.H + hd) * ((long long)p.n_blocks * T) + (long long)blk * T;
   const long long sc_off = (((long long)e * p.H + hd) * p.n_blocks + blk) * ((long long)T * Tp);
   const bool have_scores = p.scores != nullptr;
   const csn_rsrc_t Sr = csn_make_rsrc(have_scores ? p.scores + sc_off : nullptr, have_scores ? (long long)T * Tp * 4 : 0);
   const csn_rsrc_t dSr = csn_make_rsrc(BWD ? p.dscores + sc_off : nullptr, BWD ? (long long)T * Tp * 4 : 0);
 
-  // per-lane byte offsets (switched off for query rows beyond the block)
-  // (scalar offsets handed to the buffer instructions must be wave-uniform, so everything that
-  //  depends on the lane half h lives in the per-lane offset)
-  const unsigned q_off = q_ok ? (unsigned)qrow * 4u : CSN_OOB;
-  const unsigned r_off = q_ok ? (unsigned)(h * ld + qrow) * 4u : CSN_OOB;        // row 2 s + h
-  const unsigned o_off = q_ok ? (unsigned)(4 * h * ld + qrow) * 4u : CSN_OOB;    // row .. + 4 h
+  // per-lane byte offsets (scalar offsets handed to the buffer instructions must be wave-uniform, so
+  // everything that depends on the lane lives here); lanes of query rows beyond the block are switched off
+  const unsigned r_off = q_ok ? (unsigned)(kq * ld + qrow) * 4u : CSN_OOB;        // rows 4 s + kq
+  const unsigned o_off = q_ok ? (unsigned)(4 * kq * ld + qrow) * 4u : CSN_OOB;    // rows 16 c + 4 kq + r
 
-  // ---- register-resident operand R[d][q]: lane (q, h) keeps rows d = 2 s + h ------------------
-  float R[D / 2];
+  // ---- register-resident operand R[d][q]: lane (q, kq) keeps rows d = 4 s + kq ----------------
+  float R[D / 4];
 #pragma unroll
-  for (int s = 0; s < D / 2; ++s) R[s] = csn_bload(Rr, r_off, (unsigned)(2 * s) * ld * 4u);
+  for (int s = 0; s < D / 4; ++s) R[s] = csn_bload(Rr, r_off, (unsigned)(4 * s) * ld * 4u);
 
-  f32x16 O[DT];
+  f32x4v O[D / 16];
 #pragma unroll
-  for (int c = 0; c < DT; ++c)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) O[c][r] = 0.f;
+  for (int c = 0; c < D / 16; ++c) O[c] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-  float m_run = -INFINITY, l_run = 0.f;       // forward: running max / partial sum of this lane half
+  float m_run = -INFINITY, l_run = 0.f;       // forward: running max / partial sum of this lane's key quarter
   float lse_q = 0.f, delta_q = 0.f;           // backward: per-query constants
   if (BWD) {
     lse_q = q_ok ? p.lse[stat_off + qrow] : 0.f;
     delta_q = q_ok ? p.delta[stat_off + qrow] : 0.f;
   }
 
-  // ---- streamed tiles: global -> registers -> LDS ----------------------------------------------
-  // thread t moves, for i < DT, the 16 bytes at row (t + 256 i) / 8, keys 4 ((t + 256 i) % 8) ..+3
-  unsigned t_off[DT];
+  // ---- streamed tiles: global -> registers -> LDS (swizzled) ---------------------------------------
+  // piece idx = tid + 512 i  ->  row idx / 8, keys 4 (idx % 8) .. +3
   const int t_c = (tid & 7) * 4;
+  unsigned t_off[NP_T];
+  int a_dst[NP_T], b_dst[NP_T];
 #pragma unroll
-  for (int i = 0; i < DT; ++i) t_off[i] = (unsigned)(((tid + 256 * i) >> 3) * ld + t_c) * 4u;
-
-  f32x4 g[DT];
+  for (int i = 0; i < NP_T; ++i) {
+    const int idx = tid + 512 * i, row = idx >> 3;
+    t_off[i] = idx < PIECES ? (unsigned)(row * ld + t_c) * 4u : CSN_OOB;
+    a_dst[i] = row * KT + (t_c ^ (16 * (row & 1)));                    // key half swapped on odd rows
+    b_dst[i] = row * KT + 4 * ((tid & 7) ^ ((row >> 1) & 7));          // 16-byte chunk ^ (row >> 1) & 7
+  }
+  f32x4 g[NP_T];
   auto fetch = [&](const csn_rsrc_t& rs, int kt) {
     const int k0 = kt * KT;
     // T % 4 == 0: a 16-byte piece is all in or all out; pieces past the block end are switched off
     const unsigned poison = (k0 + t_c) < T ? 0u : CSN_OOB;
 #pragma unroll
-    for (int i = 0; i < DT; ++i) g[i] = csn_bload4(rs, t_off[i] | poison, (unsigned)k0 * 4u);
+    for (int i = 0; i < NP_T; ++i) g[i] = csn_bload4(rs, t_off[i] | poison, (unsigned)k0 * 4u);
   };
   auto commitA = [&](int st) {
 #pragma unroll
-    for (int i = 0; i < DT; ++i)
-      *reinterpret_cast<f32x4*>(&tileA[st][((tid + 256 * i) >> 3) * KT + t_c]) = g[i];
+    for (int i = 0; i < NP_T; ++i)
+      if (NP_T * 512 == PIECES || tid + 512 * i < PIECES) *reinterpret_cast<f32x4*>(&tileA[st][a_dst[i]]) = g[i];
   };
   auto commitB = [&](int st) {
 #pragma unroll
-    for (int i = 0; i < DT; ++i)
-      *reinterpret_cast<f32x4*>(&tileB[st][((tid + 256 * i) >> 3) * LDB + t_c]) = g[i];
+    for (int i = 0; i < NP_T; ++i)
+      if (NP_T * 512 == PIECES || tid + 512 * i < PIECES) *reinterpret_cast<f32x4*>(&tileB[st][b_dst[i]]) = g[i];
   };
+
+  // fragment read positions (lane constants)
+  const int a_col0 = (16 * (0 ^ (kq & 1))) + lq, a_col1 = (16 * (1 ^ (kq & 1))) + lq;      // tileA, key tiles j = 0, 1
+  const int b_ch0 = 4 * ((0 + kq) ^ ((lq >> 1) & 7)), b_ch1 = 4 * ((4 + kq) ^ ((lq >> 1) & 7));  // tileB chunks
 
   const int nkt = (T + KT - 1) / KT;
   fetch(Ar, 0); commitA(0);
@@ -122,81 +139,83 @@ __global__ __launch_bounds__(256, 1) void csn_attn_f32_kernel(CsnAttnArgs p) {
     const bool more = kt + 1 < nkt;
     if (more) fetch(Ar, kt + 1);
 
-    // backward: the saved scores of this tile, requested early so they land under phase 1
-    float sv[16];
-    unsigned s_off[16];
+    // score positions of this lane: tile j, reg r  ->  key kt*32 + 16 j + 4 kq + r
+    unsigned s_off[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kt * KT + csn_acc_row(r, h);
-      s_off[r] = (q_ok && key < T) ? (unsigned)(key * Tp + qrow) * 4u : CSN_OOB;
-    }
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * KT + 16 * j + 4 * kq + r;
+        s_off[4 * j + r] = (q_ok && key < T) ? (unsigned)(key * Tp + qrow) * 4u : CSN_OOB;
+      }
+    float sv[8];
     if (BWD) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sv[r] = csn_bload(Sr, s_off[r]);
+      for (int r = 0; r < 8; ++r) sv[r] = csn_bload(Sr, s_off[r]);     // saved scores, requested early
     }
 
     // ---- phase 1: T1[key][q] = sum_d tileA[d][key] R[d][q] ------------------------------------
-    f32x16 S;
+    f32x4v S0 = {0.f, 0.f, 0.f, 0.f}, S1 = {0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ tA = &tileA[cur][kq * KT];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) S[r] = 0.f;
-    const float* __restrict__ tA = &tileA[cur][h * KT + l31];
-#pragma unroll
-    for (int s = 0; s < D / 2; ++s) S = csn_mfma(tA[2 * s * KT], R[s], S);
+    for (int s = 0; s < D / 4; ++s) {
+      S0 = mfma16(tA[4 * s * KT + a_col0], R[s], S0);
+      S1 = mfma16(tA[4 * s * KT + a_col1], R[s], S1);
+    }
 
     if (more) { commitA(nxt); fetch(Br, kt + 1); }
 
     // ---- pointwise ----------------------------------------------------------------------------
+    float t1[8] = {S0[0], S0[1], S0[2], S0[3], S1[0], S1[1], S1[2], S1[3]};
     if (!BWD) {
       float mx = -INFINITY;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * KT + csn_acc_row(r, h);
-        if (key >= T) S[r] = -INFINITY;
-        csn_bstore(S[r], Sr, s_off[r]);             // (zero-sized window when scores are not kept)
-        mx = fmaxf(mx, S[r]);
+      for (int r = 0; r < 8; ++r) {
+        const int key = kt * KT + 16 * (r >> 2) + 4 * kq + (r & 3);
+        if (key >= T) t1[r] = -INFINITY;
+        csn_bstore(t1[r], Sr, s_off[r]);             // (zero-sized window when scores are not kept)
+        mx = fmaxf(mx, t1[r]);
       }
-      mx = fmaxf(mx, csn_xhalf(mx));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       // lazy rescale: only when some query's running maximum would grow by more than the threshold
       if (__any(mx > m_run + p.rescale_threshold)) {
         const float m_new = fmaxf(m_run, mx);
         const float alpha = (m_new == -INFINITY) ? 1.f : expf(m_run - m_new);
 #pragma unroll
-        for (int c = 0; c < DT; ++c)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) O[c][r] *= alpha;
+        for (int c = 0; c < D / 16; ++c) O[c] *= alpha;
         l_run *= alpha;
         m_run = m_new;
       }
       float ps = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = expf(S[r] - m_run);        // masked keys: exp(-inf) = 0
-        S[r] = pv;
-        ps += pv;
+      for (int r = 0; r < 8; ++r) {
+        t1[r] = expf(t1[r] - m_run);                 // masked keys: exp(-inf) = 0
+        ps += t1[r];
       }
       l_run += ps;
     } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < 8; ++r) {
         const bool ok = s_off[r] != CSN_OOB;
-        const float pv = ok ? expf(sv[r] - lse_q) : 0.f;          // softmax probability (csa_models.py:141)
-        const float ds = pv * (S[r] - delta_q);                    // d softmax
+        const float pv = ok ? expf(sv[r] - lse_q) : 0.f;           // softmax probability (csa_models.py:141)
+        const float ds = pv * (t1[r] - delta_q);                   // d softmax
         csn_bstore(pv, Sr, s_off[r]);
         csn_bstore(ds, dSr, s_off[r]);
-        S[r] = ds;
+        t1[r] = ds;
       }
     }
 
     // ---- phase 2: OUT[c][q] += sum_key tileB[c][key] T1[key][q] --------------------------------
-    const float* __restrict__ tB = &tileB[cur][l31 * LDB + 4 * h];
+    const float* __restrict__ tB = &tileB[cur][lq * KT];
 #pragma unroll
-    for (int c = 0; c < DT; ++c) {
+    for (int c = 0; c < D / 16; ++c) {
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(&tB[c * 16 * KT + b_ch0]);
+      const f32x4 a1 = *reinterpret_cast<const f32x4*>(&tB[c * 16 * KT + b_ch1]);
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(&tB[c * 32 * LDB + 8 * gq]);
+      for (int r = 0; r < 4; ++r) O[c] = mfma16(a0[r], t1[r], O[c]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) O[c] = csn_mfma(a[i], S[4 * gq + i], O[c]);
-      }
+      for (int r = 0; r < 4; ++r) O[c] = mfma16(a1[r], t1[4 + r], O[c]);
     }
 
     if (more) commitB(nxt);
@@ -206,22 +225,27 @@ __global__ __launch_bounds__(256, 1) void csn_attn_f32_kernel(CsnAttnArgs p) {
   // ---- epilogue -----------------------------------------------------------------------------------
   float inv = 1.f;
   if (!BWD) {
-    const float l_tot = l_run + csn_xhalf(l_run);
+    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
     inv = 1.f / l_tot;
-    if (q_ok && h == 0 && p.lse) p.lse[stat_off + qrow] = m_run + logf(l_tot);
+    if (q_ok && kq == 0 && p.lse) p.lse[stat_off + qrow] = m_run + logf(l_tot);
   }
 #pragma unroll
-  for (int c = 0; c < DT; ++c)
+  for (int c = 0; c < D / 16; ++c)
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      csn_bstore(O[c][r] * inv, Or, o_off, (unsigned)(c * 32 + csn_acc_row(r, 0)) * ld * 4u);
+    for (int r = 0; r < 4; ++r) {
+      float v = O[c][r] * inv;
+      const unsigned so = (unsigned)(c * 16 + r) * ld * 4u;
+      if (p.accumulate) v += csn_bload(Or, o_off, so);
+      csn_bstore(v, Or, o_off, so);
+    }
 }
 
 template <int DT>
 int launch_dt(const CsnAttnArgs& a, bool bwd, hipStream_t st) {
   dim3 grid((a.T + 127) / 128, a.n_blocks * a.H, a.E);
-  if (bwd) hipLaunchKernelGGL((csn_attn_f32_kernel<DT, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((csn_attn_f32_kernel<DT, false>), grid, dim3(256), 0, st, a);
+  if (bwd) hipLaunchKernelGGL((csn_attn_f32_kernel<DT, true>), grid, dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((csn_attn_f32_kernel<DT, false>), grid, dim3(512), 0, st, a);
   return (int)hipGetLastError();
 }
 

@@ -40,7 +40,7 @@ int wgrad(const float* a, long long a_stride, int lda, const float* b, long long
   g.C = operand(ws, (long long)rows * cols, 0, (long long)n_chunks * rows * cols, nullptr, cols);
   g.M = rows; g.N = cols; g.K = n_points;
   g.n0 = n_chunks; g.n1 = 1; g.k_chunk = chunk;
-  g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = 0;
+  g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = 0; g.eval_ids = nullptr;
   int rc = csn_launch_gemm_f32(g, /*b_is_nk=*/1, (int)slabs, st);
   if (rc) return rc;
   return csn_launch_slab_reduce(ws, dw, (int)slabs, (long long)rows * cols, scale, accumulate, st);
@@ -85,7 +85,7 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
   g.C = operand(out, 0, 0, out_shape_stride, nullptr, ld_out);
   g.M = rows; g.N = n_points; g.K = channels;
   g.n0 = 1; g.n1 = 1; g.k_chunk = 0;
-  g.alpha = 1.f; g.div_rows = div_rows; g.div_val = temperature; g.accumulate = 0;
+  g.alpha = 1.f; g.div_rows = div_rows; g.div_val = temperature; g.accumulate = 0; g.eval_ids = nullptr;
   return csn_launch_gemm_f32(g, /*b_is_nk=*/0, n_shapes, (hipStream_t)stream);
 }
 
@@ -108,56 +108,65 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
   a.scores = scores; a.dscores = nullptr; a.lse = lse; a.delta = nullptr;
   a.E = n_evals; a.H = n_heads; a.T = block; a.Tp = score_pitch; a.n_blocks = n_blocks;
   a.rescale_threshold = rescale_threshold;
+  a.eval_ids = nullptr; a.out_index = nullptr; a.accumulate = 0;
   return csn_launch_attn_fwd_f32(a, d_head, (hipStream_t)stream);
 }
 
-int csn_block_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* q,
-                           const float* k, const float* v, long long q_shape_stride, long long kv_shape_stride,
-                           const int* q_index, const int* kv_index, int ld, float* scores, float* dscores,
-                           const float* lse, float* delta, float* dq, float* dk, float* dv,
-                           long long grad_eval_stride, int n_evals, int n_heads, int d_head, int block,
-                           int n_blocks, int score_pitch, void* stream) {
-  if (!dctx || !ctx || !q || !k || !v || !scores || !dscores || !lse || !delta || !dq || !dk || !dv) return CSN_E_ARG;
-  if (n_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
+int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* k,
+                              const float* v, long long kv_shape_stride, const int* kv_index, int ld, float* scores,
+                              float* dscores, const float* lse, float* delta, float* dq, long long dq_slot_stride,
+                              const int* dq_index, int accumulate, const int* eval_ids, int n_launch_evals, int n_heads,
+                              int d_head, int block, int n_blocks, int score_pitch, void* stream) {
+  if (!dctx || !ctx || !k || !v || !scores || !dscores || !lse || !delta || !dq) return CSN_E_ARG;
+  if (n_launch_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
   if (!dim_ok(d_head)) return CSN_E_DIM;
   if ((ld & 3) || (block & 3) || (score_pitch & 3) || score_pitch < block) return CSN_E_ALIGN;
-  if (mis16(dctx) || mis16(q) || mis16(k) || mis16(v) || mis16(scores) || mis16(dscores) || mis16(dq) || mis16(dk) ||
-      mis16(dv))
-    return CSN_E_PTR;
-  if ((q_shape_stride & 3) || (kv_shape_stride & 3) || (ctx_eval_stride & 3) || (grad_eval_stride & 3)) return CSN_E_STRIDE;
+  if (mis16(dctx) || mis16(k) || mis16(v) || mis16(scores) || mis16(dscores) || mis16(dq)) return CSN_E_PTR;
+  if ((kv_shape_stride & 3) || (ctx_eval_stride & 3) || (dq_slot_stride & 3)) return CSN_E_STRIDE;
   hipStream_t st = (hipStream_t)stream;
-  const int n_points = n_blocks * block;
-  const int D = n_heads * d_head;
   // delta[e][h][n] = sum_c dctx * ctx   (softmax backward row constant)
-  int rc = csn_launch_rowdot_f32(dctx, ctx, delta, n_evals, n_heads, d_head, ld, n_points, ctx_eval_stride, st);
+  int rc = csn_launch_rowdot_f32(dctx, ctx, delta, eval_ids, n_launch_evals, n_heads, d_head, ld, n_blocks * block,
+                                 ctx_eval_stride, st);
   if (rc) return rc;
-  // dP -> dS, P (in place of S), dQs
   CsnAttnArgs a;
   a.q = dctx; a.k = k; a.v = v;
   a.q_shape_stride = ctx_eval_stride; a.kv_shape_stride = kv_shape_stride;
   a.q_index = nullptr; a.kv_index = kv_index; a.ld = ld;
-  a.out = dq; a.out_eval_stride = grad_eval_stride;
+  a.out = dq; a.out_eval_stride = dq_slot_stride;
   a.scores = scores; a.dscores = dscores; a.lse = const_cast<float*>(lse); a.delta = delta;
-  a.E = n_evals; a.H = n_heads; a.T = block; a.Tp = score_pitch; a.n_blocks = n_blocks;
+  a.E = n_launch_evals; a.H = n_heads; a.T = block; a.Tp = score_pitch; a.n_blocks = n_blocks;
   a.rescale_threshold = 0.f;
-  rc = csn_launch_attn_bwd_f32(a, d_head, st);
-  if (rc) return rc;
-  // dV^T[c][key] = sum_q dO^T[c][q] P^T[key][q]   and   dK^T[d][key] = sum_q Qs^T[d][q] dS^T[key][q]
+  a.eval_ids = eval_ids; a.out_index = dq_index; a.accumulate = accumulate;
+  return csn_launch_attn_bwd_f32(a, d_head, st);
+}
+
+int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
+                               const int* q_index, int ld, const float* probs, const float* dscores, float* dk,
+                               float* dv, long long dkv_slot_stride, const int* dk_index, const int* dv_index,
+                               int accumulate, const int* eval_ids, int n_launch_evals, int n_heads, int d_head,
+                               int block, int n_blocks, int score_pitch, void* stream) {
+  if (!dctx || !q || !probs || !dscores || !dk || !dv) return CSN_E_ARG;
+  if (n_launch_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
+  if (!dim_ok(d_head)) return CSN_E_DIM;
+  if ((ld & 3) || (block & 3) || (score_pitch & 3) || score_pitch < block) return CSN_E_ALIGN;
+  if (mis16(dctx) || mis16(q) || mis16(probs) || mis16(dscores) || mis16(dk) || mis16(dv)) return CSN_E_PTR;
+  if ((q_shape_stride & 3) || (ctx_eval_stride & 3) || (dkv_slot_stride & 3)) return CSN_E_STRIDE;
+  hipStream_t st = (hipStream_t)stream;
+  // dV^T[c][key] (+)= sum_q dO^T[c][q] P^T[key][q]   and   dK^T[d][key] (+)= sum_q Qs^T[d][q] dS^T[key][q]
   const long long blk_sc = (long long)block * score_pitch;
   CsnGemmArgs g;
   g.M = d_head; g.N = block; g.K = block;
   g.n0 = n_blocks; g.n1 = n_heads; g.k_chunk = 0;
-  g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = 0;
+  g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = accumulate; g.eval_ids = eval_ids;
   g.A = operand(dctx, block, (long long)d_head * ld, ctx_eval_stride, nullptr, ld);
-  g.B = operand(scores, blk_sc, blk_sc * n_blocks, blk_sc * n_blocks * n_heads, nullptr, score_pitch);
-  g.C = operand(dv, block, (long long)d_head * ld, grad_eval_stride, nullptr, ld);
-  rc = csn_launch_gemm_f32(g, 1, n_blocks * n_heads * n_evals, st);
+  g.B = operand(probs, blk_sc, blk_sc * n_blocks, blk_sc * n_blocks * n_heads, nullptr, score_pitch);
+  g.C = operand(dv, block, (long long)d_head * ld, dkv_slot_stride, dv_index, ld);
+  int rc = csn_launch_gemm_f32(g, 1, n_blocks * n_heads * n_launch_evals, st);
   if (rc) return rc;
   g.A = operand(q, block, (long long)d_head * ld, q_shape_stride, q_index, ld);
   g.B = operand(dscores, blk_sc, blk_sc * n_blocks, blk_sc * n_blocks * n_heads, nullptr, score_pitch);
-  g.C = operand(dk, block, (long long)d_head * ld, grad_eval_stride, nullptr, ld);
-  (void)D;
-  return csn_launch_gemm_f32(g, 1, n_blocks * n_heads * n_evals, st);
+  g.C = operand(dk, block, (long long)d_head * ld, dkv_slot_stride, dk_index, ld);
+  return csn_launch_gemm_f32(g, 1, n_blocks * n_heads * n_launch_evals, st);
 }
 
 int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const float* wfc, const float* xres,
@@ -200,7 +209,7 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
   g.C = operand(dctx, 0, 0, ctx_eval_stride, nullptr, ld);
   g.M = d_inner; g.N = n_points; g.K = d_model;
   g.n0 = 1; g.n1 = 1; g.k_chunk = 0;
-  g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = 0;
+  g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = 0; g.eval_ids = nullptr;
   rc = csn_launch_gemm_f32(g, 0, n_evals, st);
   if (rc) return rc;
   // dwfc[c][D] (+)= sum_{e,n} dz[e][c][n] ctx[e][D][n]

@@ -75,6 +75,7 @@ struct CsnOperand {
   int ld;
 };
 
+// z2 is first mapped through the launch's evaluation list (if any), then through the operand's own slot map
 CSN_DEVINL float* csn_operand_base(const CsnOperand& o, int z0, int z1, int z2) {
   long long i2 = o.idx2 ? (long long)o.idx2[z2] : (long long)z2;
   return o.ptr + o.s0 * z0 + o.s1 * z1 + o.s2 * i2;

@@ -12,6 +12,7 @@ struct CsnGemmArgs {
   int div_rows;      // output rows m < div_rows are divided by div_val (query scaling, csa_models.py:139)
   float div_val;
   int accumulate;    // C += result
+  const int* eval_ids;   // optional: blockIdx.z's slowest index z2 -> evaluation id, applied before the operands' idx2
 };
 
 int csn_launch_gemm_f32(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st);
@@ -32,6 +33,9 @@ struct CsnAttnArgs {
   const float* delta;                                    // backward: rowsum(dO*O) [e][h][n_blocks*T]
   int E, H, T, Tp, n_blocks;
   float rescale_threshold;
+  const int* eval_ids;                                   // launch z -> evaluation id (nullptr: identity); E = launch size
+  const int* out_index;                                  // evaluation -> output slot (nullptr: the evaluation itself)
+  int accumulate;                                        // out += result (several evaluations share an output slot)
 };
 int csn_launch_attn_fwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
 int csn_launch_attn_bwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
@@ -57,8 +61,8 @@ struct CsnLnBwdArgs {
 int csn_launch_ln_bwd_f32(const CsnLnBwdArgs& a, hipStream_t st);
 
 // delta[e][h][n] = sum_{c in head h} a[e][c][n] * b[e][c][n]
-int csn_launch_rowdot_f32(const float* a, const float* b, float* out, int E, int H, int d, int ld, int n_points,
-                          long long eval_stride, hipStream_t st);
+int csn_launch_rowdot_f32(const float* a, const float* b, float* out, const int* eval_ids, int E, int H, int d, int ld,
+                          int n_points, long long eval_stride, hipStream_t st);
 
 // ---- pooled descriptors / cross-shape mix (combine.hip) ---------------------------------------------
 int csn_launch_rowsum_f32(const float* x, float* out, long long rows, int n, long long ld, hipStream_t st);

@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_f32_kernel(CsnGemmArgs p) {
 
   int z = blockIdx.z;
   const int z0 = z % p.n0; z /= p.n0;
-  const int z1 = z % p.n1; const int z2 = z / p.n1;
+  const int z1 = z % p.n1;
+  const int z2 = p.eval_ids ? p.eval_ids[z / p.n1] : z / p.n1;
   const int lda = p.A.ld, ldb = p.B.ld, ldc = p.C.ld;
   const int M = p.M, N = p.N;
   int K = p.K;

@@ -63,6 +63,37 @@ class MHAGeometry:
         return (self.block + 31) // 32 * 32
 
 
+class EvalPlan:
+    """Host-side description of a batch of evaluations over shared slots (the shape graph of one step).
+
+    ``q_slots[e]`` / ``kv_slots[e]``: which slot evaluation e takes its queries / keys+values from
+    (values from slot ``kv_slots[e] + v_shift``).  Evaluations that share an output slot in the backward
+    pass (the query shape's Q serves K+1 evaluations, a neighbour's K/V two) are split into *colours*: within
+    a colour every output slot occurs once, so a colour is one launch that adds into the per-slot gradient
+    maps without atomics and without per-evaluation temporaries."""
+
+    def __init__(self, q_slots, kv_slots, n_slots: int, device, v_shift: int = 0):
+        import numpy as np
+        q = np.asarray(q_slots, dtype=np.int64).reshape(-1)
+        kv = np.asarray(kv_slots, dtype=np.int64).reshape(-1)
+        assert q.shape == kv.shape and q.size > 0
+        assert q.min() >= 0 and max(q.max(), kv.max() + v_shift) < n_slots
+        self.E, self.S, self.v_shift = int(q.size), int(n_slots), int(v_shift)
+        as_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+        self.q_slots, self.kv_slots, self.v_slots = as_dev(q), as_dev(kv), as_dev(kv + v_shift)
+        self.dq_colors = [as_dev(c) for c in self._colors(q)]
+        self.dkv_colors = [as_dev(c) for c in self._colors(kv)]
+
+    @staticmethod
+    def _colors(slots):
+        import numpy as np
+        seen, rank = {}, np.zeros(slots.size, dtype=np.int64)
+        for e, s in enumerate(slots.tolist()):
+            rank[e] = seen.get(s, 0)
+            seen[s] = rank[e] + 1
+        return [np.nonzero(rank == c)[0] for c in range(int(rank.max()) + 1)]
+
+
 # ------------------------------------------------------------------------------------------------------
 # raw (non-differentiable) calls — thin, typed views of the C ABI
 # ------------------------------------------------------------------------------------------------------
@@ -123,14 +154,15 @@ class _MHAEvals(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x_all, w_qs, w_ks, w_vs, w_fc, q_slots, kv_slots, geo: MHAGeometry, keep_scores: bool,
-                v_shift: int = 0):
-        _need_cuda(x_all, w_qs, w_ks, w_vs, w_fc, q_slots, kv_slots)
+    def forward(ctx, x_all, w_qs, w_ks, w_vs, w_fc, plan: EvalPlan, geo: MHAGeometry, keep_scores: bool):
+        _need_cuda(x_all, w_qs, w_ks, w_vs, w_fc)
+        q_slots, kv_slots, v_shift = plan.q_slots, plan.kv_slots, plan.v_shift
         L = _lib.lib()
         S, C, NP = x_all.shape
         H, d, D = geo.n_head, geo.d_head, geo.d_inner
         assert NP == geo.n_points and x_all.is_contiguous()
-        E = q_slots.numel()
+        assert S == plan.S
+        E = plan.E
         T, nb, Tp = geo.block, geo.n_blocks, geo.score_pitch
         dev = x_all.device
         temperature = float(d) ** 0.5                                  # csa_models.py:54
@@ -162,19 +194,20 @@ class _MHAEvals(torch.autograd.Function):
                                             _ptr(xhat), C * NP, _ptr(rstd), E, C, D, NP, NP, LN_EPS, _stream()),
                    "csn_outproj_ln_fwd_f32")
         if keep_scores:
-            ctx.save_for_backward(x_all, w_qkv, w_fc, q_slots, kv_slots, qkv, att, lse, scores, xhat, rstd)
+            ctx.save_for_backward(x_all, w_qkv, w_fc, qkv, att, lse, scores, xhat, rstd)
             ctx.geo = geo
-            ctx.v_shift = v_shift
+            ctx.plan = plan
         return xhat
 
     @staticmethod
     def backward(ctx, dxhat):
-        x_all, w_qkv, w_fc, q_slots, kv_slots, qkv, att, lse, scores, xhat, rstd = ctx.saved_tensors
+        x_all, w_qkv, w_fc, qkv, att, lse, scores, xhat, rstd = ctx.saved_tensors
         geo: MHAGeometry = ctx.geo
+        plan: EvalPlan = ctx.plan
         L = _lib.lib()
         S, C, NP = x_all.shape
         H, d, D = geo.n_head, geo.d_head, geo.d_inner
-        E = q_slots.numel()
+        E = plan.E
         T, nb, Tp = geo.block, geo.n_blocks, geo.score_pitch
         dev = x_all.device
         dxhat = dxhat.contiguous()
@@ -192,29 +225,25 @@ class _MHAEvals(torch.autograd.Function):
                                             NP, NP, 0, _stream()), "csn_outproj_ln_bwd_f32")
         del ws
 
-        # ---- attention backward ----------------------------------------------------------------------------
+        # ---- attention backward, straight into per-slot gradient maps ---------------------------------------
+        # evaluations that share a slot (Q of the query shape, K/V of each neighbour) add up: one launch per colour
         dscores = torch.empty_like(scores)
         delta = torch.empty((E, H, NP), device=dev, dtype=torch.float32)
-        dq = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
-        dk = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
-        dv = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
+        dqkv = torch.zeros((S, 3 * D, NP), device=dev, dtype=torch.float32)
         slot_stride = 3 * D * NP
-        base = qkv.data_ptr()
-        v_base = base + 8 * D * NP + 4 * ctx.v_shift * slot_stride
-        _lib.check(L.csn_block_attn_bwd_f32(_ptr(datt), _ptr(att), D * NP, base, base + 4 * D * NP, v_base,
-                                            slot_stride, slot_stride, _ptr(q_slots), _ptr(kv_slots), NP, _ptr(scores),
-                                            _ptr(dscores), _ptr(lse), _ptr(delta), _ptr(dq), _ptr(dk), _ptr(dv),
-                                            D * NP, E, H, d, T, nb, Tp, _stream()), "csn_block_attn_bwd_f32")
+        base, gbase = qkv.data_ptr(), dqkv.data_ptr()
+        v_base = base + 8 * D * NP + 4 * plan.v_shift * slot_stride
+        for ids in plan.dq_colors:
+            _lib.check(L.csn_block_attn_bwd_dq_f32(_ptr(datt), _ptr(att), D * NP, base + 4 * D * NP, v_base, slot_stride,
+                                                   _ptr(plan.kv_slots), NP, _ptr(scores), _ptr(dscores), _ptr(lse),
+                                                   _ptr(delta), gbase, slot_stride, _ptr(plan.q_slots), 1, _ptr(ids),
+                                                   ids.numel(), H, d, T, nb, Tp, _stream()), "csn_block_attn_bwd_dq_f32")
+        for ids in plan.dkv_colors:
+            _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, base, slot_stride, _ptr(plan.q_slots), NP,
+                                                    _ptr(scores), _ptr(dscores), gbase + 4 * D * NP, gbase + 8 * D * NP,
+                                                    slot_stride, _ptr(plan.kv_slots), _ptr(plan.v_slots), 1, _ptr(ids),
+                                                    ids.numel(), H, d, T, nb, Tp, _stream()), "csn_block_attn_bwd_dkv_f32")
         del dscores, delta, datt
-
-        # ---- evaluations that share a slot add up (Q of the query shape, K/V of each neighbour) -------------
-        dqkv = torch.zeros((S, 3, D * NP), device=dev, dtype=torch.float32)
-        qi, ki = q_slots.long(), kv_slots.long()
-        dqkv[:, 0].index_add_(0, qi, dq.view(E, D * NP))
-        dqkv[:, 1].index_add_(0, ki, dk.view(E, D * NP))
-        dqkv[:, 2].index_add_(0, ki + ctx.v_shift, dv.view(E, D * NP))
-        del dq, dk, dv
-        dqkv = dqkv.view(S, 3 * D, NP)
 
         # ---- projection weight gradients ------------------------------------------------------------------
         dw_qkv = project_wgrad(dqkv, x_all)
@@ -226,14 +255,14 @@ class _MHAEvals(torch.autograd.Function):
             # residual path + the three projections (not needed by the reference's training: inputs are constants)
             dqkv[:, :D] /= temperature
             dx_all = project(dqkv, w_qkv.t().contiguous())
-            dx_all.index_add_(0, qi, dz)
-        return dx_all, dw_q, dw_k, dw_v, dw_fc, None, None, None, None, None
+            dx_all.index_add_(0, plan.q_slots.long(), dz)
+        return dx_all, dw_q, dw_k, dw_v, dw_fc, None, None, None
 
 
 def mha_evals(x_all: torch.Tensor, w_qs: torch.Tensor, w_ks: torch.Tensor, w_vs: torch.Tensor, w_fc: torch.Tensor,
-              q_slots: torch.Tensor, kv_slots: torch.Tensor, geo: MHAGeometry, v_shift: int = 0) -> torch.Tensor:
+              plan: EvalPlan, geo: MHAGeometry) -> torch.Tensor:
     keep = torch.is_grad_enabled() and any(t.requires_grad for t in (x_all, w_qs, w_ks, w_vs, w_fc))
-    return _MHAEvals.apply(x_all, w_qs, w_ks, w_vs, w_fc, q_slots, kv_slots, geo, keep, v_shift)
+    return _MHAEvals.apply(x_all, w_qs, w_ks, w_vs, w_fc, plan, geo, keep)
 
 
 # ------------------------------------------------------------------------------------------------------

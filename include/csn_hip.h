@@ -68,17 +68,29 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
                            void* stream);
 
 /* ---- (3) block attention, backward (autograd of csa_models.py:139-142) -------------------------------
- * In:  dctx (gradient of ctx), ctx, q/k/v as in forward, scores (S^T from forward), lse.
- * Out: scores is overwritten with P^T, dscores receives dS^T (same geometry), delta is a
- *      [n_evals][n_heads][n_blocks*block] scratch (rowsum(dctx*ctx)),
- *      dq/dk/dv [n_evals][n_heads*d_head][ld] per-evaluation gradients w.r.t. Qs, K, V
- *      (the caller sums evaluations that share a slot). */
-int csn_block_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* q,
-                           const float* k, const float* v, long long q_shape_stride, long long kv_shape_stride,
-                           const int* q_index, const int* kv_index, int ld, float* scores, float* dscores,
-                           const float* lse, float* delta, float* dq, float* dk, float* dv,
-                           long long grad_eval_stride, int n_evals, int n_heads, int d_head, int block,
-                           int n_blocks, int score_pitch, void* stream);
+ * Two calls, because their outputs are shared differently between evaluations (the query shape's Q serves
+ * K+1 evaluations, a neighbour's K/V serve two): each call processes the `n_launch_evals` evaluations listed in
+ * `eval_ids` (NULL = 0..n-1) and writes into per-SLOT gradient maps, adding to them when `accumulate` != 0.  The
+ * caller groups evaluations so that no two evaluations of one call share an output slot.
+ *
+ * csn_block_attn_bwd_dq_f32:  in  dctx, ctx [eval][n_heads*d_head][ld], k/v + kv_index as in forward,
+ *                                 scores (S^T from forward), lse;
+ *                             out scores := P^T (in place), dscores := dS^T (same geometry),
+ *                                 delta [eval][n_heads][n_blocks*block] scratch = rowsum(dctx*ctx),
+ *                                 dq[dq_index[e]] (+)= dS K   — gradient w.r.t. the pre-scaled queries Qs.
+ * csn_block_attn_bwd_dkv_f32: in  dctx, q + q_index as in forward, probs (= scores after the dq call), dscores;
+ *                             out dv[dv_index[e]] (+)= P^T dctx,  dk[dk_index[e]] (+)= dS^T Qs.
+ * dq/dk/dv point at row 0 of the [n_heads*d_head][ld] gradient map of slot 0; *_slot_stride in floats. */
+int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* k,
+                              const float* v, long long kv_shape_stride, const int* kv_index, int ld, float* scores,
+                              float* dscores, const float* lse, float* delta, float* dq, long long dq_slot_stride,
+                              const int* dq_index, int accumulate, const int* eval_ids, int n_launch_evals, int n_heads,
+                              int d_head, int block, int n_blocks, int score_pitch, void* stream);
+int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
+                               const int* q_index, int ld, const float* probs, const float* dscores, float* dk,
+                               float* dv, long long dkv_slot_stride, const int* dk_index, const int* dv_index,
+                               int accumulate, const int* eval_ids, int n_launch_evals, int n_heads, int d_head,
+                               int block, int n_blocks, int score_pitch, void* stream);
 
 /* ---- (4) output projection + residual + LayerNorm, forward -------------------------------------------
  * z[c][n] = sum_D wfc[c][D] ctx[e][D][n] + xres[res_index[e]][c][n];  xhat = (z - mean_c z) * rstd,

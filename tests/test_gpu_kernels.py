@@ -156,10 +156,14 @@ def test_block_attn_bwd(L, S, E, H, d, T, nb):
     dscores = torch.full_like(scores, float("nan"))
     delta = torch.empty((E, H, N), device="cuda")
     dq, dk, dv = (torch.full((E, D, N), float("nan"), device="cuda") for _ in range(3))
-    rc = L.lib().csn_block_attn_bwd_f32(dd.data_ptr(), ctx.data_ptr(), D * N, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(),
-                                        D * N, D * N, qi.data_ptr(), ki.data_ptr(), N, scores.data_ptr(),
-                                        dscores.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(),
-                                        dv.data_ptr(), D * N, E, H, d, T, nb, Tp, _stream())
+    # per-evaluation outputs: identity slot maps, no accumulation (the module path uses slot maps + colours)
+    rc = L.lib().csn_block_attn_bwd_dq_f32(dd.data_ptr(), ctx.data_ptr(), D * N, kd.data_ptr(), vd.data_ptr(), D * N,
+                                           ki.data_ptr(), N, scores.data_ptr(), dscores.data_ptr(), lse.data_ptr(),
+                                           delta.data_ptr(), dq.data_ptr(), D * N, None, 0, None, E, H, d, T, nb, Tp, _stream())
+    L.check(rc, "attn bwd dq")
+    rc = L.lib().csn_block_attn_bwd_dkv_f32(dd.data_ptr(), D * N, qd.data_ptr(), D * N, qi.data_ptr(), N, scores.data_ptr(),
+                                            dscores.data_ptr(), dk.data_ptr(), dv.data_ptr(), D * N, None, None, 0, None, E,
+                                            H, d, T, nb, Tp, _stream())
     L.check(rc, "attn bwd")
     torch.cuda.synchronize()
     # float64 autograd reference, per evaluation (no sharing: the ABI returns per-evaluation gradients)
@@ -175,6 +179,28 @@ def test_block_attn_bwd(L, S, E, H, d, T, nb):
     # scores now hold P^T
     p_ref = torch.softmax(_attn_reference(q.double(), k.double(), v.double(), q_idx, kv_idx, H, d, T, nb)[2].transpose(-1, -2), dim=-1)
     assert (scores[..., :T].cpu().double().transpose(-1, -2) - p_ref).abs().max().item() < 2e-6
+
+    # slot-indexed accumulation: evaluations listed in two disjoint colours, gradients summed per slot
+    qi64, ki64 = torch.from_numpy(q_idx).long(), torch.from_numpy(kv_idx).long()
+    ref_dq = torch.zeros(S, D, N, dtype=torch.float64).index_add_(0, qi64, q64.grad)
+    ref_dk = torch.zeros(S, D, N, dtype=torch.float64).index_add_(0, ki64, k64.grad)
+    ref_dv = torch.zeros(S, D, N, dtype=torch.float64).index_add_(0, ki64, v64.grad)
+    from csn_amd.functional import EvalPlan
+    plan = EvalPlan(q_idx, kv_idx, S, "cuda")
+    _, _, scores2, _ = _run_attn_fwd(L, q, k, v, q_idx, kv_idx, H, d, T, nb)
+    sq, sk, sv_ = (torch.zeros((S, D, N), device="cuda") for _ in range(3))
+    for ids in plan.dq_colors:
+        L.check(L.lib().csn_block_attn_bwd_dq_f32(dd.data_ptr(), ctx.data_ptr(), D * N, kd.data_ptr(), vd.data_ptr(), D * N,
+                                                  ki.data_ptr(), N, scores2.data_ptr(), dscores.data_ptr(), lse.data_ptr(),
+                                                  delta.data_ptr(), sq.data_ptr(), D * N, qi.data_ptr(), 1, ids.data_ptr(),
+                                                  ids.numel(), H, d, T, nb, Tp, _stream()))
+    for ids in plan.dkv_colors:
+        L.check(L.lib().csn_block_attn_bwd_dkv_f32(dd.data_ptr(), D * N, qd.data_ptr(), D * N, qi.data_ptr(), N,
+                                                   scores2.data_ptr(), dscores.data_ptr(), sk.data_ptr(), sv_.data_ptr(), D * N,
+                                                   ki.data_ptr(), ki.data_ptr(), 1, ids.data_ptr(), ids.numel(), H, d, T, nb,
+                                                   Tp, _stream()))
+    torch.cuda.synchronize()
+    assert _maxerr(sq, ref_dq) < 2e-5 and _maxerr(sk, ref_dk) < 2e-5 and _maxerr(sv_, ref_dv) < 2e-5
 
 
 def _attn_reference_autograd(q, k, v, H, d, T, nb):
