@@ -230,15 +230,24 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
     inv = 1.f / l_tot;
     if (q_ok && kq == 0 && p.lse) p.lse[stat_off + qrow] = m_run + logf(l_tot);
   }
+  if (p.accumulate) {
+    // several evaluations share this output slot: fetch all previous partial sums first (one batch of loads in
+    // flight), then add and store — a load/add/store chain per element would serialise 64 memory round trips
+    f32x4v prev[D / 16];
+#pragma unroll
+    for (int c = 0; c < D / 16; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) prev[c][r] = csn_bload(Or, o_off, (unsigned)(c * 16 + r) * ld * 4u);
+#pragma unroll
+    for (int c = 0; c < D / 16; ++c) O[c] = O[c] * inv + prev[c];
+  } else {
+#pragma unroll
+    for (int c = 0; c < D / 16; ++c) O[c] *= inv;
+  }
 #pragma unroll
   for (int c = 0; c < D / 16; ++c)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float v = O[c][r] * inv;
-      const unsigned so = (unsigned)(c * 16 + r) * ld * 4u;
-      if (p.accumulate) v += csn_bload(Or, o_off, so);
-      csn_bstore(v, Or, o_off, so);
-    }
+    for (int r = 0; r < 4; ++r) csn_bstore(O[c][r], Or, o_off, (unsigned)(c * 16 + r) * ld * 4u);
 }
 
 template <int DT>

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_f32_kernel(CsnGemmArgs p) {
   }
 
   const float alpha = p.alpha;
+  unsigned c_off[MT][NT][16];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -146,13 +147,30 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_f32_kernel(CsnGemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ml = wm0 + 32 * i + csn_acc_row(r, h);
-        const unsigned off = ((m0 + ml) < M && (n0 + nl) < N) ? (unsigned)(ml * ldc + nl) * 4u : CSN_OOB;
+        c_off[i][j][r] = ((m0 + ml) < M && (n0 + nl) < N) ? (unsigned)(ml * ldc + nl) * 4u : CSN_OOB;
         float v = acc[i][j][r] * alpha;
         if ((m0 + ml) < p.div_rows) v = v / p.div_val;     // q / temperature (csa_models.py:139)
-        if (p.accumulate) v += csn_bload(Cr, off);
-        csn_bstore(v, Cr, off);
+        acc[i][j][r] = v;
       }
     }
+  if (p.accumulate) {
+    // batch the read-modify-write: all loads in flight first, then add + store
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        f32x16 prev;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) prev[r] = csn_bload(Cr, c_off[i][j][r]);
+        acc[i][j] += prev;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) csn_bstore(acc[i][j][r], Cr, c_off[i][j][r]);
 }
 
 // out[i] = alpha * sum_z slab[z][i]  (+ out[i] if accumulate) — closes a split-K weight gradient.

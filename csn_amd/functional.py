@@ -83,6 +83,9 @@ class EvalPlan:
         self.q_slots, self.kv_slots, self.v_slots = as_dev(q), as_dev(kv), as_dev(kv + v_shift)
         self.dq_colors = [as_dev(c) for c in self._colors(q)]
         self.dkv_colors = [as_dev(c) for c in self._colors(kv)]
+        # when every slot is some evaluation's query slot and some evaluation's key/value slot, the first colour of
+        # each pass overwrites the whole gradient map: no zero fill and no read-modify-write for that colour
+        self.full_cover = (v_shift == 0 and np.unique(q).size == n_slots and np.unique(kv).size == n_slots)
 
     @staticmethod
     def _colors(slots):
@@ -229,19 +232,22 @@ class _MHAEvals(torch.autograd.Function):
         # evaluations that share a slot (Q of the query shape, K/V of each neighbour) add up: one launch per colour
         dscores = torch.empty_like(scores)
         delta = torch.empty((E, H, NP), device=dev, dtype=torch.float32)
-        dqkv = torch.zeros((S, 3 * D, NP), device=dev, dtype=torch.float32)
+        full = plan.full_cover
+        dqkv = (torch.empty if full else torch.zeros)((S, 3 * D, NP), device=dev, dtype=torch.float32)
         slot_stride = 3 * D * NP
         base, gbase = qkv.data_ptr(), dqkv.data_ptr()
         v_base = base + 8 * D * NP + 4 * plan.v_shift * slot_stride
-        for ids in plan.dq_colors:
+        for ci, ids in enumerate(plan.dq_colors):
             _lib.check(L.csn_block_attn_bwd_dq_f32(_ptr(datt), _ptr(att), D * NP, base + 4 * D * NP, v_base, slot_stride,
                                                    _ptr(plan.kv_slots), NP, _ptr(scores), _ptr(dscores), _ptr(lse),
-                                                   _ptr(delta), gbase, slot_stride, _ptr(plan.q_slots), 1, _ptr(ids),
+                                                   _ptr(delta), gbase, slot_stride, _ptr(plan.q_slots),
+                                                   0 if (full and ci == 0) else 1, _ptr(ids),
                                                    ids.numel(), H, d, T, nb, Tp, _stream()), "csn_block_attn_bwd_dq_f32")
-        for ids in plan.dkv_colors:
+        for ci, ids in enumerate(plan.dkv_colors):
             _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, base, slot_stride, _ptr(plan.q_slots), NP,
                                                     _ptr(scores), _ptr(dscores), gbase + 4 * D * NP, gbase + 8 * D * NP,
-                                                    slot_stride, _ptr(plan.kv_slots), _ptr(plan.v_slots), 1, _ptr(ids),
+                                                    slot_stride, _ptr(plan.kv_slots), _ptr(plan.v_slots),
+                                                    0 if (full and ci == 0) else 1, _ptr(ids),
                                                     ids.numel(), H, d, T, nb, Tp, _stream()), "csn_block_attn_bwd_dkv_f32")
         del dscores, delta, datt
 
