@@ -55,8 +55,9 @@ def masked_ce(logits, label):
     return torch.nn.functional.cross_entropy(flat[keep], lab[keep])
 
 
-def cpu_baseline(K, sample_shapes, threads):
-    """Oracle's faithful port (20 x 500 chunk loop, growing cat, 2K+2 MHA calls) on the host, fwd + bwd."""
+def cpu_baseline(K, sample_shapes, threads, dropout=True):
+    """Oracle's faithful port (20 x 500 chunk loop, growing cat, 2K+2 MHA calls) on the host, fwd + bwd,
+    in the same mode as the headline run (train mode: both dropouts live, csa_training.py:192)."""
     from oracle import csa_oracle as orc
     torch.set_num_threads(threads)
     rng = np.random.default_rng(99)
@@ -69,7 +70,9 @@ def cpu_baseline(K, sample_shapes, threads):
     def step():
         for v in p.values():
             v.grad = None
-        logits = orc.forward_csa(x, nb, p, H, mha=lambda a, b, c, pp, h, **kw: orc.mha_faithful(a, b, c, pp, h))
+        pd = 0.1 if dropout else 0.0
+        logits = orc.forward_csa(x, nb, p, H, mha=lambda a, b, c, pp, h, **kw: orc.mha_faithful(a, b, c, pp, h, p_attn_drop=pd,
+                                                                                                   p_out_drop=pd))
         orc.masked_ce_loss(logits, lab).backward()
 
     step()
@@ -80,7 +83,7 @@ def cpu_baseline(K, sample_shapes, threads):
         times.append(time.perf_counter() - t0)
     t = sorted(times)[1]
     return {"value": sample_shapes * N_POINTS / t, "unit": "points/s", "cores": threads, "kind": "port",
-            "sample": f"{sample_shapes} of the 32 query shapes (K={K}, eval-mode arithmetic, fwd+bwd), median of 3 steps after "
+            "sample": f"{sample_shapes} of the 32 query shapes (K={K}, {'train mode, dropout 0.1' if dropout else 'eval-mode arithmetic'}, fwd+bwd), median of 3 steps after "
                       f"1 warm-up, {t:.2f} s/step; oracle/csa_oracle.py mha_faithful"}
 
 
@@ -115,7 +118,7 @@ def main():
     B, K = args.shapes, args.K
     S = B * world
     torch.manual_seed(0)
-    model = get_model("csa", N_CLS, H, K).to(dev).eval()      # eval-mode arithmetic (dropout off), gradients on
+    model = get_model("csa", N_CLS, H, K).to(dev)
     params = [p for n, p in model.named_parameters() if not n.startswith("fc_1")]
 
     rng = np.random.default_rng(1234 + 2 + 1000 * rank)
@@ -151,43 +154,57 @@ def main():
             shard.allreduce_grads(params)                                # one 1.6 MB bucket
         return loss
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step(record=True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
+    def timed(train_mode):
+        """W warm-up + K timed steps, barrier + synchronize on both sides, max over ranks."""
+        model.train(train_mode)                                          # train: dropout p = 0.1 live (csa_training.py:192)
+        attn_events.clear()
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step(record=True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = tmax.item()
+        ms = float(np.mean([a.elapsed_time(b) for a, b in attn_events])) if attn_events else float("nan")
+        return el, float(loss.item()), ms
+
+    elapsed_eval, loss_eval, _ = timed(False)          # secondary: eval-mode arithmetic (dropout off), gradients on
+    elapsed, loss_val, attn_ms = timed(True)           # headline: the training step as the reference runs it
+    n_evals = B * (2 * K + 2)                          # train mode: the pooled and the mixed self evaluation differ
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = S * N_POINTS * args.steps / elapsed
-        attn_ms = float(np.mean([a.elapsed_time(b) for a, b in attn_events])) if attn_events else float("nan")
-        achieved = attn_fwd_flops(B, K) / (attn_ms * 1e-3) / 1e12
+        launch_flops = n_evals * 4 * N_POINTS * T * H * D_HEAD       # QK^T + PV of every evaluation in the launch
+        achieved = launch_flops / (attn_ms * 1e-3) / 1e12
         out = {
             "metric": "CSA fwd+bwd points/sec (10k pts x 256 ch, K=3)", "value": value, "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"CSA K={K}, {B} query shapes/GPU x {N_POINTS} pts x {C} ch, n_heads={H}, d_k=d_v={D_HEAD}, "
-                                   f"20 blocks of {T}, {N_CLS} classes, fwd + masked CE + bwd, dropout off (eval arithmetic)",
+                                   f"20 blocks of {T}, {N_CLS} classes, fwd + masked CE + bwd, train mode (dropout 0.1 live, 2K+2 evaluations/shape)",
                        "shapes_total": S, "K": K, "parallelism": f"shape-graph sharded x{world}" if world > 1 else "single GPU",
-                       "loss": float(loss.item()),
+                       "loss": loss_val,
+                       "dropout_off": {"points_per_s": S * N_POINTS * args.steps / elapsed_eval,
+                                       "ms_per_step": elapsed_eval / args.steps * 1e3, "loss": loss_eval,
+                                       "note": "same step with eval-mode arithmetic (2K+1 evaluations/shape), gradients on"},
                        "step_tflops_algorithmic": 3 * algorithmic_flops_fwd(S, K) / (elapsed / args.steps) / 1e12},
             "roofline": {"bound": "mfma", "kernel": "csn_attn_f32_kernel<8,false> (fused block attention forward)",
                          "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
-                         "launch_ms": attn_ms, "flops_per_launch": attn_fwd_flops(B, K)},
+                         "launch_ms": attn_ms, "flops_per_launch": launch_flops,
+                         "note": "512 kFLOP per query point per evaluation x 10000 points x evaluations in the launch"},
         }
         if world == 1 and not args.no_cpu_baseline:
             cores = min(len(os.sched_getaffinity(0)), 16)          # the GPU box gives one GPU a 16-core share

@@ -9,7 +9,7 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
-from ctypes import c_char_p, c_float, c_int, c_longlong, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_longlong, c_ulonglong, c_void_p
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -61,18 +61,20 @@ _SIGNATURES = {
                                 c_int, c_int, c_int, c_float, c_void_p]),
     "csn_block_attn_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_void_p, c_void_p, c_int,
                                        c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                       c_int, c_float, c_void_p]),
+                                       c_int, c_float, c_float, c_ulonglong, c_void_p]),
     "csn_block_attn_bwd_dq_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_int,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_int,
-                                          c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                                          c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_ulonglong,
+                                          c_void_p]),
     "csn_block_attn_bwd_dkv_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                            c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "csn_outproj_ln_fwd_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p,
-                                       c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+                                       c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+                                       c_ulonglong, c_void_p]),
     "csn_outproj_ln_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p,
-                                       c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int,
-                                       c_int, c_int, c_void_p]),
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int,
+                                       c_int, c_int, c_int, c_float, c_ulonglong, c_void_p]),
     "csn_project_wgrad_f32": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_longlong, c_int, c_void_p, c_int, c_int,
                                       c_int, c_int, c_float, c_int, c_void_p, c_longlong, c_void_p]),
     "csn_retrieval_measure_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
@@ -98,7 +100,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.csn_version() != 1:
+        if handle.csn_version() != 2:
             raise CsnError("libcsn_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -53,10 +53,8 @@ class ScaledDotProductAttention(nn.Module):
         self.dropout = nn.Dropout(attn_dropout)
 
     def forward(self, q, k, v):
-        if self.training and self.dropout.p > 0:
-            raise NotImplementedError("attention dropout is not wired into the HIP path yet; use .eval() or p = 0")
         from .sdpa import sdpa_block
-        return sdpa_block(q, k, v, float(self.temperature))
+        return sdpa_block(q, k, v, float(self.temperature), self.dropout.p if self.training else 0.0)
 
 
 class MultiHeadAttention(nn.Module):
@@ -81,15 +79,15 @@ class MultiHeadAttention(nn.Module):
         return CF.MHAGeometry(self.n_head, self.d_k, self.block if block is None else block,
                               self.n_blocks if n_blocks is None else n_blocks)
 
-    def _check_mode(self):
-        if self.training and (self.dropout.p > 0 or self.attention.dropout.p > 0):
-            raise NotImplementedError("dropout is not wired into the HIP path yet; call .eval() or build with dropout=0")
+    def dropout_rates(self):
+        """(attention-probability p, post-fc p): live only in train mode (csa_models.py:133-141, 56, 115)."""
+        return (self.attention.dropout.p, self.dropout.p) if self.training else (0.0, 0.0)
 
     def evaluate(self, x_all: torch.Tensor, plan: CF.EvalPlan, geo: Optional[CF.MHAGeometry] = None) -> torch.Tensor:
         """Normalised (pre-affine) outputs (E, C, NP) of a batch of evaluations over shared slots."""
-        self._check_mode()
+        p_attn, p_fc = self.dropout_rates()
         return CF.mha_evals(x_all, self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight,
-                            plan, geo or self.geometry())
+                            plan, geo or self.geometry(), p_attn, p_fc)
 
     def plan(self, kind: str, B: int, K1: int, dev) -> CF.EvalPlan:
         """Cached evaluation plans (slot maps live on the device; building one costs a few small H2D copies)."""
@@ -111,6 +109,14 @@ class MultiHeadAttention(nn.Module):
                 mix_q, mix_kv = (b * K1).reshape(-1), (b * K1 + k).reshape(-1)
                 nbr = (b * K1 + k)[:, 1:].reshape(-1)
                 cache[key] = CF.EvalPlan(np.concatenate((mix_q, nbr)), np.concatenate((mix_kv, nbr)), B * K1, dev)
+            elif kind == "csa_train":
+                # with dropout live the reference's two self calls (:210 for the pooled descriptor, :232 for the mix)
+                # draw different masks, so the pooled self evaluation is a separate, last group [.. + b]
+                b, k = np.meshgrid(ar, np.arange(K1), indexing="ij")
+                mix_q, mix_kv = (b * K1).reshape(-1), (b * K1 + k).reshape(-1)
+                nbr = (b * K1 + k)[:, 1:].reshape(-1)
+                own = ar * K1
+                cache[key] = CF.EvalPlan(np.concatenate((mix_q, nbr, own)), np.concatenate((mix_kv, nbr, own)), B * K1, dev)
             else:
                 raise ValueError(kind)
         return cache[key]
@@ -245,12 +251,14 @@ class CrossShapeAt(nn.Module):
             x_all[:, 1:] = nb[:, 1:, :, :npts].to(dev, non_blocking=True)      # neighbours may arrive on the CPU (:216)
         x_all = x_all.view(B * K1, C, npts)
 
-        xhat = att.evaluate(x_all, att.plan("csa", B, K1, dev), geo)          # (E, C, NP)
-        E1 = B * K1
+        train = any(r > 0 for r in att.dropout_rates())
+        xhat = att.evaluate(x_all, att.plan("csa_train" if train else "csa", B, K1, dev), geo)          # (E, C, NP)
+        E1, E2 = B * K1, B * K
         gamma, beta = att.norm.weight, att.norm.bias
         # pooled descriptors y_k = mean_n SSA(x_k)  (:211-212, :218-219); the affine commutes with the mean
         means = CF.point_mean(xhat)                                            # (E, C), fp64-accumulated on the device
-        pooled_hat = torch.cat((means[:E1].view(B, K1, C)[:, :1], means[E1:].view(B, K, C)), dim=1)
+        own = means[E1 + E2:].view(B, 1, C) if train else means[:E1].view(B, K1, C)[:, :1]
+        pooled_hat = torch.cat((own, means[E1:E1 + E2].view(B, K, C)), dim=1)
         pooled = pooled_hat * gamma + beta                                     # (B, K+1, C)
         comp = self._compatibility(pooled)                                     # (B, K+1)
         feats = CF.csa_mix(xhat, comp, gamma, beta, B, K1)                     # sum_k comp_k * affine(xhat_k)  (:233, :238)

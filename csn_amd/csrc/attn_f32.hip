@@ -87,6 +87,11 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
 #pragma unroll
   for (int c = 0; c < D / 16; ++c) O[c] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
+  // attention-probability dropout (csa_models.py:141): P_drop = mask * P / (1 - p); element index = position in `scores`
+  const bool drop = p.dropout_p > 0.f;
+  const unsigned thr24 = csn_drop_threshold(p.dropout_p);
+  const float keep_scale = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
+
   float m_run = -INFINITY, l_run = 0.f;       // forward: running max / partial sum of this lane's key quarter
   float lse_q = 0.f, delta_q = 0.f;           // backward: per-query constants
   if (BWD) {
@@ -193,14 +198,26 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
         t1[r] = expf(t1[r] - m_run);                 // masked keys: exp(-inf) = 0
         ps += t1[r];
       }
-      l_run += ps;
+      l_run += ps;                                   // the softmax denominator sees every key, dropped or not
+      if (drop) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int key = kt * KT + 16 * (r >> 2) + 4 * kq + (r & 3);
+          t1[r] = csn_keep((unsigned long long)(sc_off + (long long)key * Tp + qrow), p.seed, thr24) ? t1[r] * keep_scale : 0.f;
+        }
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const bool ok = s_off[r] != CSN_OOB;
         const float pv = ok ? expf(sv[r] - lse_q) : 0.f;           // softmax probability (csa_models.py:141)
-        const float ds = pv * (t1[r] - delta_q);                   // d softmax
-        csn_bstore(pv, Sr, s_off[r]);
+        float md = 1.f;                                            // d P_drop / d P
+        if (drop) {
+          const int key = kt * KT + 16 * (r >> 2) + 4 * kq + (r & 3);
+          md = csn_keep((unsigned long long)(sc_off + (long long)key * Tp + qrow), p.seed, thr24) ? keep_scale : 0.f;
+        }
+        const float ds = pv * (t1[r] * md - delta_q);              // d softmax (delta = rowsum(dO * O) already has the mask)
+        csn_bstore(pv * md, Sr, s_off[r]);                         // what the dV product needs: the dropped probabilities
         csn_bstore(ds, dSr, s_off[r]);
         t1[r] = ds;
       }

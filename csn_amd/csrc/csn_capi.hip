@@ -93,7 +93,8 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
                            long long kv_shape_stride, const int* q_index, const int* kv_index, int ld, float* ctx,
                            long long ctx_eval_stride, float* scores, float* lse, int n_evals, int n_heads,
                            int d_head, int block, int n_blocks, int score_pitch, float rescale_threshold,
-                           void* stream) {
+                           float dropout_p, unsigned long long seed, void* stream) {
+  if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
   if (!q || !k || !v || !ctx || n_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
   if (!dim_ok(d_head)) return CSN_E_DIM;
   if ((ld & 3) || (block & 3) || (score_pitch & 3) || score_pitch < block) return CSN_E_ALIGN;
@@ -109,6 +110,7 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
   a.E = n_evals; a.H = n_heads; a.T = block; a.Tp = score_pitch; a.n_blocks = n_blocks;
   a.rescale_threshold = rescale_threshold;
   a.eval_ids = nullptr; a.out_index = nullptr; a.accumulate = 0;
+  a.dropout_p = dropout_p; a.seed = seed;
   return csn_launch_attn_fwd_f32(a, d_head, (hipStream_t)stream);
 }
 
@@ -116,7 +118,9 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
                               const float* v, long long kv_shape_stride, const int* kv_index, int ld, float* scores,
                               float* dscores, const float* lse, float* delta, float* dq, long long dq_slot_stride,
                               const int* dq_index, int accumulate, const int* eval_ids, int n_launch_evals, int n_heads,
-                              int d_head, int block, int n_blocks, int score_pitch, void* stream) {
+                              int d_head, int block, int n_blocks, int score_pitch, float dropout_p,
+                              unsigned long long seed, void* stream) {
+  if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
   if (!dctx || !ctx || !k || !v || !scores || !dscores || !lse || !delta || !dq) return CSN_E_ARG;
   if (n_launch_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
   if (!dim_ok(d_head)) return CSN_E_DIM;
@@ -137,6 +141,7 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
   a.E = n_launch_evals; a.H = n_heads; a.T = block; a.Tp = score_pitch; a.n_blocks = n_blocks;
   a.rescale_threshold = 0.f;
   a.eval_ids = eval_ids; a.out_index = dq_index; a.accumulate = accumulate;
+  a.dropout_p = dropout_p; a.seed = seed;
   return csn_launch_attn_bwd_f32(a, d_head, st);
 }
 
@@ -172,7 +177,8 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
 int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const float* wfc, const float* xres,
                            long long xres_shape_stride, const int* res_index, float* xhat,
                            long long xhat_eval_stride, float* rstd, int n_evals, int d_model, int d_inner, int ld,
-                           int n_points, float eps, void* stream) {
+                           int n_points, float eps, float dropout_p, unsigned long long seed, void* stream) {
+  if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
   if (!ctx || !wfc || !xres || !xhat || !rstd || n_evals <= 0 || n_points <= 0 || d_inner <= 0) return CSN_E_ARG;
   if (!dim_ok(d_model)) return CSN_E_DIM;
   if ((ld & 3) || (d_inner & 3) || (n_points & 3)) return CSN_E_ALIGN;
@@ -183,13 +189,16 @@ int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const fl
   a.xres = xres; a.xres_shape_stride = xres_shape_stride; a.res_index = res_index;
   a.xhat = xhat; a.xhat_eval_stride = xhat_eval_stride; a.rstd = rstd;
   a.E = n_evals; a.C = d_model; a.D = d_inner; a.ld = ld; a.n_points = n_points; a.eps = eps;
+  a.dropout_p = dropout_p; a.seed = seed;
   return csn_launch_outproj_ln_fwd_f32(a, (hipStream_t)stream);
 }
 
 int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* rstd, long long eval_stride,
-                           const float* ctx, long long ctx_eval_stride, const float* wfc_t, float* dz, float* dctx,
-                           float* dwfc, float* ws, long long ws_floats, int n_evals, int d_model, int d_inner,
-                           int ld, int n_points, int accumulate, void* stream) {
+                           const float* ctx, long long ctx_eval_stride, const float* wfc_t, float* dz, float* dz_res,
+                           float* dctx, float* dwfc, float* ws, long long ws_floats, int n_evals, int d_model,
+                           int d_inner, int ld, int n_points, int accumulate, float dropout_p,
+                           unsigned long long seed, void* stream) {
+  if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
   if (!dxhat || !xhat || !rstd || !ctx || !wfc_t || !dz || !dctx || !dwfc || !ws) return CSN_E_ARG;
   if (n_evals <= 0 || n_points <= 0 || d_inner <= 0 || d_model <= 0) return CSN_E_ARG;
   if ((ld & 3) || (d_inner & 3) || (d_model & 3) || (n_points & 3)) return CSN_E_ALIGN;
@@ -198,8 +207,9 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
   if ((eval_stride & 3) || (ctx_eval_stride & 3)) return CSN_E_STRIDE;
   hipStream_t st = (hipStream_t)stream;
   CsnLnBwdArgs l;
-  l.dxhat = dxhat; l.xhat = xhat; l.rstd = rstd; l.dz = dz; l.eval_stride = eval_stride;
+  l.dxhat = dxhat; l.xhat = xhat; l.rstd = rstd; l.dz = dz; l.dz_res = dz_res; l.eval_stride = eval_stride;
   l.E = n_evals; l.C = d_model; l.ld = ld; l.n_points = n_points;
+  l.dropout_p = dropout_p; l.seed = seed;
   int rc = csn_launch_ln_bwd_f32(l, st);
   if (rc) return rc;
   // dctx[e][D][n] = wfc_t[D][c] dz[e][c][n]

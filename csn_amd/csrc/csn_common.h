@@ -81,5 +81,21 @@ CSN_DEVINL float* csn_operand_base(const CsnOperand& o, int z0, int z1, int z2) 
   return o.ptr + o.s0 * z0 + o.s1 * z1 + o.s2 * i2;
 }
 
+// ---- dropout masks ------------------------------------------------------------------------------------
+// Counter-based: the keep/drop decision of an element is a pure function of (seed, 64-bit element index), so the
+// backward pass regenerates the forward's mask instead of storing it.  Two rounds of the murmur3 32-bit
+// finaliser over the index words and the seed words; keep  <=>  top 24 bits >= p * 2^24.
+// (tests/dropout_ref.py restates this function in numpy; keep the two in step.)
+CSN_DEVINL unsigned csn_mix32(unsigned h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+CSN_DEVINL bool csn_keep(unsigned long long idx, unsigned long long seed, unsigned thr24) {
+  unsigned h = csn_mix32((unsigned)idx ^ (unsigned)seed);
+  h = csn_mix32(h + ((unsigned)(idx >> 32) ^ (unsigned)(seed >> 32)) + 0x9e3779b9u);
+  return (h >> 8) >= thr24;
+}
+CSN_DEVINL unsigned csn_drop_threshold(float p) { return (unsigned)(p * 16777216.0f); }
+
 // sum / max across the two 32-lane halves of a wave (lane l <-> lane l ^ 32)
 CSN_DEVINL float csn_xhalf(float v) { return __shfl_xor(v, 32, 64); }

@@ -36,6 +36,8 @@ struct CsnAttnArgs {
   const int* eval_ids;                                   // launch z -> evaluation id (nullptr: identity); E = launch size
   const int* out_index;                                  // evaluation -> output slot (nullptr: the evaluation itself)
   int accumulate;                                        // out += result (several evaluations share an output slot)
+  float dropout_p;                                       // attention-probability dropout (csa_models.py:141); 0 = off
+  unsigned long long seed;
 };
 int csn_launch_attn_fwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
 int csn_launch_attn_bwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
@@ -49,14 +51,19 @@ struct CsnOutProjArgs {
   float* rstd;                                           // [e][n_points]
   int E, C, D, ld, n_points;
   float eps;
+  float dropout_p;                                       // dropout on the fc output (csa_models.py:115); 0 = off
+  unsigned long long seed;
 };
 int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, hipStream_t st);
 
 struct CsnLnBwdArgs {
   const float* dxhat; const float* xhat; const float* rstd;   // [e][C][ld], [e][C][ld], [e][n_points]
-  float* dz;                                                   // [e][C][ld]
+  float* dz;                                                   // [e][C][ld]  gradient w.r.t. the fc output (dropout mask applied)
+  float* dz_res;                                               // optional: gradient w.r.t. the residual input (no mask)
   long long eval_stride;
   int E, C, ld, n_points;
+  float dropout_p;
+  unsigned long long seed;
 };
 int csn_launch_ln_bwd_f32(const CsnLnBwdArgs& a, hipStream_t st);
 

@@ -93,6 +93,19 @@ __global__ __launch_bounds__(256, 2) void csn_outproj_ln_fwd_kernel(CsnOutProjAr
   const int nl = 32 * wave + l31;
   const bool n_ok = (n0 + nl) < NP;
   const unsigned n_off = n_ok ? (unsigned)(4 * h * ld + nl) * 4u : CSN_OOB;
+  // dropout on the fc output, before the residual add (csa_models.py:115-116); element index = position in xhat
+  if (p.dropout_p > 0.f) {
+    const unsigned thr24 = csn_drop_threshold(p.dropout_p);
+    const float keep_scale = 1.f / (1.f - p.dropout_p);
+    const long long ebase = (long long)e * p.xhat_eval_stride + n0 + nl;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long idx = ebase + (long long)(c * 32 + csn_acc_row(r, h)) * ld;
+        acc[c][r] = csn_keep((unsigned long long)idx, p.seed, thr24) ? acc[c][r] * keep_scale : 0.f;
+      }
+  }
   float sum = 0.f;
 #pragma unroll
   for (int c = 0; c < CT; ++c)
@@ -140,9 +153,17 @@ __global__ __launch_bounds__(256) void csn_ln_bwd_kernel(CsnLnBwdArgs p) {
   }
   const float rstd = p.rstd[(long long)e * p.n_points + n];
   const float m1 = s1 / C, m2 = s2 / C;
+  const bool drop = p.dropout_p > 0.f;
+  const unsigned thr24 = csn_drop_threshold(p.dropout_p);
+  const float keep_scale = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
+  float* __restrict__ dres = p.dz_res ? p.dz_res + (long long)e * p.eval_stride + n : nullptr;
   for (int c = 0; c < C; ++c) {
     const float g = dx[c * ld], x = xh[c * ld];
-    dz[c * ld] = rstd * (g - m1 - x * m2);
+    const float v = rstd * (g - m1 - x * m2);
+    if (dres) dres[c * ld] = v;                                   // the residual branch sees no mask
+    float vf = v;
+    if (drop) vf = csn_keep((unsigned long long)((long long)e * p.eval_stride + n + c * ld), p.seed, thr24) ? v * keep_scale : 0.f;
+    dz[c * ld] = vf;
   }
 }
 

@@ -157,8 +157,11 @@ class _MHAEvals(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x_all, w_qs, w_ks, w_vs, w_fc, plan: EvalPlan, geo: MHAGeometry, keep_scores: bool):
+    def forward(ctx, x_all, w_qs, w_ks, w_vs, w_fc, plan: EvalPlan, geo: MHAGeometry, keep_scores: bool,
+                p_attn: float = 0.0, p_fc: float = 0.0):
         _need_cuda(x_all, w_qs, w_ks, w_vs, w_fc)
+        # dropout masks are counter-based: two 62-bit seeds from torch's CPU generator (torch.manual_seed reproduces them)
+        seed_attn, seed_fc = (torch.randint(0, 2 ** 62, (2,)).tolist() if (p_attn > 0 or p_fc > 0) else (0, 0))
         q_slots, kv_slots, v_shift = plan.q_slots, plan.kv_slots, plan.v_shift
         L = _lib.lib()
         S, C, NP = x_all.shape
@@ -184,7 +187,8 @@ class _MHAEvals(torch.autograd.Function):
             ev0.record()
         _lib.check(L.csn_block_attn_fwd_f32(base, base + 4 * D * NP, v_base, slot_stride, slot_stride,
                                             _ptr(q_slots), _ptr(kv_slots), NP, _ptr(att), D * NP, _ptr(scores),
-                                            _ptr(lse), E, H, d, T, nb, Tp, RESCALE_THRESHOLD, _stream()),
+                                            _ptr(lse), E, H, d, T, nb, Tp, RESCALE_THRESHOLD, p_attn, seed_attn,
+                                            _stream()),
                    "csn_block_attn_fwd_f32")
         if EVENT_SINK is not None:
             ev1 = torch.cuda.Event(enable_timing=True)
@@ -194,12 +198,14 @@ class _MHAEvals(torch.autograd.Function):
         rstd = torch.empty((E, NP), device=dev, dtype=torch.float32)
         w_fc = w_fc.contiguous()
         _lib.check(L.csn_outproj_ln_fwd_f32(_ptr(att), D * NP, _ptr(w_fc), _ptr(x_all), C * NP, _ptr(q_slots),
-                                            _ptr(xhat), C * NP, _ptr(rstd), E, C, D, NP, NP, LN_EPS, _stream()),
+                                            _ptr(xhat), C * NP, _ptr(rstd), E, C, D, NP, NP, LN_EPS, p_fc, seed_fc,
+                                            _stream()),
                    "csn_outproj_ln_fwd_f32")
         if keep_scores:
             ctx.save_for_backward(x_all, w_qkv, w_fc, qkv, att, lse, scores, xhat, rstd)
             ctx.geo = geo
             ctx.plan = plan
+            ctx.drop = (p_attn, seed_attn, p_fc, seed_fc)
         return xhat
 
     @staticmethod
@@ -215,17 +221,20 @@ class _MHAEvals(torch.autograd.Function):
         dev = x_all.device
         dxhat = dxhat.contiguous()
         temperature = float(d) ** 0.5
+        p_attn, seed_attn, p_fc, seed_fc = ctx.drop
+        need_dx = ctx.needs_input_grad[0]
 
         # ---- LayerNorm + fc backward -------------------------------------------------------------------
         dz = torch.empty((E, C, NP), device=dev, dtype=torch.float32)
+        dz_res = torch.empty((E, C, NP), device=dev, dtype=torch.float32) if (need_dx and p_fc > 0) else None
         datt = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
         dw_fc = torch.empty((C, D), device=dev, dtype=torch.float32)
         ws_n = L.csn_wgrad_workspace_floats(C, D, E, NP)
         ws = torch.empty((ws_n,), device=dev, dtype=torch.float32)
         w_fc_t = w_fc.t().contiguous()
         _lib.check(L.csn_outproj_ln_bwd_f32(_ptr(dxhat), _ptr(xhat), _ptr(rstd), C * NP, _ptr(att), D * NP,
-                                            _ptr(w_fc_t), _ptr(dz), _ptr(datt), _ptr(dw_fc), _ptr(ws), ws_n, E, C, D,
-                                            NP, NP, 0, _stream()), "csn_outproj_ln_bwd_f32")
+                                            _ptr(w_fc_t), _ptr(dz), _ptr(dz_res), _ptr(datt), _ptr(dw_fc), _ptr(ws), ws_n,
+                                            E, C, D, NP, NP, 0, p_fc, seed_fc, _stream()), "csn_outproj_ln_bwd_f32")
         del ws
 
         # ---- attention backward, straight into per-slot gradient maps ---------------------------------------
@@ -242,7 +251,8 @@ class _MHAEvals(torch.autograd.Function):
                                                    _ptr(plan.kv_slots), NP, _ptr(scores), _ptr(dscores), _ptr(lse),
                                                    _ptr(delta), gbase, slot_stride, _ptr(plan.q_slots),
                                                    0 if (full and ci == 0) else 1, _ptr(ids),
-                                                   ids.numel(), H, d, T, nb, Tp, _stream()), "csn_block_attn_bwd_dq_f32")
+                                                   ids.numel(), H, d, T, nb, Tp, p_attn, seed_attn, _stream()),
+                       "csn_block_attn_bwd_dq_f32")
         for ci, ids in enumerate(plan.dkv_colors):
             _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, base, slot_stride, _ptr(plan.q_slots), NP,
                                                     _ptr(scores), _ptr(dscores), gbase + 4 * D * NP, gbase + 8 * D * NP,
@@ -257,18 +267,19 @@ class _MHAEvals(torch.autograd.Function):
         dw_k, dw_v = dw_qkv[D:2 * D], dw_qkv[2 * D:]
 
         dx_all = None
-        if ctx.needs_input_grad[0]:
+        if need_dx:
             # residual path + the three projections (not needed by the reference's training: inputs are constants)
             dqkv[:, :D] /= temperature
             dx_all = project(dqkv, w_qkv.t().contiguous())
-            dx_all.index_add_(0, plan.q_slots.long(), dz)
-        return dx_all, dw_q, dw_k, dw_v, dw_fc, None, None, None
+            dx_all.index_add_(0, plan.q_slots.long(), dz if dz_res is None else dz_res)
+        return dx_all, dw_q, dw_k, dw_v, dw_fc, None, None, None, None, None
 
 
 def mha_evals(x_all: torch.Tensor, w_qs: torch.Tensor, w_ks: torch.Tensor, w_vs: torch.Tensor, w_fc: torch.Tensor,
-              plan: EvalPlan, geo: MHAGeometry) -> torch.Tensor:
+              plan: EvalPlan, geo: MHAGeometry, p_attn: float = 0.0, p_fc: float = 0.0) -> torch.Tensor:
+    """p_attn / p_fc: train-mode dropout probabilities of csa_models.py:141 / :115 (0 in eval mode)."""
     keep = torch.is_grad_enabled() and any(t.requires_grad for t in (x_all, w_qs, w_ks, w_vs, w_fc))
-    return _MHAEvals.apply(x_all, w_qs, w_ks, w_vs, w_fc, plan, geo, keep)
+    return _MHAEvals.apply(x_all, w_qs, w_ks, w_vs, w_fc, plan, geo, keep, float(p_attn), float(p_fc))
 
 
 # ------------------------------------------------------------------------------------------------------

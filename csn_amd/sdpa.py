@@ -12,7 +12,7 @@ from . import functional as CF
 
 class _SDPA(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, q, k, v, temperature: float):
+    def forward(ctx, q, k, v, temperature: float, p_drop: float = 0.0):
         CF._need_cuda(q, k, v)
         B, H, T, d = q.shape
         Tk = k.shape[2]
@@ -28,13 +28,16 @@ class _SDPA(torch.autograd.Function):
         lse = torch.empty((S, 1, T), device=q.device, dtype=torch.float32)
         scores = torch.empty((S, 1, 1, T, Tp), device=q.device, dtype=torch.float32)
         L = _lib.lib()
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_drop > 0 else 0
         _lib.check(L.csn_block_attn_fwd_f32(CF._ptr(qm), CF._ptr(km), CF._ptr(vm), d * T, d * T, None, None, T,
                                             CF._ptr(att), d * T, CF._ptr(scores), CF._ptr(lse), S, 1, d, T, 1, Tp,
-                                            CF.RESCALE_THRESHOLD, CF._stream()), "csn_block_attn_fwd_f32")
-        # P[q][key] = exp(S^T[key][q] - lse[q])
+                                            CF.RESCALE_THRESHOLD, p_drop, seed, CF._stream()), "csn_block_attn_fwd_f32")
+        # P[q][key] = exp(S^T[key][q] - lse[q])   (the un-dropped probabilities; with dropout the reference returns the
+        # dropped ones — every caller in the reference discards this tensor)
         prob = torch.exp(scores[:, 0, 0, :, :T] - lse[:, 0, None, :]).transpose(1, 2).reshape(B, H, T, T)
         ctx.save_for_backward(qm, km, vm, att, lse, scores)
         ctx.temperature = temperature
+        ctx.drop = (p_drop, seed)
         ctx.dims = (B, H, T, d, Tp)
         ctx.mark_non_differentiable(prob)
         return att.transpose(1, 2).reshape(B, H, T, d), prob
@@ -52,17 +55,17 @@ class _SDPA(torch.autograd.Function):
         L = _lib.lib()
         _lib.check(L.csn_block_attn_bwd_dq_f32(CF._ptr(datt), CF._ptr(att), d * T, CF._ptr(km), CF._ptr(vm), d * T, None, T,
                                                CF._ptr(work), CF._ptr(dscores), CF._ptr(lse), CF._ptr(delta), CF._ptr(dq),
-                                               d * T, None, 0, None, S, 1, d, T, 1, Tp, CF._stream()),
-                   "csn_block_attn_bwd_dq_f32")
+                                               d * T, None, 0, None, S, 1, d, T, 1, Tp, ctx.drop[0], ctx.drop[1],
+                                               CF._stream()), "csn_block_attn_bwd_dq_f32")
         _lib.check(L.csn_block_attn_bwd_dkv_f32(CF._ptr(datt), d * T, CF._ptr(qm), d * T, None, T, CF._ptr(work),
                                                 CF._ptr(dscores), CF._ptr(dk), CF._ptr(dv), d * T, None, None, 0, None, S, 1,
                                                 d, T, 1, Tp, CF._stream()), "csn_block_attn_bwd_dkv_f32")
         back = lambda g: g.transpose(1, 2).reshape(B, H, T, d)
-        return back(dq) / ctx.temperature, back(dk), back(dv), None
+        return back(dq) / ctx.temperature, back(dk), back(dv), None, None
 
 
-def sdpa_block(q, k, v, temperature: float):
-    return _SDPA.apply(q, k, v, temperature)
+def sdpa_block(q, k, v, temperature: float, p_drop: float = 0.0):
+    return _SDPA.apply(q, k, v, temperature, float(p_drop))
 
 
 def last_block_probabilities(mha, Q, K):

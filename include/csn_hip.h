@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSN_ABI_VERSION 1
+#define CSN_ABI_VERSION 2
 
 #define CSN_E_ARG (-1)     /* null pointer / non-positive size            */
 #define CSN_E_ALIGN (-2)   /* a size or leading dimension is not % 4      */
@@ -60,12 +60,15 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
  *   scores [n_evals][n_heads][n_blocks][block][score_pitch]  raw scores S^T[key][query]; may be NULL
  *          (inference).  score_pitch >= block, % 4.
  * rescale_threshold: the running softmax maximum is only re-based when it grows by more than this
- * (0 = re-base on every key tile); results agree to fp32 rounding for any value <= ~40. */
+ * (0 = re-base on every key tile); results agree to fp32 rounding for any value <= ~40.
+ * dropout_p / seed: train-mode dropout on the probabilities (nn.Dropout(0.1), csa_models.py:133-141):
+ * P_drop = mask * P / (1 - p) with a counter-based mask, a pure function of (seed, position in `scores`), so
+ * the backward call regenerates it from the same (dropout_p, seed).  0 = eval mode. */
 int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
                            long long kv_shape_stride, const int* q_index, const int* kv_index, int ld, float* ctx,
                            long long ctx_eval_stride, float* scores, float* lse, int n_evals, int n_heads,
                            int d_head, int block, int n_blocks, int score_pitch, float rescale_threshold,
-                           void* stream);
+                           float dropout_p, unsigned long long seed, void* stream);
 
 /* ---- (3) block attention, backward (autograd of csa_models.py:139-142) -------------------------------
  * Two calls, because their outputs are shared differently between evaluations (the query shape's Q serves
@@ -75,7 +78,7 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
  *
  * csn_block_attn_bwd_dq_f32:  in  dctx, ctx [eval][n_heads*d_head][ld], k/v + kv_index as in forward,
  *                                 scores (S^T from forward), lse;
- *                             out scores := P^T (in place), dscores := dS^T (same geometry),
+ *                             out scores := P_drop^T (in place; = P^T without dropout), dscores := dS^T,
  *                                 delta [eval][n_heads][n_blocks*block] scratch = rowsum(dctx*ctx),
  *                                 dq[dq_index[e]] (+)= dS K   — gradient w.r.t. the pre-scaled queries Qs.
  * csn_block_attn_bwd_dkv_f32: in  dctx, q + q_index as in forward, probs (= scores after the dq call), dscores;
@@ -85,7 +88,8 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
                               const float* v, long long kv_shape_stride, const int* kv_index, int ld, float* scores,
                               float* dscores, const float* lse, float* delta, float* dq, long long dq_slot_stride,
                               const int* dq_index, int accumulate, const int* eval_ids, int n_launch_evals, int n_heads,
-                              int d_head, int block, int n_blocks, int score_pitch, void* stream);
+                              int d_head, int block, int n_blocks, int score_pitch, float dropout_p,
+                              unsigned long long seed, void* stream);
 int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
                                const int* q_index, int ld, const float* probs, const float* dscores, float* dk,
                                float* dv, long long dkv_slot_stride, const int* dk_index, const int* dv_index,
@@ -96,22 +100,26 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
  * z[c][n] = sum_D wfc[c][D] ctx[e][D][n] + xres[res_index[e]][c][n];  xhat = (z - mean_c z) * rstd,
  * rstd = 1/sqrt(var_c z + eps).   Replaces fc + residual + LayerNorm (csa_models.py:52,57,114-118) up to the
  * LayerNorm's affine (gamma, beta), which the caller applies (it is needed un-applied by the backward).
- *   xhat [n_evals][d_model][ld],  rstd [n_evals][n_points]. */
+ *   xhat [n_evals][d_model][ld],  rstd [n_evals][n_points].
+ * dropout_p / seed: train-mode dropout on the fc output before the residual add (csa_models.py:56,115);
+ * mask = function of (seed, position in xhat).  0 = eval mode. */
 int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const float* wfc, const float* xres,
                            long long xres_shape_stride, const int* res_index, float* xhat,
                            long long xhat_eval_stride, float* rstd, int n_evals, int d_model, int d_inner, int ld,
-                           int n_points, float eps, void* stream);
+                           int n_points, float eps, float dropout_p, unsigned long long seed, void* stream);
 
 /* ---- (5) output projection + LayerNorm, backward -------------------------------------------------------
- * dz   = LayerNorm-backward(dxhat; xhat, rstd)            [n_evals][d_model][ld]  (also = d residual)
+ * dz   = dropout-mask * LayerNorm-backward(dxhat; xhat, rstd)   [n_evals][d_model][ld]  (d fc output)
+ * dz_res = the same without the mask (d residual input); may be NULL when input gradients are not needed
  * dctx = wfc^T dz                                          [n_evals][d_inner][ld]
  * dwfc (+)= sum_{e,n} dz[e][:,n] ctx[e][:,n]^T             [d_model][d_inner]
  * wfc_t is wfc transposed, [d_inner][d_model] row-major.  `ws` is scratch of at least
  * csn_wgrad_workspace_floats(d_model, d_inner, n_evals, n_points) floats.  accumulate != 0 adds into dwfc. */
 int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* rstd, long long eval_stride,
-                           const float* ctx, long long ctx_eval_stride, const float* wfc_t, float* dz, float* dctx,
-                           float* dwfc, float* ws, long long ws_floats, int n_evals, int d_model, int d_inner,
-                           int ld, int n_points, int accumulate, void* stream);
+                           const float* ctx, long long ctx_eval_stride, const float* wfc_t, float* dz, float* dz_res,
+                           float* dctx, float* dwfc, float* ws, long long ws_floats, int n_evals, int d_model,
+                           int d_inner, int ld, int n_points, int accumulate, float dropout_p,
+                           unsigned long long seed, void* stream);
 
 /* ---- (6) projection weight gradient ----------------------------------------------------------------------
  * dw[r][c] (+)= scale * sum_{s,n} dout[s][r][n] * x[s][c][n]        (autograd of csa_models.py:103-105) */

@@ -1,0 +1,35 @@
+"""numpy restatement of the counter-based dropout mask of csn_amd/csrc/csn_common.h (csn_keep) — test infrastructure.
+keep(idx) is a pure function of (seed, 64-bit element index); the kernels regenerate it in the backward pass."""
+import numpy as np
+
+
+def _mix32(h):
+    h = h.astype(np.uint64)
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x85ebca6b)) & np.uint64(0xffffffff)
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xc2b2ae35)) & np.uint64(0xffffffff)
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def keep_mask(idx, seed: int, p: float) -> np.ndarray:
+    """idx: integer array of element indices (< 2**63).  Returns a bool array: True = kept."""
+    idx = np.asarray(idx, dtype=np.uint64)
+    lo, hi = idx & np.uint64(0xffffffff), idx >> np.uint64(32)
+    s0, s1 = np.uint64(seed & 0xffffffff), np.uint64((seed >> 32) & 0xffffffff)
+    h = _mix32(lo ^ s0)
+    h = _mix32((h + (hi ^ s1) + np.uint64(0x9e3779b9)) & np.uint64(0xffffffff))
+    thr = np.uint64(int(np.float32(p) * np.float32(16777216.0)))
+    return (h >> np.uint64(8)) >= thr
+
+
+def attention_mask(E, H, nb, T, Tp, seed, p):
+    """mask[e][h][blk][key][query] for the scores buffer geometry [E][H][nb][T][Tp] (element index = flat position)."""
+    idx = np.arange(E * H * nb * T * Tp, dtype=np.uint64).reshape(E, H, nb, T, Tp)[..., :T]
+    return keep_mask(idx, seed, p)
+
+
+def fc_mask(E, C, N, seed, p):
+    """mask[e][c][n] for the xhat buffer geometry [E][C][N]."""
+    return keep_mask(np.arange(E * C * N, dtype=np.uint64).reshape(E, C, N), seed, p)
