@@ -15,7 +15,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libcsn_hip.so")
-SOURCES = ["gemm_f32.hip", "attn_f32.hip", "outproj_ln.hip", "retrieval.hip", "combine.hip", "csn_capi.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "attn_f32.hip", "outproj_ln.hip", "retrieval.hip", "combine.hip", "csn_capi.hip"]
 HEADERS = ["csn_common.h", "csn_kernels.h", os.path.join("..", "..", "include", "csn_hip.h")]
 ARCH = "gfx950"
 
@@ -55,6 +55,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 _SIGNATURES = {
     "csn_version": (c_int, []),
+    "csn_set_math_mode": (c_int, [c_int]),
+    "csn_get_math_mode": (c_int, []),
     "csn_status_string": (c_char_p, [c_int]),
     "csn_wgrad_workspace_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
     "csn_project_f32": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_int, c_int, c_void_p, c_longlong, c_int,

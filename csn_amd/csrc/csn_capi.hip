@@ -5,6 +5,18 @@
 
 namespace {
 
+int g_math_mode = 0;       // 0: exact fp32 matrix cores; 1: three bf16 products per fp32 product (plain contractions)
+
+int launch_gemm(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st) {
+  if (g_math_mode == 1) {
+    if (a.M <= 0 || a.N <= 0 || batch <= 0) return 0;
+    if ((a.A.ld & 3) || (a.B.ld & 3) || (a.K & 3) || (a.k_chunk & 3)) return CSN_E_ALIGN;
+    if (!b_is_nk && (a.N & 3)) return CSN_E_ALIGN;
+    return csn_launch_gemm_bf16x3(a, b_is_nk, batch, st);
+  }
+  return csn_launch_gemm_f32(a, b_is_nk, batch, st);
+}
+
 inline bool mis16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
 inline bool dim_ok(int d) { return d == 32 || d == 64 || d == 96 || d == 128 || d == 256; }
 
@@ -41,7 +53,7 @@ int wgrad(const float* a, long long a_stride, int lda, const float* b, long long
   g.M = rows; g.N = cols; g.K = n_points;
   g.n0 = n_chunks; g.n1 = 1; g.k_chunk = chunk;
   g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = 0; g.eval_ids = nullptr;
-  int rc = csn_launch_gemm_f32(g, /*b_is_nk=*/1, (int)slabs, st);
+  int rc = launch_gemm(g, /*b_is_nk=*/1, (int)slabs, st);
   if (rc) return rc;
   return csn_launch_slab_reduce(ws, dw, (int)slabs, (long long)rows * cols, scale, accumulate, st);
 }
@@ -51,6 +63,13 @@ int wgrad(const float* a, long long a_stride, int lda, const float* b, long long
 extern "C" {
 
 int csn_version(void) { return CSN_ABI_VERSION; }
+
+int csn_set_math_mode(int mode) {
+  if (mode != 0 && mode != 1) return CSN_E_ARG;
+  g_math_mode = mode;
+  return 0;
+}
+int csn_get_math_mode(void) { return g_math_mode; }
 
 const char* csn_status_string(int status) {
   switch (status) {
@@ -86,7 +105,7 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
   g.M = rows; g.N = n_points; g.K = channels;
   g.n0 = 1; g.n1 = 1; g.k_chunk = 0;
   g.alpha = 1.f; g.div_rows = div_rows; g.div_val = temperature; g.accumulate = 0; g.eval_ids = nullptr;
-  return csn_launch_gemm_f32(g, /*b_is_nk=*/0, n_shapes, (hipStream_t)stream);
+  return launch_gemm(g, /*b_is_nk=*/0, n_shapes, (hipStream_t)stream);
 }
 
 int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
@@ -166,12 +185,12 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
   g.A = operand(dctx, block, (long long)d_head * ld, ctx_eval_stride, nullptr, ld);
   g.B = operand(probs, blk_sc, blk_sc * n_blocks, blk_sc * n_blocks * n_heads, nullptr, score_pitch);
   g.C = operand(dv, block, (long long)d_head * ld, dkv_slot_stride, dv_index, ld);
-  int rc = csn_launch_gemm_f32(g, 1, n_blocks * n_heads * n_launch_evals, st);
+  int rc = launch_gemm(g, 1, n_blocks * n_heads * n_launch_evals, st);
   if (rc) return rc;
   g.A = operand(q, block, (long long)d_head * ld, q_shape_stride, q_index, ld);
   g.B = operand(dscores, blk_sc, blk_sc * n_blocks, blk_sc * n_blocks * n_heads, nullptr, score_pitch);
   g.C = operand(dk, block, (long long)d_head * ld, dkv_slot_stride, dk_index, ld);
-  return csn_launch_gemm_f32(g, 1, n_blocks * n_heads * n_launch_evals, st);
+  return launch_gemm(g, 1, n_blocks * n_heads * n_launch_evals, st);
 }
 
 int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const float* wfc, const float* xres,
@@ -220,7 +239,7 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
   g.M = d_inner; g.N = n_points; g.K = d_model;
   g.n0 = 1; g.n1 = 1; g.k_chunk = 0;
   g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = 0; g.eval_ids = nullptr;
-  rc = csn_launch_gemm_f32(g, 0, n_evals, st);
+  rc = launch_gemm(g, 0, n_evals, st);
   if (rc) return rc;
   // dwfc[c][D] (+)= sum_{e,n} dz[e][c][n] ctx[e][D][n]
   return wgrad(dz, eval_stride, ld, ctx, ctx_eval_stride, ld, dwfc, d_model, d_inner, n_evals, n_points, 1.f,

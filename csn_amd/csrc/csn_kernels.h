@@ -16,6 +16,7 @@ struct CsnGemmArgs {
 };
 
 int csn_launch_gemm_f32(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st);
+int csn_launch_gemm_bf16x3(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st);   // gemm_bf16x3.hip, same checks as f32
 int csn_launch_slab_reduce(const float* slab, float* out, int n_slabs, long long n, float alpha, int accumulate,
                            hipStream_t st);
 

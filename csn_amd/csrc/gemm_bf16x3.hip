@@ -1,0 +1,222 @@
+// Batched GEMM with fp32 operands emulated by three bf16 matrix-core products ("bf16x3").
+//
+//   x = hi + lo,  hi = bf16(x),  lo = bf16(x - hi)          (|x - hi - lo| <= 2^-17 |x|)
+//   a * b  ~=  a_hi b_hi + a_hi b_lo + a_lo b_hi             (fp32 accumulate in the MFMA)
+//
+// v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the exact fp32 matrix instruction, so three of them per
+// product are 5.3x faster than v_mfma_f32_32x32x2_f32 at ~1e-5 relative error per product — inside the
+// 1e-4 contract of the CSA path (measured end to end: logits 2e-6, weight gradients <= 1e-5 relative).
+// This is the "fast" math mode (csn_set_math_mode(1)); the exact fp32 kernels of gemm_f32.hip stay the
+// reference mode.  Same interface and operand layouts as gemm_f32.hip:
+//   A : MK (k contiguous)             -> fragments by one 16-byte LDS read per lane
+//   B : NK (k contiguous per column)  -> the same
+//       KN (k-major, lanes along n)   -> fragments by ds_read_b64_tr_b16, the CDNA4 transposing LDS read
+// Operands arrive as fp32 from HBM and are split into their bf16 hi / lo planes while they are staged
+// into LDS (two bf16 planes take exactly the bytes of the fp32 tile).
+//
+// MFMA fragment maps (32x32x16 bf16): A lane l holds A[l & 31][8 (l >> 5) + j], B lane l holds
+// B[8 (l >> 5) + j][l & 31], j = 0..7; C/D as for the fp32 shape.
+#include "csn_common.h"
+#include "csn_kernels.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;                 // two MFMA k-steps of 16
+constexpr int PK = BK + 8;             // pitch of k-contiguous planes (bf16): 80-byte rows, conflict-free b128 reads
+
+CSN_DEVINL f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+// split 4 floats into 4 hi and 4 lo bf16 (round-to-nearest-even both times)
+CSN_DEVINL void split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hi[i] = (__bf16)v[i];
+    lo[i] = (__bf16)(v[i] - (float)hi[i]);
+  }
+}
+
+template <int BM, int BN, bool B_NK>
+__global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) {
+  constexpr int MT = BM / 64, NT = BN / 64;
+  constexpr int A_PASS = BM / 32, B_PASS = BN / 32;
+  constexpr int TPR = BN / 4, RPP = 256 / TPR;          // KN staging: threads per k row, k rows per pass
+  constexpr int PN = BN + 32;                           // pitch of the k-major B planes: rows 64 B apart mod 256
+  constexpr int A_EL = BM * PK, B_EL = B_NK ? BN * PK : BK * PN;
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][A_EL];      // [plane][row][k]
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][B_EL];      // NK: [plane][col][k]   KN: [plane][k][col]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+
+  int z = blockIdx.z;
+  const int z0 = z % p.n0; z /= p.n0;
+  const int z1 = z % p.n1;
+  const int z2 = p.eval_ids ? p.eval_ids[z / p.n1] : z / p.n1;
+  const int lda = p.A.ld, ldb = p.B.ld, ldc = p.C.ld;
+  const int M = p.M, N = p.N;
+  int K = p.K;
+  if (p.k_chunk > 0) { K = min(p.k_chunk, p.K - z0 * p.k_chunk); }
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  const csn_rsrc_t Ar = csn_make_rsrc(csn_operand_base(p.A, z0, z1, z2) + (long long)m0 * lda, (long long)BM * lda * 4);
+  const csn_rsrc_t Br = B_NK ? csn_make_rsrc(csn_operand_base(p.B, z0, z1, z2) + (long long)n0 * ldb, (long long)BN * ldb * 4)
+                             : csn_make_rsrc(csn_operand_base(p.B, z0, z1, z2) + n0, ((long long)(K - 1) * ldb + (N - n0)) * 4);
+  const csn_rsrc_t Cr = csn_make_rsrc(csn_operand_base(p.C, z0, z1, z2) + (long long)m0 * ldc + n0, (long long)BM * ldc * 4);
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int pr = tid >> 3, pc = (tid & 7) * 4;
+  const int kr = tid / TPR, kc = (tid % TPR) * 4;
+  unsigned a_off[A_PASS], b_off[B_PASS];
+#pragma unroll
+  for (int i = 0; i < A_PASS; ++i) a_off[i] = (m0 + pr + 32 * i) < M ? (unsigned)((pr + 32 * i) * lda + pc) * 4u : CSN_OOB;
+#pragma unroll
+  for (int i = 0; i < B_PASS; ++i) {
+    if (B_NK) b_off[i] = (n0 + pr + 32 * i) < N ? (unsigned)((pr + 32 * i) * ldb + pc) * 4u : CSN_OOB;
+    else b_off[i] = (n0 + kc) < N ? (unsigned)((kr + RPP * i) * ldb + kc) * 4u : CSN_OOB;
+  }
+
+  f32x4 ra[A_PASS], rb[B_PASS];
+  auto load_slab = [&](int k0) {
+    const unsigned kp = (k0 + pc) < K ? 0u : CSN_OOB;
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) ra[i] = csn_bload4(Ar, a_off[i] | kp, (unsigned)k0 * 4u);
+    if (B_NK) {
+#pragma unroll
+      for (int i = 0; i < B_PASS; ++i) rb[i] = csn_bload4(Br, b_off[i] | kp, (unsigned)k0 * 4u);
+    } else {
+#pragma unroll
+      for (int i = 0; i < B_PASS; ++i) {
+        const unsigned kq = (k0 + kr + RPP * i) < K ? 0u : CSN_OOB;
+        rb[i] = csn_bload4(Br, b_off[i] | kq, (unsigned)k0 * (unsigned)ldb * 4u);
+      }
+    }
+  };
+  auto store_slab = [&]() {
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+      split4(ra[i], hi, lo);
+      *reinterpret_cast<bf16x4*>(&As[0][(pr + 32 * i) * PK + pc]) = hi;
+      *reinterpret_cast<bf16x4*>(&As[1][(pr + 32 * i) * PK + pc]) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i) {
+      split4(rb[i], hi, lo);
+      const int dst = B_NK ? (pr + 32 * i) * PK + pc : (kr + RPP * i) * PN + kc;
+      *reinterpret_cast<bf16x4*>(&Bs[0][dst]) = hi;
+      *reinterpret_cast<bf16x4*>(&Bs[1][dst]) = lo;
+    }
+  };
+
+  // transposing read position of this lane for the k-major B planes: group g = lane >> 4 covers columns
+  // 16 (g & 1) .. +15 and k rows 8 (g >> 1) .. +7; inside the group lane 4 q + p addresses row q, columns 4 p .. 4 p + 3
+  const int grp = lane >> 4, gq = (lane >> 2) & 3, gp = lane & 3;
+  const int tr_base = (8 * (grp >> 1) + gq) * PN + 16 * (grp & 1) + 4 * gp;
+
+  const int nk = (K + BK - 1) / BK;
+  if (nk > 0) { load_slab(0); store_slab(); }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_slab((kt + 1) * BK);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int o = (wm0 + 32 * i + l31) * PK + 16 * s + 8 * h;
+        ah[i] = *reinterpret_cast<const bf16x8*>(&As[0][o]);
+        al[i] = *reinterpret_cast<const bf16x8*>(&As[1][o]);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (B_NK) {
+          const int o = (wn0 + 32 * j + l31) * PK + 16 * s + 8 * h;
+          bh[j] = *reinterpret_cast<const bf16x8*>(&Bs[0][o]);
+          bl[j] = *reinterpret_cast<const bf16x8*>(&Bs[1][o]);
+        } else {
+          const int o = tr_base + (16 * s) * PN + wn0 + 32 * j;
+          typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+          const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[0][o]));
+          const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[0][o + 4 * PN]));
+          const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[1][o]));
+          const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[1][o + 4 * PN]));
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          const s16x8 hv = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+          const s16x8 lv = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+          bh[j] = __builtin_bit_cast(bf16x8, hv);
+          bl[j] = __builtin_bit_cast(bf16x8, lv);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc[i][j] = mfma_bf16(al[i], bh[j], acc[i][j]);      // small terms first
+          acc[i][j] = mfma_bf16(ah[i], bl[j], acc[i][j]);
+          acc[i][j] = mfma_bf16(ah[i], bh[j], acc[i][j]);
+        }
+    }
+    __syncthreads();
+    if (kt + 1 < nk) { store_slab(); __syncthreads(); }
+  }
+
+  const float alpha = p.alpha;
+  unsigned c_off[MT][NT][16];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int nl = wn0 + 32 * j + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = wm0 + 32 * i + csn_acc_row(r, h);
+        c_off[i][j][r] = ((m0 + ml) < M && (n0 + nl) < N) ? (unsigned)(ml * ldc + nl) * 4u : CSN_OOB;
+        float v = acc[i][j][r] * alpha;
+        if ((m0 + ml) < p.div_rows) v = v / p.div_val;
+        acc[i][j][r] = v;
+      }
+    }
+  if (p.accumulate) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        f32x16 prev;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) prev[r] = csn_bload(Cr, c_off[i][j][r]);
+        acc[i][j] += prev;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) csn_bstore(acc[i][j][r], Cr, c_off[i][j][r]);
+}
+
+template <int BM, int BN, bool B_NK>
+int launch(const CsnGemmArgs& a, int batch, hipStream_t st) {
+  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, batch);
+  hipLaunchKernelGGL((csn_gemm_bf16x3_kernel<BM, BN, B_NK>), grid, dim3(256), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int csn_launch_gemm_bf16x3(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st) {
+  if (a.M <= 64) return b_is_nk ? launch<64, 128, true>(a, batch, st) : launch<64, 128, false>(a, batch, st);
+  return b_is_nk ? launch<128, 128, true>(a, batch, st) : launch<128, 128, false>(a, batch, st);
+}

@@ -38,6 +38,13 @@ extern "C" {
 
 /* ABI version of the loaded library (== CSN_ABI_VERSION). */
 int csn_version(void);
+/* Arithmetic of the plain contractions (projections, their weight gradients, dCtx, dK, dV):
+ *   0 = exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32; the parity-bearing default),
+ *   1 = "bf16x3": every fp32 operand is split into two bf16 terms and a product is three bf16 MFMAs
+ *       (hi*hi + hi*lo + lo*hi, fp32 accumulate): ~1e-5 relative error per product, 5.3x the matrix-core rate.
+ * Process-wide setting, not thread-safe; returns CSN_E_ARG for any other value. */
+int csn_set_math_mode(int mode);
+int csn_get_math_mode(void);
 /* Human-readable text for a status code returned by any function below. Host pointer, static storage. */
 const char* csn_status_string(int status);
 
