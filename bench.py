@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--shapes", type=int, default=32, help="query shapes per GPU")
     ap.add_argument("--K", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--math", choices=["fp32", "bf16x3"], default="bf16x3",
+                    help="arithmetic of the contractions: exact fp32 matrix cores, or three bf16 products per fp32 product")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,7 +115,7 @@ def main():
     from csn_amd import functional as CF
     from csn_amd.csa_models import get_model
     csn_amd.build()
-    csn_amd.lib()
+    csn_amd._lib.check(csn_amd.lib().csn_set_math_mode(1 if args.math == "bf16x3" else 0))
 
     B, K = args.shapes, args.K
     S = B * world

@@ -15,7 +15,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libcsn_hip.so")
-SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "attn_f32.hip", "outproj_ln.hip", "retrieval.hip", "combine.hip", "csn_capi.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "attn_f32.hip", "attn_bf16x3.hip", "outproj_ln.hip", "retrieval.hip", "combine.hip", "csn_capi.hip"]
 HEADERS = ["csn_common.h", "csn_kernels.h", os.path.join("..", "..", "include", "csn_hip.h")]
 ARCH = "gfx950"
 

@@ -130,7 +130,8 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
   a.rescale_threshold = rescale_threshold;
   a.eval_ids = nullptr; a.out_index = nullptr; a.accumulate = 0;
   a.dropout_p = dropout_p; a.seed = seed;
-  return csn_launch_attn_fwd_f32(a, d_head, (hipStream_t)stream);
+  return g_math_mode == 1 ? csn_launch_attn_fwd_bf16x3(a, d_head, (hipStream_t)stream)
+                          : csn_launch_attn_fwd_f32(a, d_head, (hipStream_t)stream);
 }
 
 int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* k,
@@ -161,7 +162,7 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
   a.rescale_threshold = 0.f;
   a.eval_ids = eval_ids; a.out_index = dq_index; a.accumulate = accumulate;
   a.dropout_p = dropout_p; a.seed = seed;
-  return csn_launch_attn_bwd_f32(a, d_head, st);
+  return g_math_mode == 1 ? csn_launch_attn_bwd_bf16x3(a, d_head, st) : csn_launch_attn_bwd_f32(a, d_head, st);
 }
 
 int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,

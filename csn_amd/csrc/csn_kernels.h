@@ -42,6 +42,8 @@ struct CsnAttnArgs {
 };
 int csn_launch_attn_fwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
 int csn_launch_attn_bwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
+int csn_launch_attn_fwd_bf16x3(const CsnAttnArgs& a, int d, hipStream_t st);     // attn_bf16x3.hip
+int csn_launch_attn_bwd_bf16x3(const CsnAttnArgs& a, int d, hipStream_t st);
 
 // ---- output projection + residual + LayerNorm (outproj_ln.hip) --------------------------------
 struct CsnOutProjArgs {

@@ -15,6 +15,17 @@ ROW_STRIDE = 97
 ATOL = 1e-4
 
 
+# the whole module-level contract (1e-4 on outputs, reference goldens, bit-exact kNN indices) is checked in both
+# arithmetic modes of the contractions: exact fp32 matrix cores and bf16x3
+@pytest.fixture(autouse=True, params=[0, 1], ids=["fp32", "bf16x3"])
+def math_mode(request):
+    from csn_amd import _lib
+    _lib.build()
+    _lib.check(_lib.lib().csn_set_math_mode(request.param))
+    yield request.param
+    _lib.lib().csn_set_math_mode(0)
+
+
 def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + ".npz"))
 
