@@ -60,23 +60,24 @@ _SIGNATURES = {
     "csn_status_string": (c_char_p, [c_int]),
     "csn_wgrad_workspace_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
     "csn_project_f32": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_int, c_int, c_void_p, c_longlong, c_int,
-                                c_int, c_int, c_int, c_float, c_void_p]),
+                                c_int, c_int, c_int, c_float, c_int, c_longlong, c_void_p]),
     "csn_block_attn_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_void_p, c_void_p, c_int,
                                        c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                       c_int, c_float, c_float, c_ulonglong, c_void_p]),
+                                       c_int, c_float, c_float, c_ulonglong, c_int, c_longlong, c_void_p]),
     "csn_block_attn_bwd_dq_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_int,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_int,
                                           c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_ulonglong,
-                                          c_void_p]),
+                                          c_int, c_longlong, c_int, c_longlong, c_void_p]),
     "csn_block_attn_bwd_dkv_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_void_p, c_int,
-                                           c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                                           c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_int, c_longlong,
+                                           c_void_p]),
     "csn_outproj_ln_fwd_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p,
                                        c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
                                        c_ulonglong, c_void_p]),
     "csn_outproj_ln_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int,
-                                       c_int, c_int, c_int, c_float, c_ulonglong, c_void_p]),
+                                       c_int, c_int, c_int, c_float, c_ulonglong, c_int, c_longlong, c_void_p]),
     "csn_project_wgrad_f32": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_longlong, c_int, c_void_p, c_int, c_int,
                                       c_int, c_int, c_float, c_int, c_void_p, c_longlong, c_void_p]),
     "csn_retrieval_measure_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
@@ -102,7 +103,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.csn_version() != 2:
+        if handle.csn_version() != 3:
             raise CsnError("libcsn_hip.so ABI version mismatch")
         _lib = handle
     return _lib

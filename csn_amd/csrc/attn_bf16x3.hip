@@ -11,8 +11,9 @@
 //   element j of lane (q, kq)  <->  key 4 kq + j (j < 4)  |  16 + 4 kq + (j - 4) (j >= 4),
 // and the V^T / K^T fragments are fetched in that same order (two 8-byte reads per plane).
 // The fp32 tiles coming from HBM are split into their bf16 planes while they are staged into LDS (two planes = the
-// bytes of the fp32 tile).  Swizzles (conflict-free): tileA swaps the 16-key halves on rows with bit 3 set;
-// tileB XORs the 8-byte chunk index with 2 * ((row >> 2) & 3).
+// bytes of the fp32 tile).  LDS images (conflict-free): tileA swaps the 16-key halves on rows with bit 3 set; tileB
+// stores, per row, the 8 keys of each lane quarter kq contiguously ([4kq..4kq+3 | 16+4kq..16+4kq+3], one 16-byte read
+// per fragment) and XORs that 16-byte unit index with (-(row >> 2)) & 3.
 #include "csn_common.h"
 #include "csn_kernels.h"
 
@@ -123,7 +124,10 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     const int idx = tid + 512 * i, row = idx >> 3;
     t_off[i] = idx < PIECES ? (unsigned)(row * ld + t_c) * 4u : CSN_OOB;
     a_dst[i] = row * KT + (t_c ^ (16 * ((row >> 3) & 1)));             // key halves swapped on rows with bit 3 set
-    b_dst[i] = row * KT + 4 * ((tid & 7) ^ (2 * ((row >> 2) & 3)));    // 8-byte chunk ^ 2 * ((row >> 2) & 3)
+    // tileB: 4-key chunk c8 -> 8-byte slot s8 = 2 c8 (keys 0..15) | 2 (c8 - 4) + 1 (keys 16..31); its 16-byte unit
+    // (s8 >> 1 = kq) is XORed with (-(row >> 2)) & 3
+    const int c8 = tid & 7, s8 = c8 < 4 ? 2 * c8 : 2 * (c8 - 4) + 1;
+    b_dst[i] = row * KT + 4 * (2 * ((s8 >> 1) ^ ((-((row >> 2) & 3)) & 3)) + (s8 & 1));
   }
   f32x4 g[NP_T];
   auto fetch = [&](const csn_rsrc_t& rs, int kt) {
@@ -158,9 +162,8 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   // row 8 kq + q', keys 4 p .. 4 p + 3 of the 16-key tile t (halves swapped when (row >> 3) & 1 = kq & 1 is set)
   const int tr_row = 8 * kq + (lq >> 2);
   const int a_pos0 = tr_row * KT + 16 * (0 ^ (kq & 1)) + 4 * (lq & 3), a_pos1 = tr_row * KT + 16 * (1 ^ (kq & 1)) + 4 * (lq & 3);
-  // tileB: row lq of the 16-channel tile, chunks kq and 4 + kq, XOR 2 * ((lq >> 2) & 3)
-  const int b_sw = 2 * ((lq >> 2) & 3);
-  const int b_pos0 = lq * KT + 4 * (kq ^ b_sw), b_pos1 = lq * KT + 4 * ((4 + kq) ^ b_sw);
+  // tileB: row lq of the 16-channel tile, 16-byte unit kq ^ ((-(lq >> 2)) & 3): keys 4kq..4kq+3 then 16+4kq..16+4kq+3
+  const int b_pos = lq * KT + 8 * (kq ^ ((-((lq >> 2) & 3)) & 3));
 
   const int nkt = (T + KT - 1) / KT;
   fetch(Ar, 0); commitA(0);
@@ -273,8 +276,8 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
 #pragma unroll
     for (int c = 0; c < D / 16; ++c) {
       const int o = c * 16 * KT;
-      const bf16x8 vh = join8(*reinterpret_cast<const s16x4*>(tBh + o + b_pos0), *reinterpret_cast<const s16x4*>(tBh + o + b_pos1));
-      const bf16x8 vl = join8(*reinterpret_cast<const s16x4*>(tBl + o + b_pos0), *reinterpret_cast<const s16x4*>(tBl + o + b_pos1));
+      const bf16x8 vh = *reinterpret_cast<const bf16x8*>(tBh + o + b_pos);
+      const bf16x8 vl = *reinterpret_cast<const bf16x8*>(tBl + o + b_pos);
       O[c] = mfma3(vh, vl, ph, pl, O[c]);
     }
 

@@ -24,6 +24,7 @@ CsnOperand operand(const float* p, long long s0, long long s1, long long s2, con
   CsnOperand o;
   o.ptr = const_cast<float*>(p);
   o.s0 = s0; o.s1 = s1; o.s2 = s2; o.idx2 = idx2; o.ld = ld;
+  o.planes = 0; o.plane_stride = 0;
   return o;
 }
 
@@ -93,7 +94,8 @@ long long csn_wgrad_workspace_floats(int rows, int cols, int n_maps, int n_point
 
 int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const float* w, int rows, int channels,
                     float* out, long long out_shape_stride, int ld_out, int n_shapes, int n_points, int div_rows,
-                    float temperature, void* stream) {
+                    float temperature, int out_split, long long out_plane_stride, void* stream) {
+  if (out_split && g_math_mode != 1) return CSN_E_ARG;
   if (!x || !w || !out || rows <= 0 || channels <= 0 || n_shapes <= 0 || n_points <= 0) return CSN_E_ARG;
   if ((ld_x & 3) || (ld_out & 3) || (n_points & 3) || (channels & 3)) return CSN_E_ALIGN;
   if (mis16(x) || mis16(w) || mis16(out)) return CSN_E_PTR;
@@ -102,6 +104,7 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
   g.A = operand(w, 0, 0, 0, nullptr, channels);
   g.B = operand(x, 0, 0, x_shape_stride, nullptr, ld_x);
   g.C = operand(out, 0, 0, out_shape_stride, nullptr, ld_out);
+  g.C.planes = out_split; g.C.plane_stride = out_plane_stride;
   g.M = rows; g.N = n_points; g.K = channels;
   g.n0 = 1; g.n1 = 1; g.k_chunk = 0;
   g.alpha = 1.f; g.div_rows = div_rows; g.div_val = temperature; g.accumulate = 0; g.eval_ids = nullptr;
@@ -112,8 +115,10 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
                            long long kv_shape_stride, const int* q_index, const int* kv_index, int ld, float* ctx,
                            long long ctx_eval_stride, float* scores, float* lse, int n_evals, int n_heads,
                            int d_head, int block, int n_blocks, int score_pitch, float rescale_threshold,
-                           float dropout_p, unsigned long long seed, void* stream) {
+                           float dropout_p, unsigned long long seed, int qkv_split, long long qkv_plane_stride,
+                           void* stream) {
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
+  if (qkv_split && g_math_mode != 1) return CSN_E_ARG;
   if (!q || !k || !v || !ctx || n_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
   if (!dim_ok(d_head)) return CSN_E_DIM;
   if ((ld & 3) || (block & 3) || (score_pitch & 3) || score_pitch < block) return CSN_E_ALIGN;
@@ -130,6 +135,7 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
   a.rescale_threshold = rescale_threshold;
   a.eval_ids = nullptr; a.out_index = nullptr; a.accumulate = 0;
   a.dropout_p = dropout_p; a.seed = seed;
+  a.r_planes = qkv_split; a.kv_planes = qkv_split; a.r_plane_stride = qkv_plane_stride; a.kv_plane_stride = qkv_plane_stride;
   return g_math_mode == 1 ? csn_launch_attn_fwd_bf16x3(a, d_head, (hipStream_t)stream)
                           : csn_launch_attn_fwd_f32(a, d_head, (hipStream_t)stream);
 }
@@ -139,8 +145,10 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
                               float* dscores, const float* lse, float* delta, float* dq, long long dq_slot_stride,
                               const int* dq_index, int accumulate, const int* eval_ids, int n_launch_evals, int n_heads,
                               int d_head, int block, int n_blocks, int score_pitch, float dropout_p,
-                              unsigned long long seed, void* stream) {
+                              unsigned long long seed, int dctx_split, long long dctx_plane_stride, int kv_split,
+                              long long kv_plane_stride, void* stream) {
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
+  if ((dctx_split || kv_split) && g_math_mode != 1) return CSN_E_ARG;
   if (!dctx || !ctx || !k || !v || !scores || !dscores || !lse || !delta || !dq) return CSN_E_ARG;
   if (n_launch_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
   if (!dim_ok(d_head)) return CSN_E_DIM;
@@ -150,11 +158,12 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
   hipStream_t st = (hipStream_t)stream;
   // delta[e][h][n] = sum_c dctx * ctx   (softmax backward row constant)
   int rc = csn_launch_rowdot_f32(dctx, ctx, delta, eval_ids, n_launch_evals, n_heads, d_head, ld, n_blocks * block,
-                                 ctx_eval_stride, st);
+                                 ctx_eval_stride, dctx_split, dctx_plane_stride, st);
   if (rc) return rc;
   CsnAttnArgs a;
   a.q = dctx; a.k = k; a.v = v;
-  a.q_shape_stride = ctx_eval_stride; a.kv_shape_stride = kv_shape_stride;
+  a.q_shape_stride = dctx_split ? 2 * ctx_eval_stride : ctx_eval_stride;     // split dctx: [eval][2 planes][D][ld]
+  a.kv_shape_stride = kv_shape_stride;
   a.q_index = nullptr; a.kv_index = kv_index; a.ld = ld;
   a.out = dq; a.out_eval_stride = dq_slot_stride;
   a.scores = scores; a.dscores = dscores; a.lse = const_cast<float*>(lse); a.delta = delta;
@@ -162,6 +171,7 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
   a.rescale_threshold = 0.f;
   a.eval_ids = eval_ids; a.out_index = dq_index; a.accumulate = accumulate;
   a.dropout_p = dropout_p; a.seed = seed;
+  a.r_planes = dctx_split; a.kv_planes = kv_split; a.r_plane_stride = dctx_plane_stride; a.kv_plane_stride = kv_plane_stride;
   return g_math_mode == 1 ? csn_launch_attn_bwd_bf16x3(a, d_head, st) : csn_launch_attn_bwd_f32(a, d_head, st);
 }
 
@@ -169,7 +179,9 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
                                const int* q_index, int ld, const float* probs, const float* dscores, float* dk,
                                float* dv, long long dkv_slot_stride, const int* dk_index, const int* dv_index,
                                int accumulate, const int* eval_ids, int n_launch_evals, int n_heads, int d_head,
-                               int block, int n_blocks, int score_pitch, void* stream) {
+                               int block, int n_blocks, int score_pitch, int dctx_split, long long dctx_plane_stride,
+                               int q_split, long long q_plane_stride, void* stream) {
+  if ((dctx_split || q_split) && g_math_mode != 1) return CSN_E_ARG;
   if (!dctx || !q || !probs || !dscores || !dk || !dv) return CSN_E_ARG;
   if (n_launch_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
   if (!dim_ok(d_head)) return CSN_E_DIM;
@@ -183,12 +195,14 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
   g.M = d_head; g.N = block; g.K = block;
   g.n0 = n_blocks; g.n1 = n_heads; g.k_chunk = 0;
   g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = accumulate; g.eval_ids = eval_ids;
-  g.A = operand(dctx, block, (long long)d_head * ld, ctx_eval_stride, nullptr, ld);
+  g.A = operand(dctx, block, (long long)d_head * ld, dctx_split ? 2 * ctx_eval_stride : ctx_eval_stride, nullptr, ld);
+  g.A.planes = dctx_split; g.A.plane_stride = dctx_plane_stride;
   g.B = operand(probs, blk_sc, blk_sc * n_blocks, blk_sc * n_blocks * n_heads, nullptr, score_pitch);
   g.C = operand(dv, block, (long long)d_head * ld, dkv_slot_stride, dv_index, ld);
   int rc = launch_gemm(g, 1, n_blocks * n_heads * n_launch_evals, st);
   if (rc) return rc;
   g.A = operand(q, block, (long long)d_head * ld, q_shape_stride, q_index, ld);
+  g.A.planes = q_split; g.A.plane_stride = q_plane_stride;
   g.B = operand(dscores, blk_sc, blk_sc * n_blocks, blk_sc * n_blocks * n_heads, nullptr, score_pitch);
   g.C = operand(dk, block, (long long)d_head * ld, dkv_slot_stride, dk_index, ld);
   return launch_gemm(g, 1, n_blocks * n_heads * n_launch_evals, st);
@@ -217,8 +231,9 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
                            const float* ctx, long long ctx_eval_stride, const float* wfc_t, float* dz, float* dz_res,
                            float* dctx, float* dwfc, float* ws, long long ws_floats, int n_evals, int d_model,
                            int d_inner, int ld, int n_points, int accumulate, float dropout_p,
-                           unsigned long long seed, void* stream) {
+                           unsigned long long seed, int dctx_split, long long dctx_plane_stride, void* stream) {
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
+  if (dctx_split && g_math_mode != 1) return CSN_E_ARG;
   if (!dxhat || !xhat || !rstd || !ctx || !wfc_t || !dz || !dctx || !dwfc || !ws) return CSN_E_ARG;
   if (n_evals <= 0 || n_points <= 0 || d_inner <= 0 || d_model <= 0) return CSN_E_ARG;
   if ((ld & 3) || (d_inner & 3) || (d_model & 3) || (n_points & 3)) return CSN_E_ALIGN;
@@ -236,7 +251,8 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
   CsnGemmArgs g;
   g.A = operand(wfc_t, 0, 0, 0, nullptr, d_model);
   g.B = operand(dz, 0, 0, eval_stride, nullptr, ld);
-  g.C = operand(dctx, 0, 0, ctx_eval_stride, nullptr, ld);
+  g.C = operand(dctx, 0, 0, dctx_split ? 2 * ctx_eval_stride : ctx_eval_stride, nullptr, ld);   // split: [eval][2][D][ld]
+  g.C.planes = dctx_split; g.C.plane_stride = dctx_plane_stride;
   g.M = d_inner; g.N = n_points; g.K = d_model;
   g.n0 = 1; g.n1 = 1; g.k_chunk = 0;
   g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = 0; g.eval_ids = nullptr;

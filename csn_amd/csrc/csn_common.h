@@ -50,6 +50,14 @@ CSN_DEVINL f32x4 csn_bload4(csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
 CSN_DEVINL void csn_bstore(float v, csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
 }
+// 8-byte (4 x bf16) and 2-byte (1 x bf16) accesses for split-bf16 planes
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+CSN_DEVINL u32x2 csn_bload2(csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
+  return __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+}
+CSN_DEVINL void csn_bstore_bf16(__bf16 v, csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
+  __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), r, voff, soff, 0);
+}
 
 // Guarded 16-byte load of 4 consecutive floats row[c..c+3]; elements at index >= clim read as 0.
 // row + c must be 16-byte aligned when c + 3 < clim (hosts check ld % 4 == 0 and offsets % 4 == 0).
@@ -68,11 +76,15 @@ CSN_DEVINL f32x4 csn_ldg4(const float* __restrict__ row, int c, int clim, bool r
 }
 
 // Three-level batched operand: element offset = s0*z0 + s1*z1 + s2*(idx2 ? idx2[z2] : z2)
+// `planes` != 0 (bf16x3 kernels only): ptr is the bf16 HIGH plane of a split tensor (x = hi + lo, two bf16 per
+// fp32), the LOW plane starts plane_stride bf16 elements later; strides and ld then count bf16 elements.
 struct CsnOperand {
   float* ptr;
   long long s0, s1, s2;
   const int* idx2;
   int ld;
+  int planes;
+  long long plane_stride;
 };
 
 // z2 is first mapped through the launch's evaluation list (if any), then through the operand's own slot map

@@ -39,6 +39,10 @@ struct CsnAttnArgs {
   int accumulate;                                        // out += result (several evaluations share an output slot)
   float dropout_p;                                       // attention-probability dropout (csa_models.py:141); 0 = off
   unsigned long long seed;
+  // bf16x3 kernels only: q (resp. k and v) point at bf16 HIGH planes of split tensors, the low plane follows
+  // *_plane_stride bf16 elements later; shape strides and ld then count bf16 elements
+  int r_planes, kv_planes;
+  long long r_plane_stride, kv_plane_stride;
 };
 int csn_launch_attn_fwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
 int csn_launch_attn_bwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
@@ -72,7 +76,7 @@ int csn_launch_ln_bwd_f32(const CsnLnBwdArgs& a, hipStream_t st);
 
 // delta[e][h][n] = sum_{c in head h} a[e][c][n] * b[e][c][n]
 int csn_launch_rowdot_f32(const float* a, const float* b, float* out, const int* eval_ids, int E, int H, int d, int ld,
-                          int n_points, long long eval_stride, hipStream_t st);
+                          int n_points, long long eval_stride, int a_split, long long a_plane_stride, hipStream_t st);
 
 // ---- pooled descriptors / cross-shape mix (combine.hip) ---------------------------------------------
 int csn_launch_rowsum_f32(const float* x, float* out, long long rows, int n, long long ld, hipStream_t st);

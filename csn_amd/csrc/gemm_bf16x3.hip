@@ -11,8 +11,10 @@
 //   A : MK (k contiguous)             -> fragments by one 16-byte LDS read per lane
 //   B : NK (k contiguous per column)  -> the same
 //       KN (k-major, lanes along n)   -> fragments by ds_read_b64_tr_b16, the CDNA4 transposing LDS read
-// Operands arrive as fp32 from HBM and are split into their bf16 hi / lo planes while they are staged
-// into LDS (two bf16 planes take exactly the bytes of the fp32 tile).
+// An operand arrives either as fp32 (split into its bf16 hi / lo planes while it is staged into LDS: two bf16
+// planes take exactly the bytes of the fp32 tile) or already split (CsnOperand::planes: the producer kernel's
+// epilogue did the split once, staging is then a plain copy and costs no VALU work).  C can be written as fp32 or as
+// planes for the next contraction.
 //
 // MFMA fragment maps (32x32x16 bf16): A lane l holds A[l & 31][8 (l >> 5) + j], B lane l holds
 // B[8 (l >> 5) + j][l & 31], j = 0..7; C/D as for the fp32 shape.
@@ -63,10 +65,18 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   if (p.k_chunk > 0) { K = min(p.k_chunk, p.K - z0 * p.k_chunk); }
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
-  const csn_rsrc_t Ar = csn_make_rsrc(csn_operand_base(p.A, z0, z1, z2) + (long long)m0 * lda, (long long)BM * lda * 4);
-  const csn_rsrc_t Br = B_NK ? csn_make_rsrc(csn_operand_base(p.B, z0, z1, z2) + (long long)n0 * ldb, (long long)BN * ldb * 4)
-                             : csn_make_rsrc(csn_operand_base(p.B, z0, z1, z2) + n0, ((long long)(K - 1) * ldb + (N - n0)) * 4);
-  const csn_rsrc_t Cr = csn_make_rsrc(csn_operand_base(p.C, z0, z1, z2) + (long long)m0 * ldc + n0, (long long)BM * ldc * 4);
+  // element size of each operand in HBM: 4 (fp32) or 2 (one bf16 plane; the low plane follows plane_stride elements later)
+  const bool a_pl = p.A.planes != 0, b_pl = p.B.planes != 0, c_pl = p.C.planes != 0;
+  const int a_es = a_pl ? 2 : 4, b_es = b_pl ? 2 : 4, c_es = c_pl ? 2 : 4;
+  const char* a_base = reinterpret_cast<const char*>(p.A.ptr) + (p.A.s0 * z0 + p.A.s1 * z1 + p.A.s2 * (long long)(p.A.idx2 ? p.A.idx2[z2] : z2) + (long long)m0 * lda) * a_es;
+  const char* b_base = reinterpret_cast<const char*>(p.B.ptr) + (p.B.s0 * z0 + p.B.s1 * z1 + p.B.s2 * (long long)(p.B.idx2 ? p.B.idx2[z2] : z2) + (B_NK ? (long long)n0 * ldb : (long long)n0)) * b_es;
+  char* c_base = reinterpret_cast<char*>(p.C.ptr) + (p.C.s0 * z0 + p.C.s1 * z1 + p.C.s2 * (long long)(p.C.idx2 ? p.C.idx2[z2] : z2) + (long long)m0 * ldc + n0) * c_es;
+  const long long a_win = (long long)BM * lda * a_es;
+  const long long b_win = B_NK ? (long long)BN * ldb * b_es : ((long long)(K - 1) * ldb + (N - n0)) * b_es;
+  const long long c_win = (long long)BM * ldc * c_es;
+  const csn_rsrc_t Ar = csn_make_rsrc(a_base, a_win), Arl = csn_make_rsrc(a_base + p.A.plane_stride * 2, a_pl ? a_win : 0);
+  const csn_rsrc_t Br = csn_make_rsrc(b_base, b_win), Brl = csn_make_rsrc(b_base + p.B.plane_stride * 2, b_pl ? b_win : 0);
+  const csn_rsrc_t Cr = csn_make_rsrc(c_base, c_win), Crl = csn_make_rsrc(c_base + p.C.plane_stride * 2, c_pl ? c_win : 0);
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -80,43 +90,55 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   const int kr = tid / TPR, kc = (tid % TPR) * 4;
   unsigned a_off[A_PASS], b_off[B_PASS];
 #pragma unroll
-  for (int i = 0; i < A_PASS; ++i) a_off[i] = (m0 + pr + 32 * i) < M ? (unsigned)((pr + 32 * i) * lda + pc) * 4u : CSN_OOB;
+  for (int i = 0; i < A_PASS; ++i) a_off[i] = (m0 + pr + 32 * i) < M ? (unsigned)((pr + 32 * i) * lda + pc) * (unsigned)a_es : CSN_OOB;
 #pragma unroll
   for (int i = 0; i < B_PASS; ++i) {
-    if (B_NK) b_off[i] = (n0 + pr + 32 * i) < N ? (unsigned)((pr + 32 * i) * ldb + pc) * 4u : CSN_OOB;
-    else b_off[i] = (n0 + kc) < N ? (unsigned)((kr + RPP * i) * ldb + kc) * 4u : CSN_OOB;
+    if (B_NK) b_off[i] = (n0 + pr + 32 * i) < N ? (unsigned)((pr + 32 * i) * ldb + pc) * (unsigned)b_es : CSN_OOB;
+    else b_off[i] = (n0 + kc) < N ? (unsigned)((kr + RPP * i) * ldb + kc) * (unsigned)b_es : CSN_OOB;
   }
 
+  // a staged piece = 4 consecutive elements: either one fp32x4, or 4 bf16 of the high plane (.xy) + 4 of the low (.zw)
   f32x4 ra[A_PASS], rb[B_PASS];
+  auto piece = [&](const csn_rsrc_t& hi, const csn_rsrc_t& lo, bool planes, unsigned voff, unsigned soff) -> f32x4 {
+    if (!planes) return csn_bload4(hi, voff, soff);
+    const u32x2 h2 = csn_bload2(hi, voff, soff), l2 = csn_bload2(lo, voff, soff);
+    const u32x4 v = {h2.x, h2.y, l2.x, l2.y};
+    return __builtin_bit_cast(f32x4, v);
+  };
   auto load_slab = [&](int k0) {
     const unsigned kp = (k0 + pc) < K ? 0u : CSN_OOB;
 #pragma unroll
-    for (int i = 0; i < A_PASS; ++i) ra[i] = csn_bload4(Ar, a_off[i] | kp, (unsigned)k0 * 4u);
+    for (int i = 0; i < A_PASS; ++i) ra[i] = piece(Ar, Arl, a_pl, a_off[i] | kp, (unsigned)k0 * (unsigned)a_es);
     if (B_NK) {
 #pragma unroll
-      for (int i = 0; i < B_PASS; ++i) rb[i] = csn_bload4(Br, b_off[i] | kp, (unsigned)k0 * 4u);
+      for (int i = 0; i < B_PASS; ++i) rb[i] = piece(Br, Brl, b_pl, b_off[i] | kp, (unsigned)k0 * (unsigned)b_es);
     } else {
 #pragma unroll
       for (int i = 0; i < B_PASS; ++i) {
         const unsigned kq = (k0 + kr + RPP * i) < K ? 0u : CSN_OOB;
-        rb[i] = csn_bload4(Br, b_off[i] | kq, (unsigned)k0 * (unsigned)ldb * 4u);
+        rb[i] = piece(Br, Brl, b_pl, b_off[i] | kq, (unsigned)k0 * (unsigned)ldb * (unsigned)b_es);
       }
     }
   };
-  auto store_slab = [&]() {
-    bf16x4 hi, lo;
-#pragma unroll
-    for (int i = 0; i < A_PASS; ++i) {
-      split4(ra[i], hi, lo);
-      *reinterpret_cast<bf16x4*>(&As[0][(pr + 32 * i) * PK + pc]) = hi;
-      *reinterpret_cast<bf16x4*>(&As[1][(pr + 32 * i) * PK + pc]) = lo;
+  auto put = [&](__bf16* hi_dst, __bf16* lo_dst, const f32x4 v, bool planes) {
+    if (planes) {
+      const u32x4 u = __builtin_bit_cast(u32x4, v);
+      *reinterpret_cast<u32x2*>(hi_dst) = u32x2{u.x, u.y};
+      *reinterpret_cast<u32x2*>(lo_dst) = u32x2{u.z, u.w};
+    } else {
+      bf16x4 hi, lo;
+      split4(v, hi, lo);
+      *reinterpret_cast<bf16x4*>(hi_dst) = hi;
+      *reinterpret_cast<bf16x4*>(lo_dst) = lo;
     }
+  };
+  auto store_slab = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) put(&As[0][(pr + 32 * i) * PK + pc], &As[1][(pr + 32 * i) * PK + pc], ra[i], a_pl);
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
-      split4(rb[i], hi, lo);
       const int dst = B_NK ? (pr + 32 * i) * PK + pc : (kr + RPP * i) * PN + kc;
-      *reinterpret_cast<bf16x4*>(&Bs[0][dst]) = hi;
-      *reinterpret_cast<bf16x4*>(&Bs[1][dst]) = lo;
+      put(&Bs[0][dst], &Bs[1][dst], rb[i], b_pl);
     }
   };
 
@@ -182,12 +204,26 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ml = wm0 + 32 * i + csn_acc_row(r, h);
-        c_off[i][j][r] = ((m0 + ml) < M && (n0 + nl) < N) ? (unsigned)(ml * ldc + nl) * 4u : CSN_OOB;
+        c_off[i][j][r] = ((m0 + ml) < M && (n0 + nl) < N) ? (unsigned)(ml * ldc + nl) * (unsigned)c_es : CSN_OOB;
         float v = acc[i][j][r] * alpha;
         if ((m0 + ml) < p.div_rows) v = v / p.div_val;
         acc[i][j][r] = v;
       }
     }
+  if (c_pl) {
+    // split once here, so that every consumer of C stages plain bf16 planes (no accumulation into planes)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const __bf16 hi = (__bf16)acc[i][j][r];
+          csn_bstore_bf16(hi, Cr, c_off[i][j][r]);
+          csn_bstore_bf16((__bf16)(acc[i][j][r] - (float)hi), Crl, c_off[i][j][r]);
+        }
+    return;
+  }
   if (p.accumulate) {
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -217,6 +253,7 @@ int launch(const CsnGemmArgs& a, int batch, hipStream_t st) {
 }  // namespace
 
 int csn_launch_gemm_bf16x3(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st) {
+  if (a.C.planes && a.accumulate) return -1;
   if (a.M <= 64) return b_is_nk ? launch<64, 128, true>(a, batch, st) : launch<64, 128, false>(a, batch, st);
   return b_is_nk ? launch<128, 128, true>(a, batch, st) : launch<128, 128, false>(a, batch, st);
 }

@@ -168,16 +168,28 @@ __global__ __launch_bounds__(256) void csn_ln_bwd_kernel(CsnLnBwdArgs p) {
 }
 
 // out[e][h][n] = sum_{c < d} a[e][h*d + c][n] * b[e][h*d + c][n]    (delta = rowsum(dO * O) of the softmax backward)
+// a may be a split tensor (bf16 hi plane at a, lo plane a_plane_stride bf16 elements later; same strides in elements)
 __global__ __launch_bounds__(256) void csn_rowdot_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          float* __restrict__ out, const int* __restrict__ eval_ids, int H,
-                                                         int d, int ld, int n_points, long long eval_stride) {
+                                                         int d, int ld, int n_points, long long eval_stride, int a_split,
+                                                         long long a_plane_stride) {
   const int n = blockIdx.x * 256 + threadIdx.x;
   const int hd = blockIdx.y % H;
   const int e = eval_ids ? eval_ids[blockIdx.y / H] : (int)(blockIdx.y / H);
   if (n >= n_points) return;
   const long long base = (long long)e * eval_stride + (long long)hd * d * ld + n;
   float s = 0.f;
-  for (int c = 0; c < d; ++c) s += a[base + (long long)c * ld] * b[base + (long long)c * ld];
+  if (a_split) {
+    // split layout [eval][2 planes][rows][ld]: the evaluation stride doubles
+    const __bf16* __restrict__ ah = reinterpret_cast<const __bf16*>(a) + (long long)e * eval_stride;
+    const __bf16* __restrict__ al = ah + a_plane_stride;
+    for (int c = 0; c < d; ++c) {
+      const long long i = base + (long long)c * ld;
+      s += ((float)ah[i] + (float)al[i]) * b[i];
+    }
+  } else {
+    for (int c = 0; c < d; ++c) s += a[base + (long long)c * ld] * b[base + (long long)c * ld];
+  }
   out[((long long)e * H + hd) * n_points + n] = s;
 }
 
@@ -212,9 +224,10 @@ int csn_launch_ln_bwd_f32(const CsnLnBwdArgs& a, hipStream_t st) {
 }
 
 int csn_launch_rowdot_f32(const float* a, const float* b, float* out, const int* eval_ids, int E, int H, int d, int ld,
-                          int n_points, long long eval_stride, hipStream_t st) {
+                          int n_points, long long eval_stride, int a_split, long long a_plane_stride, hipStream_t st) {
   if (E <= 0 || n_points <= 0) return 0;
   dim3 grid((n_points + 255) / 256, E * H);
-  hipLaunchKernelGGL(csn_rowdot_kernel, grid, dim3(256), 0, st, a, b, out, eval_ids, H, d, ld, n_points, eval_stride);
+  hipLaunchKernelGGL(csn_rowdot_kernel, grid, dim3(256), 0, st, a, b, out, eval_ids, H, d, ld, n_points, eval_stride, a_split,
+                     a_plane_stride);
   return (int)hipGetLastError();
 }

@@ -23,6 +23,7 @@ REF_BLOCK = 500       # MID-FC/csa_models.py:84
 REF_NBLOCKS = 20      # MID-FC/csa_models.py:83
 LN_EPS = 1e-6         # MID-FC/csa_models.py:57
 RESCALE_THRESHOLD = 8.0
+USE_SPLIT_PLANES = False     # fast math: hand Q/K/V and the attention-output gradient between kernels as bf16 hi/lo planes
 # bench.py sets this to a list to collect (start, end) HIP-event pairs around the fused attention forward launch
 EVENT_SINK = None
 
@@ -39,7 +40,7 @@ def _need_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
             raise _lib.CsnError("csn_amd ops need tensors on the MI355X (cuda) device; there is no CPU path")
-        if t is not None and t.dtype != torch.float32 and t.dtype != torch.int32:
+        if t is not None and t.dtype not in (torch.float32, torch.int32, torch.bfloat16):
             raise _lib.CsnError(f"csn_amd ops are fp32 (got {t.dtype})")
 
 
@@ -100,17 +101,28 @@ class EvalPlan:
 # ------------------------------------------------------------------------------------------------------
 # raw (non-differentiable) calls — thin, typed views of the C ABI
 # ------------------------------------------------------------------------------------------------------
+def fast_math() -> bool:
+    """True when the contractions run as three bf16 matrix-core products per fp32 product (csn_set_math_mode(1))."""
+    return _lib.lib().csn_get_math_mode() == 1
+
+
 def project(x: torch.Tensor, w: torch.Tensor, div_rows: int = 0, temperature: float = 1.0,
-            n_points: Optional[int] = None) -> torch.Tensor:
-    """x (S, C, N), w (R, C)  ->  (S, R, n_points) = w @ x[s]; rows < div_rows divided by temperature."""
+            n_points: Optional[int] = None, split: bool = False) -> torch.Tensor:
+    """x (S, C, N), w (R, C)  ->  (S, R, n_points) = w @ x[s]; rows < div_rows divided by temperature.
+    split=True (fast math only): the result is returned as bf16 planes (S, 2, R, n_points), x = hi + lo."""
     _need_cuda(x, w)
     S, C, N = x.shape
     R = w.shape[0]
     npts = N if n_points is None else n_points
     assert x.stride(2) == 1 and x.stride(1) == N and w.is_contiguous()
+    if split:
+        out = torch.empty((S, 2, R, npts), device=x.device, dtype=torch.bfloat16)
+        _lib.check(_lib.lib().csn_project_f32(_ptr(x), x.stride(0), N, _ptr(w), R, C, _ptr(out), 2 * R * npts, npts, S, npts,
+                                              div_rows, float(temperature), 1, R * npts, _stream()), "csn_project_f32")
+        return out
     out = torch.empty((S, R, npts), device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib().csn_project_f32(_ptr(x), x.stride(0), N, _ptr(w), R, C, _ptr(out), R * npts, npts, S, npts,
-                                          div_rows, float(temperature), _stream()), "csn_project_f32")
+                                          div_rows, float(temperature), 0, 0, _stream()), "csn_project_f32")
     return out
 
 
@@ -173,22 +185,27 @@ class _MHAEvals(torch.autograd.Function):
         dev = x_all.device
         temperature = float(d) ** 0.5                                  # csa_models.py:54
         w_qkv = torch.cat((w_qs, w_ks, w_vs), dim=0).contiguous()      # (3D, C)
-        qkv = project(x_all, w_qkv, div_rows=D, temperature=temperature)   # (S, 3D, NP); Q rows pre-scaled
+        # fast math: Q/K/V leave the projection already split into bf16 planes (S, 2, 3D, NP)
+        # (measured on MI355X: reading planes needs 8-byte / 2-byte loads because blocks of 500 points are only 8-byte
+        #  aligned in bf16, and that costs more than splitting fp32 tiles on the fly — so the planes stay off for now)
+        split = fast_math() and USE_SPLIT_PLANES
+        qkv = project(x_all, w_qkv, div_rows=D, temperature=temperature, split=split)   # (S, 3D, NP); Q rows pre-scaled
         att = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
         lse = torch.empty((E, H, NP), device=dev, dtype=torch.float32)
         scores = torch.empty((E, H, nb, T, Tp), device=dev, dtype=torch.float32) if keep_scores else None
-        slot_stride = 3 * D * NP
+        es = 2 if split else 4                                         # bytes per element of qkv
+        slot_stride = (2 if split else 1) * 3 * D * NP
         base = qkv.data_ptr()
         # values may come from a different slot than the keys (slot kv + v_shift): only the generic
         # MultiHeadAttention.forward(Q, K, V) with three distinct inputs uses that
-        v_base = base + 8 * D * NP + 4 * v_shift * slot_stride
+        v_base = base + es * (2 * D * NP + v_shift * slot_stride)
         if EVENT_SINK is not None:
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record()
-        _lib.check(L.csn_block_attn_fwd_f32(base, base + 4 * D * NP, v_base, slot_stride, slot_stride,
+        _lib.check(L.csn_block_attn_fwd_f32(base, base + es * D * NP, v_base, slot_stride, slot_stride,
                                             _ptr(q_slots), _ptr(kv_slots), NP, _ptr(att), D * NP, _ptr(scores),
                                             _ptr(lse), E, H, d, T, nb, Tp, RESCALE_THRESHOLD, p_attn, seed_attn,
-                                            _stream()),
+                                            1 if split else 0, 3 * D * NP, _stream()),
                    "csn_block_attn_fwd_f32")
         if EVENT_SINK is not None:
             ev1 = torch.cuda.Event(enable_timing=True)
@@ -206,6 +223,7 @@ class _MHAEvals(torch.autograd.Function):
             ctx.geo = geo
             ctx.plan = plan
             ctx.drop = (p_attn, seed_attn, p_fc, seed_fc)
+            ctx.split = split
         return xhat
 
     @staticmethod
@@ -225,16 +243,20 @@ class _MHAEvals(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
 
         # ---- LayerNorm + fc backward -------------------------------------------------------------------
+        split = ctx.split                      # fast math: qkv and the attention-output gradient live as bf16 planes
+        sp = 1 if split else 0
         dz = torch.empty((E, C, NP), device=dev, dtype=torch.float32)
         dz_res = torch.empty((E, C, NP), device=dev, dtype=torch.float32) if (need_dx and p_fc > 0) else None
-        datt = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
+        datt = (torch.empty((E, 2, D, NP), device=dev, dtype=torch.bfloat16) if split
+                else torch.empty((E, D, NP), device=dev, dtype=torch.float32))
         dw_fc = torch.empty((C, D), device=dev, dtype=torch.float32)
         ws_n = L.csn_wgrad_workspace_floats(C, D, E, NP)
         ws = torch.empty((ws_n,), device=dev, dtype=torch.float32)
         w_fc_t = w_fc.t().contiguous()
         _lib.check(L.csn_outproj_ln_bwd_f32(_ptr(dxhat), _ptr(xhat), _ptr(rstd), C * NP, _ptr(att), D * NP,
                                             _ptr(w_fc_t), _ptr(dz), _ptr(dz_res), _ptr(datt), _ptr(dw_fc), _ptr(ws), ws_n,
-                                            E, C, D, NP, NP, 0, p_fc, seed_fc, _stream()), "csn_outproj_ln_bwd_f32")
+                                            E, C, D, NP, NP, 0, p_fc, seed_fc, sp, D * NP, _stream()),
+                   "csn_outproj_ln_bwd_f32")
         del ws
 
         # ---- attention backward, straight into per-slot gradient maps ---------------------------------------
@@ -243,22 +265,26 @@ class _MHAEvals(torch.autograd.Function):
         delta = torch.empty((E, H, NP), device=dev, dtype=torch.float32)
         full = plan.full_cover
         dqkv = (torch.empty if full else torch.zeros)((S, 3 * D, NP), device=dev, dtype=torch.float32)
-        slot_stride = 3 * D * NP
+        es = 2 if split else 4
+        slot_stride = 3 * D * NP                                   # of the fp32 gradient maps
+        q_stride = (2 if split else 1) * 3 * D * NP                # of qkv (two planes per slot when split)
         base, gbase = qkv.data_ptr(), dqkv.data_ptr()
-        v_base = base + 8 * D * NP + 4 * plan.v_shift * slot_stride
+        v_base = base + es * (2 * D * NP + plan.v_shift * q_stride)
         for ci, ids in enumerate(plan.dq_colors):
-            _lib.check(L.csn_block_attn_bwd_dq_f32(_ptr(datt), _ptr(att), D * NP, base + 4 * D * NP, v_base, slot_stride,
+            _lib.check(L.csn_block_attn_bwd_dq_f32(_ptr(datt), _ptr(att), D * NP, base + es * D * NP, v_base, q_stride,
                                                    _ptr(plan.kv_slots), NP, _ptr(scores), _ptr(dscores), _ptr(lse),
                                                    _ptr(delta), gbase, slot_stride, _ptr(plan.q_slots),
                                                    0 if (full and ci == 0) else 1, _ptr(ids),
-                                                   ids.numel(), H, d, T, nb, Tp, p_attn, seed_attn, _stream()),
+                                                   ids.numel(), H, d, T, nb, Tp, p_attn, seed_attn, sp, D * NP, sp,
+                                                   3 * D * NP, _stream()),
                        "csn_block_attn_bwd_dq_f32")
         for ci, ids in enumerate(plan.dkv_colors):
-            _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, base, slot_stride, _ptr(plan.q_slots), NP,
+            _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, base, q_stride, _ptr(plan.q_slots), NP,
                                                     _ptr(scores), _ptr(dscores), gbase + 4 * D * NP, gbase + 8 * D * NP,
                                                     slot_stride, _ptr(plan.kv_slots), _ptr(plan.v_slots),
                                                     0 if (full and ci == 0) else 1, _ptr(ids),
-                                                    ids.numel(), H, d, T, nb, Tp, _stream()), "csn_block_attn_bwd_dkv_f32")
+                                                    ids.numel(), H, d, T, nb, Tp, sp, D * NP, sp, 3 * D * NP, _stream()),
+                       "csn_block_attn_bwd_dkv_f32")
         del dscores, delta, datt
 
         # ---- projection weight gradients ------------------------------------------------------------------

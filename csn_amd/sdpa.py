@@ -31,7 +31,7 @@ class _SDPA(torch.autograd.Function):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_drop > 0 else 0
         _lib.check(L.csn_block_attn_fwd_f32(CF._ptr(qm), CF._ptr(km), CF._ptr(vm), d * T, d * T, None, None, T,
                                             CF._ptr(att), d * T, CF._ptr(scores), CF._ptr(lse), S, 1, d, T, 1, Tp,
-                                            CF.RESCALE_THRESHOLD, p_drop, seed, CF._stream()), "csn_block_attn_fwd_f32")
+                                            CF.RESCALE_THRESHOLD, p_drop, seed, 0, 0, CF._stream()), "csn_block_attn_fwd_f32")
         # P[q][key] = exp(S^T[key][q] - lse[q])   (the un-dropped probabilities; with dropout the reference returns the
         # dropped ones — every caller in the reference discards this tensor)
         prob = torch.exp(scores[:, 0, 0, :, :T] - lse[:, 0, None, :]).transpose(1, 2).reshape(B, H, T, T)
@@ -55,11 +55,11 @@ class _SDPA(torch.autograd.Function):
         L = _lib.lib()
         _lib.check(L.csn_block_attn_bwd_dq_f32(CF._ptr(datt), CF._ptr(att), d * T, CF._ptr(km), CF._ptr(vm), d * T, None, T,
                                                CF._ptr(work), CF._ptr(dscores), CF._ptr(lse), CF._ptr(delta), CF._ptr(dq),
-                                               d * T, None, 0, None, S, 1, d, T, 1, Tp, ctx.drop[0], ctx.drop[1],
+                                               d * T, None, 0, None, S, 1, d, T, 1, Tp, ctx.drop[0], ctx.drop[1], 0, 0, 0, 0,
                                                CF._stream()), "csn_block_attn_bwd_dq_f32")
         _lib.check(L.csn_block_attn_bwd_dkv_f32(CF._ptr(datt), d * T, CF._ptr(qm), d * T, None, T, CF._ptr(work),
                                                 CF._ptr(dscores), CF._ptr(dk), CF._ptr(dv), d * T, None, None, 0, None, S, 1,
-                                                d, T, 1, Tp, CF._stream()), "csn_block_attn_bwd_dkv_f32")
+                                                d, T, 1, Tp, 0, 0, 0, 0, CF._stream()), "csn_block_attn_bwd_dkv_f32")
         back = lambda g: g.transpose(1, 2).reshape(B, H, T, d)
         return back(dq) / ctx.temperature, back(dk), back(dv), None, None
 

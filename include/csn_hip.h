@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSN_ABI_VERSION 2
+#define CSN_ABI_VERSION 3
 
 #define CSN_E_ARG (-1)     /* null pointer / non-positive size            */
 #define CSN_E_ALIGN (-2)   /* a size or leading dimension is not % 4      */
@@ -43,6 +43,14 @@ int csn_version(void);
  *   1 = "bf16x3": every fp32 operand is split into two bf16 terms and a product is three bf16 MFMAs
  *       (hi*hi + hi*lo + lo*hi, fp32 accumulate): ~1e-5 relative error per product, 5.3x the matrix-core rate.
  * Process-wide setting, not thread-safe; returns CSN_E_ARG for any other value. */
+/* SPLIT TENSORS (math mode 1 only).  Arguments named *_split / *_plane_stride let a kernel write, or read, an fp32
+ * tensor as two bf16 planes x = hi + lo (hi = bf16(x), lo = bf16(x - hi)): the pointer then addresses the HIGH
+ * plane (bf16 elements, cast to float* for the ABI), the LOW plane starts `plane_stride` bf16 elements later, and
+ * every stride / leading dimension of that tensor counts bf16 elements (same numbers as for the fp32 tensor).
+ * The producer's epilogue splits once; consumers stage the planes into LDS with plain copies (no conversion work per
+ * tile).  A split dctx (attention-output gradient) is laid out [evaluation][2 planes][n_heads*d_head][ld]: its
+ * evaluation stride is 2 * ctx_eval_stride and dctx_plane_stride = ctx_eval_stride.  Passing *_split != 0 in math
+ * mode 0 returns CSN_E_ARG. */
 int csn_set_math_mode(int mode);
 int csn_get_math_mode(void);
 /* Human-readable text for a status code returned by any function below. Host pointer, static storage. */
@@ -55,7 +63,7 @@ const char* csn_status_string(int status);
  * project a shape once for all of its evaluations). */
 int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const float* w, int rows, int channels,
                     float* out, long long out_shape_stride, int ld_out, int n_shapes, int n_points, int div_rows,
-                    float temperature, void* stream);
+                    float temperature, int out_split, long long out_plane_stride, void* stream);
 
 /* ---- (2) block-diagonal scaled-dot-product attention, forward ----------------------------------------
  * For evaluation e, head h, block b:  P = softmax(Qs K^T) over the block's keys, ctx = P V
@@ -75,7 +83,8 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
                            long long kv_shape_stride, const int* q_index, const int* kv_index, int ld, float* ctx,
                            long long ctx_eval_stride, float* scores, float* lse, int n_evals, int n_heads,
                            int d_head, int block, int n_blocks, int score_pitch, float rescale_threshold,
-                           float dropout_p, unsigned long long seed, void* stream);
+                           float dropout_p, unsigned long long seed, int qkv_split, long long qkv_plane_stride,
+                           void* stream);
 
 /* ---- (3) block attention, backward (autograd of csa_models.py:139-142) -------------------------------
  * Two calls, because their outputs are shared differently between evaluations (the query shape's Q serves
@@ -96,12 +105,14 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
                               float* dscores, const float* lse, float* delta, float* dq, long long dq_slot_stride,
                               const int* dq_index, int accumulate, const int* eval_ids, int n_launch_evals, int n_heads,
                               int d_head, int block, int n_blocks, int score_pitch, float dropout_p,
-                              unsigned long long seed, void* stream);
+                              unsigned long long seed, int dctx_split, long long dctx_plane_stride, int kv_split,
+                              long long kv_plane_stride, void* stream);
 int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
                                const int* q_index, int ld, const float* probs, const float* dscores, float* dk,
                                float* dv, long long dkv_slot_stride, const int* dk_index, const int* dv_index,
                                int accumulate, const int* eval_ids, int n_launch_evals, int n_heads, int d_head,
-                               int block, int n_blocks, int score_pitch, void* stream);
+                               int block, int n_blocks, int score_pitch, int dctx_split, long long dctx_plane_stride,
+                               int q_split, long long q_plane_stride, void* stream);
 
 /* ---- (4) output projection + residual + LayerNorm, forward -------------------------------------------
  * z[c][n] = sum_D wfc[c][D] ctx[e][D][n] + xres[res_index[e]][c][n];  xhat = (z - mean_c z) * rstd,
@@ -126,7 +137,7 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
                            const float* ctx, long long ctx_eval_stride, const float* wfc_t, float* dz, float* dz_res,
                            float* dctx, float* dwfc, float* ws, long long ws_floats, int n_evals, int d_model,
                            int d_inner, int ld, int n_points, int accumulate, float dropout_p,
-                           unsigned long long seed, void* stream);
+                           unsigned long long seed, int dctx_split, long long dctx_plane_stride, void* stream);
 
 /* ---- (6) projection weight gradient ----------------------------------------------------------------------
  * dw[r][c] (+)= scale * sum_{s,n} dout[s][r][n] * x[s][c][n]        (autograd of csa_models.py:103-105) */

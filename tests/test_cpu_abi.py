@@ -36,7 +36,7 @@ def test_header_symbols_are_exported(L):
 
 def test_library_loads_and_reports_version(L):
     lib = L.lib()
-    assert lib.csn_version() == 2
+    assert lib.csn_version() == 3
     assert lib.csn_status_string(0) == b"ok"
     assert b"workspace" in lib.csn_status_string(-6)
 
@@ -44,8 +44,8 @@ def test_library_loads_and_reports_version(L):
 def test_argument_validation_happens_on_the_host(L):
     lib = L.lib()
     # null pointers / bad sizes are rejected before any launch, so this is safe without a GPU
-    assert lib.csn_project_f32(None, 0, 4, None, 1, 1, None, 0, 4, 1, 4, 0, 1.0, None) == -1
-    assert lib.csn_block_attn_fwd_f32(None, None, None, 0, 0, None, None, 4, None, 0, None, None, 1, 1, 32, 4, 1, 32, 0.0, 0.0, 0, None) == -1
+    assert lib.csn_project_f32(None, 0, 4, None, 1, 1, None, 0, 4, 1, 4, 0, 1.0, 0, 0, None) == -1
+    assert lib.csn_block_attn_fwd_f32(None, None, None, 0, 0, None, None, 4, None, 0, None, None, 1, 1, 32, 4, 1, 32, 0.0, 0.0, 0, 0, 0, None) == -1
     assert lib.csn_retrieval_measure_f32(None, None, None, 1, 1, 1, 1, 4, None, 0, None) == -1
     assert lib.csn_wgrad_workspace_floats(256, 256, 0, 10) == 0
     n = lib.csn_wgrad_workspace_floats(256, 256, 128, 10000)

@@ -42,7 +42,7 @@ def test_attention_dropout_forward_backward_with_host_mask(E, H, d, T, nb, p):
     scores = torch.empty((E, H, nb, T, Tp), device="cuda")
     L.check(L.lib().csn_block_attn_fwd_f32(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), D * N, D * N, None, None, N,
                                            ctx.data_ptr(), D * N, scores.data_ptr(), lse.data_ptr(), E, H, d, T, nb, Tp, 8.0,
-                                           p, seed, _stream()))
+                                           p, seed, 0, 0, _stream()))
     mask = torch.from_numpy(dr.attention_mask(E, H, nb, T, Tp, seed, p)).double()      # [e][h][blk][key][query]
     assert abs(mask.mean().item() - (1 - p)) < 4 * math.sqrt(p * (1 - p) / mask.numel())
 
@@ -61,10 +61,10 @@ def test_attention_dropout_forward_backward_with_host_mask(E, H, d, T, nb, p):
     dq, dk, dv = (torch.empty((E, D, N), device="cuda") for _ in range(3))
     L.check(L.lib().csn_block_attn_bwd_dq_f32(dd.data_ptr(), ctx.data_ptr(), D * N, kd.data_ptr(), vd.data_ptr(), D * N, None,
                                               N, scores.data_ptr(), dscores.data_ptr(), lse.data_ptr(), delta.data_ptr(),
-                                              dq.data_ptr(), D * N, None, 0, None, E, H, d, T, nb, Tp, p, seed, _stream()))
+                                              dq.data_ptr(), D * N, None, 0, None, E, H, d, T, nb, Tp, p, seed, 0, 0, 0, 0, _stream()))
     L.check(L.lib().csn_block_attn_bwd_dkv_f32(dd.data_ptr(), D * N, qd.data_ptr(), D * N, None, N, scores.data_ptr(),
                                                dscores.data_ptr(), dk.data_ptr(), dv.data_ptr(), D * N, None, None, 0, None, E, H,
-                                               d, T, nb, Tp, _stream()))
+                                               d, T, nb, Tp, 0, 0, 0, 0, _stream()))
     torch.cuda.synchronize()
     assert _rel(dq, q64.grad) < 2e-5 and _rel(dk, k64.grad) < 2e-5 and _rel(dv, v64.grad) < 2e-5
     # the scores buffer now holds the dropped probabilities
@@ -74,7 +74,7 @@ def test_attention_dropout_forward_backward_with_host_mask(E, H, d, T, nb, p):
     ctx2, ctx3 = torch.empty_like(ctx), torch.empty_like(ctx)
     for out, sd in ((ctx2, seed + 1), (ctx3, seed)):
         L.check(L.lib().csn_block_attn_fwd_f32(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), D * N, D * N, None, None, N,
-                                               out.data_ptr(), D * N, None, lse.data_ptr(), E, H, d, T, nb, Tp, 8.0, p, sd,
+                                               out.data_ptr(), D * N, None, lse.data_ptr(), E, H, d, T, nb, Tp, 8.0, p, sd, 0, 0,
                                                _stream()))
     torch.cuda.synchronize()
     assert torch.equal(ctx3, ctx) and not torch.equal(ctx2, ctx)
@@ -105,7 +105,7 @@ def test_fc_dropout_forward_backward_with_host_mask(E, C, D, NP, p):
     wt = wd.t().contiguous()
     L.check(L.lib().csn_outproj_ln_bwd_f32(dxd.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), C * NP, attd.data_ptr(), D * NP,
                                            wt.data_ptr(), dz.data_ptr(), dz_res.data_ptr(), datt.data_ptr(), dw.data_ptr(),
-                                           ws.data_ptr(), ws_n, E, C, D, NP, NP, 0, p, seed, _stream()))
+                                           ws.data_ptr(), ws_n, E, C, D, NP, NP, 0, p, seed, 0, 0, _stream()))
     torch.cuda.synchronize()
     assert _rel(datt, a64.grad) < 2e-5 and _rel(dw, w64.grad) < 2e-5 and _rel(dz_res, x64.grad) < 2e-5
 

@@ -125,7 +125,7 @@ def _run_attn_fwd(L, q, k, v, q_idx, kv_idx, H, d, T, nb, thr=8.0, keep=True, p_
     scores = torch.full((E, H, nb, T, Tp), float("nan"), device=dev) if keep else None
     rc = L.lib().csn_block_attn_fwd_f32(qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), D * N, D * N, qi.data_ptr(),
                                         ki.data_ptr(), N, ctx.data_ptr(), D * N, scores.data_ptr() if keep else None,
-                                        lse.data_ptr(), E, H, d, T, nb, Tp, thr, p_drop, seed, _stream())
+                                        lse.data_ptr(), E, H, d, T, nb, Tp, thr, p_drop, seed, 0, 0, _stream())
     L.check(rc, "attn fwd")
     torch.cuda.synchronize()
     return ctx, lse, scores, (qd, kd, vd, qi, ki)
@@ -180,11 +180,11 @@ def test_block_attn_bwd(L, S, E, H, d, T, nb):
     rc = L.lib().csn_block_attn_bwd_dq_f32(dd.data_ptr(), ctx.data_ptr(), D * N, kd.data_ptr(), vd.data_ptr(), D * N,
                                            ki.data_ptr(), N, scores.data_ptr(), dscores.data_ptr(), lse.data_ptr(),
                                            delta.data_ptr(), dq.data_ptr(), D * N, None, 0, None, E, H, d, T, nb, Tp, 0.0, 0,
-                                           _stream())
+                                           0, 0, 0, 0, _stream())
     L.check(rc, "attn bwd dq")
     rc = L.lib().csn_block_attn_bwd_dkv_f32(dd.data_ptr(), D * N, qd.data_ptr(), D * N, qi.data_ptr(), N, scores.data_ptr(),
                                             dscores.data_ptr(), dk.data_ptr(), dv.data_ptr(), D * N, None, None, 0, None, E,
-                                            H, d, T, nb, Tp, _stream())
+                                            H, d, T, nb, Tp, 0, 0, 0, 0, _stream())
     L.check(rc, "attn bwd")
     torch.cuda.synchronize()
     # float64 autograd reference, per evaluation (no sharing: the ABI returns per-evaluation gradients)
@@ -214,12 +214,12 @@ def test_block_attn_bwd(L, S, E, H, d, T, nb):
         L.check(L.lib().csn_block_attn_bwd_dq_f32(dd.data_ptr(), ctx.data_ptr(), D * N, kd.data_ptr(), vd.data_ptr(), D * N,
                                                   ki.data_ptr(), N, scores2.data_ptr(), dscores.data_ptr(), lse.data_ptr(),
                                                   delta.data_ptr(), sq.data_ptr(), D * N, qi.data_ptr(), 1, ids.data_ptr(),
-                                                  ids.numel(), H, d, T, nb, Tp, 0.0, 0, _stream()))
+                                                  ids.numel(), H, d, T, nb, Tp, 0.0, 0, 0, 0, 0, 0, _stream()))
     for ids in plan.dkv_colors:
         L.check(L.lib().csn_block_attn_bwd_dkv_f32(dd.data_ptr(), D * N, qd.data_ptr(), D * N, qi.data_ptr(), N,
                                                    scores2.data_ptr(), dscores.data_ptr(), sk.data_ptr(), sv_.data_ptr(), D * N,
                                                    ki.data_ptr(), ki.data_ptr(), 1, ids.data_ptr(), ids.numel(), H, d, T, nb,
-                                                   Tp, _stream()))
+                                                   Tp, 0, 0, 0, 0, _stream()))
     torch.cuda.synchronize()
     assert _maxerr(sq, ref_dq) < tol(2e-5) and _maxerr(sk, ref_dk) < tol(2e-5) and _maxerr(sv_, ref_dv) < tol(2e-5)
 
@@ -267,7 +267,7 @@ def test_outproj_ln_fwd_bwd(L, S, E, C, D, NP):
     dxd = dxhat.cuda()
     L.check(L.lib().csn_outproj_ln_bwd_f32(dxd.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), C * NP, attd.data_ptr(), D * NP,
                                            wt.data_ptr(), dz.data_ptr(), None, datt.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws_n,
-                                           E, C, D, NP, NP, 0, 0.0, 0, _stream()))
+                                           E, C, D, NP, NP, 0, 0.0, 0, 0, 0, _stream()))
     ref.backward(dxhat.double())
     assert _maxerr(datt, a64.grad) < tol(2e-5)
     assert _maxerr(dw, w64.grad) < tol(2e-5)
@@ -291,11 +291,11 @@ def test_abi_rejects_bad_arguments(L):
     w = torch.zeros(32, 32, device="cuda")
     out = torch.zeros(1, 32, 36, device="cuda")
     # leading dimension not a multiple of 4
-    rc = lib.csn_project_f32(x.data_ptr(), 32 * 35, 35, w.data_ptr(), 32, 32, out.data_ptr(), 32 * 36, 36, 1, 35, 0, 1.0, _stream())
+    rc = lib.csn_project_f32(x.data_ptr(), 32 * 35, 35, w.data_ptr(), 32, 32, out.data_ptr(), 32 * 36, 36, 1, 35, 0, 1.0, 0, 0, _stream())
     assert rc == -2
     assert b"multiple of 4" in lib.csn_status_string(rc)
-    rc = lib.csn_project_f32(None, 0, 36, w.data_ptr(), 32, 32, out.data_ptr(), 32 * 36, 36, 1, 36, 0, 1.0, _stream())
+    rc = lib.csn_project_f32(None, 0, 36, w.data_ptr(), 32, 32, out.data_ptr(), 32 * 36, 36, 1, 36, 0, 1.0, 0, 0, _stream())
     assert rc == -1
     rc = lib.csn_block_attn_fwd_f32(x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, 0, None, None, 36, out.data_ptr(), 0, None,
-                                    None, 1, 1, 48, 36, 1, 64, 8.0, 0.0, 0, _stream())
+                                    None, 1, 1, 48, 36, 1, 64, 8.0, 0.0, 0, 0, 0, _stream())
     assert rc == -5
