@@ -118,7 +118,7 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
                            float dropout_p, unsigned long long seed, int qkv_split, long long qkv_plane_stride,
                            void* stream) {
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
-  if (qkv_split && g_math_mode != 1) return CSN_E_ARG;
+  if (qkv_split) return CSN_E_ARG;                                  // reserved (see header)
   if (!q || !k || !v || !ctx || n_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
   if (!dim_ok(d_head)) return CSN_E_DIM;
   if ((ld & 3) || (block & 3) || (score_pitch & 3) || score_pitch < block) return CSN_E_ALIGN;
@@ -148,7 +148,7 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
                               unsigned long long seed, int dctx_split, long long dctx_plane_stride, int kv_split,
                               long long kv_plane_stride, void* stream) {
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
-  if ((dctx_split || kv_split) && g_math_mode != 1) return CSN_E_ARG;
+  if (dctx_split || kv_split) return CSN_E_ARG;                      // reserved (see header)
   if (!dctx || !ctx || !k || !v || !scores || !dscores || !lse || !delta || !dq) return CSN_E_ARG;
   if (n_launch_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
   if (!dim_ok(d_head)) return CSN_E_DIM;
@@ -181,7 +181,7 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
                                int accumulate, const int* eval_ids, int n_launch_evals, int n_heads, int d_head,
                                int block, int n_blocks, int score_pitch, int dctx_split, long long dctx_plane_stride,
                                int q_split, long long q_plane_stride, void* stream) {
-  if ((dctx_split || q_split) && g_math_mode != 1) return CSN_E_ARG;
+  if (dctx_split || q_split) return CSN_E_ARG;                       // reserved (see header)
   if (!dctx || !q || !probs || !dscores || !dk || !dv) return CSN_E_ARG;
   if (n_launch_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
   if (!dim_ok(d_head)) return CSN_E_DIM;
@@ -224,7 +224,7 @@ int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const fl
   a.xhat = xhat; a.xhat_eval_stride = xhat_eval_stride; a.rstd = rstd;
   a.E = n_evals; a.C = d_model; a.D = d_inner; a.ld = ld; a.n_points = n_points; a.eps = eps;
   a.dropout_p = dropout_p; a.seed = seed;
-  return csn_launch_outproj_ln_fwd_f32(a, (hipStream_t)stream);
+  return csn_launch_outproj_ln_fwd_f32(a, g_math_mode == 1, (hipStream_t)stream);
 }
 
 int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* rstd, long long eval_stride,

@@ -61,7 +61,7 @@ struct CsnOutProjArgs {
   float dropout_p;                                       // dropout on the fc output (csa_models.py:115); 0 = off
   unsigned long long seed;
 };
-int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, hipStream_t st);
+int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, int fast, hipStream_t st);   // fast: bf16x3 contraction
 
 struct CsnLnBwdArgs {
   const float* dxhat; const float* xhat; const float* rstd;   // [e][C][ld], [e][C][ld], [e][n_points]

@@ -11,10 +11,11 @@
 //   A : MK (k contiguous)             -> fragments by one 16-byte LDS read per lane
 //   B : NK (k contiguous per column)  -> the same
 //       KN (k-major, lanes along n)   -> fragments by ds_read_b64_tr_b16, the CDNA4 transposing LDS read
-// An operand arrives either as fp32 (split into its bf16 hi / lo planes while it is staged into LDS: two bf16
-// planes take exactly the bytes of the fp32 tile) or already split (CsnOperand::planes: the producer kernel's
-// epilogue did the split once, staging is then a plain copy and costs no VALU work).  C can be written as fp32 or as
-// planes for the next contraction.
+// Operands arrive as fp32 and are split into their bf16 hi / lo planes while they are staged into LDS (two bf16
+// planes take exactly the bytes of the fp32 tile).  The split of slab k+1 (VALU) is issued between the matrix
+// instructions of slab k (two LDS stages, one barrier per slab), so it overlaps with the matrix pipe.  C can be written
+// as fp32 or as bf16 planes (CsnOperand::planes).  (Reading pre-split planes was tried and measured slower on this
+// path: blocks of 500 points are only 8-byte aligned in bf16, which halves the width of every staging load.)
 //
 // MFMA fragment maps (32x32x16 bf16): A lane l holds A[l & 31][8 (l >> 5) + j], B lane l holds
 // B[8 (l >> 5) + j][l & 31], j = 0..7; C/D as for the fp32 shape.
@@ -48,8 +49,8 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   constexpr int TPR = BN / 4, RPP = 256 / TPR;          // KN staging: threads per k row, k rows per pass
   constexpr int PN = BN + 32;                           // pitch of the k-major B planes: rows 64 B apart mod 256
   constexpr int A_EL = BM * PK, B_EL = B_NK ? BN * PK : BK * PN;
-  __shared__ __attribute__((aligned(16))) __bf16 As[2][A_EL];      // [plane][row][k]
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][B_EL];      // NK: [plane][col][k]   KN: [plane][k][col]
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][2][A_EL];   // [stage][plane][row][k]
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][2][B_EL];   // NK: [stage][plane][col][k]   KN: [stage][plane][k][col]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
@@ -65,17 +66,14 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   if (p.k_chunk > 0) { K = min(p.k_chunk, p.K - z0 * p.k_chunk); }
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
-  // element size of each operand in HBM: 4 (fp32) or 2 (one bf16 plane; the low plane follows plane_stride elements later)
-  const bool a_pl = p.A.planes != 0, b_pl = p.B.planes != 0, c_pl = p.C.planes != 0;
-  const int a_es = a_pl ? 2 : 4, b_es = b_pl ? 2 : 4, c_es = c_pl ? 2 : 4;
-  const char* a_base = reinterpret_cast<const char*>(p.A.ptr) + (p.A.s0 * z0 + p.A.s1 * z1 + p.A.s2 * (long long)(p.A.idx2 ? p.A.idx2[z2] : z2) + (long long)m0 * lda) * a_es;
-  const char* b_base = reinterpret_cast<const char*>(p.B.ptr) + (p.B.s0 * z0 + p.B.s1 * z1 + p.B.s2 * (long long)(p.B.idx2 ? p.B.idx2[z2] : z2) + (B_NK ? (long long)n0 * ldb : (long long)n0)) * b_es;
+  const bool c_pl = p.C.planes != 0;
+  const int c_es = c_pl ? 2 : 4;
+  const float* a_base = p.A.ptr + p.A.s0 * z0 + p.A.s1 * z1 + p.A.s2 * (long long)(p.A.idx2 ? p.A.idx2[z2] : z2) + (long long)m0 * lda;
+  const float* b_base = p.B.ptr + p.B.s0 * z0 + p.B.s1 * z1 + p.B.s2 * (long long)(p.B.idx2 ? p.B.idx2[z2] : z2) + (B_NK ? (long long)n0 * ldb : (long long)n0);
   char* c_base = reinterpret_cast<char*>(p.C.ptr) + (p.C.s0 * z0 + p.C.s1 * z1 + p.C.s2 * (long long)(p.C.idx2 ? p.C.idx2[z2] : z2) + (long long)m0 * ldc + n0) * c_es;
-  const long long a_win = (long long)BM * lda * a_es;
-  const long long b_win = B_NK ? (long long)BN * ldb * b_es : ((long long)(K - 1) * ldb + (N - n0)) * b_es;
   const long long c_win = (long long)BM * ldc * c_es;
-  const csn_rsrc_t Ar = csn_make_rsrc(a_base, a_win), Arl = csn_make_rsrc(a_base + p.A.plane_stride * 2, a_pl ? a_win : 0);
-  const csn_rsrc_t Br = csn_make_rsrc(b_base, b_win), Brl = csn_make_rsrc(b_base + p.B.plane_stride * 2, b_pl ? b_win : 0);
+  const csn_rsrc_t Ar = csn_make_rsrc(a_base, (long long)BM * lda * 4);
+  const csn_rsrc_t Br = csn_make_rsrc(b_base, B_NK ? (long long)BN * ldb * 4 : ((long long)(K - 1) * ldb + (N - n0)) * 4);
   const csn_rsrc_t Cr = csn_make_rsrc(c_base, c_win), Crl = csn_make_rsrc(c_base + p.C.plane_stride * 2, c_pl ? c_win : 0);
 
   f32x16 acc[MT][NT];
@@ -90,55 +88,43 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   const int kr = tid / TPR, kc = (tid % TPR) * 4;
   unsigned a_off[A_PASS], b_off[B_PASS];
 #pragma unroll
-  for (int i = 0; i < A_PASS; ++i) a_off[i] = (m0 + pr + 32 * i) < M ? (unsigned)((pr + 32 * i) * lda + pc) * (unsigned)a_es : CSN_OOB;
+  for (int i = 0; i < A_PASS; ++i) a_off[i] = (m0 + pr + 32 * i) < M ? (unsigned)((pr + 32 * i) * lda + pc) * 4u : CSN_OOB;
 #pragma unroll
   for (int i = 0; i < B_PASS; ++i) {
-    if (B_NK) b_off[i] = (n0 + pr + 32 * i) < N ? (unsigned)((pr + 32 * i) * ldb + pc) * (unsigned)b_es : CSN_OOB;
-    else b_off[i] = (n0 + kc) < N ? (unsigned)((kr + RPP * i) * ldb + kc) * (unsigned)b_es : CSN_OOB;
+    if (B_NK) b_off[i] = (n0 + pr + 32 * i) < N ? (unsigned)((pr + 32 * i) * ldb + pc) * 4u : CSN_OOB;
+    else b_off[i] = (n0 + kc) < N ? (unsigned)((kr + RPP * i) * ldb + kc) * 4u : CSN_OOB;
   }
 
-  // a staged piece = 4 consecutive elements: either one fp32x4, or 4 bf16 of the high plane (.xy) + 4 of the low (.zw)
   f32x4 ra[A_PASS], rb[B_PASS];
-  auto piece = [&](const csn_rsrc_t& hi, const csn_rsrc_t& lo, bool planes, unsigned voff, unsigned soff) -> f32x4 {
-    if (!planes) return csn_bload4(hi, voff, soff);
-    const u32x2 h2 = csn_bload2(hi, voff, soff), l2 = csn_bload2(lo, voff, soff);
-    const u32x4 v = {h2.x, h2.y, l2.x, l2.y};
-    return __builtin_bit_cast(f32x4, v);
-  };
   auto load_slab = [&](int k0) {
     const unsigned kp = (k0 + pc) < K ? 0u : CSN_OOB;
 #pragma unroll
-    for (int i = 0; i < A_PASS; ++i) ra[i] = piece(Ar, Arl, a_pl, a_off[i] | kp, (unsigned)k0 * (unsigned)a_es);
+    for (int i = 0; i < A_PASS; ++i) ra[i] = csn_bload4(Ar, a_off[i] | kp, (unsigned)k0 * 4u);
     if (B_NK) {
 #pragma unroll
-      for (int i = 0; i < B_PASS; ++i) rb[i] = piece(Br, Brl, b_pl, b_off[i] | kp, (unsigned)k0 * (unsigned)b_es);
+      for (int i = 0; i < B_PASS; ++i) rb[i] = csn_bload4(Br, b_off[i] | kp, (unsigned)k0 * 4u);
     } else {
 #pragma unroll
       for (int i = 0; i < B_PASS; ++i) {
         const unsigned kq = (k0 + kr + RPP * i) < K ? 0u : CSN_OOB;
-        rb[i] = piece(Br, Brl, b_pl, b_off[i] | kq, (unsigned)k0 * (unsigned)ldb * (unsigned)b_es);
+        rb[i] = csn_bload4(Br, b_off[i] | kq, (unsigned)k0 * (unsigned)ldb * 4u);
       }
     }
   };
-  auto put = [&](__bf16* hi_dst, __bf16* lo_dst, const f32x4 v, bool planes) {
-    if (planes) {
-      const u32x4 u = __builtin_bit_cast(u32x4, v);
-      *reinterpret_cast<u32x2*>(hi_dst) = u32x2{u.x, u.y};
-      *reinterpret_cast<u32x2*>(lo_dst) = u32x2{u.z, u.w};
-    } else {
-      bf16x4 hi, lo;
-      split4(v, hi, lo);
-      *reinterpret_cast<bf16x4*>(hi_dst) = hi;
-      *reinterpret_cast<bf16x4*>(lo_dst) = lo;
-    }
-  };
-  auto store_slab = [&]() {
+  auto store_slab = [&](int st) {
+    bf16x4 hi, lo;
 #pragma unroll
-    for (int i = 0; i < A_PASS; ++i) put(&As[0][(pr + 32 * i) * PK + pc], &As[1][(pr + 32 * i) * PK + pc], ra[i], a_pl);
+    for (int i = 0; i < A_PASS; ++i) {
+      split4(ra[i], hi, lo);
+      *reinterpret_cast<bf16x4*>(&As[st][0][(pr + 32 * i) * PK + pc]) = hi;
+      *reinterpret_cast<bf16x4*>(&As[st][1][(pr + 32 * i) * PK + pc]) = lo;
+    }
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
+      split4(rb[i], hi, lo);
       const int dst = B_NK ? (pr + 32 * i) * PK + pc : (kr + RPP * i) * PN + kc;
-      put(&Bs[0][dst], &Bs[1][dst], rb[i], b_pl);
+      *reinterpret_cast<bf16x4*>(&Bs[st][0][dst]) = hi;
+      *reinterpret_cast<bf16x4*>(&Bs[st][1][dst]) = lo;
     }
   };
 
@@ -148,32 +134,33 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   const int tr_base = (8 * (grp >> 1) + gq) * PN + 16 * (grp & 1) + 4 * gp;
 
   const int nk = (K + BK - 1) / BK;
-  if (nk > 0) { load_slab(0); store_slab(); }
+  if (nk > 0) { load_slab(0); store_slab(0); }
+  if (nk > 1) load_slab(BK);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) load_slab((kt + 1) * BK);
+    const int cur = kt & 1;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int o = (wm0 + 32 * i + l31) * PK + 16 * s + 8 * h;
-        ah[i] = *reinterpret_cast<const bf16x8*>(&As[0][o]);
-        al[i] = *reinterpret_cast<const bf16x8*>(&As[1][o]);
+        ah[i] = *reinterpret_cast<const bf16x8*>(&As[cur][0][o]);
+        al[i] = *reinterpret_cast<const bf16x8*>(&As[cur][1][o]);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         if (B_NK) {
           const int o = (wn0 + 32 * j + l31) * PK + 16 * s + 8 * h;
-          bh[j] = *reinterpret_cast<const bf16x8*>(&Bs[0][o]);
-          bl[j] = *reinterpret_cast<const bf16x8*>(&Bs[1][o]);
+          bh[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur][0][o]);
+          bl[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur][1][o]);
         } else {
           const int o = tr_base + (16 * s) * PN + wn0 + 32 * j;
           typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
-          const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[0][o]));
-          const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[0][o + 4 * PN]));
-          const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[1][o]));
-          const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[1][o + 4 * PN]));
+          const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][0][o]));
+          const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][0][o + 4 * PN]));
+          const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][1][o]));
+          const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][1][o + 4 * PN]));
           typedef short s16x8 __attribute__((ext_vector_type(8)));
           const s16x8 hv = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
           const s16x8 lv = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
@@ -190,8 +177,13 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
           acc[i][j] = mfma_bf16(ah[i], bh[j], acc[i][j]);
         }
     }
+    // slab kt + 1 (loaded one iteration ago) is split and written into the other stage while the matrix pipe drains;
+    // slab kt + 2 starts its trip from HBM
+    if (kt + 1 < nk) {
+      store_slab(cur ^ 1);
+      if (kt + 2 < nk) load_slab((kt + 2) * BK);
+    }
     __syncthreads();
-    if (kt + 1 < nk) { store_slab(); __syncthreads(); }
   }
 
   const float alpha = p.alpha;

@@ -134,6 +134,161 @@ __global__ __launch_bounds__(256, 2) void csn_outproj_ln_fwd_kernel(CsnOutProjAr
   if (n_ok && h == 0) p.rstd[(long long)e * NP + n0 + nl] = rstd;
 }
 
+// ---- bf16x3 variant (math mode 1): the contraction runs as three bf16 matrix-core products per fp32 product; the
+// residual add, dropout and LayerNorm epilogue are the fp32 code of the exact kernel, unchanged.  Operand split and
+// fragment maps: see gemm_bf16x3.hip.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+CSN_DEVINL bf16x8 join8(s16x4 a, s16x4 b) {
+  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+CSN_DEVINL void split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hi[i] = (__bf16)v[i];
+    lo[i] = (__bf16)(v[i] - (float)hi[i]);
+  }
+}
+
+template <int CT>
+__global__ __launch_bounds__(256, 2) void csn_outproj_ln_fwd_bf16x3_kernel(CsnOutProjArgs p) {
+  constexpr int C = 32 * CT;
+  constexpr int PK = BK + 8;                                      // k-contiguous planes: 80-byte rows (conflict-free b128)
+  constexpr int PN = BN + 32;                                     // k-major planes: rows 64 B apart mod 256 (conflict-free tr reads)
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][C * PK];   // [plane][c][k]   W_fc[c][k0..k0+31] split into bf16 hi / lo
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BK * PN];  // [plane][k][n]   Ctx^T[k0..k0+31][n0..n0+127]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int e = blockIdx.y, n0 = blockIdx.x * BN;
+  const int D = p.D, ld = p.ld, NP = p.n_points;
+  const long long rs = p.res_index ? p.res_index[e] : e;
+
+  const csn_rsrc_t Wr = csn_make_rsrc(p.wfc, (long long)C * D * 4);
+  const csn_rsrc_t Xr = csn_make_rsrc(p.ctx + (long long)e * p.ctx_eval_stride + n0, ((long long)(D - 1) * ld + (NP - n0)) * 4);
+  const csn_rsrc_t Rr = csn_make_rsrc(p.xres + rs * p.xres_shape_stride + n0, ((long long)(C - 1) * ld + (NP - n0)) * 4);
+  const csn_rsrc_t Hr = csn_make_rsrc(p.xhat + (long long)e * p.xhat_eval_stride + n0, ((long long)(C - 1) * ld + (NP - n0)) * 4);
+
+  f32x16 acc[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+  const int pr = tid >> 3, pc = (tid & 7) * 4;        // W slab piece: row pr + 32 i, k piece pc
+  const int kr = tid >> 5, kc = (tid & 31) * 4;       // Ctx slab piece: k row kr + 8 i, points kc..kc+3
+  unsigned a_off[CT], b_off[4];
+#pragma unroll
+  for (int i = 0; i < CT; ++i) a_off[i] = (unsigned)((pr + 32 * i) * D + pc) * 4u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b_off[i] = (n0 + kc) < NP ? (unsigned)((kr + 8 * i) * ld + kc) * 4u : CSN_OOB;
+
+  f32x4 ra[CT], rb[4];
+  auto load_slab = [&](int k0) {
+    const unsigned kp = (k0 + pc) < D ? 0u : CSN_OOB;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) ra[i] = csn_bload4(Wr, a_off[i] | kp, (unsigned)k0 * 4u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned kq = (k0 + kr + 8 * i) < D ? 0u : CSN_OOB;
+      rb[i] = csn_bload4(Xr, b_off[i] | kq, (unsigned)k0 * (unsigned)ld * 4u);
+    }
+  };
+  auto store_slab = [&]() {
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+      split4(ra[i], hi, lo);
+      *reinterpret_cast<bf16x4*>(&As[0][(pr + 32 * i) * PK + pc]) = hi;
+      *reinterpret_cast<bf16x4*>(&As[1][(pr + 32 * i) * PK + pc]) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      split4(rb[i], hi, lo);
+      *reinterpret_cast<bf16x4*>(&Bs[0][(kr + 8 * i) * PN + kc]) = hi;
+      *reinterpret_cast<bf16x4*>(&Bs[1][(kr + 8 * i) * PN + kc]) = lo;
+    }
+  };
+  // transposing read of the k-major Ctx planes: lane group g = lane >> 4 covers points 16 (g & 1) .. +15 of this wave's 32
+  // and k rows 8 (g >> 1) .. +7; inside the group lane 4 q + p addresses row q, points 4 p .. 4 p + 3
+  const int tr_base = (8 * (lane >> 5) + ((lane >> 2) & 3)) * PN + 32 * wave + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+  const int nk = (D + BK - 1) / BK;
+  load_slab(0);
+  store_slab();
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) load_slab((kt + 1) * BK);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int o = tr_base + 16 * s * PN;
+      const bf16x8 bh = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[0][o])),
+                              __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[0][o + 4 * PN])));
+      const bf16x8 bl = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[1][o])),
+                              __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[1][o + 4 * PN])));
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const int a = (c * 32 + l31) * PK + 16 * s + 8 * h;
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&As[0][a]);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(&As[1][a]);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[c], 0, 0, 0);      // small terms first
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[c], 0, 0, 0);
+        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[c], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (kt + 1 < nk) { store_slab(); __syncthreads(); }
+  }
+
+  // ---- + residual, LayerNorm over the C channels of each point (csa_models.py:116-118) -----------
+  const int nl = 32 * wave + l31;
+  const bool n_ok = (n0 + nl) < NP;
+  const unsigned n_off = n_ok ? (unsigned)(4 * h * ld + nl) * 4u : CSN_OOB;
+  // dropout on the fc output, before the residual add (csa_models.py:115-116); element index = position in xhat
+  if (p.dropout_p > 0.f) {
+    const unsigned thr24 = csn_drop_threshold(p.dropout_p);
+    const float keep_scale = 1.f / (1.f - p.dropout_p);
+    const long long ebase = (long long)e * p.xhat_eval_stride + n0 + nl;
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long long idx = ebase + (long long)(c * 32 + csn_acc_row(r, h)) * ld;
+        acc[c][r] = csn_keep((unsigned long long)idx, p.seed, thr24) ? acc[c][r] * keep_scale : 0.f;
+      }
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      acc[c][r] += csn_bload(Rr, n_off, (unsigned)(c * 32 + csn_acc_row(r, 0)) * (unsigned)ld * 4u);
+      sum += acc[c][r];
+    }
+  sum += csn_xhalf(sum);
+  const float mean = sum * (1.f / C);
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float dlt = acc[c][r] - mean;
+      sq += dlt * dlt;
+    }
+  sq += csn_xhalf(sq);
+  const float rstd = 1.f / sqrtf(sq * (1.f / C) + p.eps);
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      csn_bstore((acc[c][r] - mean) * rstd, Hr, n_off, (unsigned)(c * 32 + csn_acc_row(r, 0)) * (unsigned)ld * 4u);
+  if (n_ok && h == 0) p.rstd[(long long)e * NP + n0 + nl] = rstd;
+}
+
 // LayerNorm backward without the affine part:  dz = rstd * (dx - mean_c(dx) - xhat * mean_c(dx * xhat)).
 // One thread per point, lanes along n: both sweeps over the channels are 256-byte coalesced rows.
 __global__ __launch_bounds__(256) void csn_ln_bwd_kernel(CsnLnBwdArgs p) {
@@ -194,24 +349,25 @@ __global__ __launch_bounds__(256) void csn_rowdot_kernel(const float* __restrict
 }
 
 template <int CT>
-int launch_fwd(const CsnOutProjArgs& a, hipStream_t st) {
+int launch_fwd(const CsnOutProjArgs& a, int fast, hipStream_t st) {
   dim3 grid((a.n_points + BN - 1) / BN, a.E);
-  hipLaunchKernelGGL((csn_outproj_ln_fwd_kernel<CT>), grid, dim3(256), 0, st, a);
+  if (fast) hipLaunchKernelGGL((csn_outproj_ln_fwd_bf16x3_kernel<CT>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((csn_outproj_ln_fwd_kernel<CT>), grid, dim3(256), 0, st, a);
   return (int)hipGetLastError();
 }
 
 }  // namespace
 
-int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, hipStream_t st) {
+int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, int fast, hipStream_t st) {
   if (a.E <= 0 || a.n_points <= 0) return 0;
   if ((a.ld & 3) || (a.D & 3) || (a.n_points & 3)) return -2;
   if ((a.ctx_eval_stride & 3) || (a.xres_shape_stride & 3) || (a.xhat_eval_stride & 3)) return -4;
   switch (a.C) {
-    case 32: return launch_fwd<1>(a, st);
-    case 64: return launch_fwd<2>(a, st);
-    case 96: return launch_fwd<3>(a, st);
-    case 128: return launch_fwd<4>(a, st);
-    case 256: return launch_fwd<8>(a, st);
+    case 32: return launch_fwd<1>(a, fast, st);
+    case 64: return launch_fwd<2>(a, fast, st);
+    case 96: return launch_fwd<3>(a, fast, st);
+    case 128: return launch_fwd<4>(a, fast, st);
+    case 256: return launch_fwd<8>(a, fast, st);
     default: return -5;
   }
 }

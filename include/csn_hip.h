@@ -49,8 +49,11 @@ int csn_version(void);
  * every stride / leading dimension of that tensor counts bf16 elements (same numbers as for the fp32 tensor).
  * The producer's epilogue splits once; consumers stage the planes into LDS with plain copies (no conversion work per
  * tile).  A split dctx (attention-output gradient) is laid out [evaluation][2 planes][n_heads*d_head][ld]: its
- * evaluation stride is 2 * ctx_eval_stride and dctx_plane_stride = ctx_eval_stride.  Passing *_split != 0 in math
- * mode 0 returns CSN_E_ARG. */
+ * evaluation stride is 2 * ctx_eval_stride and dctx_plane_stride = ctx_eval_stride.
+ * STATUS: only the OUTPUT sides (csn_project_f32 out_split, csn_outproj_ln_bwd_f32 dctx_split) are live; the *_split
+ * INPUT arguments of the attention entry points are reserved and return CSN_E_ARG when non-zero — on MI355X the
+ * narrow (8-byte / 2-byte) loads that 8-byte-aligned 500-point blocks force on bf16 planes measured slower than
+ * splitting fp32 tiles while staging them.  Passing *_split != 0 in math mode 0 returns CSN_E_ARG. */
 int csn_set_math_mode(int mode);
 int csn_get_math_mode(void);
 /* Human-readable text for a status code returned by any function below. Host pointer, static storage. */
