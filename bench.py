@@ -32,7 +32,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4, 64 FLOP/clk/SIMD
+PEAK_BF16_MATRIX_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (the bf16x3 mode issues 3 bf16 FLOPs per algorithmic FLOP)
 N_POINTS, C, T, H, D_HEAD, N_CLS = 10000, 256, 500, 1, 256, 39
 
 
@@ -181,7 +182,12 @@ def main():
         ms = float(np.mean([a.elapsed_time(b) for a, b in attn_events])) if attn_events else float("nan")
         return el, float(loss.item()), ms
 
-    elapsed_eval, loss_eval, _ = timed(False)          # secondary: eval-mode arithmetic (dropout off), gradients on
+    # secondary runs first: the other arithmetic mode (train step), then eval-mode arithmetic in the headline mode
+    other = "fp32" if args.math == "bf16x3" else "bf16x3"
+    csn_amd._lib.check(csn_amd.lib().csn_set_math_mode(1 if other == "bf16x3" else 0))
+    elapsed_other, loss_other, attn_ms_other = timed(True)
+    csn_amd._lib.check(csn_amd.lib().csn_set_math_mode(1 if args.math == "bf16x3" else 0))
+    elapsed_eval, loss_eval, _ = timed(False)          # eval-mode arithmetic (dropout off), gradients on
     elapsed, loss_val, attn_ms = timed(True)           # headline: the training step as the reference runs it
     n_evals = B * (2 * K + 2)                          # train mode: the pooled and the mixed self evaluation differ
 
@@ -189,24 +195,41 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         value = S * N_POINTS * args.steps / elapsed
         launch_flops = n_evals * 4 * N_POINTS * T * H * D_HEAD       # QK^T + PV of every evaluation in the launch
-        achieved = launch_flops / (attn_ms * 1e-3) / 1e12
+
+        def roof(math, ms):
+            fast = math == "bf16x3"
+            ach = launch_flops / (ms * 1e-3) / 1e12
+            peak = PEAK_BF16_MATRIX_TFLOPS if fast else PEAK_F32_MATRIX_TFLOPS
+            r = {"bound": "mfma", "kernel": ("csn_attn_bf16x3_kernel<8,false>" if fast else "csn_attn_f32_kernel<8,false>")
+                                            + " (fused block attention forward)",
+                 "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "launch_ms": ms,
+                 "flops_per_launch": launch_flops,
+                 "note": "algorithmic FLOPs: 512 kFLOP per query point per evaluation x 10000 points x evaluations in the launch"}
+            if fast:
+                r["note"] += "; this mode issues 3 bf16 matrix FLOPs per algorithmic FLOP, so the matrix pipe sees 3x `achieved`"
+            return r
+
         out = {
-            "metric": "CSA fwd+bwd points/sec (10k pts x 256 ch, K=3)", "value": value, "unit": "points/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "metric": "CSA fwd+bwd points/sec (10k pts x 256 ch, K=3)", "value": S * N_POINTS * args.steps / elapsed,
+            "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16x3 (fp32 operands split into 2 bf16, 3 bf16 MFMA per product, fp32 accumulate)" if args.math == "bf16x3"
+                     else "f32",
+            "data": "synthetic",
             "config": {"workload": f"CSA K={K}, {B} query shapes/GPU x {N_POINTS} pts x {C} ch, n_heads={H}, d_k=d_v={D_HEAD}, "
-                                   f"20 blocks of {T}, {N_CLS} classes, fwd + masked CE + bwd, train mode (dropout 0.1 live, 2K+2 evaluations/shape)",
+                                   f"20 blocks of {T}, {N_CLS} classes, fwd + masked CE + bwd, train mode (dropout 0.1 live, "
+                                   f"2K+2 evaluations/shape), math mode {args.math}",
                        "shapes_total": S, "K": K, "parallelism": f"shape-graph sharded x{world}" if world > 1 else "single GPU",
                        "loss": loss_val,
                        "dropout_off": {"points_per_s": S * N_POINTS * args.steps / elapsed_eval,
                                        "ms_per_step": elapsed_eval / args.steps * 1e3, "loss": loss_eval,
                                        "note": "same step with eval-mode arithmetic (2K+1 evaluations/shape), gradients on"},
+                       f"math_{other}": {"points_per_s": S * N_POINTS * args.steps / elapsed_other,
+                                         "ms_per_step": elapsed_other / args.steps * 1e3, "loss": loss_other,
+                                         "roofline": roof(other, attn_ms_other),
+                                         "note": "the same train-mode step in the other arithmetic mode"},
                        "step_tflops_algorithmic": 3 * algorithmic_flops_fwd(S, K) / (elapsed / args.steps) / 1e12},
-            "roofline": {"bound": "mfma", "kernel": "csn_attn_f32_kernel<8,false> (fused block attention forward)",
-                         "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
-                         "launch_ms": attn_ms, "flops_per_launch": launch_flops,
-                         "note": "512 kFLOP per query point per evaluation x 10000 points x evaluations in the launch"},
+            "roofline": roof(args.math, attn_ms),
         }
         if world == 1 and not args.no_cpu_baseline:
             cores = min(len(os.sched_getaffinity(0)), 16)          # the GPU box gives one GPU a 16-core share
