@@ -52,10 +52,19 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, kq = lane >> 4;
-  const int e = p.eval_ids ? p.eval_ids[blockIdx.z] : (int)blockIdx.z;
-  const int hd = blockIdx.y % p.H, blk = blockIdx.y / p.H;
+  // XCD-aware work-group order.  A unit = one (evaluation, head, block); its QT query tiles all stream the same K/V
+  // block, so they should share one XCD's L2.  Work-groups are dealt round-robin over the 8 XCDs, hence the QT tiles of
+  // unit u get ids 8 * (QT * (u / 8) + qt) + (u % 8): same residue mod 8 (same XCD), adjacent in dispatch order.
+  // (Placement only changes speed: every tile is self-contained.)
+  const int QT = (p.T + 127) / 128;
+  const int Y = p.n_blocks * p.H;
+  const int L = blockIdx.x, slot = L & 7, jj = L >> 3;
+  const int qt = jj % QT, u = (jj / QT) * 8 + slot;
+  if (u >= Y * p.E) return;
+  const int e = p.eval_ids ? p.eval_ids[u / Y] : u / Y;
+  const int hd = (u % Y) % p.H, blk = (u % Y) / p.H;
   const int T = p.T, Tp = p.Tp, ld = p.ld;
-  const int qrow = blockIdx.x * 128 + wave * 16 + lq;          // query index inside the block
+  const int qrow = qt * 128 + wave * 16 + lq;                  // query index inside the block
   const bool q_ok = qrow < T;
 
   const long long qs = p.q_index ? p.q_index[e] : e;
@@ -269,7 +278,8 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
 
 template <int DT>
 int launch_dt(const CsnAttnArgs& a, bool bwd, hipStream_t st) {
-  dim3 grid((a.T + 127) / 128, a.n_blocks * a.H, a.E);
+  const long long units = (long long)a.n_blocks * a.H * a.E;
+  dim3 grid((unsigned)(((units + 7) / 8) * 8 * ((a.T + 127) / 128)));
   if (bwd) hipLaunchKernelGGL((csn_attn_f32_kernel<DT, true>), grid, dim3(512), 0, st, a);
   else hipLaunchKernelGGL((csn_attn_f32_kernel<DT, false>), grid, dim3(512), 0, st, a);
   return (int)hipGetLastError();

@@ -13,6 +13,7 @@ struct CsnGemmArgs {
   float div_val;
   int accumulate;    // C += result
   const int* eval_ids;   // optional: blockIdx.z's slowest index z2 -> evaluation id, applied before the operands' idx2
+  int batch;             // number of batch items z (filled in by the launcher)
 };
 
 int csn_launch_gemm_f32(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st);

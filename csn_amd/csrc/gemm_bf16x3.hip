@@ -56,7 +56,14 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   const int l31 = lane & 31, h = lane >> 5;
   const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
 
-  int z = blockIdx.z;
+  // XCD-aware work-group order: the tiles of one batch item z share its A and B panels, so they should share one
+  // XCD's L2.  Work-groups are dealt round-robin over the 8 XCDs; tile t of item z gets id 8 * (tiles * (z / 8) + t) + z % 8.
+  const int tiles_n = (p.N + BN - 1) / BN, tiles = tiles_n * ((p.M + BM - 1) / BM);
+  const int L = blockIdx.x, jj = L >> 3;
+  const int tile = jj % tiles;
+  int z = (jj / tiles) * 8 + (L & 7);
+  if (z >= p.batch) return;
+  const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
   const int z0 = z % p.n0; z /= p.n0;
   const int z1 = z % p.n1;
   const int z2 = p.eval_ids ? p.eval_ids[z / p.n1] : z / p.n1;
@@ -64,7 +71,7 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   const int M = p.M, N = p.N;
   int K = p.K;
   if (p.k_chunk > 0) { K = min(p.k_chunk, p.K - z0 * p.k_chunk); }
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const bool c_pl = p.C.planes != 0;
   const int c_es = c_pl ? 2 : 4;
@@ -237,8 +244,11 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
 
 template <int BM, int BN, bool B_NK>
 int launch(const CsnGemmArgs& a, int batch, hipStream_t st) {
-  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, batch);
-  hipLaunchKernelGGL((csn_gemm_bf16x3_kernel<BM, BN, B_NK>), grid, dim3(256), 0, st, a);
+  CsnGemmArgs b = a;
+  b.batch = batch;
+  const long long tiles = (long long)((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
+  dim3 grid((unsigned)(((batch + 7) / 8) * 8 * tiles));
+  hipLaunchKernelGGL((csn_gemm_bf16x3_kernel<BM, BN, B_NK>), grid, dim3(256), 0, st, b);
   return (int)hipGetLastError();
 }
 
