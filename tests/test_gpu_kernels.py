@@ -60,6 +60,28 @@ def test_project(L, S, C, N, R, div_rows):
     assert _maxerr(out, ref) < tol(2e-6)
 
 
+def test_project_split_output_planes(L, math_mode):
+    """bf16x3 mode only: the projection can emit its result as bf16 hi/lo planes (x = hi + lo), see csn_hip.h."""
+    from csn_amd import functional as CF
+    rng = np.random.default_rng(11)
+    S, C, N, R = 2, 96, 500, 192
+    x, w = _rand(rng, S, C, N), _rand(rng, R, C) / math.sqrt(C)
+    if math_mode == 0:
+        out = torch.empty((S, 2, R, N), device="cuda", dtype=torch.bfloat16)
+        xd, wd = x.cuda(), w.cuda()
+        rc = L.lib().csn_project_f32(xd.data_ptr(), C * N, N, wd.data_ptr(), R, C, out.data_ptr(), 2 * R * N, N, S, N, 0, 1.0,
+                                     1, R * N, _stream())
+        assert rc == -1                                    # split tensors exist only in the bf16x3 mode
+        return
+    planes = CF.project(x.cuda(), w.cuda(), split=True)    # (S, 2, R, N) bf16
+    assert planes.dtype == torch.bfloat16 and planes.shape == (S, 2, R, N)
+    ref = torch.einsum("rc,scn->srn", w.double(), x.double())
+    got = planes[:, 0].double().cpu() + planes[:, 1].double().cpu()
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 3e-5
+    hi = planes[:, 0].float().cpu()
+    assert ((hi.double() - ref).abs().max() / ref.abs().max()).item() < 5e-3      # the high plane alone is bf16-accurate
+
+
 def test_project_wgrad(L):
     from csn_amd import functional as CF
     rng = np.random.default_rng(2)
