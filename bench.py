@@ -126,6 +126,7 @@ def main():
     S = B * world
     torch.manual_seed(0)
     model = get_model("csa", N_CLS, H, K).to(dev)
+    model.trust_neighbor_slot0 = True      # the stack built below has the shape itself in slot 0, like CSADatasetK
     params = [p for n, p in model.named_parameters() if not n.startswith("fc_1")]
 
     rng = np.random.default_rng(1234 + 2 + 1000 * rank)

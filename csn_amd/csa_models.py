@@ -176,6 +176,10 @@ class CrossShapeAt(nn.Module):
         self.after_fc = after_fc
         self.device = device
         self.compat_layout = "reference"      # see get_csa_feats
+        # CSADatasetK puts the shape itself into slot 0 of neighbor_feats (features_data_loader.py:124); a caller that
+        # guarantees it can set this to let the kernels read a device-resident, contiguous neighbour stack in place
+        # (no 1.3 GB gather per step at config 3).  Default: slot 0 is taken from x, exactly like the reference (:210, :232).
+        self.trust_neighbor_slot0 = False
         if 'csa' in self.attention_type:
             self.K = K
             self.compatibility_q = nn.Linear(256, 256)
@@ -243,13 +247,17 @@ class CrossShapeAt(nn.Module):
         nb = x_neighbors
         if nb.dim() == 5:
             nb = nb.squeeze(-1)
-        x_all = torch.empty((B, K1, C, npts), device=dev, dtype=torch.float32)
-        x_all[:, 0] = xc                                                       # the query shape itself (:210, :232)
-        if K > 0:
-            if nb.shape[-1] < npts:
-                raise IndexError(f"index {npts - 1} is out of bounds for dimension 2 with size {nb.shape[-1]}")
-            x_all[:, 1:] = nb[:, 1:, :, :npts].to(dev, non_blocking=True)      # neighbours may arrive on the CPU (:216)
-        x_all = x_all.view(B * K1, C, npts)
+        if nb.shape[-1] < npts:
+            raise IndexError(f"index {npts - 1} is out of bounds for dimension 2 with size {nb.shape[-1]}")
+        if (self.trust_neighbor_slot0 and nb.is_cuda and nb.dtype == torch.float32 and nb.is_contiguous()
+                and nb.shape[-1] == npts):
+            x_all = nb.view(B * K1, C, npts)                                   # slot 0 already holds the shape itself
+        else:
+            x_all = torch.empty((B, K1, C, npts), device=dev, dtype=torch.float32)
+            x_all[:, 0] = xc                                                   # the query shape itself (:210, :232)
+            if K > 0:
+                x_all[:, 1:] = nb[:, 1:, :, :npts].to(dev, non_blocking=True)  # neighbours may arrive on the CPU (:216)
+            x_all = x_all.view(B * K1, C, npts)
 
         train = any(r > 0 for r in att.dropout_rates())
         xhat = att.evaluate(x_all, att.plan("csa_train" if train else "csa", B, K1, dev), geo)          # (E, C, NP)

@@ -290,35 +290,47 @@ __global__ __launch_bounds__(256, 2) void csn_outproj_ln_fwd_bf16x3_kernel(CsnOu
 }
 
 // LayerNorm backward without the affine part:  dz = rstd * (dx - mean_c(dx) - xhat * mean_c(dx * xhat)).
-// One thread per point, lanes along n: both sweeps over the channels are 256-byte coalesced rows.
+// Single pass over HBM: a work-group owns 64 points (lanes along n: 256-byte row segments); its 4 waves split the
+// channels (wave g takes c = 4 i + g), every thread keeps its C/4 (dx, xhat) pairs in registers, the two channel sums are
+// combined across the 4 waves through LDS, and dz is produced from the registers.
+template <int CPT>
 __global__ __launch_bounds__(256) void csn_ln_bwd_kernel(CsnLnBwdArgs p) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
   const int e = blockIdx.y;
-  if (n >= p.n_points) return;
-  const float* __restrict__ dx = p.dxhat + (long long)e * p.eval_stride + n;
-  const float* __restrict__ xh = p.xhat + (long long)e * p.eval_stride + n;
-  float* __restrict__ dz = p.dz + (long long)e * p.eval_stride + n;
-  const int C = p.C;
+  const bool ok = n < p.n_points;
+  const long long base = (long long)e * p.eval_stride + n;
   const long long ld = p.ld;
+  float gx[CPT], xx[CPT];
   float s1 = 0.f, s2 = 0.f;
-  for (int c = 0; c < C; ++c) {
-    const float g = dx[c * ld], x = xh[c * ld];
-    s1 += g;
-    s2 += g * x;
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const long long o = base + (long long)(4 * i + g) * ld;
+    gx[i] = ok ? p.dxhat[o] : 0.f;
+    xx[i] = ok ? p.xhat[o] : 0.f;
+    s1 += gx[i];
+    s2 += gx[i] * xx[i];
   }
+  red[0][g][lane] = s1;
+  red[1][g][lane] = s2;
+  __syncthreads();
+  const int C = 4 * CPT;
+  const float m1 = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) / C;
+  const float m2 = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / C;
+  if (!ok) return;
   const float rstd = p.rstd[(long long)e * p.n_points + n];
-  const float m1 = s1 / C, m2 = s2 / C;
   const bool drop = p.dropout_p > 0.f;
   const unsigned thr24 = csn_drop_threshold(p.dropout_p);
   const float keep_scale = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
-  float* __restrict__ dres = p.dz_res ? p.dz_res + (long long)e * p.eval_stride + n : nullptr;
-  for (int c = 0; c < C; ++c) {
-    const float g = dx[c * ld], x = xh[c * ld];
-    const float v = rstd * (g - m1 - x * m2);
-    if (dres) dres[c * ld] = v;                                   // the residual branch sees no mask
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    const long long o = base + (long long)(4 * i + g) * ld;
+    const float v = rstd * (gx[i] - m1 - xx[i] * m2);
+    if (p.dz_res) p.dz_res[o] = v;                               // the residual branch sees no mask
     float vf = v;
-    if (drop) vf = csn_keep((unsigned long long)((long long)e * p.eval_stride + n + c * ld), p.seed, thr24) ? v * keep_scale : 0.f;
-    dz[c * ld] = vf;
+    if (drop) vf = csn_keep((unsigned long long)o, p.seed, thr24) ? v * keep_scale : 0.f;
+    p.dz[o] = vf;
   }
 }
 
@@ -374,8 +386,15 @@ int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, int fast, hipStream_t
 
 int csn_launch_ln_bwd_f32(const CsnLnBwdArgs& a, hipStream_t st) {
   if (a.E <= 0 || a.n_points <= 0) return 0;
-  dim3 grid((a.n_points + 255) / 256, a.E);
-  hipLaunchKernelGGL(csn_ln_bwd_kernel, grid, dim3(256), 0, st, a);
+  dim3 grid((a.n_points + 63) / 64, a.E);
+  switch (a.C) {
+    case 32: hipLaunchKernelGGL((csn_ln_bwd_kernel<8>), grid, dim3(256), 0, st, a); break;
+    case 64: hipLaunchKernelGGL((csn_ln_bwd_kernel<16>), grid, dim3(256), 0, st, a); break;
+    case 96: hipLaunchKernelGGL((csn_ln_bwd_kernel<24>), grid, dim3(256), 0, st, a); break;
+    case 128: hipLaunchKernelGGL((csn_ln_bwd_kernel<32>), grid, dim3(256), 0, st, a); break;
+    case 256: hipLaunchKernelGGL((csn_ln_bwd_kernel<64>), grid, dim3(256), 0, st, a); break;
+    default: return -5;
+  }
   return (int)hipGetLastError();
 }
 
