@@ -110,8 +110,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # CSN_BENCH_BACKEND=gloo + CSN_BENCH_ONE_GPU=1 rehearse the N > 1 code path with all ranks on one GPU (no RCCL)
+        backend = os.environ.get("CSN_BENCH_BACKEND", "nccl")
+        if os.environ.get("CSN_BENCH_ONE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
