@@ -95,10 +95,11 @@ def lib() -> ctypes.CDLL:
     """The loaded library; raises CsnError if it is missing (build it with csn_amd.build())."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise CsnError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+        path = os.environ.get("CSN_LIB_PATH", LIB_PATH)      # development aid: compare two builds side by side
+        if not os.path.exists(path):
+            raise CsnError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU or eager fallback for the CSA kernels)")
-        handle = ctypes.CDLL(LIB_PATH)
+        handle = ctypes.CDLL(path)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)
             fn.restype = res

@@ -17,9 +17,15 @@
 #include "csn_common.h"
 #include "csn_kernels.h"
 
+#ifdef CSN_STAMPS
+__device__ unsigned long long csn_dbg[2048 * 8 * 4 * 8];
+extern "C" int csn_debug_read(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_dbg), bytes); }
+#endif
+
 namespace {
 
 constexpr int KT = 32;               // keys per streamed tile
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -113,57 +119,62 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
 
   // attention-probability dropout (csa_models.py:141): P_drop = mask * P / (1 - p); element index = position in `scores`
   const bool drop = p.dropout_p > 0.f;
-  const unsigned thr24 = csn_drop_threshold(p.dropout_p);
+  const unsigned thr16 = csn_drop_threshold16(p.dropout_p);
   const float keep_scale = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
+  const unsigned salt = csn_block_salt((unsigned long long)(((long long)e * p.H + hd) * p.n_blocks + blk), p.seed);
+  const unsigned pw_base = (unsigned)(2 * kq * Tp + qrow);       // pair index of this lane's keys 4 kq, 4 kq + 1
 
-  float m_run = -INFINITY, l_run = 0.f;       // forward: running max / partial sum of this lane's key quarter
-  float lse_q = 0.f, delta_q = 0.f;           // backward: per-query constants
+  // exponentials run on the hardware exp2: exp(s - m) = exp2(s * log2(e) - m2) with m2 = fl(m * log2(e)), the same m2 for
+  // every key of a query, so its rounding cancels in the normalisation; lse is rebuilt from m2 (= m2 ln 2 + ln l)
+  float m_run = -INFINITY, m2_run = -INFINITY, l_run = 0.f;   // forward: running max / partial sum of this lane's key quarter
+  float lse2_q = 0.f, delta_q = 0.f;          // backward: per-query constants
   if (BWD) {
-    lse_q = q_ok ? p.lse[stat_off + qrow] : 0.f;
+    lse2_q = q_ok ? p.lse[stat_off + qrow] * LOG2E : 0.f;
     delta_q = q_ok ? p.delta[stat_off + qrow] : 0.f;
   }
+  // score positions of this lane: tile j, reg r -> key kt*32 + 16 j + 4 kq + r, query qrow.  Lane-dependent part in one
+  // voffset per j (a 4-key group is all in or all out: T % 4 == 0), r * Tp in wave-uniform scalar offsets
+  const unsigned s_base = (unsigned)(4 * kq * Tp + qrow) * 4u;
+  const unsigned s_r1 = (unsigned)Tp * 4u, s_r2 = (unsigned)Tp * 8u, s_r3 = (unsigned)Tp * 12u;
 
   // ---- streamed tiles: global -> registers -> LDS (swizzled) ---------------------------------------
-  // piece idx = tid + 512 i  ->  row idx / 8, keys 4 (idx % 8) .. +3
-  const int t_c = (tid & 7) * 4;
-  unsigned t_off[NP_T];
-  int a_dst[NP_T], b_dst[NP_T];
-#pragma unroll
-  for (int i = 0; i < NP_T; ++i) {
-    const int idx = tid + 512 * i, row = idx >> 3;
-    t_off[i] = idx < PIECES ? (unsigned)(row * ld + t_c) * 4u : CSN_OOB;
-    a_dst[i] = row * KT + (t_c ^ (16 * ((row >> 3) & 1)));             // key halves swapped on rows with bit 3 set
-    // tileB: 4-key chunk c8 -> 8-byte slot s8 = 2 c8 (keys 0..15) | 2 (c8 - 4) + 1 (keys 16..31); its 16-byte unit
-    // (s8 >> 1 = kq) is XORed with (-(row >> 2)) & 3
-    const int c8 = tid & 7, s8 = c8 < 4 ? 2 * c8 : 2 * (c8 - 4) + 1;
-    b_dst[i] = row * KT + 4 * (2 * ((s8 >> 1) ^ ((-((row >> 2) & 3)) & 3)) + (s8 & 1));
-  }
+  // piece idx = tid + 512 i  ->  row (tid >> 3) + 64 i, keys 4 (tid % 8) .. +3.  Everything that depends on i is
+  // wave-uniform (scalar offset of the load, immediate offset of the LDS store): rows 64 apart share the swizzle.
+  const int t_c = (tid & 7) * 4, t_row = tid >> 3;
+  const unsigned t_off = (unsigned)(t_row * ld + t_c) * 4u;
+  const bool t_last_ok = tid + 512 * (NP_T - 1) < PIECES;         // only the last piece can fall beyond the tile
+  const int a_dst = t_row * KT + (t_c ^ (16 * ((t_row >> 3) & 1)));            // key halves swapped on rows with bit 3 set
+  // tileB: 4-key chunk c8 -> 8-byte slot s8 = 2 c8 (keys 0..15) | 2 (c8 - 4) + 1 (keys 16..31); its 16-byte unit
+  // (s8 >> 1 = kq) is XORed with (-(row >> 2)) & 3
+  const int c8 = tid & 7, s8 = c8 < 4 ? 2 * c8 : 2 * (c8 - 4) + 1;
+  const int b_dst = t_row * KT + 4 * (2 * ((s8 >> 1) ^ ((-((t_row >> 2) & 3)) & 3)) + (s8 & 1));
   f32x4 g[NP_T];
   auto fetch = [&](const csn_rsrc_t& rs, int kt) {
     const int k0 = kt * KT;
     // T % 4 == 0: a 16-byte piece is all in or all out; pieces past the block end are switched off
-    const unsigned poison = (k0 + t_c) < T ? 0u : CSN_OOB;
+    const unsigned off = (k0 + t_c) < T ? t_off : CSN_OOB;
 #pragma unroll
-    for (int i = 0; i < NP_T; ++i) g[i] = csn_bload4(rs, t_off[i] | poison, (unsigned)k0 * 4u);
+    for (int i = 0; i < NP_T; ++i)
+      g[i] = csn_bload4(rs, (i == NP_T - 1 && !t_last_ok) ? CSN_OOB : off, (unsigned)(k0 + 64 * i * ld) * 4u);
   };
   auto commitA = [&](int st) {
 #pragma unroll
     for (int i = 0; i < NP_T; ++i)
-      if (NP_T * 512 == PIECES || tid + 512 * i < PIECES) {
+      if (i < NP_T - 1 || t_last_ok) {
         bf16x4 hi, lo;
         split4(g[i], hi, lo);
-        *reinterpret_cast<bf16x4*>(&tileA[st][0][a_dst[i]]) = hi;
-        *reinterpret_cast<bf16x4*>(&tileA[st][1][a_dst[i]]) = lo;
+        *reinterpret_cast<bf16x4*>(&tileA[st][0][a_dst + 64 * KT * i]) = hi;
+        *reinterpret_cast<bf16x4*>(&tileA[st][1][a_dst + 64 * KT * i]) = lo;
       }
   };
   auto commitB = [&](int st) {
 #pragma unroll
     for (int i = 0; i < NP_T; ++i)
-      if (NP_T * 512 == PIECES || tid + 512 * i < PIECES) {
+      if (i < NP_T - 1 || t_last_ok) {
         bf16x4 hi, lo;
         split4(g[i], hi, lo);
-        *reinterpret_cast<bf16x4*>(&tileB[st][0][b_dst[i]]) = hi;
-        *reinterpret_cast<bf16x4*>(&tileB[st][1][b_dst[i]]) = lo;
+        *reinterpret_cast<bf16x4*>(&tileB[st][0][b_dst + 64 * KT * i]) = hi;
+        *reinterpret_cast<bf16x4*>(&tileB[st][1][b_dst + 64 * KT * i]) = lo;
       }
   };
 
@@ -175,123 +186,195 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   const int b_pos = lq * KT + 8 * (kq ^ ((-((lq >> 2) & 3)) & 3));
 
   const int nkt = (T + KT - 1) / KT;
-  fetch(Ar, 0); commitA(0);
-  fetch(Br, 0); commitB(0);
-  __syncthreads();
+  const unsigned s_r[4] = {0u, s_r1, s_r2, s_r3};
 
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1, nxt = cur ^ 1;
-    const bool more = kt + 1 < nkt;
-    if (more) fetch(Ar, kt + 1);
-
-    // score positions of this lane: tile j, reg r  ->  key kt*32 + 16 j + 4 kq + r
-    unsigned s_off[8];
+  // ---- the three phases of one key tile -------------------------------------------------------------
+  unsigned s_voff[2];
+  bool j_ok[2];
+  float sv[8];
+  f32x4v S0, S1;
+  bf16x8 ph, pl;                                        // T1 as a 32-key B fragment, split into bf16 hi / lo
+  auto score_pos = [&](int kt) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * KT + 16 * j + 4 * kq + r;
-        s_off[4 * j + r] = (q_ok && key < T) ? (unsigned)(key * Tp + qrow) * 4u : CSN_OOB;
-      }
-    float sv[8];
+    for (int j = 0; j < 2; ++j) {
+      j_ok[j] = kt * KT + 16 * j + 4 * kq < T;
+      s_voff[j] = (q_ok && j_ok[j]) ? s_base + (unsigned)((kt * KT + 16 * j) * Tp) * 4u : CSN_OOB;
+    }
+  };
+  auto load_sv = [&](int kt) {                          // backward: request the saved scores of tile kt early
     if (BWD) {
+      score_pos(kt);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) sv[r] = csn_bload(Sr, s_off[r]);     // saved scores, requested early
+      for (int r = 0; r < 8; ++r) sv[r] = csn_bload(Sr, s_voff[r >> 2], s_r[r & 3]);
     }
-
-    // ---- phase 1: T1[key][q] = sum_d tileA[d][key] R[d][q] ------------------------------------
-    f32x4v S0 = {0.f, 0.f, 0.f, 0.f}, S1 = {0.f, 0.f, 0.f, 0.f};
-    const __bf16* __restrict__ tAh = tileA[cur][0];
-    const __bf16* __restrict__ tAl = tileA[cur][1];
+  };
+  // phase 1: T1[key][q] = sum_d tileA[d][key] R[d][q]
+#ifndef CSN_PD
+#define CSN_PD 4
+#endif
+  // LDS fragment reads run CSN_PD steps ahead of the matrix instructions that consume them (explicit register ring):
+  // with two waves per SIMD nothing else hides the ~150-cycle LDS latency, and a step is only 48 matrix-pipe cycles.
+  constexpr int PD = CSN_PD;
+  auto phase1 = [&](int st) {
+    S0 = f32x4v{0.f, 0.f, 0.f, 0.f};
+    S1 = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const __bf16* __restrict__ tAh = tileA[st][0];
+    const __bf16* __restrict__ tAl = tileA[st][1];
+    constexpr int NH = 2 * (D / 32);                    // half steps: (s, 16-key tile t)
+    bf16x8 ah[PD], al[PD];
+    auto rd = [&](int h, bf16x8& fh, bf16x8& fl) {
+      const int o = 32 * (h >> 1) * KT + ((h & 1) ? a_pos1 : a_pos0);
+      fh = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAh + o)),
+                 __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAh + o + 4 * KT)));
+      fl = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAl + o)),
+                 __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAl + o + 4 * KT)));
+    };
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s = 0; s < D / 32; ++s) {
-      const int o = 32 * s * KT;
-      const bf16x8 a0h = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAh + o + a_pos0)),
-                               __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAh + o + a_pos0 + 4 * KT)));
-      const bf16x8 a0l = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAl + o + a_pos0)),
-                               __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAl + o + a_pos0 + 4 * KT)));
-      const bf16x8 a1h = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAh + o + a_pos1)),
-                               __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAh + o + a_pos1 + 4 * KT)));
-      const bf16x8 a1l = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAl + o + a_pos1)),
-                               __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAl + o + a_pos1 + 4 * KT)));
-      S0 = mfma3(a0h, a0l, Rh[s], Rl[s], S0);
-      S1 = mfma3(a1h, a1l, Rh[s], Rl[s], S1);
+    for (int h = 0; h < PD && h < NH; ++h) rd(h, ah[h], al[h]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 * (PD < NH ? PD : NH), 0);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int r = h % PD, sidx = h >> 1;
+      if (h & 1) S1 = mfma3(ah[r], al[r], Rh[sidx], Rl[sidx], S1);
+      else S0 = mfma3(ah[r], al[r], Rh[sidx], Rl[sidx], S0);
+      if (h + PD < NH) rd(h + PD, ah[r], al[r]);
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
     }
-
-    if (more) { commitA(nxt); fetch(Br, kt + 1); }
-
-    // ---- pointwise ----------------------------------------------------------------------------
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // pointwise: softmax / dropout (forward), dS (backward); leaves T1 in (ph, pl)
+  auto pointwise = [&](int kt) {
+    score_pos(kt);
     float t1[8] = {S0[0], S0[1], S0[2], S0[3], S1[0], S1[1], S1[2], S1[3]};
+    // keep decisions of this lane's 8 elements: one hash per key pair (csn_common.h)
+    bool keep[8];
+    if (drop) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const unsigned h = csn_pair_hash(pw_base + (unsigned)((kt * (KT / 2) + 8 * j + w) * Tp), salt);
+          keep[4 * j + 2 * w] = (h & 0xffffu) >= thr16;
+          keep[4 * j + 2 * w + 1] = (h >> 16) >= thr16;
+        }
+    }
     if (!BWD) {
       float mx = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const int key = kt * KT + 16 * (r >> 2) + 4 * kq + (r & 3);
-        if (key >= T) t1[r] = -INFINITY;
-        csn_bstore(t1[r], Sr, s_off[r]);             // (zero-sized window when scores are not kept)
+        if (!j_ok[r >> 2]) t1[r] = -INFINITY;
+        csn_bstore(t1[r], Sr, s_voff[r >> 2], s_r[r & 3]);     // (zero-sized window when scores are not kept)
         mx = fmaxf(mx, t1[r]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      // lazy rescale: only when some query's running maximum would grow by more than the threshold
+      // lazy rescale: only when some query's running maximum would grow by more than the threshold.  The four lanes
+      // of a query share m_run, so the cross-lane maximum is only needed inside the (rare) branch.
       if (__any(mx > m_run + p.rescale_threshold)) {
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = (m_new == -INFINITY) ? 1.f : expf(m_run - m_new);
+        const float m2_new = m_new * LOG2E;
+        const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m2_run - m2_new);
 #pragma unroll
         for (int c = 0; c < D / 16; ++c) O[c] *= alpha;
         l_run *= alpha;
         m_run = m_new;
+        m2_run = m2_new;
       }
       float ps = 0.f;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        t1[r] = __expf(t1[r] - m_run);               // hardware exp2 path (~2 ulp: far below the bf16x3 error); exp(-inf) = 0
+        t1[r] = __builtin_amdgcn_exp2f(fmaf(t1[r], LOG2E, -m2_run));     // masked keys: exp2(-inf) = 0
         ps += t1[r];
       }
       l_run += ps;                                   // the softmax denominator sees every key, dropped or not
       if (drop) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int key = kt * KT + 16 * (r >> 2) + 4 * kq + (r & 3);
-          t1[r] = csn_keep((unsigned long long)(sc_off + (long long)key * Tp + qrow), p.seed, thr24) ? t1[r] * keep_scale : 0.f;
-        }
+        for (int r = 0; r < 8; ++r) t1[r] = keep[r] ? t1[r] * keep_scale : 0.f;
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const bool ok = s_off[r] != CSN_OOB;
-        const float pv = ok ? __expf(sv[r] - lse_q) : 0.f;         // softmax probability (csa_models.py:141)
-        float md = 1.f;                                            // d P_drop / d P
-        if (drop) {
-          const int key = kt * KT + 16 * (r >> 2) + 4 * kq + (r & 3);
-          md = csn_keep((unsigned long long)(sc_off + (long long)key * Tp + qrow), p.seed, thr24) ? keep_scale : 0.f;
-        }
+        const bool ok = s_voff[r >> 2] != CSN_OOB;
+        const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(sv[r], LOG2E, -lse2_q)) : 0.f;   // softmax probability (csa_models.py:141)
+        const float md = (!drop || keep[r]) ? keep_scale : 0.f;    // d P_drop / d P
         const float ds = pv * (t1[r] * md - delta_q);              // d softmax (delta = rowsum(dO * O) already has the mask)
-        csn_bstore(pv * md, Sr, s_off[r]);                         // what the dV product needs: the dropped probabilities
-        csn_bstore(ds, dSr, s_off[r]);
+        csn_bstore(pv * md, Sr, s_voff[r >> 2], s_r[r & 3]);       // what the dV product needs: the dropped probabilities
+        csn_bstore(ds, dSr, s_voff[r >> 2], s_r[r & 3]);
         t1[r] = ds;
       }
     }
-
-    // ---- phase 2: OUT[c][q] += sum_key tileB[c][key] T1[key][q] --------------------------------
-    bf16x8 ph, pl;                                      // T1 as a 32-key B fragment, split into bf16 hi / lo
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       ph[r] = (__bf16)t1[r];
       pl[r] = (__bf16)(t1[r] - (float)ph[r]);
     }
-    const __bf16* __restrict__ tBh = tileB[cur][0];
-    const __bf16* __restrict__ tBl = tileB[cur][1];
+  };
+  // phase 2: OUT[c][q] += sum_key tileB[c][key] T1[key][q]
+  auto phase2 = [&](int st) {
+    const __bf16* __restrict__ tBh = tileB[st][0];
+    const __bf16* __restrict__ tBl = tileB[st][1];
+    constexpr int NC = D / 16;
+    bf16x8 vh[PD], vl[PD];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int c = 0; c < D / 16; ++c) {
-      const int o = c * 16 * KT;
-      const bf16x8 vh = *reinterpret_cast<const bf16x8*>(tBh + o + b_pos);
-      const bf16x8 vl = *reinterpret_cast<const bf16x8*>(tBl + o + b_pos);
-      O[c] = mfma3(vh, vl, ph, pl, O[c]);
+    for (int c = 0; c < PD && c < NC; ++c) {
+      vh[c] = *reinterpret_cast<const bf16x8*>(tBh + c * 16 * KT + b_pos);
+      vl[c] = *reinterpret_cast<const bf16x8*>(tBl + c * 16 * KT + b_pos);
     }
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (PD < NC ? PD : NC), 0);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int r = c % PD;
+      O[c] = mfma3(vh[r], vl[r], ph, pl, O[c]);
+      if (c + PD < NC) {
+        vh[r] = *reinterpret_cast<const bf16x8*>(tBh + (c + PD) * 16 * KT + b_pos);
+        vl[r] = *reinterpret_cast<const bf16x8*>(tBl + (c + PD) * 16 * KT + b_pos);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
 
+  fetch(Ar, 0); commitA(0);
+  fetch(Br, 0); commitB(0);
+  __syncthreads();
+
+  // -DCSN_STAMPS: development build that records s_memtime at the phase boundaries of tiles 4..7 (scripts/attn_stamps.py)
+#ifdef CSN_STAMPS
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (dbg_on) stamps[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+  unsigned long long stamps[8];
+#else
+#define STAMP(i)
+#endif
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1, nxt = cur ^ 1;
+    const bool more = kt + 1 < nkt;
+#ifdef CSN_STAMPS
+    const bool dbg_on = !BWD && DT == 8 && blockIdx.x < 2048 && kt >= 4 && kt < 8;
+#endif
+    STAMP(0);
+    if (more) fetch(Ar, kt + 1);
+    load_sv(kt);
+    phase1(cur);
+    STAMP(1);
+    if (more) { commitA(nxt); fetch(Br, kt + 1); }
+    STAMP(2);
+    pointwise(kt);
+    STAMP(3);
+    phase2(cur);
+    STAMP(4);
     if (more) commitB(nxt);
+    STAMP(5);
     __syncthreads();
+    STAMP(6);
+#ifdef CSN_STAMPS
+    if (dbg_on && lane == 0) {
+      for (int i = 0; i < 7; ++i) csn_dbg[((blockIdx.x * 8 + wave) * 4 + (kt - 4)) * 8 + i] = stamps[i];
+    }
+#endif
   }
 
   // ---- epilogue -----------------------------------------------------------------------------------
@@ -300,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     float l_tot = l_run + __shfl_xor(l_run, 16, 64);
     l_tot += __shfl_xor(l_tot, 32, 64);
     inv = 1.f / l_tot;
-    if (q_ok && kq == 0 && p.lse) p.lse[stat_off + qrow] = m_run + logf(l_tot);
+    if (q_ok && kq == 0 && p.lse) p.lse[stat_off + qrow] = m2_run * LN2 + logf(l_tot);
   }
   if (p.accumulate) {
     // several evaluations share this output slot: fetch all previous partial sums first (one batch of loads in

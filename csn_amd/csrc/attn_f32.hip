@@ -96,10 +96,12 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
 #pragma unroll
   for (int c = 0; c < D / 16; ++c) O[c] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
-  // attention-probability dropout (csa_models.py:141): P_drop = mask * P / (1 - p); element index = position in `scores`
+  // attention-probability dropout (csa_models.py:141): P_drop = mask * P / (1 - p); one hash per key pair (csn_common.h)
   const bool drop = p.dropout_p > 0.f;
-  const unsigned thr24 = csn_drop_threshold(p.dropout_p);
+  const unsigned thr16 = csn_drop_threshold16(p.dropout_p);
   const float keep_scale = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
+  const unsigned salt = csn_block_salt((unsigned long long)(((long long)e * p.H + hd) * p.n_blocks + blk), p.seed);
+  const unsigned pw_base = (unsigned)(2 * kq * Tp + qrow);       // pair index of this lane's keys 4 kq, 4 kq + 1
 
   float m_run = -INFINITY, l_run = 0.f;       // forward: running max / partial sum of this lane's key quarter
   float lse_q = 0.f, delta_q = 0.f;           // backward: per-query constants
@@ -181,6 +183,17 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
 
     // ---- pointwise ----------------------------------------------------------------------------
     float t1[8] = {S0[0], S0[1], S0[2], S0[3], S1[0], S1[1], S1[2], S1[3]};
+    bool keep[8];
+    if (drop) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const unsigned h = csn_pair_hash(pw_base + (unsigned)((kt * (KT / 2) + 8 * j + w) * Tp), salt);
+          keep[4 * j + 2 * w] = (h & 0xffffu) >= thr16;
+          keep[4 * j + 2 * w + 1] = (h >> 16) >= thr16;
+        }
+    }
     if (!BWD) {
       float mx = -INFINITY;
 #pragma unroll
@@ -190,10 +203,11 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
         csn_bstore(t1[r], Sr, s_off[r]);             // (zero-sized window when scores are not kept)
         mx = fmaxf(mx, t1[r]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      // lazy rescale: only when some query's running maximum would grow by more than the threshold
+      // lazy rescale: only when some query's running maximum would grow by more than the threshold.  The four lanes
+      // of a query share m_run, so the cross-lane maximum is only needed inside the (rare) branch.
       if (__any(mx > m_run + p.rescale_threshold)) {
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = (m_new == -INFINITY) ? 1.f : expf(m_run - m_new);
 #pragma unroll
@@ -210,21 +224,14 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
       l_run += ps;                                   // the softmax denominator sees every key, dropped or not
       if (drop) {
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          const int key = kt * KT + 16 * (r >> 2) + 4 * kq + (r & 3);
-          t1[r] = csn_keep((unsigned long long)(sc_off + (long long)key * Tp + qrow), p.seed, thr24) ? t1[r] * keep_scale : 0.f;
-        }
+        for (int r = 0; r < 8; ++r) t1[r] = keep[r] ? t1[r] * keep_scale : 0.f;
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const bool ok = s_off[r] != CSN_OOB;
         const float pv = ok ? expf(sv[r] - lse_q) : 0.f;           // softmax probability (csa_models.py:141)
-        float md = 1.f;                                            // d P_drop / d P
-        if (drop) {
-          const int key = kt * KT + 16 * (r >> 2) + 4 * kq + (r & 3);
-          md = csn_keep((unsigned long long)(sc_off + (long long)key * Tp + qrow), p.seed, thr24) ? keep_scale : 0.f;
-        }
+        const float md = (!drop || keep[r]) ? keep_scale : 0.f;    // d P_drop / d P
         const float ds = pv * (t1[r] * md - delta_q);              // d softmax (delta = rowsum(dO * O) already has the mask)
         csn_bstore(pv * md, Sr, s_off[r]);                         // what the dV product needs: the dropped probabilities
         csn_bstore(ds, dSr, s_off[r]);

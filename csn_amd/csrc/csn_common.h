@@ -109,5 +109,17 @@ CSN_DEVINL bool csn_keep(unsigned long long idx, unsigned long long seed, unsign
 }
 CSN_DEVINL unsigned csn_drop_threshold(float p) { return (unsigned)(p * 16777216.0f); }
 
+// Attention-probability masks (the bulk of all mask decisions: T*T per block) use a cheaper form of the same idea:
+// a score block (evaluation, head, block) draws a 32-bit salt from (seed, block id) with the two-round hash above —
+// wave-uniform, scalar unit — and ONE mixer round over (pair index ^ salt) decides two elements at once: the
+// keys 2w and 2w+1 of query q have pair index w * pitch + q and take the low / high 16 bits;
+// keep  <=>  16-bit field >= p * 2^16.
+CSN_DEVINL unsigned csn_block_salt(unsigned long long block_id, unsigned long long seed) {
+  const unsigned h = csn_mix32((unsigned)block_id ^ (unsigned)seed);
+  return csn_mix32(h + ((unsigned)(block_id >> 32) ^ (unsigned)(seed >> 32)) + 0x9e3779b9u);
+}
+CSN_DEVINL unsigned csn_pair_hash(unsigned pair_index, unsigned salt) { return csn_mix32(pair_index ^ salt); }
+CSN_DEVINL unsigned csn_drop_threshold16(float p) { return (unsigned)(p * 65536.0f); }
+
 // sum / max across the two 32-lane halves of a wave (lane l <-> lane l ^ 32)
 CSN_DEVINL float csn_xhalf(float v) { return __shfl_xor(v, 32, 64); }

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""development aid: per-phase cycle stamps of the instrumented attention build (build/v9.so, -DCSN_STAMPS)"""
+import ctypes, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("CSN_LIB_PATH", "build/v9.so")
+from csn_amd import _lib, functional as CF
+L = _lib.lib()
+H, d, T, nb = 1, 256, 500, 20
+D, NP, Tp, S, E = 256, 10000, 512, 16, 64
+qkv = torch.randn((S, 3 * D, NP), device="cuda"); qkv[:, :D] *= 0.25
+qs = torch.arange(E, device="cuda", dtype=torch.int32) % S
+ks = (torch.arange(E, device="cuda", dtype=torch.int32) * 7 + 3) % S
+att = torch.empty((E, D, NP), device="cuda"); lse = torch.empty((E, H, NP), device="cuda")
+scores = torch.empty((E, H, nb, T, Tp), device="cuda")
+base = qkv.data_ptr()
+L.csn_set_math_mode(1)
+for _ in range(2):
+    _lib.check(L.csn_block_attn_fwd_f32(base, base + 4 * D * NP, base + 8 * D * NP, 3 * D * NP, 3 * D * NP, CF._ptr(qs), CF._ptr(ks), NP,
+                                        CF._ptr(att), D * NP, CF._ptr(scores), CF._ptr(lse), E, H, d, T, nb, Tp, 8.0, 0.1, 1234, 0, 0,
+                                        CF._stream()), "fwd")
+torch.cuda.synchronize()
+n = 2048 * 8 * 4 * 8
+buf = np.zeros(n, dtype=np.uint64)
+L.csn_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+rc = L.csn_debug_read(buf.ctypes.data, n * 8)
+st = buf.reshape(2048, 8, 4, 8)[:, :, :, :7].astype(np.int64)
+d_ = np.diff(st, axis=-1)                     # [wg][wave][iter][6 segments]
+names = ["fetchA+P1", "commitA+fetchB", "pointwise", "P2", "commitB", "barrier"]
+ok = (st[..., 0] > 0).all(axis=(1, 2))
+d_ = d_[ok]
+print("rc", rc, "work-groups with stamps", ok.sum())
+for w in (0, 4, 3, 7):
+    print(f"wave {w}: " + "  ".join(f"{n}={d_[:, w, :, i].mean():7.0f}" for i, n in enumerate(names)),
+          f" total={d_[:, w].sum(axis=-1).mean():7.0f}")
+print("all waves: " + "  ".join(f"{n}={d_[..., i].mean():7.0f}" for i, n in enumerate(names)), f" total={d_.sum(axis=-1).mean():7.0f}")
+# skew between wave 0 and wave 4 at the start of P1
+print("start skew wave4 - wave0:", (st[ok][:, 4, :, 0] - st[ok][:, 0, :, 0]).mean(), " end-of-P1 skew:", (st[ok][:, 4, :, 1] - st[ok][:, 0, :, 1]).mean())

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Timing of the fused block-attention entry points alone at config-3 geometry (development aid).
+
+    python scripts/bench_attn.py [--evals 128] [--mode 1] [--drop 0.1] [--check]
+"""
+import argparse, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from csn_amd import _lib, functional as CF
+
+
+def timeit(fn, n=5):
+    fn(); torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    return sorted(a.elapsed_time(b) for a, b in ev)[n // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--evals", type=int, default=128)
+    ap.add_argument("--slots", type=int, default=32)
+    ap.add_argument("--mode", type=int, default=1)
+    ap.add_argument("--drop", type=float, default=0.1)
+    ap.add_argument("--check", action="store_true")
+    ap.add_argument("--only", default="fwd,dq,dkv")
+    a = ap.parse_args()
+    L = _lib.lib()
+    H, d, T, nb = 1, 256, 500, 20
+    D, NP, Tp = H * d, T * nb, 512
+    S, E = a.slots, a.evals
+    g = torch.Generator(device="cuda").manual_seed(1)
+    qkv = torch.randn((S, 3 * D, NP), device="cuda", generator=g)
+    qkv[:, :D] *= 0.25
+    datt = torch.randn((E, D, NP), device="cuda", generator=g)
+    qs = torch.arange(E, device="cuda", dtype=torch.int32) % S
+    ks = (torch.arange(E, device="cuda", dtype=torch.int32) * 7 + 3) % S
+    att = torch.empty((E, D, NP), device="cuda")
+    lse = torch.empty((E, H, NP), device="cuda")
+    scores = torch.empty((E, H, nb, T, Tp), device="cuda")
+    dscores = torch.empty_like(scores)
+    delta = torch.empty((E, H, NP), device="cuda")
+    dqkv = torch.zeros((E, 3 * D, NP), device="cuda")
+    base = qkv.data_ptr()
+    st = CF._stream()
+    seed = 12345678901
+
+    def fwd():
+        _lib.check(L.csn_block_attn_fwd_f32(base, base + 4 * D * NP, base + 8 * D * NP, 3 * D * NP, 3 * D * NP, CF._ptr(qs),
+                                            CF._ptr(ks), NP, CF._ptr(att), D * NP, CF._ptr(scores), CF._ptr(lse), E, H, d, T,
+                                            nb, Tp, 8.0, a.drop, seed, 0, 0, st), "fwd")
+
+    def dq():
+        _lib.check(L.csn_block_attn_bwd_dq_f32(CF._ptr(datt), CF._ptr(att), D * NP, base + 4 * D * NP, base + 8 * D * NP,
+                                               3 * D * NP, CF._ptr(ks), NP, CF._ptr(scores), CF._ptr(dscores), CF._ptr(lse),
+                                               CF._ptr(delta), dqkv.data_ptr(), 3 * D * NP, None, 0, None, E, H, d, T, nb,
+                                               Tp, a.drop, seed, 0, 0, 0, 0, st), "dq")
+
+    def dkv():
+        gb = dqkv.data_ptr()
+        _lib.check(L.csn_block_attn_bwd_dkv_f32(CF._ptr(datt), D * NP, base, 3 * D * NP, CF._ptr(qs), NP, CF._ptr(scores),
+                                                CF._ptr(dscores), gb + 4 * D * NP, gb + 8 * D * NP, 3 * D * NP, None, None,
+                                                0, None, E, H, d, T, nb, Tp, 0, 0, 0, 0, st), "dkv")
+
+    flops = 4.0 * T * d * NP * E * H
+    L.csn_set_math_mode(a.mode)
+    ref = {}
+    if a.check:
+        L.csn_set_math_mode(0)
+        fwd(); ref["att"] = att.clone(); ref["lse"] = lse.clone()
+        dq(); ref["dq"] = dqkv[:, :D].clone(); ref["p"] = scores[0].clone()
+        dkv(); ref["dk"] = dqkv[:, D:2 * D].clone(); ref["dv"] = dqkv[:, 2 * D:].clone()
+        L.csn_set_math_mode(a.mode)
+    only = a.only.split(",")
+    fwd()
+    if "fwd" in only:
+        t = timeit(fwd)
+        print(f"mode {a.mode} fwd  E={E} drop={a.drop}: {t:7.3f} ms  {flops / t / 1e9:7.1f} TF/s algorithmic", flush=True)
+    if a.check:
+        print("   att err", (att - ref["att"]).abs().max().item(), "lse err", (lse - ref["lse"]).abs().max().item())
+    if "dq" in only or "dkv" in only:
+        s0 = scores.clone()
+        def dq_fresh():
+            scores.copy_(s0); dq()
+        t_copy = timeit(lambda: scores.copy_(s0))
+        t = timeit(dq_fresh) - t_copy
+        print(f"mode {a.mode} dq   E={E}: {t:7.3f} ms  {flops / t / 1e9:7.1f} TF/s algorithmic", flush=True)
+        if a.check:
+            print("   dq err", (dqkv[:, :D] - ref["dq"]).abs().max().item(), "scale", ref["dq"].abs().max().item(),
+                  "p err", (scores[0] - ref["p"]).abs().max().item())
+    if "dkv" in only:
+        t = timeit(dkv)
+        print(f"mode {a.mode} dkv  E={E}: {t:7.3f} ms  {flops / t / 1e9:7.1f} TF/s algorithmic", flush=True)
+        if a.check:
+            print("   dk err", (dqkv[:, D:2 * D] - ref["dk"]).abs().max().item(), "scale", ref["dk"].abs().max().item(),
+                  "dv err", (dqkv[:, 2 * D:] - ref["dv"]).abs().max().item(), "scale", ref["dv"].abs().max().item())
+    L.csn_set_math_mode(0)
+
+
+if __name__ == "__main__":
+    main()

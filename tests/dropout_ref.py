@@ -24,10 +24,27 @@ def keep_mask(idx, seed: int, p: float) -> np.ndarray:
     return (h >> np.uint64(8)) >= thr
 
 
+def _hash2(idx, seed: int):
+    """the two-round hash of keep_mask, as a 32-bit value"""
+    idx = np.asarray(idx, dtype=np.uint64)
+    lo, hi = idx & np.uint64(0xffffffff), idx >> np.uint64(32)
+    s0, s1 = np.uint64(seed & 0xffffffff), np.uint64((seed >> 32) & 0xffffffff)
+    h = _mix32(lo ^ s0)
+    return _mix32((h + (hi ^ s1) + np.uint64(0x9e3779b9)) & np.uint64(0xffffffff))
+
+
 def attention_mask(E, H, nb, T, Tp, seed, p):
-    """mask[e][h][blk][key][query] for the scores buffer geometry [E][H][nb][T][Tp] (element index = flat position)."""
-    idx = np.arange(E * H * nb * T * Tp, dtype=np.uint64).reshape(E, H, nb, T, Tp)[..., :T]
-    return keep_mask(idx, seed, p)
+    """mask[e][h][blk][key][query] for the scores buffer geometry [E][H][nb][T][Tp]  (csn_block_salt / csn_pair_hash):
+    every score block draws a salt from (seed, block id); one mixer round over (pair index ^ salt) decides the keys 2w
+    (low 16 bits) and 2w+1 (high 16 bits) of query q, pair index = w * Tp + q; keep <=> field >= p * 2^16."""
+    salt = _hash2(np.arange(E * H * nb, dtype=np.uint64), seed).reshape(E, H, nb, 1, 1)
+    key = np.arange(T, dtype=np.uint64).reshape(1, 1, 1, T, 1)
+    q = np.arange(T, dtype=np.uint64).reshape(1, 1, 1, 1, T)
+    pair = ((key >> np.uint64(1)) * np.uint64(Tp) + q) & np.uint64(0xffffffff)
+    h = _mix32(pair ^ salt)
+    field = np.where((key & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xffff))
+    thr = np.uint64(int(np.float32(p) * np.float32(65536.0)))
+    return field >= thr
 
 
 def fc_mask(E, C, N, seed, p):
