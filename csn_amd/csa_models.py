@@ -83,11 +83,12 @@ class MultiHeadAttention(nn.Module):
         """(attention-probability p, post-fc p): live only in train mode (csa_models.py:133-141, 56, 115)."""
         return (self.attention.dropout.p, self.dropout.p) if self.training else (0.0, 0.0)
 
-    def evaluate(self, x_all: torch.Tensor, plan: CF.EvalPlan, geo: Optional[CF.MHAGeometry] = None) -> torch.Tensor:
-        """Normalised (pre-affine) outputs (E, C, NP) of a batch of evaluations over shared slots."""
+    def evaluate(self, x_all: torch.Tensor, plan: CF.EvalPlan, geo: Optional[CF.MHAGeometry] = None, n_head_evals: int = 0):
+        """Normalised (pre-affine) outputs (E, C, NP) of a batch of evaluations over shared slots
+        (n_head_evals > 0: also the leading maps as a second tensor, see CF.mha_evals)."""
         p_attn, p_fc = self.dropout_rates()
         return CF.mha_evals(x_all, self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight,
-                            plan, geo or self.geometry(), p_attn, p_fc)
+                            plan, geo or self.geometry(), p_attn, p_fc, n_head_evals)
 
     def plan(self, kind: str, B: int, K1: int, dev) -> CF.EvalPlan:
         """Cached evaluation plans (slot maps live on the device; building one costs a few small H2D copies)."""
@@ -206,7 +207,11 @@ class CrossShapeAt(nn.Module):
     def _logits(self, feats_cm: torch.Tensor) -> torch.Tensor:
         """1x1 conv without bias on channel-major features (csa_models.py:151,194,201) -> (B, n_cls, N, 1)."""
         w = self.logit.weight.view(self.logit.weight.shape[0], -1)
-        return torch.matmul(w, feats_cm).unsqueeze(-1)
+        n_cls = w.shape[0]
+        pad = (-n_cls) % 4                                 # the HIP GEMMs want row counts that are multiples of 4
+        if pad:
+            w = F.pad(w, (0, 0, 0, pad))
+        return CF.linear_cm(feats_cm.contiguous(), w)[:, :n_cls].unsqueeze(-1)
 
     def forward_ssa(self, x, mode=None):
         if not self.after_fc:
@@ -260,8 +265,9 @@ class CrossShapeAt(nn.Module):
             x_all = x_all.view(B * K1, C, npts)
 
         train = any(r > 0 for r in att.dropout_rates())
-        xhat = att.evaluate(x_all, att.plan("csa_train" if train else "csa", B, K1, dev), geo)          # (E, C, NP)
         E1, E2 = B * K1, B * K
+        # xhat: all (E, C, NP) maps, used only through their means; xhat_mix: the E1 maps that are mixed (same storage)
+        xhat, xhat_mix = att.evaluate(x_all, att.plan("csa_train" if train else "csa", B, K1, dev), geo, n_head_evals=E1)
         gamma, beta = att.norm.weight, att.norm.bias
         # pooled descriptors y_k = mean_n SSA(x_k)  (:211-212, :218-219); the affine commutes with the mean
         means = CF.point_mean(xhat)                                            # (E, C), fp64-accumulated on the device
@@ -269,7 +275,7 @@ class CrossShapeAt(nn.Module):
         pooled_hat = torch.cat((own, means[E1:E1 + E2].view(B, K, C)), dim=1)
         pooled = pooled_hat * gamma + beta                                     # (B, K+1, C)
         comp = self._compatibility(pooled)                                     # (B, K+1)
-        feats = CF.csa_mix(xhat, comp, gamma, beta, B, K1)                     # sum_k comp_k * affine(xhat_k)  (:233, :238)
+        feats = CF.csa_mix(xhat_mix, comp, gamma, beta, B, K1)                   # sum_k comp_k * affine(xhat_k)  (:233, :238)
         return (feats, comp, pooled) if return_parts else feats
 
     def _compatibility(self, pooled: torch.Tensor) -> torch.Tensor:

@@ -104,14 +104,22 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
 
   // ---- register-resident operand R[d][q]: lane (q, kq) keeps rows d = 32 s + 8 kq + j as bf16 hi / lo ------
   bf16x8 Rh[D / 32], Rl[D / 32];
+  // backward: delta_q = sum_d dO[d][q] O[d][q] (the softmax-backward row constant) is formed on the way, from the fp32 dO
+  const csn_rsrc_t Xr = csn_make_rsrc(BWD ? p.ctx + qs * p.q_shape_stride + head_off : nullptr, BWD ? win : 0);
+  float delta_q = 0.f;
 #pragma unroll
   for (int s = 0; s < D / 32; ++s)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float v = csn_bload(Rr, r_off, (unsigned)(32 * s + j) * ld * 4u);
+      if (BWD) delta_q = fmaf(v, csn_bload(Xr, r_off, (unsigned)(32 * s + j) * ld * 4u), delta_q);
       Rh[s][j] = (__bf16)v;
       Rl[s][j] = (__bf16)(v - (float)Rh[s][j]);
     }
+  if (BWD) {
+    delta_q += __shfl_xor(delta_q, 16, 64);
+    delta_q += __shfl_xor(delta_q, 32, 64);
+  }
 
   f32x4v O[D / 16];
 #pragma unroll
@@ -127,10 +135,10 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   // exponentials run on the hardware exp2: exp(s - m) = exp2(s * log2(e) - m2) with m2 = fl(m * log2(e)), the same m2 for
   // every key of a query, so its rounding cancels in the normalisation; lse is rebuilt from m2 (= m2 ln 2 + ln l)
   float m_run = -INFINITY, m2_run = -INFINITY, l_run = 0.f;   // forward: running max / partial sum of this lane's key quarter
-  float lse2_q = 0.f, delta_q = 0.f;          // backward: per-query constants
+  float lse2_q = 0.f;                          // backward: per-query constant
   if (BWD) {
     lse2_q = q_ok ? p.lse[stat_off + qrow] * LOG2E : 0.f;
-    delta_q = q_ok ? p.delta[stat_off + qrow] : 0.f;
+    if (q_ok && kq == 0 && p.delta) p.delta[stat_off + qrow] = delta_q;
   }
   // score positions of this lane: tile j, reg r -> key kt*32 + 16 j + 4 kq + r, query qrow.  Lane-dependent part in one
   // voffset per j (a 4-key group is all in or all out: T % 4 == 0), r * Tp in wave-uniform scalar offsets

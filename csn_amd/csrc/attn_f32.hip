@@ -89,8 +89,18 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
 
   // ---- register-resident operand R[d][q]: lane (q, kq) keeps rows d = 4 s + kq ----------------
   float R[D / 4];
+  // backward: delta_q = sum_d dO[d][q] O[d][q] (the softmax-backward row constant) is formed on the way
+  const csn_rsrc_t Xr = csn_make_rsrc(BWD ? p.ctx + qs * p.q_shape_stride + head_off : nullptr, BWD ? win : 0);
+  float delta_q = 0.f;
 #pragma unroll
-  for (int s = 0; s < D / 4; ++s) R[s] = csn_bload(Rr, r_off, (unsigned)(4 * s) * ld * 4u);
+  for (int s = 0; s < D / 4; ++s) {
+    R[s] = csn_bload(Rr, r_off, (unsigned)(4 * s) * ld * 4u);
+    if (BWD) delta_q = fmaf(R[s], csn_bload(Xr, r_off, (unsigned)(4 * s) * ld * 4u), delta_q);
+  }
+  if (BWD) {
+    delta_q += __shfl_xor(delta_q, 16, 64);
+    delta_q += __shfl_xor(delta_q, 32, 64);
+  }
 
   f32x4v O[D / 16];
 #pragma unroll
@@ -104,10 +114,10 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
   const unsigned pw_base = (unsigned)(2 * kq * Tp + qrow);       // pair index of this lane's keys 4 kq, 4 kq + 1
 
   float m_run = -INFINITY, l_run = 0.f;       // forward: running max / partial sum of this lane's key quarter
-  float lse_q = 0.f, delta_q = 0.f;           // backward: per-query constants
+  float lse_q = 0.f;                           // backward: per-query constant
   if (BWD) {
     lse_q = q_ok ? p.lse[stat_off + qrow] : 0.f;
-    delta_q = q_ok ? p.delta[stat_off + qrow] : 0.f;
+    if (q_ok && kq == 0 && p.delta) p.delta[stat_off + qrow] = delta_q;
   }
 
   // ---- streamed tiles: global -> registers -> LDS (swizzled) ---------------------------------------

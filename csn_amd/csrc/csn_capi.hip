@@ -130,7 +130,7 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
   a.q_shape_stride = q_shape_stride; a.kv_shape_stride = kv_shape_stride;
   a.q_index = q_index; a.kv_index = kv_index; a.ld = ld;
   a.out = ctx; a.out_eval_stride = ctx_eval_stride;
-  a.scores = scores; a.dscores = nullptr; a.lse = lse; a.delta = nullptr;
+  a.scores = scores; a.dscores = nullptr; a.lse = lse; a.delta = nullptr; a.ctx = nullptr;
   a.E = n_evals; a.H = n_heads; a.T = block; a.Tp = score_pitch; a.n_blocks = n_blocks;
   a.rescale_threshold = rescale_threshold;
   a.eval_ids = nullptr; a.out_index = nullptr; a.accumulate = 0;
@@ -156,11 +156,10 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
   if (mis16(dctx) || mis16(k) || mis16(v) || mis16(scores) || mis16(dscores) || mis16(dq)) return CSN_E_PTR;
   if ((kv_shape_stride & 3) || (ctx_eval_stride & 3) || (dq_slot_stride & 3)) return CSN_E_STRIDE;
   hipStream_t st = (hipStream_t)stream;
-  // delta[e][h][n] = sum_c dctx * ctx   (softmax backward row constant)
-  int rc = csn_launch_rowdot_f32(dctx, ctx, delta, eval_ids, n_launch_evals, n_heads, d_head, ld, n_blocks * block,
-                                 ctx_eval_stride, dctx_split, dctx_plane_stride, st);
-  if (rc) return rc;
+  // delta[e][h][n] = sum_c dctx * ctx (softmax backward row constant) is formed in the kernel's prologue, where
+  // the dctx columns are being loaded anyway
   CsnAttnArgs a;
+  a.ctx = ctx;
   a.q = dctx; a.k = k; a.v = v;
   a.q_shape_stride = dctx_split ? 2 * ctx_eval_stride : ctx_eval_stride;     // split dctx: [eval][2 planes][D][ld]
   a.kv_shape_stride = kv_shape_stride;
@@ -231,10 +230,12 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
                            const float* ctx, long long ctx_eval_stride, const float* wfc_t, float* dz, float* dz_res,
                            float* dctx, float* dwfc, float* ws, long long ws_floats, int n_evals, int d_model,
                            int d_inner, int ld, int n_points, int accumulate, float dropout_p,
-                           unsigned long long seed, int dctx_split, long long dctx_plane_stride, void* stream) {
+                           unsigned long long seed, int dctx_split, long long dctx_plane_stride,
+                           const float* dxhat_rows, int n_dense_evals, void* stream) {
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
   if (dctx_split && g_math_mode != 1) return CSN_E_ARG;
-  if (!dxhat || !xhat || !rstd || !ctx || !wfc_t || !dz || !dctx || !dwfc || !ws) return CSN_E_ARG;
+  if (n_dense_evals < 0 || n_dense_evals > n_evals || (n_dense_evals > 0 && !dxhat)) return CSN_E_ARG;
+  if (!xhat || !rstd || !ctx || !wfc_t || !dz || !dctx || !dwfc || !ws) return CSN_E_ARG;
   if (n_evals <= 0 || n_points <= 0 || d_inner <= 0 || d_model <= 0) return CSN_E_ARG;
   if ((ld & 3) || (d_inner & 3) || (d_model & 3) || (n_points & 3)) return CSN_E_ALIGN;
   if (mis16(dxhat) || mis16(xhat) || mis16(ctx) || mis16(wfc_t) || mis16(dz) || mis16(dctx) || mis16(dwfc) || mis16(ws))
@@ -245,6 +246,7 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
   l.dxhat = dxhat; l.xhat = xhat; l.rstd = rstd; l.dz = dz; l.dz_res = dz_res; l.eval_stride = eval_stride;
   l.E = n_evals; l.C = d_model; l.ld = ld; l.n_points = n_points;
   l.dropout_p = dropout_p; l.seed = seed;
+  l.dxhat_rows = dxhat_rows; l.n_dense = n_dense_evals;
   int rc = csn_launch_ln_bwd_f32(l, st);
   if (rc) return rc;
   // dctx[e][D][n] = wfc_t[D][c] dz[e][c][n]

@@ -32,7 +32,8 @@ struct CsnAttnArgs {
   float* scores;                                         // S^T / P^T  [e][h][blk][T][Tp]   (may be null in forward)
   float* dscores;                                        // backward: dS^T, same geometry
   float* lse;                                            // [e][h][n_blocks*T]
-  const float* delta;                                    // backward: rowsum(dO*O) [e][h][n_blocks*T]
+  float* delta;                                          // backward: rowsum(dO*O) [e][h][n_blocks*T], computed by the kernel
+  const float* ctx;                                      // backward: O^T = Ctx^T [e][H*d][ld] of the forward (for delta)
   int E, H, T, Tp, n_blocks;
   float rescale_threshold;
   const int* eval_ids;                                   // launch z -> evaluation id (nullptr: identity); E = launch size
@@ -66,6 +67,8 @@ int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, int fast, hipStream_t
 
 struct CsnLnBwdArgs {
   const float* dxhat; const float* xhat; const float* rstd;   // [e][C][ld], [e][C][ld], [e][n_points]
+  const float* dxhat_rows;                                     // optional [e][C]: added to every point of row (e, c)
+  int n_dense;                                                 // evaluations e >= n_dense have no dense dxhat (only the row term)
   float* dz;                                                   // [e][C][ld]  gradient w.r.t. the fc output (dropout mask applied)
   float* dz_res;                                               // optional: gradient w.r.t. the residual input (no mask)
   long long eval_stride;

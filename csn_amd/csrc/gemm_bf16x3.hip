@@ -22,6 +22,16 @@
 #include "csn_common.h"
 #include "csn_kernels.h"
 
+// -DCSN_STAMPS: development build that records s_memtime after the prologue, the main loop and the epilogue of every
+// work-group (scripts/gemm_stamps.py)
+#ifdef CSN_STAMPS
+__device__ unsigned long long csn_gdbg[65536 * 4];
+extern "C" int csn_gemm_debug_read(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_gdbg), bytes); }
+#define GSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); gst[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GSTAMP(i)
+#endif
+
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -53,6 +63,10 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   __shared__ __attribute__((aligned(16))) __bf16 Bs[2][2][B_EL];   // NK: [stage][plane][col][k]   KN: [stage][plane][k][col]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef CSN_STAMPS
+  unsigned long long gst[4];
+#endif
+  GSTAMP(0);
   const int l31 = lane & 31, h = lane >> 5;
   const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
 
@@ -144,6 +158,7 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   if (nk > 0) { load_slab(0); store_slab(0); }
   if (nk > 1) load_slab(BK);
   __syncthreads();
+  GSTAMP(1);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
 #pragma unroll
@@ -193,6 +208,7 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
     __syncthreads();
   }
 
+  GSTAMP(2);
   const float alpha = p.alpha;
   unsigned c_off[MT][NT][16];
 #pragma unroll
@@ -240,6 +256,11 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
     for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) csn_bstore(acc[i][j][r], Cr, c_off[i][j][r]);
+#ifdef CSN_STAMPS
+  __builtin_amdgcn_s_waitcnt(0);
+  GSTAMP(3);
+  if (tid == 0 && blockIdx.x < 65536) for (int i = 0; i < 4; ++i) csn_gdbg[blockIdx.x * 4 + i] = gst[i];
+#endif
 }
 
 template <int BM, int BN, bool B_NK>

@@ -291,47 +291,69 @@ __global__ __launch_bounds__(256, 2) void csn_outproj_ln_fwd_bf16x3_kernel(CsnOu
 
 // LayerNorm backward without the affine part:  dz = rstd * (dx - mean_c(dx) - xhat * mean_c(dx * xhat)).
 // Single pass over HBM: a work-group owns 64 points (lanes along n: 256-byte row segments); its 4 waves split the
-// channels (wave g takes c = 4 i + g), every thread keeps its C/4 (dx, xhat) pairs in registers, the two channel sums are
-// combined across the 4 waves through LDS, and dz is produced from the registers.
+// channels (wave g takes c = g C/4 + i), every thread keeps its C/4 (dx, xhat) pairs in registers, the two channel sums
+// are combined across the 4 waves through LDS, and dz is produced from the registers.
+// dx = dxhat (evaluations below n_dense only) + dxhat_rows[e][c] (constant along the points).  All loads are branch-free
+// (buffer descriptors; an absent dense part is a zero-sized window), so the 2 C/4 loads of a thread are in flight together.
 template <int CPT>
 __global__ __launch_bounds__(256) void csn_ln_bwd_kernel(CsnLnBwdArgs p) {
   __shared__ float red[2][4][64];
-  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = blockIdx.x * 64 + lane;
   const int e = blockIdx.y;
   const bool ok = n < p.n_points;
-  const long long base = (long long)e * p.eval_stride + n;
-  const long long ld = p.ld;
-  float gx[CPT], xx[CPT];
+  constexpr int C = 4 * CPT;
+  const long long win = ((long long)(C - 1) * p.ld + p.n_points) * 4;
+  const bool dense = e < p.n_dense;
+  const csn_rsrc_t Gr = csn_make_rsrc(dense ? p.dxhat + (long long)e * p.eval_stride : nullptr, dense ? win : 0);
+  const csn_rsrc_t Xr = csn_make_rsrc(p.xhat + (long long)e * p.eval_stride, win);
+  const unsigned voff = ok ? (unsigned)n * 4u : CSN_OOB;
+  const unsigned ldb = (unsigned)p.ld * 4u;
+  float gx[CPT], xx[CPT], rw[CPT];
+  if (p.dxhat_rows) {
+    const float* __restrict__ rows = p.dxhat_rows + (long long)e * C + g * CPT;      // wave-uniform: scalar loads
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) rw[i] = rows[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) rw[i] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) {
+    gx[i] = csn_bload(Gr, voff, (unsigned)(g * CPT + i) * ldb);
+    xx[i] = csn_bload(Xr, voff, (unsigned)(g * CPT + i) * ldb);
+  }
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const long long o = base + (long long)(4 * i + g) * ld;
-    gx[i] = ok ? p.dxhat[o] : 0.f;
-    xx[i] = ok ? p.xhat[o] : 0.f;
+    gx[i] += rw[i];
     s1 += gx[i];
     s2 += gx[i] * xx[i];
   }
   red[0][g][lane] = s1;
   red[1][g][lane] = s2;
   __syncthreads();
-  const int C = 4 * CPT;
   const float m1 = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) / C;
   const float m2 = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / C;
-  if (!ok) return;
-  const float rstd = p.rstd[(long long)e * p.n_points + n];
+  const float rstd = ok ? p.rstd[(long long)e * p.n_points + n] : 0.f;
   const bool drop = p.dropout_p > 0.f;
   const unsigned thr24 = csn_drop_threshold(p.dropout_p);
   const float keep_scale = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
+  const csn_rsrc_t Zr = csn_make_rsrc(p.dz + (long long)e * p.eval_stride, win);
+  const csn_rsrc_t Zres = csn_make_rsrc(p.dz_res ? p.dz_res + (long long)e * p.eval_stride : nullptr, p.dz_res ? win : 0);
+  const long long base = (long long)e * p.eval_stride + n;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    const long long o = base + (long long)(4 * i + g) * ld;
-    const float v = rstd * (gx[i] - m1 - xx[i] * m2);
-    if (p.dz_res) p.dz_res[o] = v;                               // the residual branch sees no mask
-    float vf = v;
-    if (drop) vf = csn_keep((unsigned long long)o, p.seed, thr24) ? v * keep_scale : 0.f;
-    p.dz[o] = vf;
+    gx[i] = rstd * (gx[i] - m1 - xx[i] * m2);
+    csn_bstore(gx[i], Zres, voff, (unsigned)(g * CPT + i) * ldb);     // the residual branch sees no mask (vanishes when absent)
   }
+  if (drop) {                                                         // one uniform branch, not one per element
+#pragma unroll
+    for (int i = 0; i < CPT; ++i)
+      gx[i] = csn_keep((unsigned long long)(base + (long long)(g * CPT + i) * p.ld), p.seed, thr24) ? gx[i] * keep_scale : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < CPT; ++i) csn_bstore(gx[i], Zr, voff, (unsigned)(g * CPT + i) * ldb);
 }
 
 // out[e][h][n] = sum_{c < d} a[e][h*d + c][n] * b[e][h*d + c][n]    (delta = rowsum(dO * O) of the softmax backward)

@@ -170,8 +170,9 @@ class _MHAEvals(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_all, w_qs, w_ks, w_vs, w_fc, plan: EvalPlan, geo: MHAGeometry, keep_scores: bool,
-                p_attn: float = 0.0, p_fc: float = 0.0):
+                p_attn: float = 0.0, p_fc: float = 0.0, n_head_evals: int = 0):
         _need_cuda(x_all, w_qs, w_ks, w_vs, w_fc)
+        ctx.set_materialize_grads(False)               # an unused output must not cost a zero-filled (E, C, NP) gradient
         # dropout masks are counter-based: two 62-bit seeds from torch's CPU generator (torch.manual_seed reproduces them)
         seed_attn, seed_fc = (torch.randint(0, 2 ** 62, (2,)).tolist() if (p_attn > 0 or p_fc > 0) else (0, 0))
         q_slots, kv_slots, v_shift = plan.q_slots, plan.kv_slots, plan.v_shift
@@ -224,10 +225,14 @@ class _MHAEvals(torch.autograd.Function):
             ctx.plan = plan
             ctx.drop = (p_attn, seed_attn, p_fc, seed_fc)
             ctx.split = split
-        return xhat
+        # second output: the first n_head_evals maps again (same storage).  A consumer of all maps whose gradient is
+        # constant along the points (the pooled means) and a consumer of the leading maps only (the mix) then hand the
+        # backward two cheap gradients instead of one dense (E, C, NP) sum.
+        ctx.n_head = n_head_evals
+        return xhat, xhat[:n_head_evals]
 
     @staticmethod
-    def backward(ctx, dxhat):
+    def backward(ctx, dxhat, dhead):
         x_all, w_qkv, w_fc, qkv, att, lse, scores, xhat, rstd = ctx.saved_tensors
         geo: MHAGeometry = ctx.geo
         plan: EvalPlan = ctx.plan
@@ -237,7 +242,19 @@ class _MHAEvals(torch.autograd.Function):
         E = plan.E
         T, nb, Tp = geo.block, geo.n_blocks, geo.score_pitch
         dev = x_all.device
-        dxhat = dxhat.contiguous()
+        # incoming gradient = dense maps for the first n_dense evaluations + a per-row constant (gradient of a mean)
+        rows = None
+        if dxhat is not None and dxhat.stride(2) == 0 and dxhat.stride(1) == 1:
+            rows, dxhat = dxhat[:, :, 0].contiguous(), None              # expanded (E, C, 1) -> (E, C)
+        if ctx.n_head == 0:
+            dhead = None
+        if dxhat is not None and dhead is not None:
+            dxhat = dxhat.clone()
+            dxhat[:ctx.n_head] += dhead
+            dhead = None
+        dense = dxhat if dxhat is not None else dhead
+        n_dense = 0 if dense is None else dense.shape[0]
+        dense = None if dense is None else dense.contiguous()
         temperature = float(d) ** 0.5
         p_attn, seed_attn, p_fc, seed_fc = ctx.drop
         need_dx = ctx.needs_input_grad[0]
@@ -253,9 +270,9 @@ class _MHAEvals(torch.autograd.Function):
         ws_n = L.csn_wgrad_workspace_floats(C, D, E, NP)
         ws = torch.empty((ws_n,), device=dev, dtype=torch.float32)
         w_fc_t = w_fc.t().contiguous()
-        _lib.check(L.csn_outproj_ln_bwd_f32(_ptr(dxhat), _ptr(xhat), _ptr(rstd), C * NP, _ptr(att), D * NP,
+        _lib.check(L.csn_outproj_ln_bwd_f32(_ptr(dense), _ptr(xhat), _ptr(rstd), C * NP, _ptr(att), D * NP,
                                             _ptr(w_fc_t), _ptr(dz), _ptr(dz_res), _ptr(datt), _ptr(dw_fc), _ptr(ws), ws_n,
-                                            E, C, D, NP, NP, 0, p_fc, seed_fc, sp, D * NP, _stream()),
+                                            E, C, D, NP, NP, 0, p_fc, seed_fc, sp, D * NP, _ptr(rows), n_dense, _stream()),
                    "csn_outproj_ln_bwd_f32")
         del ws
 
@@ -298,14 +315,40 @@ class _MHAEvals(torch.autograd.Function):
             dqkv[:, :D] /= temperature
             dx_all = project(dqkv, w_qkv.t().contiguous())
             dx_all.index_add_(0, plan.q_slots.long(), dz if dz_res is None else dz_res)
-        return dx_all, dw_q, dw_k, dw_v, dw_fc, None, None, None, None, None
+        return dx_all, dw_q, dw_k, dw_v, dw_fc, None, None, None, None, None, None
 
 
 def mha_evals(x_all: torch.Tensor, w_qs: torch.Tensor, w_ks: torch.Tensor, w_vs: torch.Tensor, w_fc: torch.Tensor,
-              plan: EvalPlan, geo: MHAGeometry, p_attn: float = 0.0, p_fc: float = 0.0) -> torch.Tensor:
-    """p_attn / p_fc: train-mode dropout probabilities of csa_models.py:141 / :115 (0 in eval mode)."""
+              plan: EvalPlan, geo: MHAGeometry, p_attn: float = 0.0, p_fc: float = 0.0, n_head_evals: int = 0):
+    """p_attn / p_fc: train-mode dropout probabilities of csa_models.py:141 / :115 (0 in eval mode).
+    n_head_evals > 0: returns (xhat, xhat[:n_head_evals]) — use the second for consumers of the leading maps only."""
     keep = torch.is_grad_enabled() and any(t.requires_grad for t in (x_all, w_qs, w_ks, w_vs, w_fc))
-    return _MHAEvals.apply(x_all, w_qs, w_ks, w_vs, w_fc, plan, geo, keep, float(p_attn), float(p_fc))
+    xhat, head = _MHAEvals.apply(x_all, w_qs, w_ks, w_vs, w_fc, plan, geo, keep, float(p_attn), float(p_fc),
+                                 int(n_head_evals))
+    return (xhat, head) if n_head_evals > 0 else xhat
+
+
+class _LinearCM(torch.autograd.Function):
+    """y[s] = w @ x[s] on channel-major maps: x (S, C, NP), w (R, C) -> (S, R, NP).  R and C multiples of 4."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        _need_cuda(x, w)
+        ctx.save_for_backward(x, w)
+        return project(x, w.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = project(dy, w.t().contiguous()) if ctx.needs_input_grad[0] else None
+        dw = project_wgrad(dy, x) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def linear_cm(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """Bias-free 1x1 convolution on channel-major maps through the HIP GEMMs (the logit layer, csa_models.py:151)."""
+    return _LinearCM.apply(x, w)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -358,7 +401,7 @@ class _CSAMix(torch.autograd.Function):
         dfeats = dfeats.contiguous()
         dxhat = torch.empty_like(xhat)
         if E > B * K1:
-            dxhat[B * K1:].zero_()
+            dxhat[B * K1:].zero_()                    # (callers hand in exactly the B*K1 mixed maps: nothing to clear)
         rowdot = torch.empty((B, K1, C), device=xhat.device, dtype=torch.float32)
         rowsum = torch.empty((B, C), device=xhat.device, dtype=torch.float32)
         _lib.check(_lib.lib().csn_mix_bwd_f32(_ptr(dfeats), _ptr(xhat), _ptr(comp), _ptr(gamma), _ptr(dxhat), _ptr(rowdot),

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSN_ABI_VERSION 3
+#define CSN_ABI_VERSION 4
 
 #define CSN_E_ARG (-1)     /* null pointer / non-positive size            */
 #define CSN_E_ALIGN (-2)   /* a size or leading dimension is not % 4      */
@@ -135,12 +135,16 @@ int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const fl
  * dctx = wfc^T dz                                          [n_evals][d_inner][ld]
  * dwfc (+)= sum_{e,n} dz[e][:,n] ctx[e][:,n]^T             [d_model][d_inner]
  * wfc_t is wfc transposed, [d_inner][d_model] row-major.  `ws` is scratch of at least
- * csn_wgrad_workspace_floats(d_model, d_inner, n_evals, n_points) floats.  accumulate != 0 adds into dwfc. */
+ * csn_wgrad_workspace_floats(d_model, d_inner, n_evals, n_points) floats.  accumulate != 0 adds into dwfc.
+ * The incoming gradient is  dxhat[e][c][n] (evaluations e < n_dense_evals only; the others have none)
+ *                         + dxhat_rows[e][c] (optional, NULL = none): a term that is constant along the points — the
+ * gradient of the pooled means (csa_models.py:212,219) — so that it never has to be expanded to a full map. */
 int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* rstd, long long eval_stride,
                            const float* ctx, long long ctx_eval_stride, const float* wfc_t, float* dz, float* dz_res,
                            float* dctx, float* dwfc, float* ws, long long ws_floats, int n_evals, int d_model,
                            int d_inner, int ld, int n_points, int accumulate, float dropout_p,
-                           unsigned long long seed, int dctx_split, long long dctx_plane_stride, void* stream);
+                           unsigned long long seed, int dctx_split, long long dctx_plane_stride,
+                           const float* dxhat_rows, int n_dense_evals, void* stream);
 
 /* ---- (6) projection weight gradient ----------------------------------------------------------------------
  * dw[r][c] (+)= scale * sum_{s,n} dout[s][r][n] * x[s][c][n]        (autograd of csa_models.py:103-105) */

@@ -287,10 +287,17 @@ def test_outproj_ln_fwd_bwd(L, S, E, C, D, NP):
     ws = torch.empty((ws_n,), device=dev)
     wt = wd.t().contiguous()
     dxd = dxhat.cuda()
+    # incoming gradient = dense maps for the first E-1 evaluations only + a per-row constant (the pooled-mean term)
+    rows = _rand(rng, E, C)
+    rows_d = rows.cuda()
+    nd = E - 1
     L.check(L.lib().csn_outproj_ln_bwd_f32(dxd.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), C * NP, attd.data_ptr(), D * NP,
                                            wt.data_ptr(), dz.data_ptr(), None, datt.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws_n,
-                                           E, C, D, NP, NP, 0, 0.0, 0, 0, 0, _stream()))
-    ref.backward(dxhat.double())
+                                           E, C, D, NP, NP, 0, 0.0, 0, 0, 0, rows_d.data_ptr(), nd, _stream()))
+    dx_eff = dxhat.double().clone()
+    dx_eff[nd:] = 0
+    dx_eff += rows.double()[:, :, None]
+    ref.backward(dx_eff)
     assert _maxerr(datt, a64.grad) < tol(2e-5)
     assert _maxerr(dw, w64.grad) < tol(2e-5)
 
