@@ -6,14 +6,19 @@
 //   tileA  [d][key] 32 keys, k-major: fragments by ds_read_b64_tr_b16  (fwd: K^T    bwd: V^T)     bf16 hi / lo planes
 //   tileB  [d][key] 32 keys, key-contiguous: fragments by ds_read_b64  (fwd: V^T    bwd: K^T)     bf16 hi / lo planes
 // Matrix instruction: v_mfma_f32_16x16x32_bf16 (A: lane l = A[l & 15][8 (l >> 4) + j], B: lane l = B[8 (l >> 4) + j][l & 15],
-// j = 0..7; C: reg r of lane l = C[4 (l >> 4) + r][l & 15]) — the C layout of the 16x16 fp32 shape, so the phase-1
-// accumulators of two 16-key tiles are, after the hi/lo split, the 32-key B fragment of phase 2 with the k order
-//   element j of lane (q, kq)  <->  key 4 kq + j (j < 4)  |  16 + 4 kq + (j - 4) (j >= 4),
-// and the V^T / K^T fragments are fetched in that same order (two 8-byte reads per plane).
-// The fp32 tiles coming from HBM are split into their bf16 planes while they are staged into LDS (two planes = the
-// bytes of the fp32 tile).  LDS images (conflict-free): tileA swaps the 16-key halves on rows with bit 3 set; tileB
-// stores, per row, the 8 keys of each lane quarter kq contiguously ([4kq..4kq+3 | 16+4kq..16+4kq+3], one 16-byte read
-// per fragment) and XORs that 16-byte unit index with (-(row >> 2)) & 3.
+// j = 0..7; C: reg r of lane l = C[4 (l >> 4) + r][l & 15]).  The two 16-row score tiles of a 32-key tile take the keys
+//   S0 row i  <->  key 8 (i >> 2) + (i & 3),      S1 row i  <->  key 8 (i >> 2) + 4 + (i & 3)
+// (the transposing LDS read takes a per-lane address, so any 4-key chunk can feed any row group), hence lane (q, kq)
+// ends phase 1 with the 8 CONSECUTIVE keys 8 kq .. 8 kq + 7 of its query: after the hi/lo split that is the B fragment of
+// phase 2 as it stands, and the V^T / K^T fragment of a lane is one 16-byte run of the natural [d][key] row.
+// K/V inputs, two forms:
+//   fp32 [d][point]  — tiles are split into bf16 hi/lo planes while they are staged into LDS;
+//   "tile planes"    — written by the projection (csn_project_f32, out_split = 2): per row and 500-point block, 16 tiles of
+//                      [hi: 32 keys | lo: 32 keys] bf16 (block pitch 1024, padding zero).  A tile row is then 128
+//                      contiguous, 128-byte aligned bytes, and staging is a plain copy — no conversion work per tile.
+// LDS images (conflict-free): tileA swaps the two 8-byte chunks of every 16-byte unit on rows with bit 3 set (the
+// transposing read of a 32-lane group touches rows r and r + 8 together); tileB XORs the 16-byte unit index with
+// (-(row >> 2)) & 3; the hi and lo planes are 128 bytes out of phase so that one staging store hits both without conflict.
 #include "csn_common.h"
 #include "csn_kernels.h"
 
@@ -56,14 +61,15 @@ CSN_DEVINL void split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
   }
 }
 
-template <int DT, bool BWD>
+template <int DT, bool BWD, bool KVP>
 __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) {
   constexpr int D = 32 * DT;
   constexpr int PIECES = D * 8;                         // 16-byte pieces per streamed tile
   constexpr int NP_T = (PIECES + 511) / 512;            // pieces per thread per tile
+  constexpr int PLANE = D * KT + 64;                    // plane pitch: 128 bytes of phase between hi and lo
   // [stage][plane hi/lo][row][32 keys]
-  __shared__ __attribute__((aligned(16))) __bf16 tileA[2][2][D * KT];
-  __shared__ __attribute__((aligned(16))) __bf16 tileB[2][2][D * KT];
+  __shared__ __attribute__((aligned(16))) __bf16 tileA[2][2][PLANE];
+  __shared__ __attribute__((aligned(16))) __bf16 tileB[2][2][PLANE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, kq = lane >> 4;
@@ -88,8 +94,16 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   const long long head_off = (long long)hd * D * ld + (long long)blk * T;
   const long long win = ((long long)(D - 1) * ld + T) * 4;     // bytes spanned by a [D][T] window of pitch ld
   const csn_rsrc_t Rr = csn_make_rsrc(p.q + qs * p.q_shape_stride + head_off, win);
-  const csn_rsrc_t Ar = csn_make_rsrc((BWD ? p.v : p.k) + ks * p.kv_shape_stride + head_off, win);
-  const csn_rsrc_t Br = csn_make_rsrc((BWD ? p.k : p.v) + ks * p.kv_shape_stride + head_off, win);
+  // tile planes: bf16 elements, row pitch kv_ld = n_blocks * 1024, this block's 16 tiles start at blk * 1024
+  const int kld = p.kv_ld;
+  const long long kv_off = KVP ? ks * p.kv_shape_stride + (long long)hd * D * kld + (long long)blk * 1024 : 0;
+  const long long kv_win = ((long long)(D - 1) * kld + 1024) * 2;
+  const __bf16* kpl = reinterpret_cast<const __bf16*>(BWD ? p.v : p.k);
+  const __bf16* vpl = reinterpret_cast<const __bf16*>(BWD ? p.k : p.v);
+  const csn_rsrc_t Ar = KVP ? csn_make_rsrc(kpl + kv_off, kv_win)
+                            : csn_make_rsrc((BWD ? p.v : p.k) + ks * p.kv_shape_stride + head_off, win);
+  const csn_rsrc_t Br = KVP ? csn_make_rsrc(vpl + kv_off, kv_win)
+                            : csn_make_rsrc((BWD ? p.k : p.v) + ks * p.kv_shape_stride + head_off, win);
   const csn_rsrc_t Or = csn_make_rsrc(p.out + os * p.out_eval_stride + head_off, win);
   const long long stat_off = ((long long)e * p.H + hd) * ((long long)p.n_blocks * T) + (long long)blk * T;
   const long long sc_off = (((long long)e * p.H + hd) * p.n_blocks + blk) * ((long long)T * Tp);
@@ -130,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   const unsigned thr16 = csn_drop_threshold16(p.dropout_p);
   const float keep_scale = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
   const unsigned salt = csn_block_salt((unsigned long long)(((long long)e * p.H + hd) * p.n_blocks + blk), p.seed);
-  const unsigned pw_base = (unsigned)(2 * kq * Tp + qrow);       // pair index of this lane's keys 4 kq, 4 kq + 1
+  const unsigned pw_base = (unsigned)(4 * kq * Tp + qrow);       // pair index of this lane's keys 8 kq, 8 kq + 1
 
   // exponentials run on the hardware exp2: exp(s - m) = exp2(s * log2(e) - m2) with m2 = fl(m * log2(e)), the same m2 for
   // every key of a query, so its rounding cancels in the normalisation; lse is rebuilt from m2 (= m2 ln 2 + ln l)
@@ -140,57 +154,79 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     lse2_q = q_ok ? p.lse[stat_off + qrow] * LOG2E : 0.f;
     if (q_ok && kq == 0 && p.delta) p.delta[stat_off + qrow] = delta_q;
   }
-  // score positions of this lane: tile j, reg r -> key kt*32 + 16 j + 4 kq + r, query qrow.  Lane-dependent part in one
+  // score positions of this lane: half j, reg r -> key kt*32 + 8 kq + 4 j + r, query qrow.  Lane-dependent part in one
   // voffset per j (a 4-key group is all in or all out: T % 4 == 0), r * Tp in wave-uniform scalar offsets
-  const unsigned s_base = (unsigned)(4 * kq * Tp + qrow) * 4u;
+  const unsigned s_base = (unsigned)(8 * kq * Tp + qrow) * 4u;
   const unsigned s_r1 = (unsigned)Tp * 4u, s_r2 = (unsigned)Tp * 8u, s_r3 = (unsigned)Tp * 12u;
 
   // ---- streamed tiles: global -> registers -> LDS (swizzled) ---------------------------------------
-  // piece idx = tid + 512 i  ->  row (tid >> 3) + 64 i, keys 4 (tid % 8) .. +3.  Everything that depends on i is
-  // wave-uniform (scalar offset of the load, immediate offset of the LDS store): rows 64 apart share the swizzle.
-  const int t_c = (tid & 7) * 4, t_row = tid >> 3;
-  const unsigned t_off = (unsigned)(t_row * ld + t_c) * 4u;
+  // piece idx = tid + 512 i  ->  row (tid >> 3) + 64 i.  fp32 input: keys 4 c .. 4 c + 3, c = tid % 8.  Tile planes: 16-byte
+  // unit tid % 8 of the row's 128 bytes (units 0..3: hi plane keys 8 u .. 8 u + 7, units 4..7: lo plane).  Everything that
+  // depends on i is wave-uniform (scalar offset of the load, immediate offset of the LDS store): rows 64 apart share the swizzles.
+  const int t_c = tid & 7, t_row = tid >> 3;
+  const int t_sw = (t_row >> 3) & 1, t_swz = (-((t_row >> 2) & 3)) & 3;
+  const unsigned t_off = KVP ? (unsigned)(t_row * kld * 2 + t_c * 16) : (unsigned)(t_row * ld + 4 * t_c) * 4u;
   const bool t_last_ok = tid + 512 * (NP_T - 1) < PIECES;         // only the last piece can fall beyond the tile
-  const int a_dst = t_row * KT + (t_c ^ (16 * ((t_row >> 3) & 1)));            // key halves swapped on rows with bit 3 set
-  // tileB: 4-key chunk c8 -> 8-byte slot s8 = 2 c8 (keys 0..15) | 2 (c8 - 4) + 1 (keys 16..31); its 16-byte unit
-  // (s8 >> 1 = kq) is XORed with (-(row >> 2)) & 3
-  const int c8 = tid & 7, s8 = c8 < 4 ? 2 * c8 : 2 * (c8 - 4) + 1;
-  const int b_dst = t_row * KT + 4 * (2 * ((s8 >> 1) ^ ((-((t_row >> 2) & 3)) & 3)) + (s8 & 1));
+  // fp32: 8-byte chunk c -> tileA chunk c ^ sw;  tileB unit (c >> 1) ^ swz, half c & 1
+  // planes: unit u = c & 3 of plane c >> 2 -> tileA chunks (2 u) ^ sw and (2 u + 1) ^ sw;  tileB unit u ^ swz
+  const int t_u = t_c & 3, t_pl = t_c >> 2;
+  const int a_dst = KVP ? t_pl * PLANE + t_row * KT + 8 * t_u : t_row * KT + 4 * (t_c ^ t_sw);
+  const int b_dst = KVP ? t_pl * PLANE + t_row * KT + 8 * (t_u ^ t_swz) : t_row * KT + 8 * ((t_c >> 1) ^ t_swz) + 4 * (t_c & 1);
   f32x4 g[NP_T];
   auto fetch = [&](const csn_rsrc_t& rs, int kt) {
-    const int k0 = kt * KT;
-    // T % 4 == 0: a 16-byte piece is all in or all out; pieces past the block end are switched off
-    const unsigned off = (k0 + t_c) < T ? t_off : CSN_OOB;
+    if (KVP) {
+      // keys beyond the block end are zero in the planes; units that lie entirely beyond it are not fetched at all
+      const unsigned off = (kt * KT + 8 * t_u) < T ? t_off : CSN_OOB;
 #pragma unroll
-    for (int i = 0; i < NP_T; ++i)
-      g[i] = csn_bload4(rs, (i == NP_T - 1 && !t_last_ok) ? CSN_OOB : off, (unsigned)(k0 + 64 * i * ld) * 4u);
+      for (int i = 0; i < NP_T; ++i)
+        g[i] = csn_bload4(rs, (i == NP_T - 1 && !t_last_ok) ? CSN_OOB : off, (unsigned)(kt * 128 + 64 * i * kld * 2));
+    } else {
+      const int k0 = kt * KT;
+      // T % 4 == 0: a 16-byte piece is all in or all out; pieces past the block end are switched off
+      const unsigned off = (k0 + 4 * t_c) < T ? t_off : CSN_OOB;
+#pragma unroll
+      for (int i = 0; i < NP_T; ++i)
+        g[i] = csn_bload4(rs, (i == NP_T - 1 && !t_last_ok) ? CSN_OOB : off, (unsigned)(k0 + 64 * i * ld) * 4u);
+    }
   };
   auto commitA = [&](int st) {
 #pragma unroll
     for (int i = 0; i < NP_T; ++i)
       if (i < NP_T - 1 || t_last_ok) {
-        bf16x4 hi, lo;
-        split4(g[i], hi, lo);
-        *reinterpret_cast<bf16x4*>(&tileA[st][0][a_dst + 64 * KT * i]) = hi;
-        *reinterpret_cast<bf16x4*>(&tileA[st][1][a_dst + 64 * KT * i]) = lo;
+        if (KVP) {
+          __bf16* base = &tileA[st][0][a_dst + 64 * KT * i];
+          const bf16x8 v = __builtin_bit_cast(bf16x8, g[i]);
+          *reinterpret_cast<bf16x4*>(base + 4 * t_sw) = bf16x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<bf16x4*>(base + 4 * (t_sw ^ 1)) = bf16x4{v[4], v[5], v[6], v[7]};
+        } else {
+          bf16x4 hi, lo;
+          split4(g[i], hi, lo);
+          *reinterpret_cast<bf16x4*>(&tileA[st][0][a_dst + 64 * KT * i]) = hi;
+          *reinterpret_cast<bf16x4*>(&tileA[st][1][a_dst + 64 * KT * i]) = lo;
+        }
       }
   };
   auto commitB = [&](int st) {
 #pragma unroll
     for (int i = 0; i < NP_T; ++i)
       if (i < NP_T - 1 || t_last_ok) {
-        bf16x4 hi, lo;
-        split4(g[i], hi, lo);
-        *reinterpret_cast<bf16x4*>(&tileB[st][0][b_dst + 64 * KT * i]) = hi;
-        *reinterpret_cast<bf16x4*>(&tileB[st][1][b_dst + 64 * KT * i]) = lo;
+        if (KVP) {
+          *reinterpret_cast<f32x4*>(&tileB[st][0][b_dst + 64 * KT * i]) = g[i];
+        } else {
+          bf16x4 hi, lo;
+          split4(g[i], hi, lo);
+          *reinterpret_cast<bf16x4*>(&tileB[st][0][b_dst + 64 * KT * i]) = hi;
+          *reinterpret_cast<bf16x4*>(&tileB[st][1][b_dst + 64 * KT * i]) = lo;
+        }
       }
   };
 
   // fragment read positions (lane constants).  tileA, transposing read: inside a 16-lane group lane 4 q' + p addresses
-  // row 8 kq + q', keys 4 p .. 4 p + 3 of the 16-key tile t (halves swapped when (row >> 3) & 1 = kq & 1 is set)
+  // row 8 kq + q' and the 4-key chunk that feeds score rows 4 p .. 4 p + 3: keys 8 p .. 8 p + 3 for S0, 8 p + 4 .. for S1
+  // (chunks swapped inside their 16-byte unit when (row >> 3) & 1 = kq & 1 is set)
   const int tr_row = 8 * kq + (lq >> 2);
-  const int a_pos0 = tr_row * KT + 16 * (0 ^ (kq & 1)) + 4 * (lq & 3), a_pos1 = tr_row * KT + 16 * (1 ^ (kq & 1)) + 4 * (lq & 3);
-  // tileB: row lq of the 16-channel tile, 16-byte unit kq ^ ((-(lq >> 2)) & 3): keys 4kq..4kq+3 then 16+4kq..16+4kq+3
+  const int a_pos0 = tr_row * KT + 8 * (lq & 3) + 4 * (kq & 1), a_pos1 = tr_row * KT + 8 * (lq & 3) + 4 * ((kq & 1) ^ 1);
+  // tileB: row lq of the 16-channel tile, 16-byte unit kq ^ ((-(lq >> 2)) & 3): keys 8 kq .. 8 kq + 7
   const int b_pos = lq * KT + 8 * (kq ^ ((-((lq >> 2) & 3)) & 3));
 
   const int nkt = (T + KT - 1) / KT;
@@ -205,8 +241,8 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   auto score_pos = [&](int kt) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      j_ok[j] = kt * KT + 16 * j + 4 * kq < T;
-      s_voff[j] = (q_ok && j_ok[j]) ? s_base + (unsigned)((kt * KT + 16 * j) * Tp) * 4u : CSN_OOB;
+      j_ok[j] = kt * KT + 8 * kq + 4 * j < T;
+      s_voff[j] = (q_ok && j_ok[j]) ? s_base + (unsigned)((kt * KT + 4 * j) * Tp) * 4u : CSN_OOB;
     }
   };
   auto load_sv = [&](int kt) {                          // backward: request the saved scores of tile kt early
@@ -260,13 +296,11 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     bool keep[8];
     if (drop) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int w = 0; w < 2; ++w) {
-          const unsigned h = csn_pair_hash(pw_base + (unsigned)((kt * (KT / 2) + 8 * j + w) * Tp), salt);
-          keep[4 * j + 2 * w] = (h & 0xffffu) >= thr16;
-          keep[4 * j + 2 * w + 1] = (h >> 16) >= thr16;
-        }
+      for (int w = 0; w < 4; ++w) {
+        const unsigned h = csn_pair_hash(pw_base + (unsigned)((kt * (KT / 2) + w) * Tp), salt);
+        keep[2 * w] = (h & 0xffffu) >= thr16;
+        keep[2 * w + 1] = (h >> 16) >= thr16;
+      }
     }
     if (!BWD) {
       float mx = -INFINITY;
@@ -417,8 +451,13 @@ template <int DT>
 int launch_dt(const CsnAttnArgs& a, bool bwd, hipStream_t st) {
   const long long units = (long long)a.n_blocks * a.H * a.E;
   dim3 grid((unsigned)(((units + 7) / 8) * 8 * ((a.T + 127) / 128)));
-  if (bwd) hipLaunchKernelGGL((csn_attn_bf16x3_kernel<DT, true>), grid, dim3(512), 0, st, a);
-  else hipLaunchKernelGGL((csn_attn_bf16x3_kernel<DT, false>), grid, dim3(512), 0, st, a);
+  if (a.kv_planes) {
+    if (bwd) hipLaunchKernelGGL((csn_attn_bf16x3_kernel<DT, true, true>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((csn_attn_bf16x3_kernel<DT, false, true>), grid, dim3(512), 0, st, a);
+  } else {
+    if (bwd) hipLaunchKernelGGL((csn_attn_bf16x3_kernel<DT, true, false>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((csn_attn_bf16x3_kernel<DT, false, false>), grid, dim3(512), 0, st, a);
+  }
   return (int)hipGetLastError();
 }
 
@@ -426,6 +465,7 @@ int launch_any(const CsnAttnArgs& a, int d, bool bwd, hipStream_t st) {
   if (a.E <= 0 || a.n_blocks <= 0) return 0;
   if ((a.T & 3) || (a.ld & 3) || (a.Tp & 3)) return -2;
   if ((a.q_shape_stride & 3) || (a.kv_shape_stride & 3)) return -4;
+  if (a.kv_planes && (a.T > 512 || (a.kv_ld & 7) || (a.kv_shape_stride & 7))) return -2;    // 16 tiles of 32 keys per block
   switch (d) {
     case 32: return launch_dt<1>(a, bwd, st);
     case 64: return launch_dt<2>(a, bwd, st);

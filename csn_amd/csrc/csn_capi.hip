@@ -96,7 +96,14 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
                     float* out, long long out_shape_stride, int ld_out, int n_shapes, int n_points, int div_rows,
                     float temperature, int out_split, long long out_plane_stride, void* stream) {
   if (out_split && g_math_mode != 1) return CSN_E_ARG;
+  if (out_split < 0 || out_split > 2) return CSN_E_ARG;
   if (!x || !w || !out || rows <= 0 || channels <= 0 || n_shapes <= 0 || n_points <= 0) return CSN_E_ARG;
+  if (out_split == 2) {
+    // tile planes: out_plane_stride = points per attention block (<= 512), ld_out = row pitch = n_blocks * 1024 bf16
+    if (out_plane_stride <= 0 || out_plane_stride > 512 || (ld_out & 1023)) return CSN_E_ARG;
+    if (((long long)n_points + out_plane_stride - 1) / out_plane_stride * 1024 > ld_out) return CSN_E_ARG;
+    if (out_shape_stride & 7) return CSN_E_STRIDE;
+  }
   if ((ld_x & 3) || (ld_out & 3) || (n_points & 3) || (channels & 3)) return CSN_E_ALIGN;
   if (mis16(x) || mis16(w) || mis16(out)) return CSN_E_PTR;
   if ((x_shape_stride & 3) || (out_shape_stride & 3)) return CSN_E_STRIDE;
@@ -118,7 +125,10 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
                            float dropout_p, unsigned long long seed, int qkv_split, long long qkv_plane_stride,
                            void* stream) {
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
-  if (qkv_split) return CSN_E_ARG;                                  // reserved (see header)
+  if (qkv_split && g_math_mode != 1) return CSN_E_ARG;
+  if (qkv_split && (qkv_plane_stride <= 0 || (qkv_plane_stride & 1023) || qkv_plane_stride < (long long)n_blocks * 1024 ||
+                    block > 512 || (kv_shape_stride & 7)))
+    return CSN_E_ARG;
   if (!q || !k || !v || !ctx || n_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
   if (!dim_ok(d_head)) return CSN_E_DIM;
   if ((ld & 3) || (block & 3) || (score_pitch & 3) || score_pitch < block) return CSN_E_ALIGN;
@@ -128,6 +138,7 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
   CsnAttnArgs a;
   a.q = q; a.k = k; a.v = v;
   a.q_shape_stride = q_shape_stride; a.kv_shape_stride = kv_shape_stride;
+  a.kv_ld = (int)qkv_plane_stride;
   a.q_index = q_index; a.kv_index = kv_index; a.ld = ld;
   a.out = ctx; a.out_eval_stride = ctx_eval_stride;
   a.scores = scores; a.dscores = nullptr; a.lse = lse; a.delta = nullptr; a.ctx = nullptr;
@@ -135,7 +146,7 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
   a.rescale_threshold = rescale_threshold;
   a.eval_ids = nullptr; a.out_index = nullptr; a.accumulate = 0;
   a.dropout_p = dropout_p; a.seed = seed;
-  a.r_planes = qkv_split; a.kv_planes = qkv_split; a.r_plane_stride = qkv_plane_stride; a.kv_plane_stride = qkv_plane_stride;
+  a.r_planes = 0; a.kv_planes = qkv_split; a.r_plane_stride = 0; a.kv_plane_stride = 0;
   return g_math_mode == 1 ? csn_launch_attn_fwd_bf16x3(a, d_head, (hipStream_t)stream)
                           : csn_launch_attn_fwd_f32(a, d_head, (hipStream_t)stream);
 }
@@ -148,7 +159,11 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
                               unsigned long long seed, int dctx_split, long long dctx_plane_stride, int kv_split,
                               long long kv_plane_stride, void* stream) {
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
-  if (dctx_split || kv_split) return CSN_E_ARG;                      // reserved (see header)
+  if (dctx_split) return CSN_E_ARG;                                  // reserved (see header)
+  if (kv_split && g_math_mode != 1) return CSN_E_ARG;
+  if (kv_split && (kv_plane_stride <= 0 || (kv_plane_stride & 1023) || kv_plane_stride < (long long)n_blocks * 1024 ||
+                   block > 512 || (kv_shape_stride & 7)))
+    return CSN_E_ARG;
   if (!dctx || !ctx || !k || !v || !scores || !dscores || !lse || !delta || !dq) return CSN_E_ARG;
   if (n_launch_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
   if (!dim_ok(d_head)) return CSN_E_DIM;
@@ -170,7 +185,7 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
   a.rescale_threshold = 0.f;
   a.eval_ids = eval_ids; a.out_index = dq_index; a.accumulate = accumulate;
   a.dropout_p = dropout_p; a.seed = seed;
-  a.r_planes = dctx_split; a.kv_planes = kv_split; a.r_plane_stride = dctx_plane_stride; a.kv_plane_stride = kv_plane_stride;
+  a.r_planes = 0; a.kv_planes = kv_split; a.r_plane_stride = 0; a.kv_plane_stride = 0; a.kv_ld = (int)kv_plane_stride;
   return g_math_mode == 1 ? csn_launch_attn_bwd_bf16x3(a, d_head, st) : csn_launch_attn_bwd_f32(a, d_head, st);
 }
 

@@ -41,10 +41,12 @@ struct CsnAttnArgs {
   int accumulate;                                        // out += result (several evaluations share an output slot)
   float dropout_p;                                       // attention-probability dropout (csa_models.py:141); 0 = off
   unsigned long long seed;
-  // bf16x3 kernels only: q (resp. k and v) point at bf16 HIGH planes of split tensors, the low plane follows
-  // *_plane_stride bf16 elements later; shape strides and ld then count bf16 elements
+  // bf16x3 kernels only.  kv_planes != 0: k and v point into a "tile plane" tensor written by the projection
+  // (bf16; per row and block 16 tiles of [hi: 32 keys | lo: 32 keys], block pitch 1024, row pitch kv_ld = n_blocks * 1024);
+  // kv_shape_stride then counts bf16 elements.  r_planes / *_plane_stride: reserved.
   int r_planes, kv_planes;
   long long r_plane_stride, kv_plane_stride;
+  int kv_ld;
 };
 int csn_launch_attn_fwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
 int csn_launch_attn_bwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);

@@ -88,10 +88,11 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const bool c_pl = p.C.planes != 0;
+  const bool c_tiles = p.C.planes == 2;      // "tile planes" for the attention kernels (attn_bf16x3.hip), block = plane_stride points
   const int c_es = c_pl ? 2 : 4;
   const float* a_base = p.A.ptr + p.A.s0 * z0 + p.A.s1 * z1 + p.A.s2 * (long long)(p.A.idx2 ? p.A.idx2[z2] : z2) + (long long)m0 * lda;
   const float* b_base = p.B.ptr + p.B.s0 * z0 + p.B.s1 * z1 + p.B.s2 * (long long)(p.B.idx2 ? p.B.idx2[z2] : z2) + (B_NK ? (long long)n0 * ldb : (long long)n0);
-  char* c_base = reinterpret_cast<char*>(p.C.ptr) + (p.C.s0 * z0 + p.C.s1 * z1 + p.C.s2 * (long long)(p.C.idx2 ? p.C.idx2[z2] : z2) + (long long)m0 * ldc + n0) * c_es;
+  char* c_base = reinterpret_cast<char*>(p.C.ptr) + (p.C.s0 * z0 + p.C.s1 * z1 + p.C.s2 * (long long)(p.C.idx2 ? p.C.idx2[z2] : z2) + (long long)m0 * ldc + (c_tiles ? 0 : n0)) * c_es;
   const long long c_win = (long long)BM * ldc * c_es;
   const csn_rsrc_t Ar = csn_make_rsrc(a_base, (long long)BM * lda * 4);
   const csn_rsrc_t Br = csn_make_rsrc(b_base, B_NK ? (long long)BN * ldb * 4 : ((long long)(K - 1) * ldb + (N - n0)) * 4);
@@ -225,6 +226,28 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
         acc[i][j][r] = v;
       }
     }
+  if (c_tiles) {
+    // column n of the map -> block n / Tb, key k = n % Tb -> tile k / 32, position k % 32; a row holds, per block, 16 tiles
+    // of [hi: 32 | lo: 32] bf16 (block pitch 1024; the padding of the last tile is never written: the caller keeps it zero)
+    const int Tb = (int)p.C.plane_stride;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn0 + 32 * j + l31;
+      const int blk = n / Tb, kib = n - blk * Tb;
+      const unsigned col = (unsigned)(blk * 1024 + (kib >> 5) * 64 + (kib & 31));
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = wm0 + 32 * i + csn_acc_row(r, h);
+          const unsigned off = ((m0 + ml) < M && n < N) ? ((unsigned)(ml * ldc) + col) * 2u : CSN_OOB;
+          const __bf16 hi = (__bf16)acc[i][j][r];
+          csn_bstore_bf16(hi, Cr, off);
+          csn_bstore_bf16((__bf16)(acc[i][j][r] - (float)hi), Cr, off, 64u);
+        }
+    }
+    return;
+  }
   if (c_pl) {
     // split once here, so that every consumer of C stages plain bf16 planes (no accumulation into planes)
 #pragma unroll

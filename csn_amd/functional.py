@@ -23,7 +23,7 @@ REF_BLOCK = 500       # MID-FC/csa_models.py:84
 REF_NBLOCKS = 20      # MID-FC/csa_models.py:83
 LN_EPS = 1e-6         # MID-FC/csa_models.py:57
 RESCALE_THRESHOLD = 8.0
-USE_SPLIT_PLANES = False     # fast math: hand Q/K/V and the attention-output gradient between kernels as bf16 hi/lo planes
+USE_KV_TILES = True          # fast math: K/V leave the projection as bf16 tile planes (see csn_project_f32, out_split = 2)
 # bench.py sets this to a list to collect (start, end) HIP-event pairs around the fused attention forward launch
 EVENT_SINK = None
 
@@ -186,27 +186,40 @@ class _MHAEvals(torch.autograd.Function):
         dev = x_all.device
         temperature = float(d) ** 0.5                                  # csa_models.py:54
         w_qkv = torch.cat((w_qs, w_ks, w_vs), dim=0).contiguous()      # (3D, C)
-        # fast math: Q/K/V leave the projection already split into bf16 planes (S, 2, 3D, NP)
-        # (measured on MI355X: reading planes needs 8-byte / 2-byte loads because blocks of 500 points are only 8-byte
-        #  aligned in bf16, and that costs more than splitting fp32 tiles on the fly — so the planes stay off for now)
-        split = fast_math() and USE_SPLIT_PLANES
-        qkv = project(x_all, w_qkv, div_rows=D, temperature=temperature, split=split)   # (S, 3D, NP); Q rows pre-scaled
         att = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
         lse = torch.empty((E, H, NP), device=dev, dtype=torch.float32)
         scores = torch.empty((E, H, nb, T, Tp), device=dev, dtype=torch.float32) if keep_scores else None
-        es = 2 if split else 4                                         # bytes per element of qkv
-        slot_stride = (2 if split else 1) * 3 * D * NP
-        base = qkv.data_ptr()
         # values may come from a different slot than the keys (slot kv + v_shift): only the generic
         # MultiHeadAttention.forward(Q, K, V) with three distinct inputs uses that
-        v_base = base + es * (2 * D * NP + v_shift * slot_stride)
+        tiles = fast_math() and USE_KV_TILES and T <= 512
+        if tiles:
+            # fast math: K and V leave the projection as bf16 "tile planes" (per row and block 16 tiles of [hi 32 | lo 32],
+            # 128-byte aligned), which the attention kernels stage with plain copies; Q (pre-scaled) stays fp32
+            ldp = nb * 1024
+            qkv = project(x_all, w_qkv[:D], div_rows=D, temperature=temperature)              # (S, D, NP) = Qs
+            kv = torch.empty((S, 2 * D, ldp), device=dev, dtype=torch.bfloat16)
+            if T % 32:
+                kv.view(S, 2 * D, nb, 16, 2, 32)[:, :, :, (T - 1) // 32, :, T % 32:] = 0       # padding keys of the last tile
+            _lib.check(L.csn_project_f32(_ptr(x_all), x_all.stride(0), NP, _ptr(w_qkv[D:]), 2 * D, C, _ptr(kv), 2 * D * ldp,
+                                         ldp, S, NP, 0, 1.0, 2, T, _stream()), "csn_project_f32")
+            q_ptr, q_stride = qkv.data_ptr(), D * NP
+            k_ptr, kv_stride = kv.data_ptr(), 2 * D * ldp
+            v_ptr = k_ptr + 2 * (D * ldp + v_shift * kv_stride)
+            kv_flag, kv_pitch = 1, ldp
+        else:
+            kv = None
+            qkv = project(x_all, w_qkv, div_rows=D, temperature=temperature)                  # (S, 3D, NP); Q rows pre-scaled
+            q_ptr, q_stride = qkv.data_ptr(), 3 * D * NP
+            k_ptr, kv_stride = q_ptr + 4 * D * NP, 3 * D * NP
+            v_ptr = q_ptr + 4 * (2 * D * NP + v_shift * kv_stride)
+            kv_flag, kv_pitch = 0, 0
         if EVENT_SINK is not None:
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record()
-        _lib.check(L.csn_block_attn_fwd_f32(base, base + es * D * NP, v_base, slot_stride, slot_stride,
+        _lib.check(L.csn_block_attn_fwd_f32(q_ptr, k_ptr, v_ptr, q_stride, kv_stride,
                                             _ptr(q_slots), _ptr(kv_slots), NP, _ptr(att), D * NP, _ptr(scores),
                                             _ptr(lse), E, H, d, T, nb, Tp, RESCALE_THRESHOLD, p_attn, seed_attn,
-                                            1 if split else 0, 3 * D * NP, _stream()),
+                                            kv_flag, kv_pitch, _stream()),
                    "csn_block_attn_fwd_f32")
         if EVENT_SINK is not None:
             ev1 = torch.cuda.Event(enable_timing=True)
@@ -220,11 +233,11 @@ class _MHAEvals(torch.autograd.Function):
                                             _stream()),
                    "csn_outproj_ln_fwd_f32")
         if keep_scores:
-            ctx.save_for_backward(x_all, w_qkv, w_fc, qkv, att, lse, scores, xhat, rstd)
+            ctx.save_for_backward(x_all, w_qkv, w_fc, qkv, att, lse, scores, xhat, rstd, kv)
             ctx.geo = geo
             ctx.plan = plan
             ctx.drop = (p_attn, seed_attn, p_fc, seed_fc)
-            ctx.split = split
+            ctx.ptrs = (q_stride, kv_stride, kv_flag, kv_pitch)
         # second output: the first n_head_evals maps again (same storage).  A consumer of all maps whose gradient is
         # constant along the points (the pooled means) and a consumer of the leading maps only (the mix) then hand the
         # backward two cheap gradients instead of one dense (E, C, NP) sum.
@@ -233,7 +246,7 @@ class _MHAEvals(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dxhat, dhead):
-        x_all, w_qkv, w_fc, qkv, att, lse, scores, xhat, rstd = ctx.saved_tensors
+        x_all, w_qkv, w_fc, qkv, att, lse, scores, xhat, rstd, kv = ctx.saved_tensors
         geo: MHAGeometry = ctx.geo
         plan: EvalPlan = ctx.plan
         L = _lib.lib()
@@ -260,19 +273,16 @@ class _MHAEvals(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
 
         # ---- LayerNorm + fc backward -------------------------------------------------------------------
-        split = ctx.split                      # fast math: qkv and the attention-output gradient live as bf16 planes
-        sp = 1 if split else 0
         dz = torch.empty((E, C, NP), device=dev, dtype=torch.float32)
         dz_res = torch.empty((E, C, NP), device=dev, dtype=torch.float32) if (need_dx and p_fc > 0) else None
-        datt = (torch.empty((E, 2, D, NP), device=dev, dtype=torch.bfloat16) if split
-                else torch.empty((E, D, NP), device=dev, dtype=torch.float32))
+        datt = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
         dw_fc = torch.empty((C, D), device=dev, dtype=torch.float32)
         ws_n = L.csn_wgrad_workspace_floats(C, D, E, NP)
         ws = torch.empty((ws_n,), device=dev, dtype=torch.float32)
         w_fc_t = w_fc.t().contiguous()
         _lib.check(L.csn_outproj_ln_bwd_f32(_ptr(dense), _ptr(xhat), _ptr(rstd), C * NP, _ptr(att), D * NP,
                                             _ptr(w_fc_t), _ptr(dz), _ptr(dz_res), _ptr(datt), _ptr(dw_fc), _ptr(ws), ws_n,
-                                            E, C, D, NP, NP, 0, p_fc, seed_fc, sp, D * NP, _ptr(rows), n_dense, _stream()),
+                                            E, C, D, NP, NP, 0, p_fc, seed_fc, 0, 0, _ptr(rows), n_dense, _stream()),
                    "csn_outproj_ln_bwd_f32")
         del ws
 
@@ -282,25 +292,29 @@ class _MHAEvals(torch.autograd.Function):
         delta = torch.empty((E, H, NP), device=dev, dtype=torch.float32)
         full = plan.full_cover
         dqkv = (torch.empty if full else torch.zeros)((S, 3 * D, NP), device=dev, dtype=torch.float32)
-        es = 2 if split else 4
         slot_stride = 3 * D * NP                                   # of the fp32 gradient maps
-        q_stride = (2 if split else 1) * 3 * D * NP                # of qkv (two planes per slot when split)
-        base, gbase = qkv.data_ptr(), dqkv.data_ptr()
-        v_base = base + es * (2 * D * NP + plan.v_shift * q_stride)
+        q_stride, kv_stride, kv_flag, kv_pitch = ctx.ptrs
+        gbase, q_ptr = dqkv.data_ptr(), qkv.data_ptr()
+        if kv_flag:
+            k_ptr = kv.data_ptr()
+            v_ptr = k_ptr + 2 * (D * kv_pitch + plan.v_shift * kv_stride)
+        else:
+            k_ptr = q_ptr + 4 * D * NP
+            v_ptr = q_ptr + 4 * (2 * D * NP + plan.v_shift * kv_stride)
         for ci, ids in enumerate(plan.dq_colors):
-            _lib.check(L.csn_block_attn_bwd_dq_f32(_ptr(datt), _ptr(att), D * NP, base + es * D * NP, v_base, q_stride,
+            _lib.check(L.csn_block_attn_bwd_dq_f32(_ptr(datt), _ptr(att), D * NP, k_ptr, v_ptr, kv_stride,
                                                    _ptr(plan.kv_slots), NP, _ptr(scores), _ptr(dscores), _ptr(lse),
                                                    _ptr(delta), gbase, slot_stride, _ptr(plan.q_slots),
                                                    0 if (full and ci == 0) else 1, _ptr(ids),
-                                                   ids.numel(), H, d, T, nb, Tp, p_attn, seed_attn, sp, D * NP, sp,
-                                                   3 * D * NP, _stream()),
+                                                   ids.numel(), H, d, T, nb, Tp, p_attn, seed_attn, 0, 0, kv_flag,
+                                                   kv_pitch, _stream()),
                        "csn_block_attn_bwd_dq_f32")
         for ci, ids in enumerate(plan.dkv_colors):
-            _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, base, q_stride, _ptr(plan.q_slots), NP,
+            _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, q_ptr, q_stride, _ptr(plan.q_slots), NP,
                                                     _ptr(scores), _ptr(dscores), gbase + 4 * D * NP, gbase + 8 * D * NP,
                                                     slot_stride, _ptr(plan.kv_slots), _ptr(plan.v_slots),
                                                     0 if (full and ci == 0) else 1, _ptr(ids),
-                                                    ids.numel(), H, d, T, nb, Tp, sp, D * NP, sp, 3 * D * NP, _stream()),
+                                                    ids.numel(), H, d, T, nb, Tp, 0, 0, 0, 0, _stream()),
                        "csn_block_attn_bwd_dkv_f32")
         del dscores, delta, datt
 

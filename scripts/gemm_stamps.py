@@ -14,9 +14,11 @@ dout = torch.randn((S, R, N), device="cuda")
 
 def report(name, nwg, nslab):
     torch.cuda.synchronize()
-    buf = np.zeros(65536 * 4, dtype=np.uint64)
+    buf = np.zeros(65536 * 8, dtype=np.uint64)
     L.csn_gemm_debug_read(buf.ctypes.data, buf.nbytes)
-    st = buf.reshape(65536, 4)[:min(nwg, 65536)].astype(np.int64)
+    full = buf.reshape(65536, 8)[:min(nwg, 65536)].astype(np.int64)
+    st, inner = full[:, :4], full[:, 4:]
+    print(f"   per slab: reads+mfma={inner[:,0].mean()/nslab:6.0f}  stage(split+lds write+issue loads)={inner[:,1].mean()/nslab:6.0f}  barrier={inner[:,2].mean()/nslab:6.0f}")
     d = np.diff(st, axis=1)
     t0 = st[:, 0].min()
     print(f"{name}: work-groups {nwg}  prologue={d[:,0].mean():7.0f}  loop={d[:,1].mean():7.0f} ({d[:,1].mean()/nslab:6.0f}/slab x {nslab})  "
@@ -25,5 +27,4 @@ def report(name, nwg, nslab):
 
 for _ in range(2): CF.project(x, w)
 report("project KN 768x10000x256 x32", 32 * 6 * 79, 8)
-for _ in range(2): CF.project_wgrad(dout, x)
-report("wgrad NK split-K", 10**9, 0 or 1)
+

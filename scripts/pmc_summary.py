@@ -21,7 +21,7 @@ def main():
     for f, k, d, c, v, t in rows(root):
         if flt and flt not in k:
             continue
-        k = k[:60]
+        k = k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:60]
         acc[(k, c)] += v
         if (f, d) not in cnt[(k, c)]:
             cnt[(k, c)].add((f, d))
