@@ -154,10 +154,9 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     lse2_q = q_ok ? p.lse[stat_off + qrow] * LOG2E : 0.f;
     if (q_ok && kq == 0 && p.delta) p.delta[stat_off + qrow] = delta_q;
   }
-  // score positions of this lane: half j, reg r -> key kt*32 + 8 kq + 4 j + r, query qrow.  Lane-dependent part in one
-  // voffset per j (a 4-key group is all in or all out: T % 4 == 0), r * Tp in wave-uniform scalar offsets
-  const unsigned s_base = (unsigned)(8 * kq * Tp + qrow) * 4u;
-  const unsigned s_r1 = (unsigned)Tp * 4u, s_r2 = (unsigned)Tp * 8u, s_r3 = (unsigned)Tp * 12u;
+  // score positions of this lane: the scores of a block are stored [query][key] (pitch Tp), so the 8 consecutive keys
+  // kt*32 + 8 kq .. + 7 of this lane's query are two 16-byte runs (half j = keys + 4 j .. + 3: all in or all out, T % 4 == 0)
+  const unsigned s_base = (unsigned)(qrow * Tp + 8 * kq) * 4u;
 
   // ---- streamed tiles: global -> registers -> LDS (swizzled) ---------------------------------------
   // piece idx = tid + 512 i  ->  row (tid >> 3) + 64 i.  fp32 input: keys 4 c .. 4 c + 3, c = tid % 8.  Tile planes: 16-byte
@@ -230,7 +229,6 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   const int b_pos = lq * KT + 8 * (kq ^ ((-((lq >> 2) & 3)) & 3));
 
   const int nkt = (T + KT - 1) / KT;
-  const unsigned s_r[4] = {0u, s_r1, s_r2, s_r3};
 
   // ---- the three phases of one key tile -------------------------------------------------------------
   unsigned s_voff[2];
@@ -242,14 +240,17 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       j_ok[j] = kt * KT + 8 * kq + 4 * j < T;
-      s_voff[j] = (q_ok && j_ok[j]) ? s_base + (unsigned)((kt * KT + 4 * j) * Tp) * 4u : CSN_OOB;
+      s_voff[j] = (q_ok && j_ok[j]) ? s_base + (unsigned)(kt * KT + 4 * j) * 4u : CSN_OOB;
     }
   };
   auto load_sv = [&](int kt) {                          // backward: request the saved scores of tile kt early
     if (BWD) {
       score_pos(kt);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) sv[r] = csn_bload(Sr, s_voff[r >> 2], s_r[r & 3]);
+      for (int j = 0; j < 2; ++j) {
+        const f32x4 v = csn_bload4(Sr, s_voff[j]);
+        sv[4 * j] = v[0]; sv[4 * j + 1] = v[1]; sv[4 * j + 2] = v[2]; sv[4 * j + 3] = v[3];
+      }
     }
   };
   // phase 1: T1[key][q] = sum_d tileA[d][key] R[d][q]
@@ -307,9 +308,11 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         if (!j_ok[r >> 2]) t1[r] = -INFINITY;
-        csn_bstore(t1[r], Sr, s_voff[r >> 2], s_r[r & 3]);     // (zero-sized window when scores are not kept)
         mx = fmaxf(mx, t1[r]);
       }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)                              // (zero-sized window when scores are not kept)
+        csn_bstore4(f32x4{t1[4 * j], t1[4 * j + 1], t1[4 * j + 2], t1[4 * j + 3]}, Sr, s_voff[j]);
       // lazy rescale: only when some query's running maximum would grow by more than the threshold.  The four lanes
       // of a query share m_run, so the cross-lane maximum is only needed inside the (rare) branch.
       if (__any(mx > m_run + p.rescale_threshold)) {
@@ -342,9 +345,13 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
         const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(sv[r], LOG2E, -lse2_q)) : 0.f;   // softmax probability (csa_models.py:141)
         const float md = (!drop || keep[r]) ? keep_scale : 0.f;    // d P_drop / d P
         const float ds = pv * (t1[r] * md - delta_q);              // d softmax (delta = rowsum(dO * O) already has the mask)
-        csn_bstore(pv * md, Sr, s_voff[r >> 2], s_r[r & 3]);       // what the dV product needs: the dropped probabilities
-        csn_bstore(ds, dSr, s_voff[r >> 2], s_r[r & 3]);
+        sv[r] = pv * md;                                           // what the dV product needs: the dropped probabilities
         t1[r] = ds;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        csn_bstore4(f32x4{sv[4 * j], sv[4 * j + 1], sv[4 * j + 2], sv[4 * j + 3]}, Sr, s_voff[j]);
+        csn_bstore4(f32x4{t1[4 * j], t1[4 * j + 1], t1[4 * j + 2], t1[4 * j + 3]}, dSr, s_voff[j]);
       }
     }
 #pragma unroll
@@ -382,6 +389,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
 
   fetch(Ar, 0); commitA(0);
   fetch(Br, 0); commitB(0);
+  if (nkt > 1) fetch(Ar, 1);
   __syncthreads();
 
   // -DCSN_STAMPS: development build that records s_memtime at the phase boundaries of tiles 4..7 (scripts/attn_stamps.py)
@@ -391,6 +399,16 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
 #else
 #define STAMP(i)
 #endif
+  // Staggered schedule.  A tile is two barrier-delimited segments,
+  //   seg 1: phase 1 (matrix)              + commit K tile kt+1, request V tile kt+1
+  //   seg 2: pointwise (vector) + phase 2  + commit V tile kt+1, request K tile kt+2
+  // and waves 4..7 — the SIMD partners of waves 0..3 — run ONE SEGMENT BEHIND (one extra barrier before their loop,
+  // one after the loop of the first half): a SIMD then always has one wave in the matrix-only segment beside one that
+  // starts with its vector work, instead of two waves fighting over the same pipe.  With the commits placed as above the
+  // shift is hazard-free: a K stage is rewritten in segments 2kt / 2kt+1 (early / late half), last read in 2kt-1 and
+  // next read in 2kt+2; a V stage is rewritten in 2kt+1 / 2kt+2, last read in 2kt and next read in 2kt+3.
+  const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+  if (late) __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1, nxt = cur ^ 1;
     const bool more = kt + 1 < nkt;
@@ -398,23 +416,24 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     const bool dbg_on = !BWD && DT == 8 && blockIdx.x < 2048 && kt >= 4 && kt < 8;
 #endif
     STAMP(0);
-    if (more) fetch(Ar, kt + 1);
     load_sv(kt);
     phase1(cur);
     STAMP(1);
     if (more) { commitA(nxt); fetch(Br, kt + 1); }
     STAMP(2);
-    pointwise(kt);
-    STAMP(3);
-    phase2(cur);
-    STAMP(4);
-    if (more) commitB(nxt);
-    STAMP(5);
     __syncthreads();
+    STAMP(3);
+    pointwise(kt);
+    STAMP(4);
+    phase2(cur);
+    STAMP(5);
+    if (more) { commitB(nxt); if (kt + 2 < nkt) fetch(Ar, kt + 2); }
     STAMP(6);
+    __syncthreads();
+    STAMP(7);
 #ifdef CSN_STAMPS
     if (dbg_on && lane == 0) {
-      for (int i = 0; i < 7; ++i) csn_dbg[((blockIdx.x * 8 + wave) * 4 + (kt - 4)) * 8 + i] = stamps[i];
+      for (int i = 0; i < 8; ++i) csn_dbg[((blockIdx.x * 8 + wave) * 4 + (kt - 4)) * 8 + i] = stamps[i];
     }
 #endif
   }
@@ -445,6 +464,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   for (int c = 0; c < D / 16; ++c)
 #pragma unroll
     for (int r = 0; r < 4; ++r) csn_bstore(O[c][r], Or, o_off, (unsigned)(c * 16 + r) * ld * 4u);
+  if (!late) __syncthreads();                           // pairs with the last barrier of the late half
 }
 
 template <int DT>

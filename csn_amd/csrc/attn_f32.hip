@@ -166,18 +166,22 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
     if (more) fetch(Ar, kt + 1);
 
     // score positions of this lane: tile j, reg r  ->  key kt*32 + 16 j + 4 kq + r
+    // scores of a block are stored [query][key] (pitch Tp): this lane's keys kt*32 + 16 j + 4 kq .. + 3 are one 16-byte run
     unsigned s_off[8];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kt * KT + 16 * j + 4 * kq + r;
-        s_off[4 * j + r] = (q_ok && key < T) ? (unsigned)(key * Tp + qrow) * 4u : CSN_OOB;
+        s_off[4 * j + r] = (q_ok && key < T) ? (unsigned)(qrow * Tp + key) * 4u : CSN_OOB;
       }
     float sv[8];
     if (BWD) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) sv[r] = csn_bload(Sr, s_off[r]);     // saved scores, requested early
+      for (int j = 0; j < 2; ++j) {                                    // saved scores, requested early
+        const f32x4 v = csn_bload4(Sr, s_off[4 * j]);
+        sv[4 * j] = v[0]; sv[4 * j + 1] = v[1]; sv[4 * j + 2] = v[2]; sv[4 * j + 3] = v[3];
+      }
     }
 
     // ---- phase 1: T1[key][q] = sum_d tileA[d][key] R[d][q] ------------------------------------
@@ -210,9 +214,11 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
       for (int r = 0; r < 8; ++r) {
         const int key = kt * KT + 16 * (r >> 2) + 4 * kq + (r & 3);
         if (key >= T) t1[r] = -INFINITY;
-        csn_bstore(t1[r], Sr, s_off[r]);             // (zero-sized window when scores are not kept)
         mx = fmaxf(mx, t1[r]);
       }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)                    // (zero-sized window when scores are not kept)
+        csn_bstore4(f32x4{t1[4 * j], t1[4 * j + 1], t1[4 * j + 2], t1[4 * j + 3]}, Sr, s_off[4 * j]);
       // lazy rescale: only when some query's running maximum would grow by more than the threshold.  The four lanes
       // of a query share m_run, so the cross-lane maximum is only needed inside the (rare) branch.
       if (__any(mx > m_run + p.rescale_threshold)) {
@@ -243,9 +249,13 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
         const float pv = ok ? expf(sv[r] - lse_q) : 0.f;           // softmax probability (csa_models.py:141)
         const float md = (!drop || keep[r]) ? keep_scale : 0.f;    // d P_drop / d P
         const float ds = pv * (t1[r] * md - delta_q);              // d softmax (delta = rowsum(dO * O) already has the mask)
-        csn_bstore(pv * md, Sr, s_off[r]);                         // what the dV product needs: the dropped probabilities
-        csn_bstore(ds, dSr, s_off[r]);
+        sv[r] = pv * md;                                           // what the dV product needs: the dropped probabilities
         t1[r] = ds;
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        csn_bstore4(f32x4{sv[4 * j], sv[4 * j + 1], sv[4 * j + 2], sv[4 * j + 3]}, Sr, s_off[4 * j]);
+        csn_bstore4(f32x4{t1[4 * j], t1[4 * j + 1], t1[4 * j + 2], t1[4 * j + 3]}, dSr, s_off[4 * j]);
       }
     }
 

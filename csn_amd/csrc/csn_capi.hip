@@ -203,7 +203,8 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
   if (mis16(dctx) || mis16(q) || mis16(probs) || mis16(dscores) || mis16(dk) || mis16(dv)) return CSN_E_PTR;
   if ((q_shape_stride & 3) || (ctx_eval_stride & 3) || (dkv_slot_stride & 3)) return CSN_E_STRIDE;
   hipStream_t st = (hipStream_t)stream;
-  // dV^T[c][key] (+)= sum_q dO^T[c][q] P^T[key][q]   and   dK^T[d][key] (+)= sum_q Qs^T[d][q] dS^T[key][q]
+  // dV^T[c][key] (+)= sum_q dO^T[c][q] P[q][key]   and   dK^T[d][key] (+)= sum_q Qs^T[d][q] dS[q][key]
+  // (the score blocks are stored [query][key]: k-major B operands)
   const long long blk_sc = (long long)block * score_pitch;
   CsnGemmArgs g;
   g.M = d_head; g.N = block; g.K = block;
@@ -213,13 +214,13 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
   g.A.planes = dctx_split; g.A.plane_stride = dctx_plane_stride;
   g.B = operand(probs, blk_sc, blk_sc * n_blocks, blk_sc * n_blocks * n_heads, nullptr, score_pitch);
   g.C = operand(dv, block, (long long)d_head * ld, dkv_slot_stride, dv_index, ld);
-  int rc = launch_gemm(g, 1, n_blocks * n_heads * n_launch_evals, st);
+  int rc = launch_gemm(g, 0, n_blocks * n_heads * n_launch_evals, st);
   if (rc) return rc;
   g.A = operand(q, block, (long long)d_head * ld, q_shape_stride, q_index, ld);
   g.A.planes = q_split; g.A.plane_stride = q_plane_stride;
   g.B = operand(dscores, blk_sc, blk_sc * n_blocks, blk_sc * n_blocks * n_heads, nullptr, score_pitch);
   g.C = operand(dk, block, (long long)d_head * ld, dkv_slot_stride, dk_index, ld);
-  return launch_gemm(g, 1, n_blocks * n_heads * n_launch_evals, st);
+  return launch_gemm(g, 0, n_blocks * n_heads * n_launch_evals, st);
 }
 
 int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const float* wfc, const float* xres,

@@ -50,6 +50,9 @@ CSN_DEVINL f32x4 csn_bload4(csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
 CSN_DEVINL void csn_bstore(float v, csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
 }
+CSN_DEVINL void csn_bstore4(f32x4 v, csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+}
 // 8-byte (4 x bf16) and 2-byte (1 x bf16) accesses for split-bf16 planes
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 CSN_DEVINL u32x2 csn_bload2(csn_rsrc_t r, unsigned voff, unsigned soff = 0) {

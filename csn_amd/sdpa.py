@@ -32,9 +32,9 @@ class _SDPA(torch.autograd.Function):
         _lib.check(L.csn_block_attn_fwd_f32(CF._ptr(qm), CF._ptr(km), CF._ptr(vm), d * T, d * T, None, None, T,
                                             CF._ptr(att), d * T, CF._ptr(scores), CF._ptr(lse), S, 1, d, T, 1, Tp,
                                             CF.RESCALE_THRESHOLD, p_drop, seed, 0, 0, CF._stream()), "csn_block_attn_fwd_f32")
-        # P[q][key] = exp(S^T[key][q] - lse[q])   (the un-dropped probabilities; with dropout the reference returns the
+        # P[q][key] = exp(S[q][key] - lse[q])   (the un-dropped probabilities; with dropout the reference returns the
         # dropped ones — every caller in the reference discards this tensor)
-        prob = torch.exp(scores[:, 0, 0, :, :T] - lse[:, 0, None, :]).transpose(1, 2).reshape(B, H, T, T)
+        prob = torch.exp(scores[:, 0, 0, :, :T] - lse[:, 0, :, None]).reshape(B, H, T, T)
         ctx.save_for_backward(qm, km, vm, att, lse, scores)
         ctx.temperature = temperature
         ctx.drop = (p_drop, seed)
@@ -49,7 +49,7 @@ class _SDPA(torch.autograd.Function):
         S = B * H
         datt = dout.reshape(S, T, d).transpose(1, 2).contiguous()
         dq, dk, dv = (torch.empty((S, d, T), device=dout.device, dtype=torch.float32) for _ in range(3))
-        work = scores.clone()                      # backward overwrites the scores with P^T
+        work = scores.clone()                      # backward overwrites the scores with the (dropped) probabilities
         dscores = torch.empty_like(scores)
         delta = torch.empty((S, 1, T), device=dout.device, dtype=torch.float32)
         L = _lib.lib()

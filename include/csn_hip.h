@@ -50,10 +50,16 @@ int csn_version(void);
  * The producer's epilogue splits once; consumers stage the planes into LDS with plain copies (no conversion work per
  * tile).  A split dctx (attention-output gradient) is laid out [evaluation][2 planes][n_heads*d_head][ld]: its
  * evaluation stride is 2 * ctx_eval_stride and dctx_plane_stride = ctx_eval_stride.
- * STATUS: only the OUTPUT sides (csn_project_f32 out_split, csn_outproj_ln_bwd_f32 dctx_split) are live; the *_split
- * INPUT arguments of the attention entry points are reserved and return CSN_E_ARG when non-zero — on MI355X the
- * narrow (8-byte / 2-byte) loads that 8-byte-aligned 500-point blocks force on bf16 planes measured slower than
- * splitting fp32 tiles while staging them.  Passing *_split != 0 in math mode 0 returns CSN_E_ARG. */
+ * TILE PLANES (math mode 1 only): the form in which keys and values travel from the projection to the attention kernels.
+ * csn_project_f32 with out_split = 2 writes, per output row and per attention block of `out_plane_stride` (<= 512) points,
+ * 16 tiles of [hi: 32 keys | lo: 32 keys] bf16 — block pitch 1024, row pitch ld_out = n_blocks * 1024, out_shape_stride in
+ * bf16 elements; the padding keys of a block's last tile are not written and must be zero.  Every 32-key tile row is then
+ * 128 contiguous, 128-byte aligned bytes that the attention kernels stage into LDS with plain copies.  The attention
+ * entry points take such a tensor for k and v when qkv_split / kv_split != 0 (then *_plane_stride = that row pitch and
+ * kv_shape_stride counts bf16 elements); q stays fp32.
+ * STATUS: live are csn_project_f32 out_split (1: whole planes, 2: tile planes), csn_outproj_ln_bwd_f32 dctx_split, and the
+ * k/v tile planes of csn_block_attn_fwd_f32 / csn_block_attn_bwd_dq_f32; dctx_split / q_split INPUTS are reserved
+ * (CSN_E_ARG).  Passing *_split != 0 in math mode 0 returns CSN_E_ARG. */
 int csn_set_math_mode(int mode);
 int csn_get_math_mode(void);
 /* Human-readable text for a status code returned by any function below. Host pointer, static storage. */
@@ -75,7 +81,7 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
  * slot 0; evaluation e reads slot q_index[e] (queries) and kv_index[e] (keys, values); NULL = identity.
  *   ctx    [n_evals][n_heads*d_head][ld]   (eval stride given)         — csa_models.py:114 before `fc`
  *   lse    [n_evals][n_heads][n_blocks*block]   log-sum-exp of every score row (for the backward)
- *   scores [n_evals][n_heads][n_blocks][block][score_pitch]  raw scores S^T[key][query]; may be NULL
+ *   scores [n_evals][n_heads][n_blocks][block][score_pitch]  raw scores S[query][key]; may be NULL
  *          (inference).  score_pitch >= block, % 4.
  * rescale_threshold: the running softmax maximum is only re-based when it grows by more than this
  * (0 = re-base on every key tile); results agree to fp32 rounding for any value <= ~40.
@@ -96,8 +102,8 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
  * caller groups evaluations so that no two evaluations of one call share an output slot.
  *
  * csn_block_attn_bwd_dq_f32:  in  dctx, ctx [eval][n_heads*d_head][ld], k/v + kv_index as in forward,
- *                                 scores (S^T from forward), lse;
- *                             out scores := P_drop^T (in place; = P^T without dropout), dscores := dS^T,
+ *                                 scores (S[query][key] from forward), lse;
+ *                             out scores := P_drop (in place; = P without dropout), dscores := dS,
  *                                 delta [eval][n_heads][n_blocks*block] scratch = rowsum(dctx*ctx),
  *                                 dq[dq_index[e]] (+)= dS K   — gradient w.r.t. the pre-scaled queries Qs.
  * csn_block_attn_bwd_dkv_f32: in  dctx, q + q_index as in forward, probs (= scores after the dq call), dscores;

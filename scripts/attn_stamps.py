@@ -3,8 +3,10 @@
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("CSN_LIB_PATH", "build/v9.so")
 from csn_amd import _lib, functional as CF
+from bench_attn import to_tiles
 L = _lib.lib()
 H, d, T, nb = 1, 256, 500, 20
 D, NP, Tp, S, E = 256, 10000, 512, 16, 64
@@ -14,19 +16,21 @@ ks = (torch.arange(E, device="cuda", dtype=torch.int32) * 7 + 3) % S
 att = torch.empty((E, D, NP), device="cuda"); lse = torch.empty((E, H, NP), device="cuda")
 scores = torch.empty((E, H, nb, T, Tp), device="cuda")
 base = qkv.data_ptr()
+kvt = to_tiles(qkv[:, D:], T, nb)
+kp = kvt.data_ptr()
 L.csn_set_math_mode(1)
 for _ in range(2):
-    _lib.check(L.csn_block_attn_fwd_f32(base, base + 4 * D * NP, base + 8 * D * NP, 3 * D * NP, 3 * D * NP, CF._ptr(qs), CF._ptr(ks), NP,
-                                        CF._ptr(att), D * NP, CF._ptr(scores), CF._ptr(lse), E, H, d, T, nb, Tp, 8.0, 0.1, 1234, 0, 0,
+    _lib.check(L.csn_block_attn_fwd_f32(base, kp, kp + 2 * D * nb * 1024, 3 * D * NP, 2 * D * nb * 1024, CF._ptr(qs), CF._ptr(ks), NP,
+                                        CF._ptr(att), D * NP, CF._ptr(scores), CF._ptr(lse), E, H, d, T, nb, Tp, 8.0, 0.1, 1234, 1, nb * 1024,
                                         CF._stream()), "fwd")
 torch.cuda.synchronize()
 n = 2048 * 8 * 4 * 8
 buf = np.zeros(n, dtype=np.uint64)
 L.csn_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
 rc = L.csn_debug_read(buf.ctypes.data, n * 8)
-st = buf.reshape(2048, 8, 4, 8)[:, :, :, :7].astype(np.int64)
+st = buf.reshape(2048, 8, 4, 8).astype(np.int64)
 d_ = np.diff(st, axis=-1)                     # [wg][wave][iter][6 segments]
-names = ["fetchA+P1", "commitA+fetchB", "pointwise", "P2", "commitB", "barrier"]
+names = ["P1", "commitA+fetchB", "barrierX", "pointwise", "P2", "commitB+fetchA", "barrierY"]
 ok = (st[..., 0] > 0).all(axis=(1, 2))
 d_ = d_[ok]
 print("rc", rc, "work-groups with stamps", ok.sum())

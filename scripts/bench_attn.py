@@ -18,8 +18,20 @@ def timeit(fn, n=5):
     return sorted(a.elapsed_time(b) for a, b in ev)[n // 2]
 
 
+def to_tiles(kv, T, nb):
+    """fp32 (S, R, nb*T) -> bf16 tile planes (S, R, nb*1024): per row and block 16 tiles of [hi 32 | lo 32]."""
+    S, R, _ = kv.shape
+    x = torch.zeros((S, R, nb, 512), device=kv.device, dtype=torch.float32)
+    x[..., :T] = kv.view(S, R, nb, T)
+    x = x.view(S, R, nb, 16, 32)
+    hi = x.bfloat16()
+    lo = (x - hi.float()).bfloat16()
+    return torch.stack((hi, lo), dim=4).reshape(S, R, nb * 1024).contiguous()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--tiles", action="store_true", help="K/V as bf16 tile planes (math mode 1)")
     ap.add_argument("--evals", type=int, default=128)
     ap.add_argument("--slots", type=int, default=32)
     ap.add_argument("--mode", type=int, default=1)
@@ -44,19 +56,28 @@ def main():
     delta = torch.empty((E, H, NP), device="cuda")
     dqkv = torch.zeros((E, 3 * D, NP), device="cuda")
     base = qkv.data_ptr()
+    if a.tiles:
+        kvt = to_tiles(qkv[:, D:], T, nb)
+        k_ptr, v_ptr, kv_stride, kvf, kvp = kvt.data_ptr(), kvt.data_ptr() + 2 * D * nb * 1024, 2 * D * nb * 1024, 1, nb * 1024
+    else:
+        k_ptr, v_ptr, kv_stride, kvf, kvp = base + 4 * D * NP, base + 8 * D * NP, 3 * D * NP, 0, 0
     st = CF._stream()
     seed = 12345678901
 
     def fwd():
-        _lib.check(L.csn_block_attn_fwd_f32(base, base + 4 * D * NP, base + 8 * D * NP, 3 * D * NP, 3 * D * NP, CF._ptr(qs),
+        tl = a.tiles and L.csn_get_math_mode() == 1
+        _lib.check(L.csn_block_attn_fwd_f32(base, k_ptr if tl else base + 4 * D * NP, v_ptr if tl else base + 8 * D * NP,
+                                            3 * D * NP, kv_stride if tl else 3 * D * NP, CF._ptr(qs),
                                             CF._ptr(ks), NP, CF._ptr(att), D * NP, CF._ptr(scores), CF._ptr(lse), E, H, d, T,
-                                            nb, Tp, 8.0, a.drop, seed, 0, 0, st), "fwd")
+                                            nb, Tp, 8.0, a.drop, seed, kvf if tl else 0, kvp if tl else 0, st), "fwd")
 
     def dq():
-        _lib.check(L.csn_block_attn_bwd_dq_f32(CF._ptr(datt), CF._ptr(att), D * NP, base + 4 * D * NP, base + 8 * D * NP,
-                                               3 * D * NP, CF._ptr(ks), NP, CF._ptr(scores), CF._ptr(dscores), CF._ptr(lse),
+        tl = a.tiles and L.csn_get_math_mode() == 1
+        _lib.check(L.csn_block_attn_bwd_dq_f32(CF._ptr(datt), CF._ptr(att), D * NP, k_ptr if tl else base + 4 * D * NP,
+                                               v_ptr if tl else base + 8 * D * NP,
+                                               kv_stride if tl else 3 * D * NP, CF._ptr(ks), NP, CF._ptr(scores), CF._ptr(dscores), CF._ptr(lse),
                                                CF._ptr(delta), dqkv.data_ptr(), 3 * D * NP, None, 0, None, E, H, d, T, nb,
-                                               Tp, a.drop, seed, 0, 0, 0, 0, st), "dq")
+                                               Tp, a.drop, seed, 0, 0, kvf if tl else 0, kvp if tl else 0, st), "dq")
 
     def dkv():
         gb = dqkv.data_ptr()

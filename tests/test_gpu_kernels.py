@@ -94,7 +94,7 @@ def test_project_wgrad(L):
 
 # ---------------------------------------------------------------------------------------------------------
 def _attn_reference(q, k, v, q_idx, kv_idx, H, d, T, nb):
-    """q,k,v: (S, H*d, N) float64 channel-major (q already scaled). Returns ctx (E,H*d,NP), lse (E,H,NP), scores^T."""
+    """q,k,v: (S, H*d, N) float64 channel-major (q already scaled). Returns ctx (E,H*d,NP), lse (E,H,NP), scores [query][key]."""
     E = len(q_idx)
     NP = T * nb
     ctx = torch.zeros(E, H * d, NP, dtype=torch.float64)
@@ -111,7 +111,7 @@ def _attn_reference(q, k, v, q_idx, kv_idx, H, d, T, nb):
                 p = torch.softmax(s, dim=-1)
                 ctx[e, h * d:(h + 1) * d, sl] = (p @ vv.t()).t()
                 lse[e, h, sl] = torch.logsumexp(s, dim=-1)
-                sc[e, h, b] = s.t()                               # [key][query]
+                sc[e, h, b] = s                                   # [query][key]
     return ctx, lse, sc
 
 
@@ -219,9 +219,9 @@ def test_block_attn_bwd(L, S, E, H, d, T, nb):
     assert _maxerr(dq, q64.grad) < tol(2e-5)
     assert _maxerr(dk, k64.grad) < tol(2e-5)
     assert _maxerr(dv, v64.grad) < tol(2e-5)
-    # scores now hold P^T
-    p_ref = torch.softmax(_attn_reference(q.double(), k.double(), v.double(), q_idx, kv_idx, H, d, T, nb)[2].transpose(-1, -2), dim=-1)
-    assert (scores[..., :T].cpu().double().transpose(-1, -2) - p_ref).abs().max().item() < tol(2e-6)
+    # scores now hold P
+    p_ref = torch.softmax(_attn_reference(q.double(), k.double(), v.double(), q_idx, kv_idx, H, d, T, nb)[2], dim=-1)
+    assert (scores[..., :T].cpu().double() - p_ref).abs().max().item() < tol(2e-6)
 
     # slot-indexed accumulation: evaluations listed in two disjoint colours, gradients summed per slot
     qi64, ki64 = torch.from_numpy(q_idx).long(), torch.from_numpy(kv_idx).long()
