@@ -67,11 +67,11 @@ _SIGNATURES = {
     "csn_block_attn_bwd_dq_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_int,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_int,
                                           c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_ulonglong,
-                                          c_int, c_longlong, c_int, c_longlong, c_void_p]),
+                                          c_int, c_longlong, c_int, c_longlong, c_int, c_void_p]),
     "csn_block_attn_bwd_dkv_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                            c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_int, c_longlong,
-                                           c_void_p]),
+                                           c_int, c_void_p]),
     "csn_outproj_ln_fwd_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p,
                                        c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
                                        c_ulonglong, c_void_p]),
@@ -105,7 +105,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.csn_version() != 4:
+        if handle.csn_version() != 5:
             raise CsnError("libcsn_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -348,16 +348,34 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
         sv[r] = pv * md;                                           // what the dV product needs: the dropped probabilities
         t1[r] = ds;
       }
+      if (!p.sc_tiles) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        csn_bstore4(f32x4{sv[4 * j], sv[4 * j + 1], sv[4 * j + 2], sv[4 * j + 3]}, Sr, s_voff[j]);
-        csn_bstore4(f32x4{t1[4 * j], t1[4 * j + 1], t1[4 * j + 2], t1[4 * j + 3]}, dSr, s_voff[j]);
+        for (int j = 0; j < 2; ++j) {
+          csn_bstore4(f32x4{sv[4 * j], sv[4 * j + 1], sv[4 * j + 2], sv[4 * j + 3]}, Sr, s_voff[j]);
+          csn_bstore4(f32x4{t1[4 * j], t1[4 * j + 1], t1[4 * j + 2], t1[4 * j + 3]}, dSr, s_voff[j]);
+        }
       }
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       ph[r] = (__bf16)t1[r];
       pl[r] = (__bf16)(t1[r] - (float)ph[r]);
+    }
+    if (BWD && p.sc_tiles) {
+      // P and dS leave as bf16 tile planes, per query row 16 tiles of [hi: 32 keys | lo: 32 keys] — the k-major operand
+      // the dV / dK products stage without conversion work.  P overwrites exactly the bytes of the scores of this tile
+      // (already consumed by this wave); keys beyond the block end are written as zeros.
+      const unsigned tv = q_ok ? (unsigned)(qrow * Tp) * 4u + (unsigned)(kt * 128 + 16 * kq) : CSN_OOB;
+      bf16x8 qh, ql;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        qh[r] = (__bf16)sv[r];
+        ql[r] = (__bf16)(sv[r] - (float)qh[r]);
+      }
+      csn_bstore4(__builtin_bit_cast(f32x4, qh), Sr, tv);
+      csn_bstore4(__builtin_bit_cast(f32x4, ql), Sr, tv, 64u);
+      csn_bstore4(__builtin_bit_cast(f32x4, ph), dSr, tv);
+      csn_bstore4(__builtin_bit_cast(f32x4, pl), dSr, tv, 64u);
     }
   };
   // phase 2: OUT[c][q] += sum_key tileB[c][key] T1[key][q]
@@ -485,6 +503,7 @@ int launch_any(const CsnAttnArgs& a, int d, bool bwd, hipStream_t st) {
   if (a.E <= 0 || a.n_blocks <= 0) return 0;
   if ((a.T & 3) || (a.ld & 3) || (a.Tp & 3)) return -2;
   if ((a.q_shape_stride & 3) || (a.kv_shape_stride & 3)) return -4;
+  if (a.sc_tiles && a.Tp < (a.T + 31) / 32 * 32) return -2;
   if (a.kv_planes && (a.T > 512 || (a.kv_ld & 7) || (a.kv_shape_stride & 7))) return -2;    // 16 tiles of 32 keys per block
   switch (d) {
     case 32: return launch_dt<1>(a, bwd, st);

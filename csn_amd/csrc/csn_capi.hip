@@ -146,7 +146,7 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
   a.rescale_threshold = rescale_threshold;
   a.eval_ids = nullptr; a.out_index = nullptr; a.accumulate = 0;
   a.dropout_p = dropout_p; a.seed = seed;
-  a.r_planes = 0; a.kv_planes = qkv_split; a.r_plane_stride = 0; a.kv_plane_stride = 0;
+  a.r_planes = 0; a.kv_planes = qkv_split; a.r_plane_stride = 0; a.kv_plane_stride = 0; a.sc_tiles = 0;
   return g_math_mode == 1 ? csn_launch_attn_fwd_bf16x3(a, d_head, (hipStream_t)stream)
                           : csn_launch_attn_fwd_f32(a, d_head, (hipStream_t)stream);
 }
@@ -157,7 +157,8 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
                               const int* dq_index, int accumulate, const int* eval_ids, int n_launch_evals, int n_heads,
                               int d_head, int block, int n_blocks, int score_pitch, float dropout_p,
                               unsigned long long seed, int dctx_split, long long dctx_plane_stride, int kv_split,
-                              long long kv_plane_stride, void* stream) {
+                              long long kv_plane_stride, int probs_tiles, void* stream) {
+  if (probs_tiles && (g_math_mode != 1 || score_pitch < (block + 31) / 32 * 32)) return CSN_E_ARG;
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
   if (dctx_split) return CSN_E_ARG;                                  // reserved (see header)
   if (kv_split && g_math_mode != 1) return CSN_E_ARG;
@@ -186,6 +187,7 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
   a.eval_ids = eval_ids; a.out_index = dq_index; a.accumulate = accumulate;
   a.dropout_p = dropout_p; a.seed = seed;
   a.r_planes = 0; a.kv_planes = kv_split; a.r_plane_stride = 0; a.kv_plane_stride = 0; a.kv_ld = (int)kv_plane_stride;
+  a.sc_tiles = probs_tiles;
   return g_math_mode == 1 ? csn_launch_attn_bwd_bf16x3(a, d_head, st) : csn_launch_attn_bwd_f32(a, d_head, st);
 }
 
@@ -194,7 +196,8 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
                                float* dv, long long dkv_slot_stride, const int* dk_index, const int* dv_index,
                                int accumulate, const int* eval_ids, int n_launch_evals, int n_heads, int d_head,
                                int block, int n_blocks, int score_pitch, int dctx_split, long long dctx_plane_stride,
-                               int q_split, long long q_plane_stride, void* stream) {
+                               int q_split, long long q_plane_stride, int probs_tiles, void* stream) {
+  if (probs_tiles && (g_math_mode != 1 || score_pitch < (block + 31) / 32 * 32)) return CSN_E_ARG;
   if (dctx_split || q_split) return CSN_E_ARG;                       // reserved (see header)
   if (!dctx || !q || !probs || !dscores || !dk || !dv) return CSN_E_ARG;
   if (n_launch_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
@@ -212,13 +215,17 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
   g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = accumulate; g.eval_ids = eval_ids;
   g.A = operand(dctx, block, (long long)d_head * ld, dctx_split ? 2 * ctx_eval_stride : ctx_eval_stride, nullptr, ld);
   g.A.planes = dctx_split; g.A.plane_stride = dctx_plane_stride;
-  g.B = operand(probs, blk_sc, blk_sc * n_blocks, blk_sc * n_blocks * n_heads, nullptr, score_pitch);
+  // tile planes: the same buffers viewed as bf16 (two bf16 per float: strides and pitch double)
+  const int bm = probs_tiles ? 2 : 1;
+  g.B = operand(probs, bm * blk_sc, bm * blk_sc * n_blocks, bm * blk_sc * n_blocks * n_heads, nullptr, bm * score_pitch);
+  g.B.planes = probs_tiles ? 2 : 0;
   g.C = operand(dv, block, (long long)d_head * ld, dkv_slot_stride, dv_index, ld);
   int rc = launch_gemm(g, 0, n_blocks * n_heads * n_launch_evals, st);
   if (rc) return rc;
   g.A = operand(q, block, (long long)d_head * ld, q_shape_stride, q_index, ld);
   g.A.planes = q_split; g.A.plane_stride = q_plane_stride;
-  g.B = operand(dscores, blk_sc, blk_sc * n_blocks, blk_sc * n_blocks * n_heads, nullptr, score_pitch);
+  g.B = operand(dscores, bm * blk_sc, bm * blk_sc * n_blocks, bm * blk_sc * n_blocks * n_heads, nullptr, bm * score_pitch);
+  g.B.planes = probs_tiles ? 2 : 0;
   g.C = operand(dk, block, (long long)d_head * ld, dkv_slot_stride, dk_index, ld);
   return launch_gemm(g, 0, n_blocks * n_heads * n_launch_evals, st);
 }

@@ -25,7 +25,7 @@
 // -DCSN_STAMPS: development build that records s_memtime after the prologue, the main loop and the epilogue of every
 // work-group (scripts/gemm_stamps.py)
 #ifdef CSN_STAMPS
-__device__ unsigned long long csn_gdbg[65536 * 4];
+__device__ unsigned long long csn_gdbg[65536 * 8];
 extern "C" int csn_gemm_debug_read(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_gdbg), bytes); }
 #define GSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); gst[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -52,8 +52,13 @@ CSN_DEVINL void split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
   }
 }
 
-template <int BM, int BN, bool B_NK>
+// BT: the k-major B operand arrives as bf16 "tile planes" (see attn_bf16x3.hip): per k row, consecutive 32-column tiles of
+// [hi 32 | lo 32] (B.ld = row pitch in bf16 elements, B strides in bf16 elements; padding columns inside a tile are zero).
+// Its staging is then a plain copy — 16-byte loads, 16-byte LDS stores, no conversion work.  This is how the attention
+// backward hands the probabilities P and the score gradients dS to the dV / dK products.
+template <int BM, int BN, bool B_NK, bool BT = false>
 __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) {
+  static_assert(!BT || (!B_NK && BN == 128), "tile-plane B: k-major, 128-column tiles");
   constexpr int MT = BM / 64, NT = BN / 64;
   constexpr int A_PASS = BM / 32, B_PASS = BN / 32;
   constexpr int TPR = BN / 4, RPP = 256 / TPR;          // KN staging: threads per k row, k rows per pass
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef CSN_STAMPS
-  unsigned long long gst[4];
+  unsigned long long gst[4], gin[4] = {0, 0, 0, 0}, gt0 = 0, gt1 = 0;
 #endif
   GSTAMP(0);
   const int l31 = lane & 31, h = lane >> 5;
@@ -91,11 +96,14 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   const bool c_tiles = p.C.planes == 2;      // "tile planes" for the attention kernels (attn_bf16x3.hip), block = plane_stride points
   const int c_es = c_pl ? 2 : 4;
   const float* a_base = p.A.ptr + p.A.s0 * z0 + p.A.s1 * z1 + p.A.s2 * (long long)(p.A.idx2 ? p.A.idx2[z2] : z2) + (long long)m0 * lda;
-  const float* b_base = p.B.ptr + p.B.s0 * z0 + p.B.s1 * z1 + p.B.s2 * (long long)(p.B.idx2 ? p.B.idx2[z2] : z2) + (B_NK ? (long long)n0 * ldb : (long long)n0);
+  const long long b_el = p.B.s0 * z0 + p.B.s1 * z1 + p.B.s2 * (long long)(p.B.idx2 ? p.B.idx2[z2] : z2);
+  const float* b_base = BT ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(p.B.ptr) + b_el)
+                           : p.B.ptr + b_el + (B_NK ? (long long)n0 * ldb : (long long)n0);
   char* c_base = reinterpret_cast<char*>(p.C.ptr) + (p.C.s0 * z0 + p.C.s1 * z1 + p.C.s2 * (long long)(p.C.idx2 ? p.C.idx2[z2] : z2) + (long long)m0 * ldc + (c_tiles ? 0 : n0)) * c_es;
   const long long c_win = (long long)BM * ldc * c_es;
   const csn_rsrc_t Ar = csn_make_rsrc(a_base, (long long)BM * lda * 4);
-  const csn_rsrc_t Br = csn_make_rsrc(b_base, B_NK ? (long long)BN * ldb * 4 : ((long long)(K - 1) * ldb + (N - n0)) * 4);
+  const csn_rsrc_t Br = csn_make_rsrc(b_base, BT ? (long long)K * ldb * 2
+                                                 : (B_NK ? (long long)BN * ldb * 4 : ((long long)(K - 1) * ldb + (N - n0)) * 4));
   const csn_rsrc_t Cr = csn_make_rsrc(c_base, c_win), Crl = csn_make_rsrc(c_base + p.C.plane_stride * 2, c_pl ? c_win : 0);
 
   f32x16 acc[MT][NT];
@@ -111,9 +119,11 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   unsigned a_off[A_PASS], b_off[B_PASS];
 #pragma unroll
   for (int i = 0; i < A_PASS; ++i) a_off[i] = (m0 + pr + 32 * i) < M ? (unsigned)((pr + 32 * i) * lda + pc) * 4u : CSN_OOB;
+  const int t_u8 = tid & 7, t_u = t_u8 & 3, t_pl = t_u8 >> 2;       // tile planes: 16-byte unit of a 128-byte tile row
 #pragma unroll
   for (int i = 0; i < B_PASS; ++i) {
-    if (B_NK) b_off[i] = (n0 + pr + 32 * i) < N ? (unsigned)((pr + 32 * i) * ldb + pc) * 4u : CSN_OOB;
+    if (BT) b_off[i] = (n0 + 32 * i + 8 * t_u) < N ? (unsigned)(pr * ldb) * 2u + (unsigned)((n0 >> 5) + i) * 128u + (unsigned)t_u8 * 16u : CSN_OOB;
+    else if (B_NK) b_off[i] = (n0 + pr + 32 * i) < N ? (unsigned)((pr + 32 * i) * ldb + pc) * 4u : CSN_OOB;
     else b_off[i] = (n0 + kc) < N ? (unsigned)((kr + RPP * i) * ldb + kc) * 4u : CSN_OOB;
   }
 
@@ -122,7 +132,11 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
     const unsigned kp = (k0 + pc) < K ? 0u : CSN_OOB;
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) ra[i] = csn_bload4(Ar, a_off[i] | kp, (unsigned)k0 * 4u);
-    if (B_NK) {
+    if (BT) {
+      const unsigned kb = (k0 + pr) < K ? 0u : CSN_OOB;               // k row pr of the slab, tile i of the 128 columns
+#pragma unroll
+      for (int i = 0; i < B_PASS; ++i) rb[i] = csn_bload4(Br, b_off[i] | kb, (unsigned)k0 * (unsigned)ldb * 2u);
+    } else if (B_NK) {
 #pragma unroll
       for (int i = 0; i < B_PASS; ++i) rb[i] = csn_bload4(Br, b_off[i] | kp, (unsigned)k0 * 4u);
     } else {
@@ -140,6 +154,11 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
       split4(ra[i], hi, lo);
       *reinterpret_cast<bf16x4*>(&As[st][0][(pr + 32 * i) * PK + pc]) = hi;
       *reinterpret_cast<bf16x4*>(&As[st][1][(pr + 32 * i) * PK + pc]) = lo;
+    }
+    if (BT) {
+#pragma unroll
+      for (int i = 0; i < B_PASS; ++i) *reinterpret_cast<f32x4*>(&Bs[st][t_pl][pr * PN + 32 * i + 8 * t_u]) = rb[i];
+      return;
     }
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
@@ -160,8 +179,16 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   if (nk > 1) load_slab(BK);
   __syncthreads();
   GSTAMP(1);
+#ifdef CSN_STAMPS
+#define GIN(i, a, b) do { __builtin_amdgcn_sched_barrier(0); a = __builtin_amdgcn_s_memtime(); gin[i] += a - b; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define GIN(i, a, b)
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
+#ifdef CSN_STAMPS
+    __builtin_amdgcn_sched_barrier(0); gt0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
@@ -202,11 +229,15 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
     }
     // slab kt + 1 (loaded one iteration ago) is split and written into the other stage while the matrix pipe drains;
     // slab kt + 2 starts its trip from HBM
+    GIN(0, gt1, gt0);
     if (kt + 1 < nk) {
       store_slab(cur ^ 1);
+      GIN(1, gt0, gt1);
       if (kt + 2 < nk) load_slab((kt + 2) * BK);
     }
+    GIN(3, gt1, gt0);
     __syncthreads();
+    GIN(2, gt0, gt1);
   }
 
   GSTAMP(2);
@@ -282,17 +313,17 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
 #ifdef CSN_STAMPS
   __builtin_amdgcn_s_waitcnt(0);
   GSTAMP(3);
-  if (tid == 0 && blockIdx.x < 65536) for (int i = 0; i < 4; ++i) csn_gdbg[blockIdx.x * 4 + i] = gst[i];
+  if (tid == 0 && blockIdx.x < 65536) for (int i = 0; i < 4; ++i) { csn_gdbg[blockIdx.x * 8 + i] = gst[i]; csn_gdbg[blockIdx.x * 8 + 4 + i] = gin[i]; }
 #endif
 }
 
-template <int BM, int BN, bool B_NK>
+template <int BM, int BN, bool B_NK, bool BT = false>
 int launch(const CsnGemmArgs& a, int batch, hipStream_t st) {
   CsnGemmArgs b = a;
   b.batch = batch;
   const long long tiles = (long long)((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
   dim3 grid((unsigned)(((batch + 7) / 8) * 8 * tiles));
-  hipLaunchKernelGGL((csn_gemm_bf16x3_kernel<BM, BN, B_NK>), grid, dim3(256), 0, st, b);
+  hipLaunchKernelGGL((csn_gemm_bf16x3_kernel<BM, BN, B_NK, BT>), grid, dim3(256), 0, st, b);
   return (int)hipGetLastError();
 }
 
@@ -300,6 +331,10 @@ int launch(const CsnGemmArgs& a, int batch, hipStream_t st) {
 
 int csn_launch_gemm_bf16x3(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st) {
   if (a.C.planes && a.accumulate) return -1;
+  if (a.B.planes == 2) {                                            // tile-plane B: k-major only
+    if (b_is_nk || (a.B.ld & 7)) return -1;
+    return launch<128, 128, false, true>(a, batch, st);
+  }
   if (a.M <= 64) return b_is_nk ? launch<64, 128, true>(a, batch, st) : launch<64, 128, false>(a, batch, st);
   return b_is_nk ? launch<128, 128, true>(a, batch, st) : launch<128, 128, false>(a, batch, st);
 }

@@ -301,20 +301,21 @@ class _MHAEvals(torch.autograd.Function):
         else:
             k_ptr = q_ptr + 4 * D * NP
             v_ptr = q_ptr + 4 * (2 * D * NP + plan.v_shift * kv_stride)
+        pt = 1 if (fast_math() and Tp >= (T + 31) // 32 * 32) else 0    # P / dS travel to the dV / dK products as bf16 tile planes
         for ci, ids in enumerate(plan.dq_colors):
             _lib.check(L.csn_block_attn_bwd_dq_f32(_ptr(datt), _ptr(att), D * NP, k_ptr, v_ptr, kv_stride,
                                                    _ptr(plan.kv_slots), NP, _ptr(scores), _ptr(dscores), _ptr(lse),
                                                    _ptr(delta), gbase, slot_stride, _ptr(plan.q_slots),
                                                    0 if (full and ci == 0) else 1, _ptr(ids),
                                                    ids.numel(), H, d, T, nb, Tp, p_attn, seed_attn, 0, 0, kv_flag,
-                                                   kv_pitch, _stream()),
+                                                   kv_pitch, pt, _stream()),
                        "csn_block_attn_bwd_dq_f32")
         for ci, ids in enumerate(plan.dkv_colors):
             _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, q_ptr, q_stride, _ptr(plan.q_slots), NP,
                                                     _ptr(scores), _ptr(dscores), gbase + 4 * D * NP, gbase + 8 * D * NP,
                                                     slot_stride, _ptr(plan.kv_slots), _ptr(plan.v_slots),
                                                     0 if (full and ci == 0) else 1, _ptr(ids),
-                                                    ids.numel(), H, d, T, nb, Tp, 0, 0, 0, 0, _stream()),
+                                                    ids.numel(), H, d, T, nb, Tp, 0, 0, 0, 0, pt, _stream()),
                        "csn_block_attn_bwd_dkv_f32")
         del dscores, delta, datt
 

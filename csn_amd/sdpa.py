@@ -55,11 +55,11 @@ class _SDPA(torch.autograd.Function):
         L = _lib.lib()
         _lib.check(L.csn_block_attn_bwd_dq_f32(CF._ptr(datt), CF._ptr(att), d * T, CF._ptr(km), CF._ptr(vm), d * T, None, T,
                                                CF._ptr(work), CF._ptr(dscores), CF._ptr(lse), CF._ptr(delta), CF._ptr(dq),
-                                               d * T, None, 0, None, S, 1, d, T, 1, Tp, ctx.drop[0], ctx.drop[1], 0, 0, 0, 0,
+                                               d * T, None, 0, None, S, 1, d, T, 1, Tp, ctx.drop[0], ctx.drop[1], 0, 0, 0, 0, 0,
                                                CF._stream()), "csn_block_attn_bwd_dq_f32")
         _lib.check(L.csn_block_attn_bwd_dkv_f32(CF._ptr(datt), d * T, CF._ptr(qm), d * T, None, T, CF._ptr(work),
                                                 CF._ptr(dscores), CF._ptr(dk), CF._ptr(dv), d * T, None, None, 0, None, S, 1,
-                                                d, T, 1, Tp, 0, 0, 0, 0, CF._stream()), "csn_block_attn_bwd_dkv_f32")
+                                                d, T, 1, Tp, 0, 0, 0, 0, 0, CF._stream()), "csn_block_attn_bwd_dkv_f32")
         back = lambda g: g.transpose(1, 2).reshape(B, H, T, d)
         return back(dq) / ctx.temperature, back(dk), back(dv), None, None
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSN_ABI_VERSION 4
+#define CSN_ABI_VERSION 5
 
 #define CSN_E_ARG (-1)     /* null pointer / non-positive size            */
 #define CSN_E_ALIGN (-2)   /* a size or leading dimension is not % 4      */
@@ -108,20 +108,23 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
  *                                 dq[dq_index[e]] (+)= dS K   — gradient w.r.t. the pre-scaled queries Qs.
  * csn_block_attn_bwd_dkv_f32: in  dctx, q + q_index as in forward, probs (= scores after the dq call), dscores;
  *                             out dv[dv_index[e]] (+)= P^T dctx,  dk[dk_index[e]] (+)= dS^T Qs.
- * dq/dk/dv point at row 0 of the [n_heads*d_head][ld] gradient map of slot 0; *_slot_stride in floats. */
+ * dq/dk/dv point at row 0 of the [n_heads*d_head][ld] gradient map of slot 0; *_slot_stride in floats.
+ * probs_tiles != 0 (math mode 1; score_pitch >= block rounded up to 32): the dq call leaves P_drop and dS as bf16 TILE
+ * PLANES — per query row 16 tiles of [hi: 32 keys | lo: 32 keys], the bytes of the fp32 row — and the dkv call must be
+ * told the same; the dV / dK products then stage them with plain copies. */
 int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* k,
                               const float* v, long long kv_shape_stride, const int* kv_index, int ld, float* scores,
                               float* dscores, const float* lse, float* delta, float* dq, long long dq_slot_stride,
                               const int* dq_index, int accumulate, const int* eval_ids, int n_launch_evals, int n_heads,
                               int d_head, int block, int n_blocks, int score_pitch, float dropout_p,
                               unsigned long long seed, int dctx_split, long long dctx_plane_stride, int kv_split,
-                              long long kv_plane_stride, void* stream);
+                              long long kv_plane_stride, int probs_tiles, void* stream);
 int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
                                const int* q_index, int ld, const float* probs, const float* dscores, float* dk,
                                float* dv, long long dkv_slot_stride, const int* dk_index, const int* dv_index,
                                int accumulate, const int* eval_ids, int n_launch_evals, int n_heads, int d_head,
                                int block, int n_blocks, int score_pitch, int dctx_split, long long dctx_plane_stride,
-                               int q_split, long long q_plane_stride, void* stream);
+                               int q_split, long long q_plane_stride, int probs_tiles, void* stream);
 
 /* ---- (4) output projection + residual + LayerNorm, forward -------------------------------------------
  * z[c][n] = sum_D wfc[c][D] ctx[e][D][n] + xres[res_index[e]][c][n];  xhat = (z - mean_c z) * rstd,

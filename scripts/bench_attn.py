@@ -77,13 +77,13 @@ def main():
                                                v_ptr if tl else base + 8 * D * NP,
                                                kv_stride if tl else 3 * D * NP, CF._ptr(ks), NP, CF._ptr(scores), CF._ptr(dscores), CF._ptr(lse),
                                                CF._ptr(delta), dqkv.data_ptr(), 3 * D * NP, None, 0, None, E, H, d, T, nb,
-                                               Tp, a.drop, seed, 0, 0, kvf if tl else 0, kvp if tl else 0, st), "dq")
+                                               Tp, a.drop, seed, 0, 0, kvf if tl else 0, kvp if tl else 0, 1 if tl else 0, st), "dq")
 
     def dkv():
         gb = dqkv.data_ptr()
         _lib.check(L.csn_block_attn_bwd_dkv_f32(CF._ptr(datt), D * NP, base, 3 * D * NP, CF._ptr(qs), NP, CF._ptr(scores),
                                                 CF._ptr(dscores), gb + 4 * D * NP, gb + 8 * D * NP, 3 * D * NP, None, None,
-                                                0, None, E, H, d, T, nb, Tp, 0, 0, 0, 0, st), "dkv")
+                                                0, None, E, H, d, T, nb, Tp, 0, 0, 0, 0, 1 if (a.tiles and L.csn_get_math_mode() == 1) else 0, st), "dkv")
 
     flops = 4.0 * T * d * NP * E * H
     L.csn_set_math_mode(a.mode)
@@ -117,6 +117,18 @@ def main():
         if a.check:
             print("   dk err", (dqkv[:, D:2 * D] - ref["dk"]).abs().max().item(), "scale", ref["dk"].abs().max().item(),
                   "dv err", (dqkv[:, 2 * D:] - ref["dv"]).abs().max().item(), "scale", ref["dv"].abs().max().item())
+    if hasattr(L, "csn_gemm_debug_read") or os.environ.get("CSN_GEMM_STAMPS"):
+        import ctypes
+        L.csn_gemm_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+        buf = np.zeros(65536 * 8, dtype=np.uint64)
+        L.csn_gemm_debug_read(buf.ctypes.data, buf.nbytes)
+        full = buf.reshape(65536, 8).astype(np.int64)
+        st, inner = full[:, :4], full[:, 4:]
+        d_ = np.diff(st, axis=1)
+        nslab = 16
+        print(f"GEMM stamps (last launch, first 65536 work-groups): prologue={d_[:,0].mean():7.0f} loop={d_[:,1].mean():7.0f} epilogue={d_[:,2].mean():7.0f}"
+              f" | per slab: reads+mfma={inner[:,0].mean()/nslab:6.0f} split+lds-write={inner[:,1].mean()/nslab:6.0f} "
+              f"issue loads={inner[:,3].mean()/nslab:6.0f} barrier={inner[:,2].mean()/nslab:6.0f}")
     L.csn_set_math_mode(0)
 
 

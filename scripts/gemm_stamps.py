@@ -21,6 +21,8 @@ def report(name, nwg, nslab):
     print(f"   per slab: reads+mfma={inner[:,0].mean()/nslab:6.0f}  stage(split+lds write+issue loads)={inner[:,1].mean()/nslab:6.0f}  barrier={inner[:,2].mean()/nslab:6.0f}")
     d = np.diff(st, axis=1)
     t0 = st[:, 0].min()
+    span = st[:, 3].max() - t0
+    print(f"   span={span} cycles, sum of WG lifetimes / span / 256 CUs = {(st[:,3]-st[:,0]).sum() / span / 256:5.2f} concurrent WGs per CU")
     print(f"{name}: work-groups {nwg}  prologue={d[:,0].mean():7.0f}  loop={d[:,1].mean():7.0f} ({d[:,1].mean()/nslab:6.0f}/slab x {nslab})  "
           f"epilogue={d[:,2].mean():7.0f}  wg total={(st[:,3]-st[:,0]).mean():7.0f}  kernel span={(st[:,3].max()-t0)}  "
           f"concurrency={(st[:,3]-st[:,0]).sum()/(st[:,3].max()-t0)/256:5.2f} WG/CU")

@@ -198,15 +198,16 @@ def test_block_attn_bwd(L, S, E, H, d, T, nb):
     dscores = torch.full_like(scores, float("nan"))
     delta = torch.empty((E, H, N), device="cuda")
     dq, dk, dv = (torch.full((E, D, N), float("nan"), device="cuda") for _ in range(3))
+    pt = 1 if _mode["m"] == 1 else 0          # bf16x3: P / dS travel from the dq call to the dkv call as bf16 tile planes
     # per-evaluation outputs: identity slot maps, no accumulation (the module path uses slot maps + colours)
     rc = L.lib().csn_block_attn_bwd_dq_f32(dd.data_ptr(), ctx.data_ptr(), D * N, kd.data_ptr(), vd.data_ptr(), D * N,
                                            ki.data_ptr(), N, scores.data_ptr(), dscores.data_ptr(), lse.data_ptr(),
                                            delta.data_ptr(), dq.data_ptr(), D * N, None, 0, None, E, H, d, T, nb, Tp, 0.0, 0,
-                                           0, 0, 0, 0, _stream())
+                                           0, 0, 0, 0, pt, _stream())
     L.check(rc, "attn bwd dq")
     rc = L.lib().csn_block_attn_bwd_dkv_f32(dd.data_ptr(), D * N, qd.data_ptr(), D * N, qi.data_ptr(), N, scores.data_ptr(),
                                             dscores.data_ptr(), dk.data_ptr(), dv.data_ptr(), D * N, None, None, 0, None, E,
-                                            H, d, T, nb, Tp, 0, 0, 0, 0, _stream())
+                                            H, d, T, nb, Tp, 0, 0, 0, 0, pt, _stream())
     L.check(rc, "attn bwd")
     torch.cuda.synchronize()
     # float64 autograd reference, per evaluation (no sharing: the ABI returns per-evaluation gradients)
@@ -221,7 +222,14 @@ def test_block_attn_bwd(L, S, E, H, d, T, nb):
     assert _maxerr(dv, v64.grad) < tol(2e-5)
     # scores now hold P
     p_ref = torch.softmax(_attn_reference(q.double(), k.double(), v.double(), q_idx, kv_idx, H, d, T, nb)[2], dim=-1)
-    assert (scores[..., :T].cpu().double() - p_ref).abs().max().item() < tol(2e-6)
+    if pt:      # per query row: tiles of [hi 32 | lo 32] bf16 over the bytes of the fp32 row
+        pl = scores.view(torch.bfloat16).view(E, H, nb, T, Tp // 32, 2, 32).float()
+        got = (pl[..., 0, :] + pl[..., 1, :]).reshape(E, H, nb, T, Tp)
+    else:
+        got = scores
+    assert (got[..., :T].cpu().double() - p_ref).abs().max().item() < tol(2e-6)
+    if pt:
+        assert (got[..., T:] == 0).all()                          # keys beyond the block end are written as zeros
 
     # slot-indexed accumulation: evaluations listed in two disjoint colours, gradients summed per slot
     qi64, ki64 = torch.from_numpy(q_idx).long(), torch.from_numpy(kv_idx).long()
@@ -236,12 +244,12 @@ def test_block_attn_bwd(L, S, E, H, d, T, nb):
         L.check(L.lib().csn_block_attn_bwd_dq_f32(dd.data_ptr(), ctx.data_ptr(), D * N, kd.data_ptr(), vd.data_ptr(), D * N,
                                                   ki.data_ptr(), N, scores2.data_ptr(), dscores.data_ptr(), lse.data_ptr(),
                                                   delta.data_ptr(), sq.data_ptr(), D * N, qi.data_ptr(), 1, ids.data_ptr(),
-                                                  ids.numel(), H, d, T, nb, Tp, 0.0, 0, 0, 0, 0, 0, _stream()))
+                                                  ids.numel(), H, d, T, nb, Tp, 0.0, 0, 0, 0, 0, 0, pt, _stream()))
     for ids in plan.dkv_colors:
         L.check(L.lib().csn_block_attn_bwd_dkv_f32(dd.data_ptr(), D * N, qd.data_ptr(), D * N, qi.data_ptr(), N,
                                                    scores2.data_ptr(), dscores.data_ptr(), sk.data_ptr(), sv_.data_ptr(), D * N,
                                                    ki.data_ptr(), ki.data_ptr(), 1, ids.data_ptr(), ids.numel(), H, d, T, nb,
-                                                   Tp, 0, 0, 0, 0, _stream()))
+                                                   Tp, 0, 0, 0, 0, pt, _stream()))
     torch.cuda.synchronize()
     assert _maxerr(sq, ref_dq) < tol(2e-5) and _maxerr(sk, ref_dk) < tol(2e-5) and _maxerr(sv_, ref_dv) < tol(2e-5)
 
