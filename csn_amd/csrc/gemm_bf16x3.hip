@@ -317,6 +317,229 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
 #endif
 }
 
+// ---- 256 x 256 x 32 tiles, 8 waves -----------------------------------------------------------------------------------
+// Why a second kernel: on this machine the price of a slab is not only its matrix instructions — every 1 KiB wave load
+// costs the issuing wave ~90 cycles, and every staged fp32 word a few VALU — and both scale with the BYTES staged per
+// FLOP.  A 256 x 256 tile stages half the bytes per FLOP of a 128 x 128 one (64 KB for 4.2 MFLOP), at the same 8 loads per
+// thread and slab.  Waves: 4 (M) x 2 (N), 64 x 128 accumulators each (128 registers).  LDS: k-contiguous planes are not
+// padded but XOR-swizzled (16-byte unit u of row r lives at u ^ ((r >> 2) & 3): conflict-free 16-byte fragment reads),
+// 128 KB (136 KB with a k-major B) for two stages.
+template <bool B_NK, bool BT>
+__global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs p) {
+  static_assert(!BT || !B_NK, "tile-plane B is k-major");
+  constexpr int BM = 256, BN = 256, MT = 2, NT = 4;
+  constexpr int PN = BN + 32;                           // pitch of the k-major B planes
+  constexpr int A_EL = BM * BK, B_EL = B_NK ? BN * BK : BK * PN;
+  __shared__ __attribute__((aligned(16))) __bf16 As[2][2][A_EL];   // [stage][plane][row][k ^ swizzle]
+  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][2][B_EL];   // NK: like A   KN: [stage][plane][k][col]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 128;
+
+  const int tiles_n = (p.N + BN - 1) / BN, tiles = tiles_n * ((p.M + BM - 1) / BM);
+  const int L = blockIdx.x, jj = L >> 3;
+  const int tile = jj % tiles;
+  int z = (jj / tiles) * 8 + (L & 7);                   // XCD-aware order, as in the kernel above
+  if (z >= p.batch) return;
+  const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
+  const int z0 = z % p.n0; z /= p.n0;
+  const int z1 = z % p.n1;
+  const int z2 = p.eval_ids ? p.eval_ids[z / p.n1] : z / p.n1;
+  const int lda = p.A.ld, ldb = p.B.ld, ldc = p.C.ld;
+  const int M = p.M, N = p.N;
+  int K = p.K;
+  if (p.k_chunk > 0) { K = min(p.k_chunk, p.K - z0 * p.k_chunk); }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const bool c_pl = p.C.planes != 0;
+  const bool c_tiles = p.C.planes == 2;
+  const int c_es = c_pl ? 2 : 4;
+  const float* a_base = p.A.ptr + p.A.s0 * z0 + p.A.s1 * z1 + p.A.s2 * (long long)(p.A.idx2 ? p.A.idx2[z2] : z2) + (long long)m0 * lda;
+  const long long b_el = p.B.s0 * z0 + p.B.s1 * z1 + p.B.s2 * (long long)(p.B.idx2 ? p.B.idx2[z2] : z2);
+  const float* b_base = BT ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(p.B.ptr) + b_el)
+                           : p.B.ptr + b_el + (B_NK ? (long long)n0 * ldb : (long long)n0);
+  char* c_base = reinterpret_cast<char*>(p.C.ptr) + (p.C.s0 * z0 + p.C.s1 * z1 + p.C.s2 * (long long)(p.C.idx2 ? p.C.idx2[z2] : z2) + (long long)m0 * ldc + (c_tiles ? 0 : n0)) * c_es;
+  const long long c_win = (long long)BM * ldc * c_es;
+  const csn_rsrc_t Ar = csn_make_rsrc(a_base, (long long)BM * lda * 4);
+  const csn_rsrc_t Br = csn_make_rsrc(b_base, BT ? (long long)K * ldb * 2
+                                                 : (B_NK ? (long long)BN * ldb * 4 : ((long long)(K - 1) * ldb + (N - n0)) * 4));
+  const csn_rsrc_t Cr = csn_make_rsrc(c_base, c_win), Crl = csn_make_rsrc(c_base + p.C.plane_stride * 2, c_pl ? c_win : 0);
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // staging: 4 A pieces + 4 B pieces of 16 bytes per thread and slab
+  const int pr = tid >> 3, pc = (tid & 7) * 4;          // k-contiguous operands: row pr + 64 i, k = pc .. pc + 3
+  const int kr = tid >> 6, kc = (tid & 63) * 4;         // k-major B: k row kr + 8 i, columns kc .. kc + 3
+  const int t_u8 = tid & 7, t_u = t_u8 & 3, t_pl = t_u8 >> 2, t_kr = (tid >> 3) & 31, t_tg = tid >> 8;   // tile-plane B
+  const int sw_dst = pr * BK + ((((pc >> 3) ^ ((pr >> 2) & 3)) << 3) | (pc & 4));     // rows 64 apart share the swizzle
+  unsigned a_off[4], b_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a_off[i] = (m0 + pr + 64 * i) < M ? (unsigned)((pr + 64 * i) * lda + pc) * 4u : CSN_OOB;
+    if (BT) b_off[i] = (n0 + 32 * (t_tg + 2 * i) + 8 * t_u) < N
+                           ? (unsigned)(t_kr * ldb) * 2u + (unsigned)((n0 >> 5) + t_tg + 2 * i) * 128u + (unsigned)t_u8 * 16u : CSN_OOB;
+    else if (B_NK) b_off[i] = (n0 + pr + 64 * i) < N ? (unsigned)((pr + 64 * i) * ldb + pc) * 4u : CSN_OOB;
+    else b_off[i] = (n0 + kc) < N ? (unsigned)((kr + 8 * i) * ldb + kc) * 4u : CSN_OOB;
+  }
+  f32x4 ra[4], rb[4];
+  auto load_slab = [&](int k0) {
+    const unsigned kp = (k0 + pc) < K ? 0u : CSN_OOB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = csn_bload4(Ar, a_off[i] | kp, (unsigned)k0 * 4u);
+    if (BT) {
+      const unsigned kb = (k0 + t_kr) < K ? 0u : CSN_OOB;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb[i] = csn_bload4(Br, b_off[i] | kb, (unsigned)k0 * (unsigned)ldb * 2u);
+    } else if (B_NK) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rb[i] = csn_bload4(Br, b_off[i] | kp, (unsigned)k0 * 4u);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned kq = (k0 + kr + 8 * i) < K ? 0u : CSN_OOB;
+        rb[i] = csn_bload4(Br, b_off[i] | kq, (unsigned)k0 * (unsigned)ldb * 4u);
+      }
+    }
+  };
+  auto store_slab = [&](int st) {
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      split4(ra[i], hi, lo);
+      *reinterpret_cast<bf16x4*>(&As[st][0][sw_dst + 64 * BK * i]) = hi;
+      *reinterpret_cast<bf16x4*>(&As[st][1][sw_dst + 64 * BK * i]) = lo;
+    }
+    if (BT) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&Bs[st][t_pl][t_kr * PN + 32 * (t_tg + 2 * i) + 8 * t_u]) = rb[i];
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      split4(rb[i], hi, lo);
+      const int dst = B_NK ? sw_dst + 64 * BK * i : (kr + 8 * i) * PN + kc;
+      *reinterpret_cast<bf16x4*>(&Bs[st][0][dst]) = hi;
+      *reinterpret_cast<bf16x4*>(&Bs[st][1][dst]) = lo;
+    }
+  };
+
+  // fragment read positions (lane constants): k-contiguous planes, row l31 of a 32-row tile, 16-byte unit (2 s + h) ^ swizzle
+  const int fr_sw = (l31 >> 2) & 3;
+  const int grp = lane >> 4, gq = (lane >> 2) & 3, gp = lane & 3;
+  const int tr_base = (8 * (grp >> 1) + gq) * PN + 16 * (grp & 1) + 4 * gp;
+
+  const int nk = (K + BK - 1) / BK;
+  if (nk > 0) { load_slab(0); store_slab(0); }
+  if (nk > 1) load_slab(BK);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 ah[MT], al[MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const int o = (wm0 + 32 * i + l31) * BK + (((2 * s + h) ^ fr_sw) << 3);
+        ah[i] = *reinterpret_cast<const bf16x8*>(&As[cur][0][o]);
+        al[i] = *reinterpret_cast<const bf16x8*>(&As[cur][1][o]);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        bf16x8 bh, bl;
+        if (B_NK) {
+          const int o = (wn0 + 32 * j + l31) * BK + (((2 * s + h) ^ fr_sw) << 3);
+          bh = *reinterpret_cast<const bf16x8*>(&Bs[cur][0][o]);
+          bl = *reinterpret_cast<const bf16x8*>(&Bs[cur][1][o]);
+        } else {
+          const int o = tr_base + (16 * s) * PN + wn0 + 32 * j;
+          typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+          const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][0][o]));
+          const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][0][o + 4 * PN]));
+          const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][1][o]));
+          const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][1][o + 4 * PN]));
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          const s16x8 hv = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+          const s16x8 lv = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+          bh = __builtin_bit_cast(bf16x8, hv);
+          bl = __builtin_bit_cast(bf16x8, lv);
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          acc[i][j] = mfma_bf16(al[i], bh, acc[i][j]);        // small terms first
+          acc[i][j] = mfma_bf16(ah[i], bl, acc[i][j]);
+          acc[i][j] = mfma_bf16(ah[i], bh, acc[i][j]);
+        }
+      }
+    }
+    if (kt + 1 < nk) {
+      store_slab(cur ^ 1);
+      if (kt + 2 < nk) load_slab((kt + 2) * BK);
+    }
+    __syncthreads();
+  }
+
+  // epilogue, one 32 x 32 accumulator tile at a time (offsets are not kept: the accumulators own the registers)
+  const float alpha = p.alpha;
+  const int Tb = (int)p.C.plane_stride;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int nl = wn0 + 32 * j + l31, n = n0 + nl;
+    unsigned col = 0;
+    if (c_tiles) {
+      const int blk = n / Tb, kib = n - blk * Tb;
+      col = (unsigned)(blk * 1024 + (kib >> 5) * 64 + (kib & 31));
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      unsigned off[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = wm0 + 32 * i + csn_acc_row(r, h);
+        const bool ok = (m0 + ml) < M && n < N;
+        off[r] = !ok ? CSN_OOB : (c_tiles ? ((unsigned)(ml * ldc) + col) * 2u : (unsigned)(ml * ldc + nl) * (unsigned)c_es);
+        float v = acc[i][j][r] * alpha;
+        if ((m0 + ml) < p.div_rows) v = v / p.div_val;
+        acc[i][j][r] = v;
+      }
+      if (c_pl) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const __bf16 hi = (__bf16)acc[i][j][r];
+          csn_bstore_bf16(hi, Cr, off[r]);
+          if (c_tiles) csn_bstore_bf16((__bf16)(acc[i][j][r] - (float)hi), Cr, off[r], 64u);
+          else csn_bstore_bf16((__bf16)(acc[i][j][r] - (float)hi), Crl, off[r]);
+        }
+      } else {
+        if (p.accumulate) {
+          f32x16 prev;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) prev[r] = csn_bload(Cr, off[r]);
+          acc[i][j] += prev;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) csn_bstore(acc[i][j][r], Cr, off[r]);
+      }
+    }
+  }
+}
+
+template <bool B_NK, bool BT = false>
+int launch_big(const CsnGemmArgs& a, int batch, hipStream_t st) {
+  CsnGemmArgs b = a;
+  b.batch = batch;
+  const long long tiles = (long long)((a.N + 255) / 256) * ((a.M + 255) / 256);
+  dim3 grid((unsigned)(((batch + 7) / 8) * 8 * tiles));
+  hipLaunchKernelGGL((csn_gemm_bf16x3_big_kernel<B_NK, BT>), grid, dim3(512), 0, st, b);
+  return (int)hipGetLastError();
+}
+
 template <int BM, int BN, bool B_NK, bool BT = false>
 int launch(const CsnGemmArgs& a, int batch, hipStream_t st) {
   CsnGemmArgs b = a;
@@ -329,12 +552,18 @@ int launch(const CsnGemmArgs& a, int batch, hipStream_t st) {
 
 }  // namespace
 
+int csn_gemm_big_tiles = 1;      // development switch (csn_debug_set_big_tiles)
+extern "C" void csn_debug_set_big_tiles(int on) { csn_gemm_big_tiles = on; }
+
 int csn_launch_gemm_bf16x3(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st) {
   if (a.C.planes && a.accumulate) return -1;
+  // tiles of 256 x 256 where the output is big enough to fill them (a ragged last tile wastes at most ~3 % here)
+  const bool big = csn_gemm_big_tiles && a.M >= 192 && a.N >= 224;
   if (a.B.planes == 2) {                                            // tile-plane B: k-major only
     if (b_is_nk || (a.B.ld & 7)) return -1;
-    return launch<128, 128, false, true>(a, batch, st);
+    return big ? launch_big<false, true>(a, batch, st) : launch<128, 128, false, true>(a, batch, st);
   }
+  if (big) return b_is_nk ? launch_big<true>(a, batch, st) : launch_big<false>(a, batch, st);
   if (a.M <= 64) return b_is_nk ? launch<64, 128, true>(a, batch, st) : launch<64, 128, false>(a, batch, st);
   return b_is_nk ? launch<128, 128, true>(a, batch, st) : launch<128, 128, false>(a, batch, st);
 }
