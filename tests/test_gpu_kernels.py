@@ -82,6 +82,47 @@ def test_project_split_output_planes(L, math_mode):
     assert ((hi.double() - ref).abs().max() / ref.abs().max()).item() < 5e-3      # the high plane alone is bf16-accurate
 
 
+@pytest.mark.parametrize("S,C,R,T,nb", [(2, 96, 192, 100, 3), (1, 256, 512, 500, 2), (1, 32, 64, 36, 2)])
+def test_project_tile_planes_feed_attention(L, math_mode, S, C, R, T, nb):
+    """bf16x3 mode: csn_project_f32(out_split = 2) writes K/V as tile planes — per row and block, 16 tiles of
+    [hi 32 | lo 32] bf16 at block pitch 1024 — and the attention forward fed with them agrees with the fp32-fed one."""
+    if math_mode == 0:
+        return
+    rng = np.random.default_rng(21)
+    N = T * nb
+    x, w = _rand(rng, S, C, N), _rand(rng, R, C) / math.sqrt(C)
+    xd, wd = x.cuda(), w.cuda()
+    ldp = nb * 1024
+    kv = torch.full((S, R, ldp), float("nan"), device="cuda", dtype=torch.bfloat16)
+    L.check(L.lib().csn_project_f32(xd.data_ptr(), C * N, N, wd.data_ptr(), R, C, kv.data_ptr(), R * ldp, ldp, S, N, 0, 1.0, 2, T,
+                                    _stream()))
+    t = kv.view(S, R, nb, 16, 2, 32).float().cpu()
+    got = (t[..., 0, :] + t[..., 1, :]).reshape(S, R, nb, 512)
+    ref = torch.einsum("rc,scn->srn", w.double(), x.double()).view(S, R, nb, T)
+    assert ((got[..., :T].double() - ref).abs().max() / ref.abs().max()).item() < 3e-5
+    assert torch.isnan(got[..., T:]).all()                       # padding is the caller's (it must hold zeros for the kernels)
+    # attention forward: K = rows [0, R/2), V = rows [R/2, R) as tile planes vs the same values as fp32 maps
+    d = R // 2
+    if d not in (32, 64, 96, 128, 256):
+        return
+    kv.view(S, R, nb, 16, 2, 32)[:, :, :, (T - 1) // 32, :, T % 32:] = 0
+    kv.view(S, R, nb, 16, 2, 32)[:, :, :, (T + 31) // 32:] = 0
+    q = (_rand(rng, S, d, N) / math.sqrt(d)).cuda()              # logits of O(1): operand rounding is not amplified by exp
+    kvf = torch.einsum("rc,scn->srn", wd, xd).contiguous()       # fp32 (torch) K|V maps: same values up to fp32 rounding
+    Tp = (T + 31) // 32 * 32
+    outs = []
+    for tiles in (0, 1):
+        ctx = torch.empty((S, d, N), device="cuda")
+        lse = torch.empty((S, 1, N), device="cuda")
+        kp = kv.data_ptr() if tiles else kvf.data_ptr()
+        vp = kp + (2 * d * ldp if tiles else 4 * d * N)
+        L.check(L.lib().csn_block_attn_fwd_f32(q.data_ptr(), kp, vp, d * N, (R * ldp) if tiles else (R * N), None, None, N,
+                                               ctx.data_ptr(), d * N, None, lse.data_ptr(), S, 1, d, T, nb, Tp, 8.0, 0.0, 0,
+                                               tiles, ldp if tiles else 0, _stream()))
+        outs.append((ctx, lse))
+    assert _maxerr(outs[1][0], outs[0][0].cpu()) < 1e-4 and _maxerr(outs[1][1], outs[0][1].cpu()) < 1e-4
+
+
 def test_project_wgrad(L):
     from csn_amd import functional as CF
     rng = np.random.default_rng(2)
