@@ -72,6 +72,13 @@ _SIGNATURES = {
                                            c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                            c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_int, c_longlong,
                                            c_int, c_void_p]),
+    "csn_cross_attn_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_int, c_int, c_void_p, c_longlong,
+                                       c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
+                                       c_ulonglong, c_void_p]),
+    "csn_cross_attn_bwd_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong, c_longlong,
+                                       c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_longlong, c_longlong, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                       c_ulonglong, c_void_p]),
     "csn_outproj_ln_fwd_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p,
                                        c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
                                        c_ulonglong, c_void_p]),
@@ -105,7 +112,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.csn_version() != 5:
+        if handle.csn_version() != 6:
             raise CsnError("libcsn_hip.so ABI version mismatch")
         _lib = handle
     return _lib

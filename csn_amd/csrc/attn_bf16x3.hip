@@ -77,22 +77,26 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   // block, so they should share one XCD's L2.  Work-groups are dealt round-robin over the 8 XCDs, hence the QT tiles of
   // unit u get ids 8 * (QT * (u / 8) + qt) + (u % 8): same residue mod 8 (same XCD), adjacent in dispatch order.
   // (Placement only changes speed: every tile is self-contained.)
-  const int QT = (p.T + 127) / 128;
+  const int Tq = p.Tq > 0 ? p.Tq : p.T;                       // queries per block (T: keys per block)
+  const int QT = (Tq + 127) / 128;
   const int Y = p.n_blocks * p.H;
   const int L = blockIdx.x, slot = L & 7, jj = L >> 3;
   const int qt = jj % QT, u = (jj / QT) * 8 + slot;
   if (u >= Y * p.E) return;
   const int e = p.eval_ids ? p.eval_ids[u / Y] : u / Y;
   const int hd = (u % Y) % p.H, blk = (u % Y) / p.H;
-  const int T = p.T, Tp = p.Tp, ld = p.ld;
+  const int T = p.T, Tp = p.Tp, ld = p.ld, ldk = p.ld_kv > 0 ? p.ld_kv : p.ld;
+  const bool ragged = (T & 3) != 0;                            // keys of the last 4-key group are masked one by one
   const int qrow = qt * 128 + wave * 16 + lq;                  // query index inside the block
-  const bool q_ok = qrow < T;
+  const bool q_ok = qrow < Tq;
 
   const long long qs = p.q_index ? p.q_index[e] : e;
   const long long ks = p.kv_index ? p.kv_index[e] : e;
   const long long os = p.out_index ? p.out_index[e] : e;
-  const long long head_off = (long long)hd * D * ld + (long long)blk * T;
-  const long long win = ((long long)(D - 1) * ld + T) * 4;     // bytes spanned by a [D][T] window of pitch ld
+  const long long head_off = (long long)hd * D * ld + (long long)blk * Tq;
+  const long long win = ((long long)(D - 1) * ld + Tq) * 4;    // bytes spanned by a [D][Tq] window of pitch ld
+  const long long head_off_kv = (long long)hd * D * ldk + (long long)blk * T;
+  const long long win_kv = ((long long)(D - 1) * ldk + (T + 3) / 4 * 4) * 4;
   const csn_rsrc_t Rr = csn_make_rsrc(p.q + qs * p.q_shape_stride + head_off, win);
   // tile planes: bf16 elements, row pitch kv_ld = n_blocks * 1024, this block's 16 tiles start at blk * 1024
   const int kld = p.kv_ld;
@@ -101,15 +105,15 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   const __bf16* kpl = reinterpret_cast<const __bf16*>(BWD ? p.v : p.k);
   const __bf16* vpl = reinterpret_cast<const __bf16*>(BWD ? p.k : p.v);
   const csn_rsrc_t Ar = KVP ? csn_make_rsrc(kpl + kv_off, kv_win)
-                            : csn_make_rsrc((BWD ? p.v : p.k) + ks * p.kv_shape_stride + head_off, win);
+                            : csn_make_rsrc((BWD ? p.v : p.k) + ks * p.kv_shape_stride + head_off_kv, win_kv);
   const csn_rsrc_t Br = KVP ? csn_make_rsrc(vpl + kv_off, kv_win)
-                            : csn_make_rsrc((BWD ? p.k : p.v) + ks * p.kv_shape_stride + head_off, win);
+                            : csn_make_rsrc((BWD ? p.k : p.v) + ks * p.kv_shape_stride + head_off_kv, win_kv);
   const csn_rsrc_t Or = csn_make_rsrc(p.out + os * p.out_eval_stride + head_off, win);
-  const long long stat_off = ((long long)e * p.H + hd) * ((long long)p.n_blocks * T) + (long long)blk * T;
-  const long long sc_off = (((long long)e * p.H + hd) * p.n_blocks + blk) * ((long long)T * Tp);
+  const long long stat_off = ((long long)e * p.H + hd) * ((long long)p.n_blocks * Tq) + (long long)blk * Tq;
+  const long long sc_off = (((long long)e * p.H + hd) * p.n_blocks + blk) * ((long long)Tq * Tp);
   const bool have_scores = p.scores != nullptr;
-  const csn_rsrc_t Sr = csn_make_rsrc(have_scores ? p.scores + sc_off : nullptr, have_scores ? (long long)T * Tp * 4 : 0);
-  const csn_rsrc_t dSr = csn_make_rsrc(BWD ? p.dscores + sc_off : nullptr, BWD ? (long long)T * Tp * 4 : 0);
+  const csn_rsrc_t Sr = csn_make_rsrc(have_scores ? p.scores + sc_off : nullptr, have_scores ? (long long)Tq * Tp * 4 : 0);
+  const csn_rsrc_t dSr = csn_make_rsrc(BWD ? p.dscores + sc_off : nullptr, BWD ? (long long)Tq * Tp * 4 : 0);
 
   // per-lane byte offsets (scalar offsets handed to the buffer instructions must be wave-uniform, so
   // everything that depends on the lane lives here); lanes of query rows beyond the block are switched off
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   // depends on i is wave-uniform (scalar offset of the load, immediate offset of the LDS store): rows 64 apart share the swizzles.
   const int t_c = tid & 7, t_row = tid >> 3;
   const int t_sw = (t_row >> 3) & 1, t_swz = (-((t_row >> 2) & 3)) & 3;
-  const unsigned t_off = KVP ? (unsigned)(t_row * kld * 2 + t_c * 16) : (unsigned)(t_row * ld + 4 * t_c) * 4u;
+  const unsigned t_off = KVP ? (unsigned)(t_row * kld * 2 + t_c * 16) : (unsigned)(t_row * ldk + 4 * t_c) * 4u;
   const bool t_last_ok = tid + 512 * (NP_T - 1) < PIECES;         // only the last piece can fall beyond the tile
   // fp32: 8-byte chunk c -> tileA chunk c ^ sw;  tileB unit (c >> 1) ^ swz, half c & 1
   // planes: unit u = c & 3 of plane c >> 2 -> tileA chunks (2 u) ^ sw and (2 u + 1) ^ sw;  tileB unit u ^ swz
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
       const unsigned off = (k0 + 4 * t_c) < T ? t_off : CSN_OOB;
 #pragma unroll
       for (int i = 0; i < NP_T; ++i)
-        g[i] = csn_bload4(rs, (i == NP_T - 1 && !t_last_ok) ? CSN_OOB : off, (unsigned)(k0 + 64 * i * ld) * 4u);
+        g[i] = csn_bload4(rs, (i == NP_T - 1 && !t_last_ok) ? CSN_OOB : off, (unsigned)(k0 + 64 * i * ldk) * 4u);
     }
   };
   auto commitA = [&](int st) {
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
       float mx = -INFINITY;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        if (!j_ok[r >> 2]) t1[r] = -INFINITY;
+        if (!j_ok[r >> 2] || (ragged && kt * KT + 8 * kq + r >= T)) t1[r] = -INFINITY;
         mx = fmaxf(mx, t1[r]);
       }
 #pragma unroll
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     } else {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const bool ok = s_voff[r >> 2] != CSN_OOB;
+        const bool ok = s_voff[r >> 2] != CSN_OOB && !(ragged && kt * KT + 8 * kq + r >= T);
         const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(sv[r], LOG2E, -lse2_q)) : 0.f;   // softmax probability (csa_models.py:141)
         const float md = (!drop || keep[r]) ? keep_scale : 0.f;    // d P_drop / d P
         const float ds = pv * (t1[r] * md - delta_q);              // d softmax (delta = rowsum(dO * O) already has the mask)
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
 template <int DT>
 int launch_dt(const CsnAttnArgs& a, bool bwd, hipStream_t st) {
   const long long units = (long long)a.n_blocks * a.H * a.E;
-  dim3 grid((unsigned)(((units + 7) / 8) * 8 * ((a.T + 127) / 128)));
+  dim3 grid((unsigned)(((units + 7) / 8) * 8 * (((a.Tq > 0 ? a.Tq : a.T) + 127) / 128)));
   if (a.kv_planes) {
     if (bwd) hipLaunchKernelGGL((csn_attn_bf16x3_kernel<DT, true, true>), grid, dim3(512), 0, st, a);
     else hipLaunchKernelGGL((csn_attn_bf16x3_kernel<DT, false, true>), grid, dim3(512), 0, st, a);
@@ -501,7 +505,8 @@ int launch_dt(const CsnAttnArgs& a, bool bwd, hipStream_t st) {
 
 int launch_any(const CsnAttnArgs& a, int d, bool bwd, hipStream_t st) {
   if (a.E <= 0 || a.n_blocks <= 0) return 0;
-  if ((a.T & 3) || (a.ld & 3) || (a.Tp & 3)) return -2;
+  if ((a.ld & 3) || (a.Tp & 3) || (a.ld_kv & 3)) return -2;
+  if ((a.T & 3) && a.kv_planes) return -2;                          // ragged key counts: fp32 K/V maps only
   if ((a.q_shape_stride & 3) || (a.kv_shape_stride & 3)) return -4;
   if (a.sc_tiles && a.Tp < (a.T + 31) / 32 * 32) return -2;
   if (a.kv_planes && (a.T > 512 || (a.kv_ld & 7) || (a.kv_shape_stride & 7))) return -2;    // 16 tiles of 32 keys per block

@@ -56,31 +56,34 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
   // block, so they should share one XCD's L2.  Work-groups are dealt round-robin over the 8 XCDs, hence the QT tiles of
   // unit u get ids 8 * (QT * (u / 8) + qt) + (u % 8): same residue mod 8 (same XCD), adjacent in dispatch order.
   // (Placement only changes speed: every tile is self-contained.)
-  const int QT = (p.T + 127) / 128;
+  const int Tq = p.Tq > 0 ? p.Tq : p.T;                       // queries per block (T: keys per block)
+  const int QT = (Tq + 127) / 128;
   const int Y = p.n_blocks * p.H;
   const int L = blockIdx.x, slot = L & 7, jj = L >> 3;
   const int qt = jj % QT, u = (jj / QT) * 8 + slot;
   if (u >= Y * p.E) return;
   const int e = p.eval_ids ? p.eval_ids[u / Y] : u / Y;
   const int hd = (u % Y) % p.H, blk = (u % Y) / p.H;
-  const int T = p.T, Tp = p.Tp, ld = p.ld;
+  const int T = p.T, Tp = p.Tp, ld = p.ld, ldk = p.ld_kv > 0 ? p.ld_kv : p.ld;
   const int qrow = qt * 128 + wave * 16 + lq;                  // query index inside the block
-  const bool q_ok = qrow < T;
+  const bool q_ok = qrow < Tq;
 
   const long long qs = p.q_index ? p.q_index[e] : e;
   const long long ks = p.kv_index ? p.kv_index[e] : e;
   const long long os = p.out_index ? p.out_index[e] : e;
-  const long long head_off = (long long)hd * D * ld + (long long)blk * T;
-  const long long win = ((long long)(D - 1) * ld + T) * 4;     // bytes spanned by a [D][T] window of pitch ld
+  const long long head_off = (long long)hd * D * ld + (long long)blk * Tq;
+  const long long win = ((long long)(D - 1) * ld + Tq) * 4;    // bytes spanned by a [D][Tq] window of pitch ld
+  const long long head_off_kv = (long long)hd * D * ldk + (long long)blk * T;
+  const long long win_kv = ((long long)(D - 1) * ldk + (T + 3) / 4 * 4) * 4;
   const csn_rsrc_t Rr = csn_make_rsrc(p.q + qs * p.q_shape_stride + head_off, win);
-  const csn_rsrc_t Ar = csn_make_rsrc((BWD ? p.v : p.k) + ks * p.kv_shape_stride + head_off, win);
-  const csn_rsrc_t Br = csn_make_rsrc((BWD ? p.k : p.v) + ks * p.kv_shape_stride + head_off, win);
+  const csn_rsrc_t Ar = csn_make_rsrc((BWD ? p.v : p.k) + ks * p.kv_shape_stride + head_off_kv, win_kv);
+  const csn_rsrc_t Br = csn_make_rsrc((BWD ? p.k : p.v) + ks * p.kv_shape_stride + head_off_kv, win_kv);
   const csn_rsrc_t Or = csn_make_rsrc(p.out + os * p.out_eval_stride + head_off, win);
-  const long long stat_off = ((long long)e * p.H + hd) * ((long long)p.n_blocks * T) + (long long)blk * T;
-  const long long sc_off = (((long long)e * p.H + hd) * p.n_blocks + blk) * ((long long)T * Tp);
+  const long long stat_off = ((long long)e * p.H + hd) * ((long long)p.n_blocks * Tq) + (long long)blk * Tq;
+  const long long sc_off = (((long long)e * p.H + hd) * p.n_blocks + blk) * ((long long)Tq * Tp);
   const bool have_scores = p.scores != nullptr;
-  const csn_rsrc_t Sr = csn_make_rsrc(have_scores ? p.scores + sc_off : nullptr, have_scores ? (long long)T * Tp * 4 : 0);
-  const csn_rsrc_t dSr = csn_make_rsrc(BWD ? p.dscores + sc_off : nullptr, BWD ? (long long)T * Tp * 4 : 0);
+  const csn_rsrc_t Sr = csn_make_rsrc(have_scores ? p.scores + sc_off : nullptr, have_scores ? (long long)Tq * Tp * 4 : 0);
+  const csn_rsrc_t dSr = csn_make_rsrc(BWD ? p.dscores + sc_off : nullptr, BWD ? (long long)Tq * Tp * 4 : 0);
 
   // per-lane byte offsets (scalar offsets handed to the buffer instructions must be wave-uniform, so
   // everything that depends on the lane lives here); lanes of query rows beyond the block are switched off
@@ -128,14 +131,14 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
 #pragma unroll
   for (int i = 0; i < NP_T; ++i) {
     const int idx = tid + 512 * i, row = idx >> 3;
-    t_off[i] = idx < PIECES ? (unsigned)(row * ld + t_c) * 4u : CSN_OOB;
+    t_off[i] = idx < PIECES ? (unsigned)(row * ldk + t_c) * 4u : CSN_OOB;
     a_dst[i] = row * KT + (t_c ^ (16 * (row & 1)));                    // key half swapped on odd rows
     b_dst[i] = row * KT + 4 * ((tid & 7) ^ ((row >> 1) & 7));          // 16-byte chunk ^ (row >> 1) & 7
   }
   f32x4 g[NP_T];
   auto fetch = [&](const csn_rsrc_t& rs, int kt) {
     const int k0 = kt * KT;
-    // T % 4 == 0: a 16-byte piece is all in or all out; pieces past the block end are switched off
+    // pieces past the block end are switched off (a ragged last piece is fetched whole: its extra keys are masked below)
     const unsigned poison = (k0 + t_c) < T ? 0u : CSN_OOB;
 #pragma unroll
     for (int i = 0; i < NP_T; ++i) g[i] = csn_bload4(rs, t_off[i] | poison, (unsigned)k0 * 4u);
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
 template <int DT>
 int launch_dt(const CsnAttnArgs& a, bool bwd, hipStream_t st) {
   const long long units = (long long)a.n_blocks * a.H * a.E;
-  dim3 grid((unsigned)(((units + 7) / 8) * 8 * ((a.T + 127) / 128)));
+  dim3 grid((unsigned)(((units + 7) / 8) * 8 * (((a.Tq > 0 ? a.Tq : a.T) + 127) / 128)));
   if (bwd) hipLaunchKernelGGL((csn_attn_f32_kernel<DT, true>), grid, dim3(512), 0, st, a);
   else hipLaunchKernelGGL((csn_attn_f32_kernel<DT, false>), grid, dim3(512), 0, st, a);
   return (int)hipGetLastError();
@@ -314,7 +317,7 @@ int launch_dt(const CsnAttnArgs& a, bool bwd, hipStream_t st) {
 
 int launch_any(const CsnAttnArgs& a, int d, bool bwd, hipStream_t st) {
   if (a.E <= 0 || a.n_blocks <= 0) return 0;
-  if ((a.T & 3) || (a.ld & 3) || (a.Tp & 3)) return -2;
+  if ((a.ld & 3) || (a.Tp & 3) || (a.ld_kv & 3)) return -2;
   if ((a.q_shape_stride & 3) || (a.kv_shape_stride & 3)) return -4;
   switch (d) {
     case 32: return launch_dt<1>(a, bwd, st);

@@ -118,12 +118,17 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
   return launch_gemm(g, /*b_is_nk=*/0, n_shapes, (hipStream_t)stream);
 }
 
-int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
-                           long long kv_shape_stride, const int* q_index, const int* kv_index, int ld, float* ctx,
-                           long long ctx_eval_stride, float* scores, float* lse, int n_evals, int n_heads,
-                           int d_head, int block, int n_blocks, int score_pitch, float rescale_threshold,
-                           float dropout_p, unsigned long long seed, int qkv_split, long long qkv_plane_stride,
-                           void* stream) {
+static int attn_fwd_impl(const float* q, const float* k, const float* v, long long q_shape_stride,
+                         long long kv_shape_stride, const int* q_index, const int* kv_index, int ld, float* ctx,
+                         long long ctx_eval_stride, float* scores, float* lse, int n_evals, int n_heads,
+                         int d_head, int block, int n_blocks, int score_pitch, float rescale_threshold,
+                         float dropout_p, unsigned long long seed, int qkv_split, long long qkv_plane_stride,
+                         int block_q, int ld_kv, void* stream) {
+  // block_q / ld_kv != 0: the queries of a block are counted separately from its keys (block = keys) and K/V maps have
+  // their own leading dimension; key counts need not be multiples of 4 then (fp32 K/V maps only)
+  const int bq = block_q > 0 ? block_q : block, lk = ld_kv > 0 ? ld_kv : ld;
+  if (block_q < 0 || ld_kv < 0 || (ld_kv & 3) || (long long)n_blocks * ((block + 3) / 4 * 4) > lk) return CSN_E_ARG;
+  if ((block & 3) && (block_q == 0 || qkv_split)) return CSN_E_ALIGN;
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
   if (qkv_split && g_math_mode != 1) return CSN_E_ARG;
   if (qkv_split && (qkv_plane_stride <= 0 || (qkv_plane_stride & 1023) || qkv_plane_stride < (long long)n_blocks * 1024 ||
@@ -131,11 +136,12 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
     return CSN_E_ARG;
   if (!q || !k || !v || !ctx || n_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
   if (!dim_ok(d_head)) return CSN_E_DIM;
-  if ((ld & 3) || (block & 3) || (score_pitch & 3) || score_pitch < block) return CSN_E_ALIGN;
+  if ((ld & 3) || (score_pitch & 3) || score_pitch < (block + 3) / 4 * 4) return CSN_E_ALIGN;
   if (mis16(q) || mis16(k) || mis16(v) || mis16(ctx) || mis16(scores)) return CSN_E_PTR;
   if ((q_shape_stride & 3) || (kv_shape_stride & 3) || (ctx_eval_stride & 3)) return CSN_E_STRIDE;
-  if ((long long)n_blocks * block > ld) return CSN_E_ARG;
+  if ((long long)n_blocks * bq > ld) return CSN_E_ARG;
   CsnAttnArgs a;
+  a.Tq = block_q; a.ld_kv = ld_kv;
   a.q = q; a.k = k; a.v = v;
   a.q_shape_stride = q_shape_stride; a.kv_shape_stride = kv_shape_stride;
   a.kv_ld = (int)qkv_plane_stride;
@@ -151,13 +157,36 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
                           : csn_launch_attn_fwd_f32(a, d_head, (hipStream_t)stream);
 }
 
-int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* k,
-                              const float* v, long long kv_shape_stride, const int* kv_index, int ld, float* scores,
-                              float* dscores, const float* lse, float* delta, float* dq, long long dq_slot_stride,
-                              const int* dq_index, int accumulate, const int* eval_ids, int n_launch_evals, int n_heads,
-                              int d_head, int block, int n_blocks, int score_pitch, float dropout_p,
-                              unsigned long long seed, int dctx_split, long long dctx_plane_stride, int kv_split,
-                              long long kv_plane_stride, int probs_tiles, void* stream) {
+int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
+                           long long kv_shape_stride, const int* q_index, const int* kv_index, int ld, float* ctx,
+                           long long ctx_eval_stride, float* scores, float* lse, int n_evals, int n_heads,
+                           int d_head, int block, int n_blocks, int score_pitch, float rescale_threshold,
+                           float dropout_p, unsigned long long seed, int qkv_split, long long qkv_plane_stride,
+                           void* stream) {
+  return attn_fwd_impl(q, k, v, q_shape_stride, kv_shape_stride, q_index, kv_index, ld, ctx, ctx_eval_stride, scores, lse,
+                       n_evals, n_heads, d_head, block, n_blocks, score_pitch, rescale_threshold, dropout_p, seed, qkv_split,
+                       qkv_plane_stride, 0, 0, stream);
+}
+
+int csn_cross_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
+                           long long kv_shape_stride, int ld_q, int ld_kv, float* ctx, long long ctx_eval_stride,
+                           float* scores, float* lse, int n_evals, int n_heads, int d_head, int n_queries, int n_keys,
+                           int score_pitch, float rescale_threshold, float dropout_p, unsigned long long seed, void* stream) {
+  if (n_queries <= 0 || n_keys <= 0) return CSN_E_ARG;
+  return attn_fwd_impl(q, k, v, q_shape_stride, kv_shape_stride, nullptr, nullptr, ld_q, ctx, ctx_eval_stride, scores, lse,
+                       n_evals, n_heads, d_head, n_keys, 1, score_pitch, rescale_threshold, dropout_p, seed, 0, 0, n_queries,
+                       ld_kv, stream);
+}
+
+static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* k,
+                            const float* v, long long kv_shape_stride, const int* kv_index, int ld, float* scores,
+                            float* dscores, const float* lse, float* delta, float* dq, long long dq_slot_stride,
+                            const int* dq_index, int accumulate, const int* eval_ids, int n_launch_evals, int n_heads,
+                            int d_head, int block, int n_blocks, int score_pitch, float dropout_p,
+                            unsigned long long seed, int dctx_split, long long dctx_plane_stride, int kv_split,
+                            long long kv_plane_stride, int probs_tiles, int block_q, int ld_kv, void* stream) {
+  if (block_q < 0 || ld_kv < 0 || (ld_kv & 3)) return CSN_E_ARG;
+  if ((block & 3) && (block_q == 0 || kv_split)) return CSN_E_ALIGN;
   if (probs_tiles && (g_math_mode != 1 || score_pitch < (block + 31) / 32 * 32)) return CSN_E_ARG;
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
   if (dctx_split) return CSN_E_ARG;                                  // reserved (see header)
@@ -168,7 +197,7 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
   if (!dctx || !ctx || !k || !v || !scores || !dscores || !lse || !delta || !dq) return CSN_E_ARG;
   if (n_launch_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
   if (!dim_ok(d_head)) return CSN_E_DIM;
-  if ((ld & 3) || (block & 3) || (score_pitch & 3) || score_pitch < block) return CSN_E_ALIGN;
+  if ((ld & 3) || (score_pitch & 3) || score_pitch < (block + 3) / 4 * 4) return CSN_E_ALIGN;
   if (mis16(dctx) || mis16(k) || mis16(v) || mis16(scores) || mis16(dscores) || mis16(dq)) return CSN_E_PTR;
   if ((kv_shape_stride & 3) || (ctx_eval_stride & 3) || (dq_slot_stride & 3)) return CSN_E_STRIDE;
   hipStream_t st = (hipStream_t)stream;
@@ -176,6 +205,7 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
   // the dctx columns are being loaded anyway
   CsnAttnArgs a;
   a.ctx = ctx;
+  a.Tq = block_q; a.ld_kv = ld_kv;
   a.q = dctx; a.k = k; a.v = v;
   a.q_shape_stride = dctx_split ? 2 * ctx_eval_stride : ctx_eval_stride;     // split dctx: [eval][2 planes][D][ld]
   a.kv_shape_stride = kv_shape_stride;
@@ -191,43 +221,92 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
   return g_math_mode == 1 ? csn_launch_attn_bwd_bf16x3(a, d_head, st) : csn_launch_attn_bwd_f32(a, d_head, st);
 }
 
+int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* k,
+                              const float* v, long long kv_shape_stride, const int* kv_index, int ld, float* scores,
+                              float* dscores, const float* lse, float* delta, float* dq, long long dq_slot_stride,
+                              const int* dq_index, int accumulate, const int* eval_ids, int n_launch_evals, int n_heads,
+                              int d_head, int block, int n_blocks, int score_pitch, float dropout_p,
+                              unsigned long long seed, int dctx_split, long long dctx_plane_stride, int kv_split,
+                              long long kv_plane_stride, int probs_tiles, void* stream) {
+  return attn_bwd_dq_impl(dctx, ctx, ctx_eval_stride, k, v, kv_shape_stride, kv_index, ld, scores, dscores, lse, delta, dq,
+                          dq_slot_stride, dq_index, accumulate, eval_ids, n_launch_evals, n_heads, d_head, block, n_blocks,
+                          score_pitch, dropout_p, seed, dctx_split, dctx_plane_stride, kv_split, kv_plane_stride, probs_tiles,
+                          0, 0, stream);
+}
+
+static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
+                             const int* q_index, int ld, const float* probs, const float* dscores, float* dk,
+                             float* dv, long long dkv_slot_stride, const int* dk_index, const int* dv_index,
+                             int accumulate, const int* eval_ids, int n_launch_evals, int n_heads, int d_head,
+                             int block, int n_blocks, int score_pitch, int dctx_split, long long dctx_plane_stride,
+                             int q_split, long long q_plane_stride, int probs_tiles, int block_q, int ld_kv, void* stream) {
+  // block_q / ld_kv != 0 (cross-length attention): block counts the keys, block_q (% 4) the queries that are contracted;
+  // dk / dv are [d][ld_kv] maps whose columns block .. round-up-4(block) are written as zeros
+  if (block_q < 0 || ld_kv < 0 || (ld_kv & 3) || (block_q & 3)) return CSN_E_ARG;
+  if ((block & 3) && block_q == 0) return CSN_E_ALIGN;
+  const int bq = block_q > 0 ? block_q : block, lk = ld_kv > 0 ? ld_kv : ld, bk4 = (block + 3) / 4 * 4;
+  if ((long long)n_blocks * bk4 > lk) return CSN_E_ARG;
+  if (probs_tiles && (g_math_mode != 1 || score_pitch < (block + 31) / 32 * 32)) return CSN_E_ARG;
+  if (dctx_split || q_split) return CSN_E_ARG;                       // reserved (see header)
+  if (!dctx || !q || !probs || !dscores || !dk || !dv) return CSN_E_ARG;
+  if (n_launch_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
+  if (!dim_ok(d_head)) return CSN_E_DIM;
+  if ((ld & 3) || (score_pitch & 3) || score_pitch < bk4) return CSN_E_ALIGN;
+  if (mis16(dctx) || mis16(q) || mis16(probs) || mis16(dscores) || mis16(dk) || mis16(dv)) return CSN_E_PTR;
+  if ((q_shape_stride & 3) || (ctx_eval_stride & 3) || (dkv_slot_stride & 3)) return CSN_E_STRIDE;
+  hipStream_t st = (hipStream_t)stream;
+  // dV^T[c][key] (+)= sum_q dO^T[c][q] P[q][key]   and   dK^T[d][key] (+)= sum_q Qs^T[d][q] dS[q][key]
+  // (the score blocks are stored [query][key]: k-major B operands)
+  const long long blk_sc = (long long)bq * score_pitch;
+  CsnGemmArgs g;
+  g.M = d_head; g.N = bk4; g.K = bq;
+  g.n0 = n_blocks; g.n1 = n_heads; g.k_chunk = 0;
+  g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = accumulate; g.eval_ids = eval_ids;
+  g.A = operand(dctx, bq, (long long)d_head * ld, dctx_split ? 2 * ctx_eval_stride : ctx_eval_stride, nullptr, ld);
+  g.A.planes = dctx_split; g.A.plane_stride = dctx_plane_stride;
+  // tile planes: the same buffers viewed as bf16 (two bf16 per float: strides and pitch double)
+  const int bm = probs_tiles ? 2 : 1;
+  g.B = operand(probs, bm * blk_sc, bm * blk_sc * n_blocks, bm * blk_sc * n_blocks * n_heads, nullptr, bm * score_pitch);
+  g.B.planes = probs_tiles ? 2 : 0;
+  g.C = operand(dv, block, (long long)d_head * lk, dkv_slot_stride, dv_index, lk);
+  int rc = launch_gemm(g, 0, n_blocks * n_heads * n_launch_evals, st);
+  if (rc) return rc;
+  g.A = operand(q, bq, (long long)d_head * ld, q_shape_stride, q_index, ld);
+  g.A.planes = q_split; g.A.plane_stride = q_plane_stride;
+  g.B = operand(dscores, bm * blk_sc, bm * blk_sc * n_blocks, bm * blk_sc * n_blocks * n_heads, nullptr, bm * score_pitch);
+  g.B.planes = probs_tiles ? 2 : 0;
+  g.C = operand(dk, block, (long long)d_head * lk, dkv_slot_stride, dk_index, lk);
+  return launch_gemm(g, 0, n_blocks * n_heads * n_launch_evals, st);
+}
+
 int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
                                const int* q_index, int ld, const float* probs, const float* dscores, float* dk,
                                float* dv, long long dkv_slot_stride, const int* dk_index, const int* dv_index,
                                int accumulate, const int* eval_ids, int n_launch_evals, int n_heads, int d_head,
                                int block, int n_blocks, int score_pitch, int dctx_split, long long dctx_plane_stride,
                                int q_split, long long q_plane_stride, int probs_tiles, void* stream) {
-  if (probs_tiles && (g_math_mode != 1 || score_pitch < (block + 31) / 32 * 32)) return CSN_E_ARG;
-  if (dctx_split || q_split) return CSN_E_ARG;                       // reserved (see header)
-  if (!dctx || !q || !probs || !dscores || !dk || !dv) return CSN_E_ARG;
-  if (n_launch_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
-  if (!dim_ok(d_head)) return CSN_E_DIM;
-  if ((ld & 3) || (block & 3) || (score_pitch & 3) || score_pitch < block) return CSN_E_ALIGN;
-  if (mis16(dctx) || mis16(q) || mis16(probs) || mis16(dscores) || mis16(dk) || mis16(dv)) return CSN_E_PTR;
-  if ((q_shape_stride & 3) || (ctx_eval_stride & 3) || (dkv_slot_stride & 3)) return CSN_E_STRIDE;
-  hipStream_t st = (hipStream_t)stream;
-  // dV^T[c][key] (+)= sum_q dO^T[c][q] P[q][key]   and   dK^T[d][key] (+)= sum_q Qs^T[d][q] dS[q][key]
-  // (the score blocks are stored [query][key]: k-major B operands)
-  const long long blk_sc = (long long)block * score_pitch;
-  CsnGemmArgs g;
-  g.M = d_head; g.N = block; g.K = block;
-  g.n0 = n_blocks; g.n1 = n_heads; g.k_chunk = 0;
-  g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = accumulate; g.eval_ids = eval_ids;
-  g.A = operand(dctx, block, (long long)d_head * ld, dctx_split ? 2 * ctx_eval_stride : ctx_eval_stride, nullptr, ld);
-  g.A.planes = dctx_split; g.A.plane_stride = dctx_plane_stride;
-  // tile planes: the same buffers viewed as bf16 (two bf16 per float: strides and pitch double)
-  const int bm = probs_tiles ? 2 : 1;
-  g.B = operand(probs, bm * blk_sc, bm * blk_sc * n_blocks, bm * blk_sc * n_blocks * n_heads, nullptr, bm * score_pitch);
-  g.B.planes = probs_tiles ? 2 : 0;
-  g.C = operand(dv, block, (long long)d_head * ld, dkv_slot_stride, dv_index, ld);
-  int rc = launch_gemm(g, 0, n_blocks * n_heads * n_launch_evals, st);
+  return attn_bwd_dkv_impl(dctx, ctx_eval_stride, q, q_shape_stride, q_index, ld, probs, dscores, dk, dv, dkv_slot_stride,
+                           dk_index, dv_index, accumulate, eval_ids, n_launch_evals, n_heads, d_head, block, n_blocks,
+                           score_pitch, dctx_split, dctx_plane_stride, q_split, q_plane_stride, probs_tiles, 0, 0, stream);
+}
+
+/* cross-length attention backward (MinkowskiNet/models/attention.py: one unchunked block per evaluation, n_queries != n_keys;
+ * gradients flow to queries, keys and values).  n_queries % 4 == 0 (pad with zero points); n_keys arbitrary. */
+int csn_cross_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* q, const float* k,
+                           const float* v, long long q_shape_stride, long long kv_shape_stride, int ld_q, int ld_kv,
+                           float* scores, float* dscores, const float* lse, float* delta, float* dq, float* dk, float* dv,
+                           long long dq_eval_stride, long long dkv_eval_stride, int n_evals, int n_heads, int d_head,
+                           int n_queries, int n_keys, int score_pitch, float dropout_p, unsigned long long seed,
+                           void* stream) {
+  if (n_queries <= 0 || n_keys <= 0 || (n_queries & 3)) return CSN_E_ARG;
+  const int pt = (g_math_mode == 1 && score_pitch >= (n_keys + 31) / 32 * 32) ? 1 : 0;
+  int rc = attn_bwd_dq_impl(dctx, ctx, ctx_eval_stride, k, v, kv_shape_stride, nullptr, ld_q, scores, dscores, lse, delta, dq,
+                            dq_eval_stride, nullptr, 0, nullptr, n_evals, n_heads, d_head, n_keys, 1, score_pitch, dropout_p,
+                            seed, 0, 0, 0, 0, pt, n_queries, ld_kv, stream);
   if (rc) return rc;
-  g.A = operand(q, block, (long long)d_head * ld, q_shape_stride, q_index, ld);
-  g.A.planes = q_split; g.A.plane_stride = q_plane_stride;
-  g.B = operand(dscores, bm * blk_sc, bm * blk_sc * n_blocks, bm * blk_sc * n_blocks * n_heads, nullptr, bm * score_pitch);
-  g.B.planes = probs_tiles ? 2 : 0;
-  g.C = operand(dk, block, (long long)d_head * ld, dkv_slot_stride, dk_index, ld);
-  return launch_gemm(g, 0, n_blocks * n_heads * n_launch_evals, st);
+  return attn_bwd_dkv_impl(dctx, ctx_eval_stride, q, q_shape_stride, nullptr, ld_q, scores, dscores, dk, dv, dkv_eval_stride,
+                           nullptr, nullptr, 0, nullptr, n_evals, n_heads, d_head, n_keys, 1, score_pitch, 0, 0, 0, 0, pt,
+                           n_queries, ld_kv, stream);
 }
 
 int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const float* wfc, const float* xres,

@@ -47,6 +47,8 @@ struct CsnAttnArgs {
   int r_planes, kv_planes;
   long long r_plane_stride, kv_plane_stride;
   int kv_ld;
+  int Tq;                                                // queries per block (0: = T); T counts the keys
+  int ld_kv;                                             // leading dimension of the fp32 K/V maps (0: = ld)
   int sc_tiles;                                          // backward (bf16x3): P and dS leave as bf16 tile planes [query][tile: hi 32 | lo 32]
 };
 int csn_launch_attn_fwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);

@@ -10,62 +10,76 @@ from . import _lib
 from . import functional as CF
 
 
+def _up(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
 class _SDPA(torch.autograd.Function):
+    """softmax(q k^T / temperature) v for (B, H, Tq, d) x (B, H, Tk, d) x (B, H, Tk, d): every (batch, head) pair is one
+    evaluation of the cross-length entry points (csn_cross_attn_fwd_f32 / _bwd_f32); Tq and Tk are arbitrary."""
+
     @staticmethod
     def forward(ctx, q, k, v, temperature: float, p_drop: float = 0.0):
         CF._need_cuda(q, k, v)
-        B, H, T, d = q.shape
+        B, H, Tq, d = q.shape
         Tk = k.shape[2]
-        if T != Tk:
-            raise NotImplementedError("query and key blocks must have the same length")
+        if v.shape[2] != Tk:
+            raise ValueError("keys and values must have the same length")
         S = B * H
-        # channel-major maps [d][T]; the scale divides q before the product (csa_models.py:139)
-        qm = (q / temperature).reshape(S, T, d).transpose(1, 2).contiguous()
-        km = k.reshape(S, T, d).transpose(1, 2).contiguous()
-        vm = v.reshape(S, T, d).transpose(1, 2).contiguous()
-        Tp = (T + 31) // 32 * 32
-        att = torch.empty((S, d, T), device=q.device, dtype=torch.float32)
-        lse = torch.empty((S, 1, T), device=q.device, dtype=torch.float32)
-        scores = torch.empty((S, 1, 1, T, Tp), device=q.device, dtype=torch.float32)
+        Tq4, Tk4, Tp = _up(Tq, 4), _up(Tk, 4), _up(Tk, 32)
+
+        def cm(x, T, Tpad, scale=1.0):     # channel-major maps [d][T], zero points appended up to a multiple of 4
+            out = torch.zeros((S, d, Tpad), device=x.device, dtype=torch.float32)
+            out[:, :, :T] = (x / scale if scale != 1.0 else x).reshape(S, T, d).transpose(1, 2)
+            return out
+
+        qm = cm(q, Tq, Tq4, temperature)   # the scale divides q before the product (csa_models.py:139)
+        km, vm = cm(k, Tk, Tk4), cm(v, Tk, Tk4)
+        att = torch.empty((S, d, Tq4), device=q.device, dtype=torch.float32)
+        lse = torch.empty((S, 1, Tq4), device=q.device, dtype=torch.float32)
+        scores = torch.empty((S, 1, Tq4, Tp), device=q.device, dtype=torch.float32)
         L = _lib.lib()
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_drop > 0 else 0
-        _lib.check(L.csn_block_attn_fwd_f32(CF._ptr(qm), CF._ptr(km), CF._ptr(vm), d * T, d * T, None, None, T,
-                                            CF._ptr(att), d * T, CF._ptr(scores), CF._ptr(lse), S, 1, d, T, 1, Tp,
-                                            CF.RESCALE_THRESHOLD, p_drop, seed, 0, 0, CF._stream()), "csn_block_attn_fwd_f32")
+        _lib.check(L.csn_cross_attn_fwd_f32(CF._ptr(qm), CF._ptr(km), CF._ptr(vm), d * Tq4, d * Tk4, Tq4, Tk4, CF._ptr(att),
+                                            d * Tq4, CF._ptr(scores), CF._ptr(lse), S, 1, d, Tq4, Tk, Tp, CF.RESCALE_THRESHOLD,
+                                            p_drop, seed, CF._stream()), "csn_cross_attn_fwd_f32")
         # P[q][key] = exp(S[q][key] - lse[q])   (the un-dropped probabilities; with dropout the reference returns the
         # dropped ones — every caller in the reference discards this tensor)
-        prob = torch.exp(scores[:, 0, 0, :, :T] - lse[:, 0, :, None]).reshape(B, H, T, T)
+        prob = torch.exp(scores[:, 0, :Tq, :Tk] - lse[:, 0, :Tq, None]).reshape(B, H, Tq, Tk)
         ctx.save_for_backward(qm, km, vm, att, lse, scores)
         ctx.temperature = temperature
         ctx.drop = (p_drop, seed)
-        ctx.dims = (B, H, T, d, Tp)
+        ctx.dims = (B, H, Tq, Tk, d, Tp)
         ctx.mark_non_differentiable(prob)
-        return att.transpose(1, 2).reshape(B, H, T, d), prob
+        return att[:, :, :Tq].transpose(1, 2).reshape(B, H, Tq, d), prob
 
     @staticmethod
     def backward(ctx, dout, _dprob):
         qm, km, vm, att, lse, scores = ctx.saved_tensors
-        B, H, T, d, Tp = ctx.dims
+        B, H, Tq, Tk, d, Tp = ctx.dims
         S = B * H
-        datt = dout.reshape(S, T, d).transpose(1, 2).contiguous()
-        dq, dk, dv = (torch.empty((S, d, T), device=dout.device, dtype=torch.float32) for _ in range(3))
+        Tq4, Tk4 = qm.shape[2], km.shape[2]
+        datt = torch.zeros((S, d, Tq4), device=dout.device, dtype=torch.float32)
+        datt[:, :, :Tq] = dout.reshape(S, Tq, d).transpose(1, 2)
+        dq = torch.empty((S, d, Tq4), device=dout.device, dtype=torch.float32)
+        dk, dv = (torch.empty((S, d, Tk4), device=dout.device, dtype=torch.float32) for _ in range(2))
         work = scores.clone()                      # backward overwrites the scores with the (dropped) probabilities
         dscores = torch.empty_like(scores)
-        delta = torch.empty((S, 1, T), device=dout.device, dtype=torch.float32)
+        delta = torch.empty((S, 1, Tq4), device=dout.device, dtype=torch.float32)
         L = _lib.lib()
-        _lib.check(L.csn_block_attn_bwd_dq_f32(CF._ptr(datt), CF._ptr(att), d * T, CF._ptr(km), CF._ptr(vm), d * T, None, T,
-                                               CF._ptr(work), CF._ptr(dscores), CF._ptr(lse), CF._ptr(delta), CF._ptr(dq),
-                                               d * T, None, 0, None, S, 1, d, T, 1, Tp, ctx.drop[0], ctx.drop[1], 0, 0, 0, 0, 0,
-                                               CF._stream()), "csn_block_attn_bwd_dq_f32")
-        _lib.check(L.csn_block_attn_bwd_dkv_f32(CF._ptr(datt), d * T, CF._ptr(qm), d * T, None, T, CF._ptr(work),
-                                                CF._ptr(dscores), CF._ptr(dk), CF._ptr(dv), d * T, None, None, 0, None, S, 1,
-                                                d, T, 1, Tp, 0, 0, 0, 0, 0, CF._stream()), "csn_block_attn_bwd_dkv_f32")
-        back = lambda g: g.transpose(1, 2).reshape(B, H, T, d)
-        return back(dq) / ctx.temperature, back(dk), back(dv), None, None
+        _lib.check(L.csn_cross_attn_bwd_f32(CF._ptr(datt), CF._ptr(att), d * Tq4, CF._ptr(qm), CF._ptr(km), CF._ptr(vm), d * Tq4,
+                                            d * Tk4, Tq4, Tk4, CF._ptr(work), CF._ptr(dscores), CF._ptr(lse), CF._ptr(delta),
+                                            CF._ptr(dq), CF._ptr(dk), CF._ptr(dv), d * Tq4, d * Tk4, S, 1, d, Tq4, Tk, Tp,
+                                            ctx.drop[0], ctx.drop[1], CF._stream()), "csn_cross_attn_bwd_f32")
+        back = lambda g, T: g[:, :, :T].transpose(1, 2).reshape(B, H, T, d)
+        return back(dq, Tq) / ctx.temperature, back(dk, Tk), back(dv, Tk), None, None
 
 
 def sdpa_block(q, k, v, temperature: float, p_drop: float = 0.0):
     return _SDPA.apply(q, k, v, temperature, float(p_drop))
+
+
+sdpa_cross = sdpa_block        # same entry: query and key counts may differ (MinkowskiNet/models/attention.py:59-73)
 
 
 def last_block_probabilities(mha, Q, K):

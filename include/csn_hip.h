@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSN_ABI_VERSION 5
+#define CSN_ABI_VERSION 6
 
 #define CSN_E_ARG (-1)     /* null pointer / non-positive size            */
 #define CSN_E_ALIGN (-2)   /* a size or leading dimension is not % 4      */
@@ -125,6 +125,28 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
                                int accumulate, const int* eval_ids, int n_launch_evals, int n_heads, int d_head,
                                int block, int n_blocks, int score_pitch, int dctx_split, long long dctx_plane_stride,
                                int q_split, long long q_plane_stride, int probs_tiles, void* stream);
+
+/* ---- (3b) cross-length attention: one unchunked block per evaluation, n_queries != n_keys -------------
+ * The MinkowskiNet variant of the layer (MinkowskiNet/models/attention.py:31-75, used per shape pair by
+ * MinkowskiNet/models/hrnet.py:378-410, 456-470): softmax(Qs K^T) V over ALL keys of the other shape, gradients flowing
+ * to queries, keys and values.  Same kernels as (2)/(3) with n_blocks = 1 and separate query / key counts:
+ *   q, ctx, dctx, dq : [n_evals][n_heads*d_head][ld_q]   (n_queries <= ld_q)
+ *   k, v, dk, dv     : [n_evals][n_heads*d_head][ld_kv]  (round-up-4(n_keys) <= ld_kv; the padding columns of dk / dv
+ *                                                          are written as zeros)
+ *   scores, dscores  : [n_evals][n_heads][n_queries][score_pitch], score_pitch >= round-up-4(n_keys) (32 in math mode 1)
+ *   lse, delta       : [n_evals][n_heads][n_queries]
+ * n_keys is arbitrary; n_queries must be a multiple of 4 in the backward (pad with zero points: their rows cost nothing
+ * and contribute nothing).  Evaluation e reads maps e (no slot indices, no accumulation). */
+int csn_cross_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
+                           long long kv_shape_stride, int ld_q, int ld_kv, float* ctx, long long ctx_eval_stride,
+                           float* scores, float* lse, int n_evals, int n_heads, int d_head, int n_queries, int n_keys,
+                           int score_pitch, float rescale_threshold, float dropout_p, unsigned long long seed, void* stream);
+int csn_cross_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* q, const float* k,
+                           const float* v, long long q_shape_stride, long long kv_shape_stride, int ld_q, int ld_kv,
+                           float* scores, float* dscores, const float* lse, float* delta, float* dq, float* dk, float* dv,
+                           long long dq_eval_stride, long long dkv_eval_stride, int n_evals, int n_heads, int d_head,
+                           int n_queries, int n_keys, int score_pitch, float dropout_p, unsigned long long seed,
+                           void* stream);
 
 /* ---- (4) output projection + residual + LayerNorm, forward -------------------------------------------
  * z[c][n] = sum_D wfc[c][D] ctx[e][D][n] + xres[res_index[e]][c][n];  xhat = (z - mean_c z) * rstd,

@@ -164,6 +164,35 @@ def mha_full_self(x: torch.Tensor, p: Params, n_head: int, d_k: int, d_v: int,
 
 
 # ------------------------------------------------------------------------------------------------
+# the MinkowskiNet variant, MultiHeadAttention.forward of MinkowskiNet/models/attention.py:31-56
+# (+ ScaledDotProductAttention :68-73).  That file imports MinkowskiEngine at module level (absent here), so it cannot be
+# run: this is a restatement only — "parity unpinned" against the reference itself; it IS pinned against the MID-FC
+# restatement above (same arithmetic, tests/test_oracle_golden.py::test_pointmajor_mha_equals_full_self).
+# ------------------------------------------------------------------------------------------------
+def mha_pointmajor(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, p: Params, n_head: int, d_k: int, d_v: int,
+                   prefix: str = "attention.", attn_mask: Optional[torch.Tensor] = None, p_attn: float = 0.0,
+                   out_mask: Optional[torch.Tensor] = None, p_out: float = 0.0):
+    """q (b, lq, C), k / v (b, lk, C) point-major -> (out (b, lq, C), attn (b, H, lq, lk)).
+    attn_mask / out_mask: optional keep-masks standing in for the two nn.Dropout layers (:70, :50)."""
+    b, lq, _ = q.shape
+    lk = k.shape[1]
+    residual = q                                                                          # :35
+    qh = (q @ p[prefix + "w_qs.weight"].t()).view(b, lq, n_head, d_k).transpose(1, 2)       # :39, :44
+    kh = (k @ p[prefix + "w_ks.weight"].t()).view(b, lk, n_head, d_k).transpose(1, 2)       # :40
+    vh = (v @ p[prefix + "w_vs.weight"].t()).view(b, lk, n_head, d_v).transpose(1, 2)       # :41
+    attn = torch.softmax((qh / (d_k ** 0.5)) @ kh.transpose(2, 3), dim=-1)                  # :68-70
+    if attn_mask is not None:
+        attn = attn * attn_mask / (1.0 - p_attn)
+    o = (attn @ vh).transpose(1, 2).contiguous().view(b, lq, -1)                            # :71, :50
+    o = o @ p[prefix + "fc.weight"].t()                                                     # :51
+    if out_mask is not None:
+        o = o * out_mask / (1.0 - p_out)
+    o = o + residual                                                                        # :52
+    o = torch.nn.functional.layer_norm(o, (o.shape[-1],), p[prefix + "norm.weight"], p[prefix + "norm.bias"], 1e-6)   # :54
+    return o, attn
+
+
+# ------------------------------------------------------------------------------------------------
 # a4/a5  CrossShapeAt.get_ssa_feats / get_csa_feats  (csa_models.py:204-242)
 # ------------------------------------------------------------------------------------------------
 def ssa_feats(x: torch.Tensor, p: Params, n_head: int, mha=mha_blockdiag, **kw) -> torch.Tensor:

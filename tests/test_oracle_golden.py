@@ -178,3 +178,18 @@ def test_compat_layout_is_the_reference_one_for_batches():
     uk = torch.nn.functional.normalize(torch.nn.functional.linear(keys, p["compatibility_k.weight"], p["compatibility_k.bias"]), dim=-1)
     ref = torch.softmax(torch.einsum("bc,bkc->bk", uq, uk), dim=-1)
     assert torch.allclose(a, ref, atol=1e-7)
+
+
+def test_pointmajor_mha_equals_full_self():
+    """The MinkowskiNet restatement (oracle.mha_pointmajor) on q = k = v reproduces the MID-FC unchunked self-attention
+    restatement, which the G2 goldens pin to the reference."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    H, C, N = 4, 256, 96
+    p = orc.make_params(rng, H, d_model=C, d_k=C // H, d_v=C // H)
+    x = orc.synth_points(rng, (2, C, N, 1))
+    ref = orc.mha_full_self(x, p, H, C // H, C // H)                       # (B, N, C)
+    pts = x.squeeze(-1).permute(0, 2, 1).contiguous()                      # (B, N, C) point-major
+    out, attn = orc.mha_pointmajor(pts, pts, pts, p, H, C // H, C // H)
+    assert (out - ref).abs().max().item() < 2e-5
+    assert attn.shape == (2, H, N, N) and (attn.sum(-1) - 1).abs().max().item() < 1e-5
