@@ -133,6 +133,33 @@ def test_three_distinct_inputs():
     assert (y.detach().cpu() - ref.detach()).abs().max().item() < ATOL
 
 
+def test_config5_channel_count_96_forward_backward():
+    """BASELINE config 5 geometry (C = D = 96, blocks of 500): self and cross evaluations with weight gradients against the
+    oracle's closed form — in bf16x3 mode this drives the K/V tile planes with a head dimension that does not fill the
+    staging threads evenly (768 pieces on 512 threads)."""
+    from csn_amd.csa_models import MultiHeadAttention
+    rng = np.random.default_rng(16)
+    C, H, T, nb = 96, 1, 500, 4
+    N = T * nb
+    p = orc.make_params(rng, H, d_model=C, d_k=C, d_v=C, csa=False)
+    m = MultiHeadAttention(H, C, C, C, block=T, n_blocks=nb).cuda().eval()
+    m.load_state_dict({k[len("attention."):]: v for k, v in p.items() if k.startswith("attention.")})
+    xa, xb = (orc.synth_points(rng, (2, C, N, 1)) for _ in range(2))
+    ys, _ = m(xa.cuda(), xa.cuda(), xa.cuda(), "test")
+    yc, _ = m(xa.cuda(), xb.cuda(), xb.cuda(), "test")
+    gs, gc = (torch.from_numpy(rng.standard_normal((2, N, C)).astype(np.float32)) for _ in range(2))
+    ((ys * gs.cuda()).sum() + (yc * gc.cuda()).sum()).backward()
+    p64 = {k: v.double().requires_grad_(True) for k, v in p.items() if k.startswith("attention.")}
+    rs = orc.mha_blockdiag(xa.double(), xa.double(), xa.double(), p64, H, d_k=C, d_v=C, block=T, n_blocks=nb)
+    rc = orc.mha_blockdiag(xa.double(), xb.double(), xb.double(), p64, H, d_k=C, d_v=C, block=T, n_blocks=nb)
+    ((rs * gs.double()).sum() + (rc * gc.double()).sum()).backward()
+    assert (ys.detach().cpu().double() - rs.detach()).abs().max().item() < ATOL
+    assert (yc.detach().cpu().double() - rc.detach()).abs().max().item() < ATOL
+    for name, prm in m.named_parameters():
+        ref = p64["attention." + name].grad
+        assert ((prm.grad.cpu().double() - ref).abs().max() / ref.abs().max()).item() < 2e-4, name
+
+
 def _grad_check(model, g, key, expect):
     seen = 0
     for name, prm in model.named_parameters():
