@@ -69,6 +69,7 @@ struct CsnOutProjArgs {
   unsigned long long seed;
 };
 int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, int fast, hipStream_t st);   // fast: bf16x3 contraction
+int csn_launch_outproj_ln_big(const CsnOutProjArgs& a, hipStream_t st);                 // gemm_bf16x3.hip: C = 256, 256 x 256 tiles
 
 struct CsnLnBwdArgs {
   const float* dxhat; const float* xhat; const float* rstd;   // [e][C][ld], [e][C][ld], [e][n_points]

@@ -324,9 +324,13 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
 // thread and slab.  Waves: 4 (M) x 2 (N), 64 x 128 accumulators each (128 registers).  LDS: k-contiguous planes are not
 // padded but XOR-swizzled (16-byte unit u of row r lives at u ^ ((r >> 2) & 3): conflict-free 16-byte fragment reads),
 // 128 KB (136 KB with a k-major B) for two stages.
-template <bool B_NK, bool BT>
-__global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs p) {
+// LN: the out-projection of the attention layer (csa_models.py:114-118) — M = d_model = 256 is exactly one tile, so the
+// epilogue can apply the fc dropout, add the residual and LayerNorm every point over its 256 channels (per-point sums are
+// combined across the four M-waves through LDS) before anything is written: C = xhat, q carries the epilogue's operands.
+template <bool B_NK, bool BT, bool LN = false>
+__global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs p, CsnOutProjArgs q) {
   static_assert(!BT || !B_NK, "tile-plane B is k-major");
+  static_assert(!LN || (!B_NK && !BT), "LayerNorm epilogue: W_fc (MK) x Ctx^T (KN)");
   constexpr int BM = 256, BN = 256, MT = 2, NT = 4;
   constexpr int PN = BN + 32;                           // pitch of the k-major B planes
   constexpr int A_EL = BM * BK, B_EL = B_NK ? BN * BK : BK * PN;
@@ -485,6 +489,69 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
     __syncthreads();
   }
 
+  if constexpr (LN) {
+    // ---- fc dropout, + residual, LayerNorm over the 256 channels of each point, write xhat and rstd ------------------
+    float* red = reinterpret_cast<float*>(&As[0][0][0]);            // [2][4 M-waves][256 points] (the tile loop is over)
+    const int wmi = wave >> 1;
+    const long long rs = q.res_index ? q.res_index[z2] : z2;
+    const csn_rsrc_t Rr = csn_make_rsrc(q.xres + rs * q.xres_shape_stride + n0, ((long long)(BM - 1) * ldc + (N - n0)) * 4);
+    const bool drop = q.dropout_p > 0.f;
+    const unsigned thr24 = csn_drop_threshold(q.dropout_p);
+    const float keep_scale = drop ? 1.f / (1.f - q.dropout_p) : 1.f;
+    float mean[NT], rstd[NT];
+    unsigned voff[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int nl = wn0 + 32 * j + l31;
+      voff[j] = (n0 + nl) < N ? (unsigned)(4 * h * ldc + nl) * 4u : CSN_OOB;
+      const long long ebase = (long long)z2 * q.xhat_eval_stride + n0 + nl;
+      float s1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm0 + 32 * i + csn_acc_row(r, 0);         // + 4 h lives in the lane offset
+          float v = acc[i][j][r];
+          if (drop) v = csn_keep((unsigned long long)(ebase + (long long)(row + 4 * h) * ldc), q.seed, thr24) ? v * keep_scale : 0.f;
+          v += csn_bload(Rr, voff[j], (unsigned)row * (unsigned)ldc * 4u);
+          acc[i][j][r] = v;
+          s1 += v;
+        }
+      s1 += csn_xhalf(s1);
+      if (h == 0) red[wmi * 256 + nl] = s1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int nl = wn0 + 32 * j + l31;
+      mean[j] = (red[nl] + red[256 + nl] + red[512 + nl] + red[768 + nl]) * (1.f / BM);
+      float s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float dl = acc[i][j][r] - mean[j];
+          s2 += dl * dl;
+        }
+      s2 += csn_xhalf(s2);
+      if (h == 0) red[1024 + wmi * 256 + nl] = s2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int nl = wn0 + 32 * j + l31;
+      rstd[j] = 1.f / sqrtf((red[1024 + nl] + red[1280 + nl] + red[1536 + nl] + red[1792 + nl]) * (1.f / BM) + q.eps);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          csn_bstore((acc[i][j][r] - mean[j]) * rstd[j], Cr, voff[j],
+                     (unsigned)(wm0 + 32 * i + csn_acc_row(r, 0)) * (unsigned)ldc * 4u);
+      if (wmi == 0 && h == 0 && (n0 + nl) < N) q.rstd[(long long)z2 * q.n_points + n0 + nl] = rstd[j];
+    }
+    return;
+  }
+
   // epilogue, one 32 x 32 accumulator tile at a time (offsets are not kept: the accumulators own the registers)
   const float alpha = p.alpha;
   const int Tb = (int)p.C.plane_stride;
@@ -530,13 +597,15 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
   }
 }
 
-template <bool B_NK, bool BT = false>
-int launch_big(const CsnGemmArgs& a, int batch, hipStream_t st) {
+template <bool B_NK, bool BT = false, bool LN = false>
+int launch_big(const CsnGemmArgs& a, int batch, hipStream_t st, const CsnOutProjArgs* ln = nullptr) {
   CsnGemmArgs b = a;
   b.batch = batch;
   const long long tiles = (long long)((a.N + 255) / 256) * ((a.M + 255) / 256);
   dim3 grid((unsigned)(((batch + 7) / 8) * 8 * tiles));
-  hipLaunchKernelGGL((csn_gemm_bf16x3_big_kernel<B_NK, BT>), grid, dim3(512), 0, st, b);
+  CsnOutProjArgs q{};
+  if (ln) q = *ln;
+  hipLaunchKernelGGL((csn_gemm_bf16x3_big_kernel<B_NK, BT, LN>), grid, dim3(512), 0, st, b, q);
   return (int)hipGetLastError();
 }
 
@@ -554,6 +623,19 @@ int launch(const CsnGemmArgs& a, int batch, hipStream_t st) {
 
 int csn_gemm_big_tiles = 1;      // development switch (csn_debug_set_big_tiles)
 extern "C" void csn_debug_set_big_tiles(int on) { csn_gemm_big_tiles = on; }
+
+// out-projection + residual + LayerNorm for d_model = 256 on the 256 x 256 tiles (math mode 1): xhat = LN(W_fc Ctx^T (+drop) + x)
+int csn_launch_outproj_ln_big(const CsnOutProjArgs& a, hipStream_t st) {
+  if (a.C != 256 || (a.D & 3) || (a.ld & 3) || (a.n_points & 3)) return -5;
+  CsnGemmArgs g;
+  g.A = CsnOperand{const_cast<float*>(a.wfc), 0, 0, 0, nullptr, a.D, 0, 0};
+  g.B = CsnOperand{const_cast<float*>(a.ctx), 0, 0, a.ctx_eval_stride, nullptr, a.ld, 0, 0};
+  g.C = CsnOperand{a.xhat, 0, 0, a.xhat_eval_stride, nullptr, a.ld, 0, 0};
+  g.M = 256; g.N = a.n_points; g.K = a.D;
+  g.n0 = 1; g.n1 = 1; g.k_chunk = 0;
+  g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = 0; g.eval_ids = nullptr;
+  return launch_big<false, false, true>(g, a.E, st, &a);
+}
 
 int csn_launch_gemm_bf16x3(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st) {
   if (a.C.planes && a.accumulate) return -1;

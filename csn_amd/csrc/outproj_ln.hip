@@ -396,6 +396,7 @@ int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, int fast, hipStream_t
   if (a.E <= 0 || a.n_points <= 0) return 0;
   if ((a.ld & 3) || (a.D & 3) || (a.n_points & 3)) return -2;
   if ((a.ctx_eval_stride & 3) || (a.xres_shape_stride & 3) || (a.xhat_eval_stride & 3)) return -4;
+  if (fast && a.C == 256 && a.n_points >= 224) return csn_launch_outproj_ln_big(a, st);     // 256 x 256 tiles (gemm_bf16x3.hip)
   switch (a.C) {
     case 32: return launch_fwd<1>(a, fast, st);
     case 64: return launch_fwd<2>(a, fast, st);
