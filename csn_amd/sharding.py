@@ -40,7 +40,11 @@ class ShapeGraphShard:
         if (own == np.arange(self.first, self.first + shapes_per_rank)[:, None]).any():
             raise ValueError("a shape may not be its own neighbour (slot 0 already is the shape itself)")
         self.local_graph = torch.from_numpy(own).to(device)                   # (B, K) global shape ids
+        # slot table of the neighbour stack: row b = [own shape b, its K neighbours] as global shape ids
+        ids = np.concatenate((np.arange(self.first, self.first + shapes_per_rank)[:, None], own), axis=1)
+        self.stack_ids = torch.from_numpy(ids.reshape(-1)).to(device)          # (B * (K+1),)
         self._gathered: Optional[torch.Tensor] = None
+        self._stack: Optional[torch.Tensor] = None
 
     # -- the one data-path collective ----------------------------------------------------------------------
     def exchange(self, feats: torch.Tensor) -> torch.Tensor:
@@ -55,8 +59,16 @@ class ShapeGraphShard:
     def neighbour_stack(self, feats: torch.Tensor, collection: torch.Tensor) -> torch.Tensor:
         """(B, K+1, C, N, 1) exactly as CSADatasetK hands it to the model (features_data_loader.py:124-140):
         slot 0 = the shape itself, slots 1..K = its neighbours in graph order."""
-        nb = collection[self.local_graph]                                      # (B, K, C, N)
-        return torch.cat((feats[:, None], nb), dim=1).unsqueeze(-1)
+        if self.world == 1 or collection.shape[0] != self.S:
+            nb = collection[self.local_graph]                                  # (B, K, C, N)
+            return torch.cat((feats[:, None], nb), dim=1).unsqueeze(-1)
+        # one indexed gather out of the all-gathered collection (slot 0 is the rank's own copy inside it): a single pass over
+        # the 1.3 GB stack instead of a gather plus a concatenation
+        shape = (self.B * (self.K + 1),) + tuple(collection.shape[1:])
+        if self._stack is None or self._stack.shape != shape or self._stack.dtype != collection.dtype:
+            self._stack = torch.empty(shape, device=collection.device, dtype=collection.dtype)
+        torch.index_select(collection, 0, self.stack_ids, out=self._stack)
+        return self._stack.view((self.B, self.K + 1) + tuple(collection.shape[1:])).unsqueeze(-1)
 
     # -- gradient reduction ------------------------------------------------------------------------------------
     def allreduce_grads(self, params: Iterable[torch.nn.Parameter], average: bool = True) -> None:
