@@ -435,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     const int cur = kt & 1, nxt = cur ^ 1;
     const bool more = kt + 1 < nkt;
 #ifdef CSN_STAMPS
-    const bool dbg_on = !BWD && DT == 8 && blockIdx.x < 2048 && kt >= 4 && kt < 8;
+    const bool dbg_on = (BWD == (CSN_STAMPS != 0)) && DT == 8 && blockIdx.x < 2048 && kt >= 4 && kt < 8;   // -DCSN_STAMPS=0: forward, =1: backward
 #endif
     STAMP(0);
     load_sv(kt);

@@ -23,6 +23,13 @@ for _ in range(2):
     _lib.check(L.csn_block_attn_fwd_f32(base, kp, kp + 2 * D * nb * 1024, 3 * D * NP, 2 * D * nb * 1024, CF._ptr(qs), CF._ptr(ks), NP,
                                         CF._ptr(att), D * NP, CF._ptr(scores), CF._ptr(lse), E, H, d, T, nb, Tp, 8.0, 0.1, 1234, 1, nb * 1024,
                                         CF._stream()), "fwd")
+if os.environ.get("CSN_STAMP_BWD") == "1":       # library built with -DCSN_STAMPS=1: stamps come from the backward (dq) kernel
+    datt = torch.randn((E, D, NP), device="cuda")
+    dscores = torch.empty_like(scores); delta = torch.empty((E, H, NP), device="cuda"); dq = torch.empty((E, D, NP), device="cuda")
+    _lib.check(L.csn_block_attn_bwd_dq_f32(CF._ptr(datt), CF._ptr(att), D * NP, kp, kp + 2 * D * nb * 1024, 2 * D * nb * 1024,
+                                           CF._ptr(ks), NP, CF._ptr(scores), CF._ptr(dscores), CF._ptr(lse), CF._ptr(delta),
+                                           CF._ptr(dq), D * NP, None, 0, None, E, H, d, T, nb, Tp, 0.1, 1234, 0, 0, 1, nb * 1024, 1,
+                                           CF._stream()), "dq")
 torch.cuda.synchronize()
 n = 2048 * 8 * 4 * 8
 buf = np.zeros(n, dtype=np.uint64)

@@ -32,6 +32,7 @@ def to_tiles(kv, T, nb):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tiles", action="store_true", help="K/V as bf16 tile planes (math mode 1)")
+    ap.add_argument("--noscores", action="store_true", help="forward without saving the scores (inference form)")
     ap.add_argument("--evals", type=int, default=128)
     ap.add_argument("--slots", type=int, default=32)
     ap.add_argument("--mode", type=int, default=1)
@@ -68,7 +69,7 @@ def main():
         tl = a.tiles and L.csn_get_math_mode() == 1
         _lib.check(L.csn_block_attn_fwd_f32(base, k_ptr if tl else base + 4 * D * NP, v_ptr if tl else base + 8 * D * NP,
                                             3 * D * NP, kv_stride if tl else 3 * D * NP, CF._ptr(qs),
-                                            CF._ptr(ks), NP, CF._ptr(att), D * NP, CF._ptr(scores), CF._ptr(lse), E, H, d, T,
+                                            CF._ptr(ks), NP, CF._ptr(att), D * NP, None if a.noscores else CF._ptr(scores), CF._ptr(lse), E, H, d, T,
                                             nb, Tp, 8.0, a.drop, seed, kvf if tl else 0, kvp if tl else 0, st), "fwd")
 
     def dq():
