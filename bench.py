@@ -153,12 +153,16 @@ def main():
         shard = ShapeGraphShard(regular_graph(S, K), B, rank, world, dev)
 
     attn_events = []
+    exchange_mode = os.environ.get("CSN_EXCHANGE", "allgather")          # "alltoall": neighbour-only exchange (sharding.py)
 
     def step(record=False):
         for p in params:
             p.grad = None
         if shard is not None:
-            x_nb = shard.neighbour_stack(feats, shard.exchange(feats))   # all-gather of point features over xGMI
+            if exchange_mode == "alltoall":
+                x_nb = shard.exchange_neighbours(feats)                  # neighbour-only all-to-all (opt-in)
+            else:
+                x_nb = shard.neighbour_stack(feats, shard.exchange(feats))   # all-gather of point features over xGMI
         else:
             x_nb = x_nb_resident                                         # (B, K+1, C, N, 1), slot 0 = self
         if record:

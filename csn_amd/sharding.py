@@ -45,6 +45,31 @@ class ShapeGraphShard:
         self.stack_ids = torch.from_numpy(ids.reshape(-1)).to(device)          # (B * (K+1),)
         self._gathered: Optional[torch.Tensor] = None
         self._stack: Optional[torch.Tensor] = None
+        # neighbour-only exchange plan (the same on every rank: it is a function of the global graph).  need[r][s] = sorted
+        # global ids of the shapes owned by rank s that some shape of rank r has as a neighbour (s != r)
+        B = shapes_per_rank
+        need = [[np.zeros(0, np.int64) for _ in range(world)] for _ in range(world)]
+        for r in range(world):
+            nb = np.unique(graph[r * B:(r + 1) * B].reshape(-1))
+            for src in range(world):
+                if src != r:
+                    need[r][src] = nb[(nb >= src * B) & (nb < (src + 1) * B)]
+        self._send_ids = torch.from_numpy(np.concatenate([need[r][rank] - self.first for r in range(world)])).to(device)
+        self._send_splits = [int(need[r][rank].size) for r in range(world)]
+        self._recv_splits = [int(need[rank][src].size) for src in range(world)]
+        recv_ids = np.concatenate([need[rank][src] for src in range(world)])          # global ids in arrival order
+        # neighbour-stack slots (b, k >= 1): row of the pool [received shapes ; own shapes] that fills them
+        pos = {int(g): i for i, g in enumerate(recv_ids)}
+        n_recv = int(recv_ids.size)
+        pool_rows = np.empty((B, K + 1), np.int64)
+        pool_rows[:, 0] = n_recv + np.arange(B)
+        for b in range(B):
+            for k in range(K):
+                g = int(own[b, k])
+                pool_rows[b, k + 1] = n_recv + (g - self.first) if self.first <= g < self.first + B else pos[g]
+        self._pool_rows = torch.from_numpy(pool_rows.reshape(-1)).to(device)
+        self._n_recv = n_recv
+        self._pool: Optional[torch.Tensor] = None
 
     # -- the one data-path collective ----------------------------------------------------------------------
     def exchange(self, feats: torch.Tensor) -> torch.Tensor:
@@ -55,6 +80,25 @@ class ShapeGraphShard:
             self._gathered = torch.empty((self.S,) + tuple(feats.shape[1:]), device=feats.device, dtype=feats.dtype)
         dist.all_gather_into_tensor(self._gathered, feats.contiguous())
         return self._gathered
+
+    def exchange_neighbours(self, feats: torch.Tensor) -> torch.Tensor:
+        """Neighbour-only form of exchange + neighbour_stack: every rank sends each other rank only the shapes that rank's
+        graph rows reference (one all-to-all with uneven splits: at 8 ranks and K = 3 at most 96 of the 224 remote shapes),
+        and the (B, K+1, C, N, 1) stack is gathered out of [received ; own].  Opt-in (bench: CSN_EXCHANGE=alltoall)."""
+        if self.world == 1:
+            raise ValueError("exchange_neighbours needs world > 1")
+        tail = tuple(feats.shape[1:])
+        if self._pool is None or self._pool.shape[1:] != tail or self._pool.dtype != feats.dtype:
+            self._pool = torch.empty((self._n_recv + self.B,) + tail, device=feats.device, dtype=feats.dtype)
+        send = feats.index_select(0, self._send_ids) if self._send_ids.numel() else feats[:0]
+        recv = self._pool[:self._n_recv]
+        dist.all_to_all_single(recv, send.contiguous(), self._recv_splits, self._send_splits)
+        self._pool[self._n_recv:].copy_(feats)
+        shape = (self.B * (self.K + 1),) + tail
+        if self._stack is None or self._stack.shape != shape or self._stack.dtype != feats.dtype:
+            self._stack = torch.empty(shape, device=feats.device, dtype=feats.dtype)
+        torch.index_select(self._pool, 0, self._pool_rows, out=self._stack)
+        return self._stack.view((self.B, self.K + 1) + tail).unsqueeze(-1)
 
     def neighbour_stack(self, feats: torch.Tensor, collection: torch.Tensor) -> torch.Tensor:
         """(B, K+1, C, N, 1) exactly as CSADatasetK hands it to the model (features_data_loader.py:124-140):

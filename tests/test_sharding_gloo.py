@@ -51,6 +51,7 @@ def _worker(rank, world, port, out_dir):
     for b in range(B_PER_RANK):
         for k in range(K):
             assert torch.equal(stack[b, k + 1, :, :, 0], feats[graph[lo + b, k]])
+    assert torch.equal(shard.exchange_neighbours(mine), stack)             # neighbour-only all-to-all builds the same stack
     loss = _loss(params, stack, mine, labels[lo:hi])
     loss.backward()
     shard.allreduce_grads(params.values(), average=True)
@@ -88,6 +89,32 @@ def test_two_rank_sharded_step_equals_single_process(tmp_path):
             got = res[r]["grads"][k]
             assert torch.allclose(got, v.grad, rtol=1e-4, atol=1e-7), k
         assert torch.equal(res[0]["grads"][k], res[1]["grads"][k])         # ranks agree bit-for-bit after the all-reduce
+
+
+def _a2a_worker(rank, world, port):
+    from csn_amd.sharding import ShapeGraphShard, regular_graph
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    B, Kn = 3, 3
+    S = B * world
+    feats = torch.arange(S * 4 * 5, dtype=torch.float32).reshape(S, 4, 5)
+    graph = regular_graph(S, Kn, seed=5)
+    shard = ShapeGraphShard(graph, B, rank, world, torch.device("cpu"))
+    mine = feats[shard.first:shard.first + B].clone()
+    for _ in range(2):                                                      # buffers are reused between steps
+        stack = shard.exchange_neighbours(mine)
+        ref = shard.neighbour_stack(mine, feats)
+        assert torch.equal(stack, ref)
+    assert sum(shard._recv_splits) <= min(B * Kn, S - B)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_neighbour_only_exchange_four_ranks():
+    """all_to_all_single with uneven splits over 4 gloo ranks: every rank receives only the shapes its graph rows name."""
+    mp.spawn(_a2a_worker, args=(4, _free_port()), nprocs=4, join=True)
 
 
 def test_graph_rejects_self_neighbours_and_bad_sizes():
