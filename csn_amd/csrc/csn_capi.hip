@@ -100,7 +100,7 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
   if (!x || !w || !out || rows <= 0 || channels <= 0 || n_shapes <= 0 || n_points <= 0) return CSN_E_ARG;
   if (out_split == 2) {
     // tile planes: out_plane_stride = points per attention block (<= 512), ld_out = row pitch = n_blocks * 1024 bf16
-    if (out_plane_stride <= 0 || out_plane_stride > 512 || (ld_out & 1023)) return CSN_E_ARG;
+    if (out_plane_stride <= 0 || out_plane_stride > 512 || (out_plane_stride & 3) || (ld_out & 1023)) return CSN_E_ARG;
     if (((long long)n_points + out_plane_stride - 1) / out_plane_stride * 1024 > ld_out) return CSN_E_ARG;
     if (out_shape_stride & 7) return CSN_E_STRIDE;
   }

@@ -489,8 +489,16 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
     __syncthreads();
   }
 
+  // per-wave 16 KB of LDS for the epilogues (the tile loop is over; waves 0..3 take As, 4..7 Bs): 32 rows x 128 columns fp32
+  float* wbuf = reinterpret_cast<float*>(wave < 4 ? reinterpret_cast<char*>(&As[0][0][0]) : reinterpret_cast<char*>(&Bs[0][0][0]))
+                + (wave & 3) * 4096;
+  const int cc = lane & 31, rsub = lane >> 5;                         // chunk column (4 floats) and row parity of this lane
+  const int col = wn0 + 4 * cc, n = n0 + col;
+  const bool n_ok = n < N;                                            // N % 4 == 0: a chunk is all in or all out
+
   if constexpr (LN) {
     // ---- fc dropout, + residual, LayerNorm over the 256 channels of each point, write xhat and rstd ------------------
+    // (stays in the accumulator layout: the 16-byte path through LDS of the plain epilogue spills here and measured 20 % slower)
     float* red = reinterpret_cast<float*>(&As[0][0][0]);            // [2][4 M-waves][256 points] (the tile loop is over)
     const int wmi = wave >> 1;
     const long long rs = q.res_index ? q.res_index[z2] : z2;
@@ -552,47 +560,58 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
     return;
   }
 
-  // epilogue, one 32 x 32 accumulator tile at a time (offsets are not kept: the accumulators own the registers)
+  // ---- epilogue --------------------------------------------------------------------------------------------------
+  // A wave-level memory instruction costs the issuing wave ~100 cycles whatever its width, and an accumulator layout store
+  // moves 4 bytes per lane: 128 of them per wave were a third of a short-K tile's time.  So every wave transposes its
+  // 64 x 128 block through its own 16 KB of LDS (32 rows at a time; the tile loop is over, no cross-wave traffic) and
+  // writes 16 contiguous bytes per lane: 32 stores (and 32 loads when accumulating) instead of 128.
   const float alpha = p.alpha;
-  const int Tb = (int)p.C.plane_stride;
+  unsigned tcol = 0;
+  if (c_tiles) {
+    const int Tb = (int)p.C.plane_stride;
+    const int blk = n / Tb, kib = n - blk * Tb;                        // Tb % 4 == 0: the 4 points share block and tile
+    tcol = (unsigned)(blk * 1024 + (kib >> 5) * 64 + (kib & 31));
+  }
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int nl = wn0 + 32 * j + l31, n = n0 + nl;
-    unsigned col = 0;
-    if (c_tiles) {
-      const int blk = n / Tb, kib = n - blk * Tb;
-      col = (unsigned)(blk * 1024 + (kib >> 5) * 64 + (kib & 31));
-    }
+  for (int i = 0; i < MT; ++i) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      unsigned off[16];
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int ml = wm0 + 32 * i + csn_acc_row(r, h);
-        const bool ok = (m0 + ml) < M && n < N;
-        off[r] = !ok ? CSN_OOB : (c_tiles ? ((unsigned)(ml * ldc) + col) * 2u : (unsigned)(ml * ldc + nl) * (unsigned)c_es);
         float v = acc[i][j][r] * alpha;
-        if ((m0 + ml) < p.div_rows) v = v / p.div_val;
-        acc[i][j][r] = v;
+        if ((m0 + wm0 + 32 * i + csn_acc_row(r, h)) < p.div_rows) v = v / p.div_val;
+        wbuf[csn_acc_row(r, h) * 128 + 32 * j + l31] = v;
       }
-      if (c_pl) {
+    f32x4 vals[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const __bf16 hi = (__bf16)acc[i][j][r];
-          csn_bstore_bf16(hi, Cr, off[r]);
-          if (c_tiles) csn_bstore_bf16((__bf16)(acc[i][j][r] - (float)hi), Cr, off[r], 64u);
-          else csn_bstore_bf16((__bf16)(acc[i][j][r] - (float)hi), Crl, off[r]);
-        }
-      } else {
-        if (p.accumulate) {
-          f32x16 prev;
+    for (int t = 0; t < 16; ++t) vals[t] = *reinterpret_cast<const f32x4*>(&wbuf[(2 * t + rsub) * 128 + 4 * cc]);
+    unsigned off[16];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) prev[r] = csn_bload(Cr, off[r]);
-          acc[i][j] += prev;
-        }
+    for (int t = 0; t < 16; ++t) {
+      const int ml = wm0 + 32 * i + 2 * t + rsub;
+      const bool ok = n_ok && (m0 + ml) < M;
+      off[t] = !ok ? CSN_OOB : (c_tiles ? ((unsigned)(ml * ldc) + tcol) * 2u : (unsigned)(ml * ldc + col) * (unsigned)c_es);
+    }
+    if (c_pl) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) csn_bstore(acc[i][j][r], Cr, off[r]);
+      for (int t = 0; t < 16; ++t) {
+        bf16x4 hi, lo;
+        split4(vals[t], hi, lo);
+        const u32x2 h2 = __builtin_bit_cast(u32x2, hi), l2 = __builtin_bit_cast(u32x2, lo);
+        __builtin_amdgcn_raw_buffer_store_b64(h2, Cr, off[t], 0, 0);
+        if (c_tiles) __builtin_amdgcn_raw_buffer_store_b64(l2, Cr, off[t], 64, 0);
+        else __builtin_amdgcn_raw_buffer_store_b64(l2, Crl, off[t], 0, 0);
       }
+    } else {
+      if (p.accumulate) {
+        f32x4 prev[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) prev[t] = csn_bload4(Cr, off[t]);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) vals[t] += prev[t];
+      }
+#pragma unroll
+      for (int t = 0; t < 16; ++t) csn_bstore4(vals[t], Cr, off[t]);
     }
   }
 }
