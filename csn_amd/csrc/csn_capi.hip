@@ -172,7 +172,7 @@ int csn_cross_attn_fwd_f32(const float* q, const float* k, const float* v, long 
                            long long kv_shape_stride, int ld_q, int ld_kv, float* ctx, long long ctx_eval_stride,
                            float* scores, float* lse, int n_evals, int n_heads, int d_head, int n_queries, int n_keys,
                            int score_pitch, float rescale_threshold, float dropout_p, unsigned long long seed, void* stream) {
-  if (n_queries <= 0 || n_keys <= 0) return CSN_E_ARG;
+  if (n_queries <= 0 || n_keys <= 0 || (n_queries & 3)) return CSN_E_ARG;
   return attn_fwd_impl(q, k, v, q_shape_stride, kv_shape_stride, nullptr, nullptr, ld_q, ctx, ctx_eval_stride, scores, lse,
                        n_evals, n_heads, d_head, n_keys, 1, score_pitch, rescale_threshold, dropout_p, seed, 0, 0, n_queries,
                        ld_kv, stream);

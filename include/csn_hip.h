@@ -135,8 +135,8 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
  *                                                          are written as zeros)
  *   scores, dscores  : [n_evals][n_heads][n_queries][score_pitch], score_pitch >= round-up-4(n_keys) (32 in math mode 1)
  *   lse, delta       : [n_evals][n_heads][n_queries]
- * n_keys is arbitrary; n_queries must be a multiple of 4 in the backward (pad with zero points: their rows cost nothing
- * and contribute nothing).  Evaluation e reads maps e (no slot indices, no accumulation). */
+ * n_keys is arbitrary; n_queries must be a multiple of 4 (pad with zero points: their rows cost little and contribute
+ * nothing to any gradient).  Evaluation e reads maps e (no slot indices, no accumulation). */
 int csn_cross_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
                            long long kv_shape_stride, int ld_q, int ld_kv, float* ctx, long long ctx_eval_stride,
                            float* scores, float* lse, int n_evals, int n_heads, int d_head, int n_queries, int n_keys,
