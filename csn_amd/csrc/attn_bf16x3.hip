@@ -4,7 +4,7 @@
 // Same skeleton, tiling, LDS budget and HBM data flow as attn_f32.hip (read that header first):
 //   R      [d][q]   register operand, 16 query points per wave        (fwd: Qs^T   bwd: dO^T)    as bf16 hi/lo fragments
 //   tileA  [d][key] 32 keys, k-major: fragments by ds_read_b64_tr_b16  (fwd: K^T    bwd: V^T)     bf16 hi / lo planes
-//   tileB  [d][key] 32 keys, key-contiguous: fragments by ds_read_b64  (fwd: V^T    bwd: K^T)     bf16 hi / lo planes
+//   tileB  [d][key] 32 keys, key-contiguous: fragments by ds_read_b128 (fwd: V^T    bwd: K^T)     bf16 hi / lo planes
 // Matrix instruction: v_mfma_f32_16x16x32_bf16 (A: lane l = A[l & 15][8 (l >> 4) + j], B: lane l = B[8 (l >> 4) + j][l & 15],
 // j = 0..7; C: reg r of lane l = C[4 (l >> 4) + r][l & 15]).  The two 16-row score tiles of a 32-key tile take the keys
 //   S0 row i  <->  key 8 (i >> 2) + (i & 3),      S1 row i  <->  key 8 (i >> 2) + 4 + (i & 3)
@@ -19,6 +19,9 @@
 // LDS images (conflict-free): tileA swaps the two 8-byte chunks of every 16-byte unit on rows with bit 3 set (the
 // transposing read of a 32-lane group touches rows r and r + 8 together); tileB XORs the 16-byte unit index with
 // (-(row >> 2)) & 3; the hi and lo planes are 128 bytes out of phase so that one staging store hits both without conflict.
+// Schedule: LDS fragment reads run 4 steps ahead of their matrix instructions (explicit register ring); a tile is two barrier
+// segments and waves 4..7 run one segment behind waves 0..3; the register operand, the delta inputs and the output travel
+// as 16-byte rows through an LDS transpose (a wave-level memory instruction costs ~100 cycles whatever its width).
 #include "csn_common.h"
 #include "csn_kernels.h"
 
