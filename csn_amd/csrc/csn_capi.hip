@@ -30,12 +30,14 @@ CsnOperand operand(const float* p, long long s0, long long s1, long long s2, con
 
 // points contracted per work-group of a split weight gradient
 int wgrad_chunk(int n_maps, int n_points) {
+  // ~512 equal slabs: every map is cut into the same number of equal chunks (unequal tails leave CUs idle at the end)
   long long total = (long long)n_maps * n_points;
-  long long want = (total + 511) / 512;                   // aim at ~512 slabs
-  long long c = ((want + 31) / 32) * 32;
-  if (c < 256) c = 256;
-  if (c > 4096) c = 4096;
-  if (c > n_points) c = ((n_points + 3) / 4) * 4;
+  long long want = (total + 511) / 512;
+  if (want < 256) want = 256;
+  long long n_chunks = (n_points + want - 1) / want;
+  if (n_chunks < 1) n_chunks = 1;
+  long long c = (n_points + n_chunks - 1) / n_chunks;
+  c = ((c + 3) / 4) * 4;
   return (int)c;
 }
 
