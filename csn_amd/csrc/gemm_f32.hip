@@ -35,8 +35,11 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_f32_kernel(CsnGemmArgs p) {
   constexpr int B_PASS = BN / 32;                      // 16-byte pieces per thread for the B slab
   constexpr int TPR = BN / 4;                          // KN: threads per k row
   constexpr int RPP = 256 / TPR;                       // KN: k rows per pass
-  __shared__ __attribute__((aligned(16))) float As[BM * LDK];
-  __shared__ __attribute__((aligned(16))) float Bs[B_NK ? BN * LDK : BK * BN];
+  constexpr int A_EL = BM * LDK, B_EL = B_NK ? BN * LDK : BK * BN;
+  constexpr int STAGE_EL = 4 * 32 * (BN / 2);                          // epilogue: 32 rows x (BN/2) columns per wave
+  __shared__ __attribute__((aligned(16))) float smem[(A_EL + B_EL) > STAGE_EL ? (A_EL + B_EL) : STAGE_EL];
+  float* As = smem;
+  float* Bs = smem + A_EL;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
@@ -144,40 +147,47 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_f32_kernel(CsnGemmArgs p) {
     if (kt + 1 < nk) { store_slab(); __syncthreads(); }
   }
 
+  // ---- epilogue: every wave transposes its block through LDS (32 rows at a time: the slab buffers are idle now) and moves
+  // 16 contiguous bytes per lane — a wave-level memory instruction costs ~100 cycles whatever its width, and the
+  // accumulator layout would need 4x as many of them (see gemm_bf16x3.hip)
   const float alpha = p.alpha;
-  unsigned c_off[MT][NT][16];
+  constexpr int WN = BN / 2;                                           // columns of a wave's block (64)
+  constexpr int CPR = WN / 4;                                          // 16-byte chunks per row (16)
+  constexpr int RPI = 64 / CPR;                                        // rows covered by one wave-wide chunk access (4)
+  constexpr int NCH = 32 / RPI;                                        // chunk accesses per 32-row pass (8)
+  float* wbuf = smem + wave * 32 * WN;
+  const int cc = lane % CPR, rsub = lane / CPR;
+  const int col = wn0 + 4 * cc;
+  const bool n_ok = (n0 + col) < N;                                    // N % 4 == 0: a chunk is all in or all out
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int nl = wn0 + 32 * j + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ml = wm0 + 32 * i + csn_acc_row(r, h);
-        c_off[i][j][r] = ((m0 + ml) < M && (n0 + nl) < N) ? (unsigned)(ml * ldc + nl) * 4u : CSN_OOB;
-        float v = acc[i][j][r] * alpha;
-        if ((m0 + ml) < p.div_rows) v = v / p.div_val;     // q / temperature (csa_models.py:139)
-        acc[i][j][r] = v;
-      }
-    }
-  if (p.accumulate) {
-    // batch the read-modify-write: all loads in flight first, then add + store
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        f32x16 prev;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) prev[r] = csn_bload(Cr, c_off[i][j][r]);
-        acc[i][j] += prev;
-      }
-  }
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int i = 0; i < MT; ++i) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) csn_bstore(acc[i][j][r], Cr, c_off[i][j][r]);
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[i][j][r] * alpha;
+        if ((m0 + wm0 + 32 * i + csn_acc_row(r, h)) < p.div_rows) v = v / p.div_val;     // q / temperature (csa_models.py:139)
+        wbuf[csn_acc_row(r, h) * WN + 32 * j + l31] = v;
+      }
+    f32x4 vals[NCH];
+    unsigned off[NCH];
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) {
+      const int row = RPI * t + rsub;
+      vals[t] = *reinterpret_cast<const f32x4*>(&wbuf[row * WN + 4 * cc]);
+      const int ml = wm0 + 32 * i + row;
+      off[t] = (n_ok && (m0 + ml) < M) ? (unsigned)(ml * ldc + col) * 4u : CSN_OOB;
+    }
+    if (p.accumulate) {                                                // all loads in flight first, then add + store
+      f32x4 prev[NCH];
+#pragma unroll
+      for (int t = 0; t < NCH; ++t) prev[t] = csn_bload4(Cr, off[t]);
+#pragma unroll
+      for (int t = 0; t < NCH; ++t) vals[t] += prev[t];
+    }
+#pragma unroll
+    for (int t = 0; t < NCH; ++t) csn_bstore4(vals[t], Cr, off[t]);
+  }
 }
 
 // out[i] = alpha * sum_z slab[z][i]  (+ out[i] if accumulate) — closes a split-K weight gradient.
