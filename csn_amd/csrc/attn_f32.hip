@@ -47,8 +47,11 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
   constexpr int D = 32 * DT;
   constexpr int PIECES = D * 8;                         // 16-byte pieces per streamed tile
   constexpr int NP_T = (PIECES + 511) / 512;            // pieces per thread per tile
-  __shared__ __attribute__((aligned(16))) float tileA[2][D * KT];
-  __shared__ __attribute__((aligned(16))) float tileB[2][D * KT];
+  // [A | B][stage][row][32 keys] — one array, so that the prologue / epilogue can use all of it as a [D][128 queries] block
+  __shared__ __attribute__((aligned(16))) float tiles[2][2][D * KT];
+  auto& tileA = tiles[0];
+  auto& tileB = tiles[1];
+  static_assert(sizeof(tiles) >= D * 128 * 4, "staging block");
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, kq = lane >> 4;
@@ -87,23 +90,44 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
 
   // per-lane byte offsets (scalar offsets handed to the buffer instructions must be wave-uniform, so
   // everything that depends on the lane lives here); lanes of query rows beyond the block are switched off
-  const unsigned r_off = q_ok ? (unsigned)(kq * ld + qrow) * 4u : CSN_OOB;        // rows 4 s + kq
-  const unsigned o_off = q_ok ? (unsigned)(4 * kq * ld + qrow) * 4u : CSN_OOB;    // rows 16 c + 4 kq + r
 
   // ---- register-resident operand R[d][q]: lane (q, kq) keeps rows d = 4 s + kq ----------------
+  // fetched by the work-group as 16-byte rows into LDS (the tile buffers are still idle) and picked from there: a
+  // wave-level memory instruction costs ~100 cycles whatever its width (see attn_bf16x3.hip).  Chunk c of row r sits at
+  // c ^ 4 (r & 1): the lane quarters read rows 1 apart.  Backward: delta_q = sum_d dO[d][q] O[d][q] from a second round with O.
   float R[D / 4];
-  // backward: delta_q = sum_d dO[d][q] O[d][q] (the softmax-backward row constant) is formed on the way
-  const csn_rsrc_t Xr = csn_make_rsrc(BWD ? p.ctx + qs * p.q_shape_stride + head_off : nullptr, BWD ? win : 0);
-  float delta_q = 0.f;
+  float* xbuf = &tiles[0][0][0];
+  constexpr int CH_T = D / 16;                                     // 16-byte chunks per thread: D rows x 32 chunks / 512
+  const int cc = tid & 31, crow = tid >> 5;
+  const unsigned c_off = (qt * 128 + 4 * cc) < Tq ? (unsigned)(crow * ld + qt * 128 + 4 * cc) * 4u : CSN_OOB;
+  const int col = 16 * wave + lq;
+  auto stage_in = [&](const csn_rsrc_t& rs) {
+    f32x4 ch[CH_T];
 #pragma unroll
-  for (int s = 0; s < D / 4; ++s) {
-    R[s] = csn_bload(Rr, r_off, (unsigned)(4 * s) * ld * 4u);
-    if (BWD) delta_q = fmaf(R[s], csn_bload(Xr, r_off, (unsigned)(4 * s) * ld * 4u), delta_q);
-  }
+    for (int t = 0; t < CH_T; ++t) ch[t] = csn_bload4(rs, c_off, (unsigned)(16 * t * ld) * 4u);
+#pragma unroll
+    for (int t = 0; t < CH_T; ++t) {
+      const int row = crow + 16 * t;
+      *reinterpret_cast<f32x4*>(&xbuf[row * 128 + ((cc ^ (4 * (row & 1))) << 2)]) = ch[t];
+    }
+  };
+  auto pick = [&](int row) { return xbuf[row * 128 + ((((col >> 2) ^ (4 * (row & 1))) << 2) | (col & 3))]; };
+  stage_in(Rr);
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < D / 4; ++s) R[s] = pick(4 * s + kq);
+  float delta_q = 0.f;
   if (BWD) {
+    const csn_rsrc_t Xr = csn_make_rsrc(p.ctx + qs * p.q_shape_stride + head_off, win);
+    __syncthreads();
+    stage_in(Xr);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < D / 4; ++s) delta_q = fmaf(R[s], pick(4 * s + kq), delta_q);
     delta_q += __shfl_xor(delta_q, 16, 64);
     delta_q += __shfl_xor(delta_q, 32, 64);
   }
+  __syncthreads();                                                 // the staging block becomes the tile buffers
 
   f32x4v O[D / 16];
 #pragma unroll
@@ -286,24 +310,33 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
     inv = 1.f / l_tot;
     if (q_ok && kq == 0 && p.lse) p.lse[stat_off + qrow] = m_run + logf(l_tot);
   }
-  if (p.accumulate) {
-    // several evaluations share this output slot: fetch all previous partial sums first (one batch of loads in
-    // flight), then add and store — a load/add/store chain per element would serialise 64 memory round trips
-    f32x4v prev[D / 16];
-#pragma unroll
-    for (int c = 0; c < D / 16; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) prev[c][r] = csn_bload(Or, o_off, (unsigned)(c * 16 + r) * ld * 4u);
-#pragma unroll
-    for (int c = 0; c < D / 16; ++c) O[c] = O[c] * inv + prev[c];
-  } else {
-#pragma unroll
-    for (int c = 0; c < D / 16; ++c) O[c] *= inv;
-  }
+  // OUT leaves through the same [D][128] LDS block as 16-byte rows (chunk c of row r at c ^ 4 ((r >> 2) & 1)); when several
+  // evaluations share the output slot, the previous partial sums are fetched first — one batch of loads — then added
 #pragma unroll
   for (int c = 0; c < D / 16; ++c)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) csn_bstore(O[c][r], Or, o_off, (unsigned)(c * 16 + r) * ld * 4u);
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * c + 4 * kq + r;
+      xbuf[row * 128 + ((((col >> 2) ^ (4 * ((row >> 2) & 1))) << 2) | (col & 3))] = O[c][r] * inv;
+    }
+  __syncthreads();
+  {
+    f32x4 ch[CH_T];
+#pragma unroll
+    for (int t = 0; t < CH_T; ++t) {
+      const int row = crow + 16 * t;
+      ch[t] = *reinterpret_cast<const f32x4*>(&xbuf[row * 128 + ((cc ^ (4 * ((row >> 2) & 1))) << 2)]);
+    }
+    if (p.accumulate) {
+      f32x4 prev[CH_T];
+#pragma unroll
+      for (int t = 0; t < CH_T; ++t) prev[t] = csn_bload4(Or, c_off, (unsigned)(16 * t * ld) * 4u);
+#pragma unroll
+      for (int t = 0; t < CH_T; ++t) ch[t] += prev[t];
+    }
+#pragma unroll
+    for (int t = 0; t < CH_T; ++t) csn_bstore4(ch[t], Or, c_off, (unsigned)(16 * t * ld) * 4u);
+  }
 }
 
 template <int DT>
