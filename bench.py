@@ -154,12 +154,15 @@ def main():
 
     attn_events = []
     exchange_mode = os.environ.get("CSN_EXCHANGE", "allgather")          # "alltoall": neighbour-only exchange (sharding.py)
+    overlap = os.environ.get("CSN_OVERLAP", "1") != "0"                  # all-gather in flight under the self-attention evaluations
 
     def step(record=False):
         for p in params:
             p.grad = None
         if shard is not None:
-            if exchange_mode == "alltoall":
+            if exchange_mode == "allgather" and overlap:
+                x_nb = shard.exchange_async(feats)                       # the model overlaps its self-attention with it
+            elif exchange_mode == "alltoall":
                 x_nb = shard.exchange_neighbours(feats)                  # neighbour-only all-to-all (opt-in)
             else:
                 x_nb = shard.neighbour_stack(feats, shard.exchange(feats))   # all-gather of point features over xGMI

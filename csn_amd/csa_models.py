@@ -118,6 +118,15 @@ class MultiHeadAttention(nn.Module):
                 nbr = (b * K1 + k)[:, 1:].reshape(-1)
                 own = ar * K1
                 cache[key] = CF.EvalPlan(np.concatenate((mix_q, nbr, own)), np.concatenate((mix_kv, nbr, own)), B * K1, dev)
+            elif kind == "self2":         # train mode, own shapes only: [b] mixed self, [B + b] pooled self (separate masks)
+                cache[key] = CF.EvalPlan(np.concatenate((ar, ar)), np.concatenate((ar, ar)), B, dev)
+            elif kind == "csa_cross":
+                # the part of "csa" that needs neighbour data: [b*K + k-1] MHA(x_b, x_bk, x_bk) (mixed), then
+                # [B*K + b*K + k-1] MHA(x_bk, x_bk, x_bk) (only its mean is used); slots as in "csa"
+                b, k = np.meshgrid(ar, np.arange(K1), indexing="ij")
+                nbr = (b * K1 + k)[:, 1:].reshape(-1)
+                own = (b * K1)[:, 1:].reshape(-1)
+                cache[key] = CF.EvalPlan(np.concatenate((own, nbr)), np.concatenate((nbr, nbr)), B * K1, dev)
             else:
                 raise ValueError(kind)
         return cache[key]
@@ -246,6 +255,8 @@ class CrossShapeAt(nn.Module):
         npts = geo.n_points
         xc = _channel_major(x, npts)                                           # (B, C, NP)
         B, C, _ = xc.shape
+        if callable(getattr(x_neighbors, "wait", None)):
+            return self._csa_cm_overlapped(xc, x_neighbors, return_parts)
         K1 = x_neighbors.shape[1]
         K = K1 - 1
         dev = xc.device
@@ -276,6 +287,40 @@ class CrossShapeAt(nn.Module):
         pooled = pooled_hat * gamma + beta                                     # (B, K+1, C)
         comp = self._compatibility(pooled)                                     # (B, K+1)
         feats = CF.csa_mix(xhat_mix, comp, gamma, beta, B, K1)                   # sum_k comp_k * affine(xhat_k)  (:233, :238)
+        return (feats, comp, pooled) if return_parts else feats
+
+    def _csa_cm_overlapped(self, xc, pending, return_parts: bool = False):
+        """The same features when the neighbour stack is still on its way (``pending.wait()`` returns the (B, K+1, C, N[, 1])
+        device stack with slot 0 = the shape itself; csn_amd.sharding.PendingStack): the evaluations that need only the
+        query shapes — a quarter of the work at K = 3 — run first, under the exchange; everything that reads neighbour data
+        follows the wait.  Same arithmetic as ``_csa_cm`` (in train mode the dropout masks are drawn in a different order)."""
+        att = self.attention
+        geo = att.geometry()
+        npts = geo.n_points
+        B, C, _ = xc.shape
+        dev = xc.device
+        train = any(r > 0 for r in att.dropout_rates())
+        xc = xc.contiguous()
+        # phase 1 (no neighbour data): [b] mixed self, and in train mode [B + b] the pooled self with its own masks
+        xh1, head1 = att.evaluate(xc, att.plan("self2" if train else "self", B, 1, dev), geo, n_head_evals=B)
+        nb = pending.wait()
+        if nb.dim() == 5:
+            nb = nb.squeeze(-1)
+        K1 = nb.shape[1]
+        K = K1 - 1
+        if not (nb.is_cuda and nb.dtype == torch.float32 and nb.is_contiguous() and nb.shape[-1] == npts):
+            raise ValueError("a pending neighbour stack must resolve to a contiguous fp32 device tensor (B, K+1, C, n_points)")
+        x_all = nb.view(B * K1, C, npts)
+        # phase 2: [b*K + k-1] cross evaluations (mixed), [B*K + b*K + k-1] neighbour self-attention (pooled only)
+        xh2, head2 = att.evaluate(x_all, att.plan("csa_cross", B, K1, dev), geo, n_head_evals=B * K)
+        xhat_mix = torch.cat((head1.view(B, 1, C, npts), head2.view(B, K, C, npts)), dim=1).view(B * K1, C, npts)
+        gamma, beta = att.norm.weight, att.norm.bias
+        m1, m2 = CF.point_mean(xh1), CF.point_mean(xh2)
+        own = m1[B:] if train else m1[:B]
+        pooled_hat = torch.cat((own.view(B, 1, C), m2[B * K:].view(B, K, C)), dim=1)
+        pooled = pooled_hat * gamma + beta
+        comp = self._compatibility(pooled)
+        feats = CF.csa_mix(xhat_mix, comp, gamma, beta, B, K1)
         return (feats, comp, pooled) if return_parts else feats
 
     def _compatibility(self, pooled: torch.Tensor) -> torch.Tensor:

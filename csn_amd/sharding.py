@@ -100,6 +100,18 @@ class ShapeGraphShard:
         torch.index_select(self._pool, 0, self._pool_rows, out=self._stack)
         return self._stack.view((self.B, self.K + 1) + tail).unsqueeze(-1)
 
+    def exchange_async(self, feats: torch.Tensor) -> "PendingStack":
+        """Start the all-gather and return at once: ``wait()`` on the result yields the neighbour stack.  A model that is
+        handed the pending object (CrossShapeAt accepts it in place of the neighbour tensor) runs the evaluations that
+        need no neighbour data — the self-attention of its own shapes — while the exchange is in flight."""
+        if self.world == 1:
+            raise ValueError("exchange_async needs world > 1")
+        if self._gathered is None or self._gathered.shape[1:] != feats.shape[1:]:
+            self._gathered = torch.empty((self.S,) + tuple(feats.shape[1:]), device=feats.device, dtype=feats.dtype)
+        feats = feats.contiguous()
+        work = dist.all_gather_into_tensor(self._gathered, feats, async_op=True)
+        return PendingStack(self, feats, work)
+
     def neighbour_stack(self, feats: torch.Tensor, collection: torch.Tensor) -> torch.Tensor:
         """(B, K+1, C, N, 1) exactly as CSADatasetK hands it to the model (features_data_loader.py:124-140):
         slot 0 = the shape itself, slots 1..K = its neighbours in graph order."""
@@ -128,3 +140,17 @@ class ShapeGraphShard:
         for p in plist:
             p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
             off += p.numel()
+
+
+class PendingStack:
+    """A neighbour stack whose exchange is still in flight (ShapeGraphShard.exchange_async)."""
+
+    def __init__(self, shard: ShapeGraphShard, feats: torch.Tensor, work):
+        self._shard, self._feats, self._work = shard, feats, work
+        self._stack: Optional[torch.Tensor] = None
+
+    def wait(self) -> torch.Tensor:
+        if self._stack is None:
+            self._work.wait()                                  # orders the compute stream behind the collective
+            self._stack = self._shard.neighbour_stack(self._feats, self._shard._gathered)
+        return self._stack

@@ -52,6 +52,8 @@ def _worker(rank, world, port, out_dir):
         for k in range(K):
             assert torch.equal(stack[b, k + 1, :, :, 0], feats[graph[lo + b, k]])
     assert torch.equal(shard.exchange_neighbours(mine), stack)             # neighbour-only all-to-all builds the same stack
+    pending = shard.exchange_async(mine)                                   # the overlapped form: the model calls wait() late
+    assert torch.equal(pending.wait(), stack) and pending.wait() is pending.wait()
     loss = _loss(params, stack, mine, labels[lo:hi])
     loss.backward()
     shard.allreduce_grads(params.values(), average=True)
