@@ -84,9 +84,12 @@ class EvalPlan:
         self.q_slots, self.kv_slots, self.v_slots = as_dev(q), as_dev(kv), as_dev(kv + v_shift)
         self.dq_colors = [as_dev(c) for c in self._colors(q)]
         self.dkv_colors = [as_dev(c) for c in self._colors(kv)]
-        # when every slot is some evaluation's query slot and some evaluation's key/value slot, the first colour of
-        # each pass overwrites the whole gradient map: no zero fill and no read-modify-write for that colour
-        self.full_cover = (v_shift == 0 and np.unique(q).size == n_slots and np.unique(kv).size == n_slots)
+        # the first colour of a pass holds the first evaluation of EVERY slot the pass writes, so it may overwrite; only the
+        # gradient maps of slots a pass never writes need a zero fill (the weight gradients read all of them)
+        all_slots = np.arange(n_slots)
+        self.q_unwritten = as_dev(np.setdiff1d(all_slots, q)).long()
+        self.k_unwritten = as_dev(np.setdiff1d(all_slots, kv)).long()
+        self.v_unwritten = as_dev(np.setdiff1d(all_slots, kv + v_shift)).long()
 
     @staticmethod
     def _colors(slots):
@@ -290,8 +293,13 @@ class _MHAEvals(torch.autograd.Function):
         # evaluations that share a slot (Q of the query shape, K/V of each neighbour) add up: one launch per colour
         dscores = torch.empty_like(scores)
         delta = torch.empty((E, H, NP), device=dev, dtype=torch.float32)
-        full = plan.full_cover
-        dqkv = (torch.empty if full else torch.zeros)((S, 3 * D, NP), device=dev, dtype=torch.float32)
+        dqkv = torch.empty((S, 3 * D, NP), device=dev, dtype=torch.float32)
+        if plan.q_unwritten.numel():
+            dqkv[:, :D].index_fill_(0, plan.q_unwritten, 0.0)
+        if plan.k_unwritten.numel():
+            dqkv[:, D:2 * D].index_fill_(0, plan.k_unwritten, 0.0)
+        if plan.v_unwritten.numel():
+            dqkv[:, 2 * D:].index_fill_(0, plan.v_unwritten, 0.0)
         slot_stride = 3 * D * NP                                   # of the fp32 gradient maps
         q_stride, kv_stride, kv_flag, kv_pitch = ctx.ptrs
         gbase, q_ptr = dqkv.data_ptr(), qkv.data_ptr()
@@ -306,7 +314,7 @@ class _MHAEvals(torch.autograd.Function):
             _lib.check(L.csn_block_attn_bwd_dq_f32(_ptr(datt), _ptr(att), D * NP, k_ptr, v_ptr, kv_stride,
                                                    _ptr(plan.kv_slots), NP, _ptr(scores), _ptr(dscores), _ptr(lse),
                                                    _ptr(delta), gbase, slot_stride, _ptr(plan.q_slots),
-                                                   0 if (full and ci == 0) else 1, _ptr(ids),
+                                                   0 if ci == 0 else 1, _ptr(ids),
                                                    ids.numel(), H, d, T, nb, Tp, p_attn, seed_attn, 0, 0, kv_flag,
                                                    kv_pitch, pt, _stream()),
                        "csn_block_attn_bwd_dq_f32")
@@ -314,7 +322,7 @@ class _MHAEvals(torch.autograd.Function):
             _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, q_ptr, q_stride, _ptr(plan.q_slots), NP,
                                                     _ptr(scores), _ptr(dscores), gbase + 4 * D * NP, gbase + 8 * D * NP,
                                                     slot_stride, _ptr(plan.kv_slots), _ptr(plan.v_slots),
-                                                    0 if (full and ci == 0) else 1, _ptr(ids),
+                                                    0 if ci == 0 else 1, _ptr(ids),
                                                     ids.numel(), H, d, T, nb, Tp, 0, 0, 0, 0, pt, _stream()),
                        "csn_block_attn_bwd_dkv_f32")
         del dscores, delta, datt
