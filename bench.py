@@ -156,6 +156,17 @@ def main():
     exchange_mode = os.environ.get("CSN_EXCHANGE", "allgather")          # "alltoall": neighbour-only exchange (sharding.py)
     overlap = os.environ.get("CSN_OVERLAP", "1") != "0"                  # all-gather in flight under the self-attention evaluations
 
+    # CSN_BENCH_SPLIT=1 (N = 1, development aid): run the two-phase evaluation order of the multi-GPU path with the stack
+    # already complete, to price its extra work against the single call
+    split_probe = world == 1 and os.environ.get("CSN_BENCH_SPLIT") == "1"
+
+    class _ReadyStack:
+        def __init__(self, stack):
+            self.stack = stack
+
+        def wait(self):
+            return self.stack
+
     def step(record=False):
         for p in params:
             p.grad = None
@@ -168,6 +179,8 @@ def main():
                 x_nb = shard.neighbour_stack(feats, shard.exchange(feats))   # all-gather of point features over xGMI
         else:
             x_nb = x_nb_resident                                         # (B, K+1, C, N, 1), slot 0 = self
+            if split_probe:
+                x_nb = _ReadyStack(x_nb)
         if record:
             CF.EVENT_SINK = attn_events
         logits = model(feats.unsqueeze(-1), "train", x_nb)

@@ -91,9 +91,10 @@ _SIGNATURES = {
     "csn_retrieval_measure_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                           c_longlong, c_void_p]),
     "csn_rowsum_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_longlong, c_void_p]),
-    "csn_mix_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "csn_mix_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                c_void_p]),
     "csn_mix_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                c_int, c_void_p]),
+                                c_int, c_void_p, c_void_p, c_void_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -112,7 +113,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.csn_version() != 6:
+        if handle.csn_version() != 7:
             raise CsnError("libcsn_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -313,14 +313,13 @@ class CrossShapeAt(nn.Module):
         x_all = nb.view(B * K1, C, npts)
         # phase 2: [b*K + k-1] cross evaluations (mixed), [B*K + b*K + k-1] neighbour self-attention (pooled only)
         xh2, head2 = att.evaluate(x_all, att.plan("csa_cross", B, K1, dev), geo, n_head_evals=B * K)
-        xhat_mix = torch.cat((head1.view(B, 1, C, npts), head2.view(B, K, C, npts)), dim=1).view(B * K1, C, npts)
         gamma, beta = att.norm.weight, att.norm.bias
         m1, m2 = CF.point_mean(xh1), CF.point_mean(xh2)
         own = m1[B:] if train else m1[:B]
         pooled_hat = torch.cat((own.view(B, 1, C), m2[B * K:].view(B, K, C)), dim=1)
         pooled = pooled_hat * gamma + beta
         comp = self._compatibility(pooled)
-        feats = CF.csa_mix(xhat_mix, comp, gamma, beta, B, K1)
+        feats = CF.csa_mix(head2, comp, gamma, beta, B, K1, xself=head1)   # own maps and cross maps stay where they are
         return (feats, comp, pooled) if return_parts else feats
 
     def _compatibility(self, pooled: torch.Tensor) -> torch.Tensor:

@@ -34,20 +34,25 @@ __global__ __launch_bounds__(256) void csn_rowsum_kernel(const float* __restrict
 }
 
 // feats[b][c][n] = gamma[c] * sum_k comp[b][k] xhat[(b*K1+k)][c][n] + beta[c] * sum_k comp[b][k]
+// xhat0 != null: the k = 0 maps live in their own tensor xhat0[b][c][n] and xhat holds the K1 - 1 others, [b*(K1-1) + k-1]
 __global__ __launch_bounds__(256) void csn_mix_fwd_kernel(const float* __restrict__ xhat, const float* __restrict__ comp,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                          float* __restrict__ feats, int K1, int C, int NP) {
+                                                          float* __restrict__ feats, int K1, int C, int NP,
+                                                          const float* __restrict__ xhat0) {
   const int c = blockIdx.x % C, b = blockIdx.x / C;
   float w[8];
   float csum = 0.f;
   for (int k = 0; k < K1; ++k) { w[k] = comp[b * K1 + k]; csum += w[k]; }
   const float g = gamma[c], bb = beta[c] * csum;
-  const float* __restrict__ x0 = xhat + ((long long)b * K1 * C + c) * NP;
+  const float* xk[8];
+  for (int k = 0; k < K1; ++k)
+    xk[k] = !xhat0 ? xhat + ((long long)(b * K1 + k) * C + c) * NP
+                   : (k == 0 ? xhat0 + ((long long)b * C + c) * NP : xhat + ((long long)(b * (K1 - 1) + k - 1) * C + c) * NP);
   float* __restrict__ o = feats + ((long long)b * C + c) * NP;
   for (int i = threadIdx.x * 4; i < NP; i += 1024) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < K1; ++k) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x0 + (long long)k * C * NP + i);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xk[k] + i);
       acc += v * w[k];
     }
     *reinterpret_cast<f32x4*>(o + i) = acc * g + bb;
@@ -59,14 +64,21 @@ __global__ __launch_bounds__(256) void csn_mix_fwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void csn_mix_bwd_kernel(const float* __restrict__ dfeats, const float* __restrict__ xhat,
                                                           const float* __restrict__ comp, const float* __restrict__ gamma,
                                                           float* __restrict__ dxhat, float* __restrict__ rowdot,
-                                                          float* __restrict__ rowsum, int K1, int C, int NP) {
+                                                          float* __restrict__ rowsum, int K1, int C, int NP,
+                                                          const float* __restrict__ xhat0, float* __restrict__ dxhat0) {
   __shared__ double red[4];
   const int c = blockIdx.x % C, b = blockIdx.x / C;
   float w[8];
   for (int k = 0; k < K1; ++k) w[k] = comp[b * K1 + k] * gamma[c];
   const float* __restrict__ d = dfeats + ((long long)b * C + c) * NP;
-  const float* __restrict__ x0 = xhat + ((long long)b * K1 * C + c) * NP;
-  float* __restrict__ o0 = dxhat + ((long long)b * K1 * C + c) * NP;
+  const float* xk[8];
+  float* ok[8];
+  for (int k = 0; k < K1; ++k) {
+    const long long off = !xhat0 ? ((long long)(b * K1 + k) * C + c) * NP
+                                 : (k == 0 ? ((long long)b * C + c) * NP : ((long long)(b * (K1 - 1) + k - 1) * C + c) * NP);
+    xk[k] = ((xhat0 && k == 0) ? xhat0 : xhat) + off;
+    ok[k] = ((xhat0 && k == 0) ? dxhat0 : dxhat) + off;
+  }
   double dot[8];
   for (int k = 0; k < 8; ++k) dot[k] = 0.0;
   double sum = 0.0;
@@ -74,9 +86,9 @@ __global__ __launch_bounds__(256) void csn_mix_bwd_kernel(const float* __restric
     const f32x4 g = *reinterpret_cast<const f32x4*>(d + i);
     sum += ((double)g.x + (double)g.y) + ((double)g.z + (double)g.w);
     for (int k = 0; k < K1; ++k) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x0 + (long long)k * C * NP + i);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xk[k] + i);
       dot[k] += ((double)g.x * v.x + (double)g.y * v.y) + ((double)g.z * v.z + (double)g.w * v.w);
-      *reinterpret_cast<f32x4*>(o0 + (long long)k * C * NP + i) = g * w[k];
+      *reinterpret_cast<f32x4*>(ok[k] + i) = g * w[k];
     }
   }
   for (int k = 0; k < K1; ++k) {
@@ -96,14 +108,16 @@ int csn_launch_rowsum_f32(const float* x, float* out, long long rows, int n, lon
 }
 
 int csn_launch_mix_fwd_f32(const float* xhat, const float* comp, const float* gamma, const float* beta, float* feats, int B,
-                           int K1, int C, int NP, hipStream_t st) {
-  hipLaunchKernelGGL(csn_mix_fwd_kernel, dim3((unsigned)(B * C)), dim3(256), 0, st, xhat, comp, gamma, beta, feats, K1, C, NP);
+                           int K1, int C, int NP, const float* xhat0, hipStream_t st) {
+  hipLaunchKernelGGL(csn_mix_fwd_kernel, dim3((unsigned)(B * C)), dim3(256), 0, st, xhat, comp, gamma, beta, feats, K1, C, NP,
+                     xhat0);
   return (int)hipGetLastError();
 }
 
 int csn_launch_mix_bwd_f32(const float* dfeats, const float* xhat, const float* comp, const float* gamma, float* dxhat,
-                           float* rowdot, float* rowsum, int B, int K1, int C, int NP, hipStream_t st) {
+                           float* rowdot, float* rowsum, int B, int K1, int C, int NP, const float* xhat0, float* dxhat0,
+                           hipStream_t st) {
   hipLaunchKernelGGL(csn_mix_bwd_kernel, dim3((unsigned)(B * C)), dim3(256), 0, st, dfeats, xhat, comp, gamma, dxhat, rowdot,
-                     rowsum, K1, C, NP);
+                     rowsum, K1, C, NP, xhat0, dxhat0);
   return (int)hipGetLastError();
 }

@@ -399,22 +399,27 @@ int csn_rowsum_f32(const float* x, float* out, long long rows, int n_points, lon
 }
 
 int csn_mix_fwd_f32(const float* xhat, const float* comp, const float* gamma, const float* beta, float* feats,
-                    int n_shapes, int k1, int channels, int n_points, void* stream) {
-  if (!xhat || !comp || !gamma || !beta || !feats || n_shapes <= 0 || k1 <= 0 || k1 > 8 || channels <= 0 || n_points <= 0)
+                    int n_shapes, int k1, int channels, int n_points, const float* xhat_self, void* stream) {
+  if (!comp || !gamma || !beta || !feats || n_shapes <= 0 || k1 <= 0 || k1 > 8 || channels <= 0 || n_points <= 0)
     return CSN_E_ARG;
+  if (!xhat && !(xhat_self && k1 == 1)) return CSN_E_ARG;
   if (n_points & 3) return CSN_E_ALIGN;
-  if (mis16(xhat) || mis16(feats)) return CSN_E_PTR;
-  return csn_launch_mix_fwd_f32(xhat, comp, gamma, beta, feats, n_shapes, k1, channels, n_points, (hipStream_t)stream);
+  if (mis16(xhat) || mis16(feats) || mis16(xhat_self)) return CSN_E_PTR;
+  return csn_launch_mix_fwd_f32(xhat, comp, gamma, beta, feats, n_shapes, k1, channels, n_points, xhat_self,
+                                (hipStream_t)stream);
 }
 
 int csn_mix_bwd_f32(const float* dfeats, const float* xhat, const float* comp, const float* gamma, float* dxhat,
-                    float* rowdot, float* rowsum, int n_shapes, int k1, int channels, int n_points, void* stream) {
-  if (!dfeats || !xhat || !comp || !gamma || !dxhat || !rowdot || !rowsum) return CSN_E_ARG;
+                    float* rowdot, float* rowsum, int n_shapes, int k1, int channels, int n_points, const float* xhat_self,
+                    float* dxhat_self, void* stream) {
+  if (!dfeats || !comp || !gamma || !rowdot || !rowsum) return CSN_E_ARG;
+  if ((!xhat || !dxhat) && !(xhat_self && k1 == 1)) return CSN_E_ARG;
+  if ((xhat_self == nullptr) != (dxhat_self == nullptr)) return CSN_E_ARG;
   if (n_shapes <= 0 || k1 <= 0 || k1 > 8 || channels <= 0 || n_points <= 0) return CSN_E_ARG;
   if (n_points & 3) return CSN_E_ALIGN;
-  if (mis16(dfeats) || mis16(xhat) || mis16(dxhat)) return CSN_E_PTR;
-  return csn_launch_mix_bwd_f32(dfeats, xhat, comp, gamma, dxhat, rowdot, rowsum, n_shapes, k1, channels, n_points,
-                                (hipStream_t)stream);
+  if (mis16(dfeats) || mis16(xhat) || mis16(dxhat) || mis16(xhat_self) || mis16(dxhat_self)) return CSN_E_PTR;
+  return csn_launch_mix_bwd_f32(dfeats, xhat, comp, gamma, dxhat, rowdot, rowsum, n_shapes, k1, channels, n_points, xhat_self,
+                                dxhat_self, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -91,8 +91,9 @@ int csn_launch_rowdot_f32(const float* a, const float* b, float* out, const int*
 // ---- pooled descriptors / cross-shape mix (combine.hip) ---------------------------------------------
 int csn_launch_rowsum_f32(const float* x, float* out, long long rows, int n, long long ld, hipStream_t st);
 int csn_launch_mix_fwd_f32(const float* xhat, const float* comp, const float* gamma, const float* beta, float* feats, int B,
-                           int K1, int C, int NP, hipStream_t st);
+                           int K1, int C, int NP, const float* xhat0, hipStream_t st);
 int csn_launch_mix_bwd_f32(const float* dfeats, const float* xhat, const float* comp, const float* gamma, float* dxhat,
-                           float* rowdot, float* rowsum, int B, int K1, int C, int NP, hipStream_t st);
+                           float* rowdot, float* rowsum, int B, int K1, int C, int NP, const float* xhat0, float* dxhat0,
+                           hipStream_t st);
 int csn_launch_retrieval_f32(const float* f1, const float* f2, float* out, int s1, int n1, int s2, int n2, int C,
                              float* ws, hipStream_t st);

@@ -401,41 +401,47 @@ def point_mean(x: torch.Tensor) -> torch.Tensor:
 
 
 class _CSAMix(torch.autograd.Function):
-    """feats[b] = sum_k comp[b,k] * (gamma * xhat[b*K1+k] + beta)   for the first B*K1 maps of xhat."""
+    """feats[b] = sum_k comp[b,k] * (gamma * xhat_k + beta).  xhat holds the maps [b*K1 + k]; when ``xself`` is given the
+    k = 0 maps come from it ([b]) and xhat holds the K1 - 1 others ([b*(K1-1) + k-1])."""
 
     @staticmethod
-    def forward(ctx, xhat, comp, gamma, beta, B: int, K1: int):
-        _need_cuda(xhat, comp, gamma, beta)
+    def forward(ctx, xhat, comp, gamma, beta, B: int, K1: int, xself=None):
+        _need_cuda(xhat, comp, gamma, beta, xself)
         E, C, NP = xhat.shape
-        assert xhat.is_contiguous() and E >= B * K1
+        assert xhat.is_contiguous() and E >= B * (K1 if xself is None else K1 - 1)
+        assert xself is None or (xself.is_contiguous() and xself.shape == (B, C, NP))
         comp = comp.contiguous()
         feats = torch.empty((B, C, NP), device=xhat.device, dtype=torch.float32)
         _lib.check(_lib.lib().csn_mix_fwd_f32(_ptr(xhat), _ptr(comp), _ptr(gamma), _ptr(beta), _ptr(feats), B, K1, C, NP,
-                                              _stream()), "csn_mix_fwd_f32")
-        ctx.save_for_backward(xhat, comp, gamma, beta)
+                                              _ptr(xself), _stream()), "csn_mix_fwd_f32")
+        ctx.save_for_backward(xhat, comp, gamma, beta, xself)
         ctx.dims = (B, K1)
         return feats
 
     @staticmethod
     def backward(ctx, dfeats):
-        xhat, comp, gamma, beta = ctx.saved_tensors
+        xhat, comp, gamma, beta, xself = ctx.saved_tensors
         B, K1 = ctx.dims
         E, C, NP = xhat.shape
         dfeats = dfeats.contiguous()
         dxhat = torch.empty_like(xhat)
-        if E > B * K1:
-            dxhat[B * K1:].zero_()                    # (callers hand in exactly the B*K1 mixed maps: nothing to clear)
+        n_mixed = B * (K1 if xself is None else K1 - 1)
+        if E > n_mixed:
+            dxhat[n_mixed:].zero_()                   # (callers hand in exactly the mixed maps: nothing to clear)
+        dxself = torch.empty_like(xself) if xself is not None else None
         rowdot = torch.empty((B, K1, C), device=xhat.device, dtype=torch.float32)
         rowsum = torch.empty((B, C), device=xhat.device, dtype=torch.float32)
         _lib.check(_lib.lib().csn_mix_bwd_f32(_ptr(dfeats), _ptr(xhat), _ptr(comp), _ptr(gamma), _ptr(dxhat), _ptr(rowdot),
-                                              _ptr(rowsum), B, K1, C, NP, _stream()), "csn_mix_bwd_f32")
+                                              _ptr(rowsum), B, K1, C, NP, _ptr(xself), _ptr(dxself), _stream()),
+                   "csn_mix_bwd_f32")
         rd, rs = rowdot.double(), rowsum.double()
         g64, b64, c64 = gamma.double(), beta.double(), comp.double()
         dcomp = (rd * g64).sum(dim=2) + (rs * b64).sum(dim=1, keepdim=True)          # (B, K1)
         dgamma = torch.einsum("bk,bkc->c", c64, rd)
         dbeta = (c64.sum(dim=1, keepdim=True) * rs).sum(dim=0)
-        return dxhat, dcomp.float(), dgamma.float(), dbeta.float(), None, None
+        return dxhat, dcomp.float(), dgamma.float(), dbeta.float(), None, None, dxself
 
 
-def csa_mix(xhat: torch.Tensor, comp: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B: int, K1: int) -> torch.Tensor:
-    return _CSAMix.apply(xhat, comp, gamma, beta, B, K1)
+def csa_mix(xhat: torch.Tensor, comp: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B: int, K1: int,
+            xself: Optional[torch.Tensor] = None) -> torch.Tensor:
+    return _CSAMix.apply(xhat, comp, gamma, beta, B, K1, xself)

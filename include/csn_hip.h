@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSN_ABI_VERSION 6
+#define CSN_ABI_VERSION 7
 
 #define CSN_E_ARG (-1)     /* null pointer / non-positive size            */
 #define CSN_E_ALIGN (-2)   /* a size or leading dimension is not % 4      */
@@ -202,12 +202,16 @@ int csn_retrieval_measure_f32(const float* f1, const float* f2, float* out, int 
  * csn_mix_bwd_f32: dxhat[b*k1 + k][c][n] = comp[b][k] gamma[c] dfeats[b][c][n];
  *                  rowdot[b][k][c] = sum_n dfeats[b][c][n] xhat[b*k1+k][c][n];  rowsum[b][c] = sum_n dfeats[b][c][n]
  *                  (fp64 accumulation) from which d comp, d gamma, d beta follow with O(B*k1*C) host-side math.
+ * xhat_self / dxhat_self != NULL: the k = 0 maps (the shape's own evaluation) live in their own tensors [b][c][n] and
+ * xhat / dxhat hold the k1 - 1 others, [b*(k1-1) + k-1] — the form the overlapped multi-GPU path produces (own shapes are
+ * evaluated while the neighbour exchange is in flight), so that no concatenation of the two is ever built.
  * All maps dense channel-major [..][channels][n_points], n_points % 4 == 0, k1 <= 8. */
 int csn_rowsum_f32(const float* x, float* out, long long rows, int n_points, long long ld, void* stream);
 int csn_mix_fwd_f32(const float* xhat, const float* comp, const float* gamma, const float* beta, float* feats,
-                    int n_shapes, int k1, int channels, int n_points, void* stream);
+                    int n_shapes, int k1, int channels, int n_points, const float* xhat_self, void* stream);
 int csn_mix_bwd_f32(const float* dfeats, const float* xhat, const float* comp, const float* gamma, float* dxhat,
-                    float* rowdot, float* rowsum, int n_shapes, int k1, int channels, int n_points, void* stream);
+                    float* rowdot, float* rowsum, int n_shapes, int k1, int channels, int n_points, const float* xhat_self,
+                    float* dxhat_self, void* stream);
 
 #ifdef __cplusplus
 }

@@ -352,6 +352,43 @@ def test_outproj_ln_fwd_bwd(L, S, E, C, D, NP):
 
 
 # ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("split", [False, True], ids=["one-tensor", "self-separate"])
+@pytest.mark.parametrize("B,K1,C,NP", [(3, 4, 24, 100), (2, 1, 16, 36), (5, 3, 40, 1000)])
+def test_mix_forward_backward(L, B, K1, C, NP, split):
+    """csn_mix_fwd_f32 / csn_mix_bwd_f32: feats[b] = sum_k comp[b,k] (gamma xhat[b,k] + beta), the k = 0 maps either in the
+    same tensor or (overlapped multi-GPU path) in their own."""
+    from csn_amd import functional as CF
+    if split and K1 == 1:
+        pytest.skip("k1 = 1 has no second tensor")
+    rng = np.random.default_rng(B * 100 + K1)
+    xh = _rand(rng, B, K1, C, NP)
+    comp = torch.softmax(_rand(rng, B, K1), dim=1)
+    gamma, beta = _rand(rng, C), _rand(rng, C)
+    dfe = _rand(rng, B, C, NP)
+    x64, c64, g64, b64 = (t.double().requires_grad_() for t in (xh, comp, gamma, beta))
+    ref = (c64[:, :, None, None] * (x64 * g64[None, None, :, None] + b64[None, None, :, None])).sum(dim=1)
+    ref.backward(dfe.double())
+    cg, gg, bg = (t.cuda().requires_grad_() for t in (comp, gamma, beta))
+    if split:
+        own = xh[:, 0].contiguous().cuda().requires_grad_()
+        rest = xh[:, 1:].reshape(B * (K1 - 1), C, NP).contiguous().cuda().requires_grad_()
+        got = CF.csa_mix(rest, cg, gg, bg, B, K1, xself=own)
+    else:
+        allm = xh.reshape(B * K1, C, NP).cuda().requires_grad_()
+        got = CF.csa_mix(allm, cg, gg, bg, B, K1)
+    got.backward(dfe.cuda())
+    assert _maxerr(got, ref) < 1e-5
+    if split:
+        dx = torch.cat((own.grad.view(B, 1, C, NP), rest.grad.view(B, K1 - 1, C, NP)), dim=1)
+    else:
+        dx = allm.grad.view(B, K1, C, NP)
+    assert _maxerr(dx, x64.grad) < 1e-5
+    assert _maxerr(cg.grad, c64.grad) < 1e-4 * max(1.0, c64.grad.abs().max().item())
+    assert _maxerr(gg.grad, g64.grad) < 1e-4 * max(1.0, g64.grad.abs().max().item())
+    assert _maxerr(bg.grad, b64.grad) < 1e-4 * max(1.0, b64.grad.abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------------------------
 def test_retrieval_measure_against_oracle(L):
     from csn_amd import functional as CF
     from oracle import csa_oracle as orc
