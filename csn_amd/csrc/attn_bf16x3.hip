@@ -28,6 +28,14 @@
 #ifdef CSN_STAMPS
 __device__ unsigned long long csn_dbg[2048 * 8 * 4 * 8];
 extern "C" int csn_debug_read(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_dbg), bytes); }
+// whole-kernel stamps per wave: entry, tile loop start, tile loop end, exit
+__device__ unsigned long long csn_dbg_wg[2048 * 8 * 4];
+__device__ unsigned long long csn_dbg_rt[2048 * 8 * 2];     // s_memrealtime (100 MHz) at entry and exit: in-kernel clock
+extern "C" int csn_debug_read_wg(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_dbg_wg), bytes); }
+extern "C" int csn_debug_read_rt(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_dbg_rt), bytes); }
+#define WGSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if ((BWD == (CSN_STAMPS != 0)) && DT == 8 && blockIdx.x >= 4096 && blockIdx.x < 6144 && (threadIdx.x & 63) == 0) { csn_dbg_wg[((blockIdx.x - 4096) * 8 + (threadIdx.x >> 6)) * 4 + i] = __builtin_amdgcn_s_memtime(); if (i == 0 || i == 3) csn_dbg_rt[((blockIdx.x - 4096) * 8 + (threadIdx.x >> 6)) * 2 + (i == 3)] = __builtin_amdgcn_s_memrealtime(); } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define WGSTAMP(i)
 #endif
 
 namespace {
@@ -79,6 +87,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, kq = lane >> 4;
+  WGSTAMP(0);
   // XCD-aware work-group order.  A unit = one (evaluation, head, block); its QT query tiles all stream the same K/V
   // block, so they should share one XCD's L2.  Work-groups are dealt round-robin over the 8 XCDs, hence the QT tiles of
   // unit u get ids 8 * (QT * (u / 8) + qt) + (u % 8): same residue mod 8 (same XCD), adjacent in dispatch order.
@@ -466,6 +475,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   // shift is hazard-free: a K stage is rewritten in segments 2kt / 2kt+1 (early / late half), last read in 2kt-1 and
   // next read in 2kt+2; a V stage is rewritten in 2kt+1 / 2kt+2, last read in 2kt and next read in 2kt+3.
   const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+  WGSTAMP(1);
   if (late) __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1, nxt = cur ^ 1;
@@ -497,6 +507,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   }
 
   // ---- epilogue -----------------------------------------------------------------------------------
+  WGSTAMP(2);
   if (!late) __syncthreads();                           // pairs with the last barrier of the late half: tiles are idle now
   float inv = 1.f;
   if (!BWD) {
@@ -533,6 +544,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
 #pragma unroll
     for (int t = 0; t < CH_T; ++t) csn_bstore4(ch[t], Or, c_off, (unsigned)(16 * t * ld) * 4u);
   }
+  WGSTAMP(3);
 }
 
 template <int DT>

@@ -11,7 +11,7 @@ which is how tests/test_sharding_gloo.py covers the N > 1 path without a GPU.
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Optional
+from typing import Callable, Iterable, List, Optional
 
 import numpy as np
 import torch
@@ -154,3 +154,45 @@ class PendingStack:
             self._work.wait()                                  # orders the compute stream behind the collective
             self._stack = self._shard.neighbour_stack(self._feats, self._shard._gathered)
         return self._stack
+
+
+# -- kNN shape graph, rows of the retrieval matrix sharded by query shape (collective 4) --------------------
+def _gather_shards(local: torch.Tensor, group=None) -> torch.Tensor:
+    """Concatenation over ranks (in rank order) of per-rank tensors (n_r, ...) whose leading sizes may differ."""
+    world = dist.get_world_size(group)
+    n = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
+    counts = torch.empty((world,), device=local.device, dtype=torch.int64)
+    dist.all_gather_into_tensor(counts, n, group=group)
+    counts = counts.tolist()
+    n_max = max(counts)
+    if n_max == 0:
+        return local
+    padded = local if local.shape[0] == n_max else torch.cat(
+        (local, local.new_zeros((n_max - local.shape[0],) + tuple(local.shape[1:]))), dim=0)
+    out = local.new_empty((world * n_max,) + tuple(local.shape[1:]))
+    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    if all(c == n_max for c in counts):
+        return out
+    return torch.cat([out[r * n_max:r * n_max + c] for r, c in enumerate(counts)], dim=0)
+
+
+@torch.no_grad()
+def knn_graph_sharded(query_local: torch.Tensor, K: int, measure: Callable[[torch.Tensor, torch.Tensor], torch.Tensor],
+                      cand_local: Optional[torch.Tensor] = None, pair_budget: int = 2 ** 28, group=None) -> torch.Tensor:
+    """The (S_q, K+1) int64 kNN table of get_knn_graph (MID-FC/csa_models.py:270-280, called at csa_training.py:157-163),
+    built by all ranks together: rank r holds the point-major SSA features (n_r, N, C) of its own query shapes
+    (``query_local``) and of its share of the candidate shapes (``cand_local``; None = the queries are the candidates, the
+    train-vs-train graph).  The candidates are all-gathered (the same payload as the point-feature exchange of the training
+    step), every rank scores ITS query rows against all candidates with ``measure(f_q, f_c) -> (n_q, S_c)`` —
+    csn_amd.functional.retrieval_measure on the GPU — takes topk(K+1) locally, and the index rows are all-gathered, so every
+    rank returns the whole table, row order = rank order.  Every (query, candidate) score is computed by exactly one rank with
+    the arithmetic of the single-process path, so the table is bit-identical to it."""
+    cand = _gather_shards(query_local if cand_local is None else cand_local, group)
+    n_q, N = query_local.shape[0], query_local.shape[1]
+    S_c = cand.shape[0]
+    if S_c < K + 1:
+        raise ValueError(f"{S_c} candidate shapes cannot give {K + 1} neighbours")
+    rows = max(1, min(max(n_q, 1), pair_budget // max(1, S_c * N)))          # bound the per-point maxima scratch
+    parts = [measure(query_local[i:i + rows], cand).topk(K + 1, dim=-1)[1] for i in range(0, n_q, rows)]
+    mine = torch.cat(parts, dim=0) if parts else torch.empty((0, K + 1), device=query_local.device, dtype=torch.int64)
+    return _gather_shards(mine.to(torch.int64), group)

@@ -19,7 +19,13 @@ base = qkv.data_ptr()
 kvt = to_tiles(qkv[:, D:], T, nb)
 kp = kvt.data_ptr()
 L.csn_set_math_mode(1)
-for _ in range(2):
+import time
+t_end = time.time() + float(os.environ.get("CSN_STAMP_SUSTAIN", "2.0"))     # sustained load first: the clock settles
+n_launch = 0
+while n_launch < 2 or time.time() < t_end:
+    n_launch += 1
+    if n_launch % 8 == 0:
+        torch.cuda.synchronize()
     _lib.check(L.csn_block_attn_fwd_f32(base, kp, kp + 2 * D * nb * 1024, 3 * D * NP, 2 * D * nb * 1024, CF._ptr(qs), CF._ptr(ks), NP,
                                         CF._ptr(att), D * NP, CF._ptr(scores), CF._ptr(lse), E, H, d, T, nb, Tp, 8.0, 0.1, 1234, 1, nb * 1024,
                                         CF._stream()), "fwd")
@@ -47,3 +53,24 @@ for w in (0, 4, 3, 7):
 print("all waves: " + "  ".join(f"{n}={d_[..., i].mean():7.0f}" for i, n in enumerate(names)), f" total={d_.sum(axis=-1).mean():7.0f}")
 # skew between wave 0 and wave 4 at the start of P1
 print("start skew wave4 - wave0:", (st[ok][:, 4, :, 0] - st[ok][:, 0, :, 0]).mean(), " end-of-P1 skew:", (st[ok][:, 4, :, 1] - st[ok][:, 0, :, 1]).mean())
+
+# whole-kernel stamps (work-groups 4096..6143, i.e. well inside the launch): entry, loop start, loop end, exit
+m = 2048 * 8 * 4
+wb = np.zeros(m, dtype=np.uint64)
+L.csn_debug_read_wg.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+L.csn_debug_read_wg(wb.ctypes.data, m * 8)
+w = wb.reshape(2048, 8, 4).astype(np.int64)
+okw = (w[..., 0] > 0).all(axis=1)
+w = w[okw]
+dw = np.diff(w, axis=-1)
+t0 = w[:, :, 0].min(axis=1, keepdims=True)
+print("whole kernel, work-groups:", okw.sum(), " (s_memtime ticks = 100 MHz x ? — same unit as above)")
+print("  per wave mean: prologue=%.0f loop=%.0f epilogue=%.0f total=%.0f" % (dw[..., 0].mean(), dw[..., 1].mean(), dw[..., 2].mean(), (w[..., 3] - w[..., 0]).mean()))
+print("  per work-group (first entry -> last exit): %.0f" % (w[:, :, 3].max(axis=1) - w[:, :, 0].min(axis=1)).mean())
+rb = np.zeros(2048 * 8 * 2, dtype=np.uint64)
+L.csn_debug_read_rt.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+L.csn_debug_read_rt(rb.ctypes.data, rb.nbytes)
+r = rb.reshape(2048, 8, 2).astype(np.int64)[okw]
+clk = (w[..., 3] - w[..., 0]) / np.maximum(r[..., 1] - r[..., 0], 1) * 100.0
+print("  in-kernel clock (d s_memtime / d s_memrealtime x 100 MHz): median %.0f MHz  (p10 %.0f, p90 %.0f);  work-group wall %.1f us" %
+      (np.median(clk), np.percentile(clk, 10), np.percentile(clk, 90), np.median(r[..., 1] - r[..., 0]) / 100.0))

@@ -130,3 +130,45 @@ def test_graph_rejects_self_neighbours_and_bad_sizes():
     bad[1, 0] = 1
     with pytest.raises(ValueError):
         ShapeGraphShard(bad, 4, 0, 2, torch.device("cpu"))
+
+
+# ---- kNN graph build sharded by query shape (SURVEY §8e collective 4) ----------------------------------------------------
+_KNN_Q, _KNN_C = (3, 2, 1), (2, 2, 3)            # query / candidate shapes per rank (uneven on purpose)
+
+
+def _knn_sets():
+    rng = np.random.default_rng(91)
+    return orc.synth_clustered_feats(rng, sum(_KNN_Q), 40, C=32), orc.synth_clustered_feats(rng, sum(_KNN_C), 52, C=32)
+
+
+def _knn_worker(rank, world, port, out_dir):
+    from csn_amd.sharding import knn_graph_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    q, c = _knn_sets()
+    q0, c0 = sum(_KNN_Q[:rank]), sum(_KNN_C[:rank])
+    ql, cl = q[q0:q0 + _KNN_Q[rank]].clone(), c[c0:c0 + _KNN_C[rank]].clone()
+    g_qc = knn_graph_sharded(ql, 2, orc.retrieval_measure, cand_local=cl, pair_budget=7 * 40)   # one query row per chunk
+    g_qq = knn_graph_sharded(ql, 2, orc.retrieval_measure)                                      # queries = candidates
+    torch.save({"qc": g_qc, "qq": g_qq}, os.path.join(out_dir, f"knn{rank}.pt"))
+    with pytest.raises(ValueError):
+        knn_graph_sharded(ql, 7, orc.retrieval_measure, cand_local=cl)                          # 7 candidates, 8 wanted
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_knn_graph_sharded_three_ranks_uneven(tmp_path):
+    """Every rank scores its own query rows against the all-gathered candidates; the gathered index table equals the
+    single-process get_knn_graph bit for bit, on every rank, with uneven shards."""
+    world = 3
+    mp.spawn(_knn_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    q, c = _knn_sets()
+    ref_qc, ref_qq = orc.knn_graph(q, c, 2), orc.knn_graph(q, q, 2)
+    assert ref_qc.dtype == torch.int64 and ref_qc.shape == (sum(_KNN_Q), 3)
+    assert torch.equal(ref_qq[:, 0], torch.arange(sum(_KNN_Q)))                      # a shape retrieves itself first
+    for r in range(world):
+        got = torch.load(os.path.join(tmp_path, f"knn{r}.pt"))
+        assert got["qc"].dtype == torch.int64 and torch.equal(got["qc"], ref_qc)
+        assert torch.equal(got["qq"], ref_qq)
