@@ -33,6 +33,17 @@ __global__ __launch_bounds__(256) void csn_rowsum_kernel(const float* __restrict
   if (threadIdx.x == 0) out[blockIdx.x] = (float)s;
 }
 
+// out[e][c] = sum_t ws[e][t][c]  (per-tile partial sums of the out-projection epilogue; fp64 accumulation, fixed order)
+__global__ __launch_bounds__(256) void csn_partial_sums_kernel(const float* __restrict__ ws, float* __restrict__ out,
+                                                               int tiles, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float* __restrict__ p = ws + (long long)blockIdx.y * tiles * C + c;
+  double s = 0.0;
+  for (int t = 0; t < tiles; ++t) s += (double)p[(long long)t * C];
+  out[(long long)blockIdx.y * C + c] = (float)s;
+}
+
 // feats[b][c][n] = gamma[c] * sum_k comp[b][k] xhat[(b*K1+k)][c][n] + beta[c] * sum_k comp[b][k]
 // xhat0 != null: the k = 0 maps live in their own tensor xhat0[b][c][n] and xhat holds the K1 - 1 others, [b*(K1-1) + k-1]
 __global__ __launch_bounds__(256) void csn_mix_fwd_kernel(const float* __restrict__ xhat, const float* __restrict__ comp,
@@ -104,6 +115,13 @@ __global__ __launch_bounds__(256) void csn_mix_bwd_kernel(const float* __restric
 int csn_launch_rowsum_f32(const float* x, float* out, long long rows, int n, long long ld, hipStream_t st) {
   if (rows <= 0) return 0;
   hipLaunchKernelGGL(csn_rowsum_kernel, dim3((unsigned)rows), dim3(256), 0, st, x, out, n, ld);
+  return (int)hipGetLastError();
+}
+
+int csn_launch_partial_sums_f32(const float* ws, float* out, long long rows_outer, int tiles, int C, hipStream_t st) {
+  if (rows_outer <= 0) return 0;
+  hipLaunchKernelGGL(csn_partial_sums_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)rows_outer), dim3(256), 0, st, ws, out,
+                     tiles, C);
   return (int)hipGetLastError();
 }
 

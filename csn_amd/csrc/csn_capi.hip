@@ -314,9 +314,11 @@ int csn_cross_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_ev
 int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const float* wfc, const float* xres,
                            long long xres_shape_stride, const int* res_index, float* xhat,
                            long long xhat_eval_stride, float* rstd, int n_evals, int d_model, int d_inner, int ld,
-                           int n_points, float eps, float dropout_p, unsigned long long seed, void* stream) {
+                           int n_points, float eps, float dropout_p, unsigned long long seed, float* xhat_sum,
+                           float* sum_ws, long long sum_ws_floats, void* stream) {
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
   if (!ctx || !wfc || !xres || !xhat || !rstd || n_evals <= 0 || n_points <= 0 || d_inner <= 0) return CSN_E_ARG;
+  if (xhat_sum && xhat_eval_stride != (long long)d_model * ld) return CSN_E_STRIDE;     // the row-sum pass walks dense maps
   if (!dim_ok(d_model)) return CSN_E_DIM;
   if ((ld & 3) || (d_inner & 3) || (n_points & 3)) return CSN_E_ALIGN;
   if (mis16(ctx) || mis16(wfc) || mis16(xres) || mis16(xhat)) return CSN_E_PTR;
@@ -327,6 +329,7 @@ int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const fl
   a.xhat = xhat; a.xhat_eval_stride = xhat_eval_stride; a.rstd = rstd;
   a.E = n_evals; a.C = d_model; a.D = d_inner; a.ld = ld; a.n_points = n_points; a.eps = eps;
   a.dropout_p = dropout_p; a.seed = seed;
+  a.xhat_sum = xhat_sum; a.sum_ws = sum_ws; a.sum_ws_floats = sum_ws ? sum_ws_floats : 0;
   return csn_launch_outproj_ln_fwd_f32(a, g_math_mode == 1, (hipStream_t)stream);
 }
 

@@ -67,7 +67,12 @@ struct CsnOutProjArgs {
   float eps;
   float dropout_p;                                       // dropout on the fc output (csa_models.py:115); 0 = off
   unsigned long long seed;
+  // optional: xhat_sum[e][c] = sum over points of xhat (the pooled descriptor of csa_models.py:211-212 before the affine).
+  // The 256 x 256-tile kernel forms per-tile partial sums in its epilogue (sum_ws [e][ceil(n_points/256)][C], reduced by a
+  // small second kernel in fp64); the other kernels are followed by the streaming row-sum pass.
+  float* xhat_sum; float* sum_ws; long long sum_ws_floats;
 };
+int csn_launch_partial_sums_f32(const float* ws, float* out, long long rows_outer, int tiles, int C, hipStream_t st);
 int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, int fast, hipStream_t st);   // fast: bf16x3 contraction
 int csn_launch_outproj_ln_big(const CsnOutProjArgs& a, hipStream_t st);                 // gemm_bf16x3.hip: C = 256, 256 x 256 tiles
 

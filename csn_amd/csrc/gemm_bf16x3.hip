@@ -549,13 +549,36 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
     for (int j = 0; j < NT; ++j) {
       const int nl = wn0 + 32 * j + l31;
       rstd[j] = 1.f / sqrtf((red[1024 + nl] + red[1280 + nl] + red[1536 + nl] + red[1792 + nl]) * (1.f / BM) + q.eps);
+      const bool pt_ok = (n0 + nl) < N;
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          csn_bstore((acc[i][j][r] - mean[j]) * rstd[j], Cr, voff[j],
-                     (unsigned)(wm0 + 32 * i + csn_acc_row(r, 0)) * (unsigned)ldc * 4u);
-      if (wmi == 0 && h == 0 && (n0 + nl) < N) q.rstd[(long long)z2 * q.n_points + n0 + nl] = rstd[j];
+        for (int r = 0; r < 16; ++r) {
+          const float xh = (acc[i][j][r] - mean[j]) * rstd[j];
+          csn_bstore(xh, Cr, voff[j], (unsigned)(wm0 + 32 * i + csn_acc_row(r, 0)) * (unsigned)ldc * 4u);
+          acc[i][j][r] = pt_ok ? xh : 0.f;
+        }
+      if (wmi == 0 && h == 0 && pt_ok) q.rstd[(long long)z2 * q.n_points + n0 + nl] = rstd[j];
+    }
+    if (q.sum_ws) {
+      // per-channel sums of xhat over this tile's points (the pooled descriptor needs mean_n xhat): lane partials over the
+      // wave's 4 column tiles go to LDS as psum[row][wn][32 lanes]; thread (row, wn) adds its 32 (conflict-free rotation),
+      // the pair is combined and one float per row leaves for sum_ws[e][tile_n][row]
+      float* psum = reinterpret_cast<float*>(&Bs[0][0][0]);         // 64 KB; `red` lives in As
+      const int wn = wave & 1;
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm0 + 32 * i + csn_acc_row(r, h);
+          psum[(row * 2 + wn) * 32 + l31] = (acc[i][0][r] + acc[i][1][r]) + (acc[i][2][r] + acc[i][3][r]);
+        }
+      __syncthreads();
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 32; ++k) s += psum[tid * 32 + ((k + tid) & 31)];
+      s += __shfl_xor(s, 1, 64);
+      if ((tid & 1) == 0) q.sum_ws[((long long)z2 * tiles_n + tile_n) * 256 + (tid >> 1)] = s;
     }
     return;
   }
@@ -653,7 +676,14 @@ int csn_launch_outproj_ln_big(const CsnOutProjArgs& a, hipStream_t st) {
   g.M = 256; g.N = a.n_points; g.K = a.D;
   g.n0 = 1; g.n1 = 1; g.k_chunk = 0;
   g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = 0; g.eval_ids = nullptr;
-  return launch_big<false, false, true>(g, a.E, st, &a);
+  const int tiles_n = (a.n_points + 255) / 256;
+  CsnOutProjArgs b = a;
+  const bool fused_sums = a.xhat_sum && a.sum_ws && a.sum_ws_floats >= (long long)a.E * tiles_n * 256;
+  if (!fused_sums) b.sum_ws = nullptr;
+  int rc = launch_big<false, false, true>(g, a.E, st, &b);
+  if (rc || !a.xhat_sum) return rc;
+  if (fused_sums) return csn_launch_partial_sums_f32(a.sum_ws, a.xhat_sum, a.E, tiles_n, 256, st);
+  return csn_launch_rowsum_f32(a.xhat, a.xhat_sum, (long long)a.E * a.C, a.n_points, a.ld, st);
 }
 
 int csn_launch_gemm_bf16x3(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st) {

@@ -397,14 +397,17 @@ int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, int fast, hipStream_t
   if ((a.ld & 3) || (a.D & 3) || (a.n_points & 3)) return -2;
   if ((a.ctx_eval_stride & 3) || (a.xres_shape_stride & 3) || (a.xhat_eval_stride & 3)) return -4;
   if (fast && a.C == 256 && a.n_points >= 224) return csn_launch_outproj_ln_big(a, st);     // 256 x 256 tiles (gemm_bf16x3.hip)
+  int rc;
   switch (a.C) {
-    case 32: return launch_fwd<1>(a, fast, st);
-    case 64: return launch_fwd<2>(a, fast, st);
-    case 96: return launch_fwd<3>(a, fast, st);
-    case 128: return launch_fwd<4>(a, fast, st);
-    case 256: return launch_fwd<8>(a, fast, st);
+    case 32: rc = launch_fwd<1>(a, fast, st); break;
+    case 64: rc = launch_fwd<2>(a, fast, st); break;
+    case 96: rc = launch_fwd<3>(a, fast, st); break;
+    case 128: rc = launch_fwd<4>(a, fast, st); break;
+    case 256: rc = launch_fwd<8>(a, fast, st); break;
     default: return -5;
   }
+  if (rc || !a.xhat_sum) return rc;
+  return csn_launch_rowsum_f32(a.xhat, a.xhat_sum, (long long)a.E * a.C, a.n_points, a.ld, st);   // streaming pass over xhat
 }
 
 int csn_launch_ln_bwd_f32(const CsnLnBwdArgs& a, hipStream_t st) {

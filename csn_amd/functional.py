@@ -12,6 +12,7 @@ evaluations over K+1 slots (csa_models.py:209-242); each slot is projected to Q/
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -24,6 +25,7 @@ REF_NBLOCKS = 20      # MID-FC/csa_models.py:83
 LN_EPS = 1e-6         # MID-FC/csa_models.py:57
 RESCALE_THRESHOLD = 8.0
 USE_KV_TILES = True          # fast math: K/V leave the projection as bf16 tile planes (see csn_project_f32, out_split = 2)
+FUSED_POINT_SUMS = os.environ.get("CSN_FUSED_SUMS", "1") != "0"   # 0: pooled sums by a streaming pass (development A/B)
 # bench.py sets this to a list to collect (start, end) HIP-event pairs around the fused attention forward launch
 EVENT_SINK = None
 
@@ -173,7 +175,7 @@ class _MHAEvals(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_all, w_qs, w_ks, w_vs, w_fc, plan: EvalPlan, geo: MHAGeometry, keep_scores: bool,
-                p_attn: float = 0.0, p_fc: float = 0.0, n_head_evals: int = 0):
+                p_attn: float = 0.0, p_fc: float = 0.0, n_head_evals: int = 0, want_sums: bool = False):
         _need_cuda(x_all, w_qs, w_ks, w_vs, w_fc)
         ctx.set_materialize_grads(False)               # an unused output must not cost a zero-filled (E, C, NP) gradient
         # dropout masks are counter-based: two 62-bit seeds from torch's CPU generator (torch.manual_seed reproduces them)
@@ -231,10 +233,16 @@ class _MHAEvals(torch.autograd.Function):
         xhat = torch.empty((E, C, NP), device=dev, dtype=torch.float32)
         rstd = torch.empty((E, NP), device=dev, dtype=torch.float32)
         w_fc = w_fc.contiguous()
+        # third output (want_sums): sums[e][c] = sum_n xhat[e][c][n], formed in the epilogue of the out-projection (per-tile
+        # partials in sum_ws) instead of a separate streaming pass over the 2.6 GB of maps
+        sums = torch.empty((E, C), device=dev, dtype=torch.float32) if want_sums else None
+        sum_ws_n = E * ((NP + 255) // 256) * C if (want_sums and FUSED_POINT_SUMS) else 0
+        sum_ws = torch.empty((sum_ws_n,), device=dev, dtype=torch.float32) if sum_ws_n else None
         _lib.check(L.csn_outproj_ln_fwd_f32(_ptr(att), D * NP, _ptr(w_fc), _ptr(x_all), C * NP, _ptr(q_slots),
                                             _ptr(xhat), C * NP, _ptr(rstd), E, C, D, NP, NP, LN_EPS, p_fc, seed_fc,
-                                            _stream()),
+                                            _ptr(sums), _ptr(sum_ws), sum_ws_n, _stream()),
                    "csn_outproj_ln_fwd_f32")
+        del sum_ws
         if keep_scores:
             ctx.save_for_backward(x_all, w_qkv, w_fc, qkv, att, lse, scores, xhat, rstd, kv)
             ctx.geo = geo
@@ -245,10 +253,10 @@ class _MHAEvals(torch.autograd.Function):
         # constant along the points (the pooled means) and a consumer of the leading maps only (the mix) then hand the
         # backward two cheap gradients instead of one dense (E, C, NP) sum.
         ctx.n_head = n_head_evals
-        return xhat, xhat[:n_head_evals]
+        return xhat, xhat[:n_head_evals], sums
 
     @staticmethod
-    def backward(ctx, dxhat, dhead):
+    def backward(ctx, dxhat, dhead, dsums=None):
         x_all, w_qkv, w_fc, qkv, att, lse, scores, xhat, rstd, kv = ctx.saved_tensors
         geo: MHAGeometry = ctx.geo
         plan: EvalPlan = ctx.plan
@@ -262,6 +270,8 @@ class _MHAEvals(torch.autograd.Function):
         rows = None
         if dxhat is not None and dxhat.stride(2) == 0 and dxhat.stride(1) == 1:
             rows, dxhat = dxhat[:, :, 0].contiguous(), None              # expanded (E, C, 1) -> (E, C)
+        if dsums is not None:                                            # gradient of the fused point sums: the same row term
+            rows = dsums.contiguous() if rows is None else rows + dsums
         if ctx.n_head == 0:
             dhead = None
         if dxhat is not None and dhead is not None:
@@ -338,17 +348,22 @@ class _MHAEvals(torch.autograd.Function):
             dqkv[:, :D] /= temperature
             dx_all = project(dqkv, w_qkv.t().contiguous())
             dx_all.index_add_(0, plan.q_slots.long(), dz if dz_res is None else dz_res)
-        return dx_all, dw_q, dw_k, dw_v, dw_fc, None, None, None, None, None, None
+        return dx_all, dw_q, dw_k, dw_v, dw_fc, None, None, None, None, None, None, None
 
 
 def mha_evals(x_all: torch.Tensor, w_qs: torch.Tensor, w_ks: torch.Tensor, w_vs: torch.Tensor, w_fc: torch.Tensor,
-              plan: EvalPlan, geo: MHAGeometry, p_attn: float = 0.0, p_fc: float = 0.0, n_head_evals: int = 0):
+              plan: EvalPlan, geo: MHAGeometry, p_attn: float = 0.0, p_fc: float = 0.0, n_head_evals: int = 0,
+              want_sums: bool = False):
     """p_attn / p_fc: train-mode dropout probabilities of csa_models.py:141 / :115 (0 in eval mode).
-    n_head_evals > 0: returns (xhat, xhat[:n_head_evals]) — use the second for consumers of the leading maps only."""
+    n_head_evals > 0: returns (xhat, xhat[:n_head_evals]) — use the second for consumers of the leading maps only.
+    want_sums: a further result, the (E, C) sums over the points of every map (differentiable; the pooled descriptors)."""
     keep = torch.is_grad_enabled() and any(t.requires_grad for t in (x_all, w_qs, w_ks, w_vs, w_fc))
-    xhat, head = _MHAEvals.apply(x_all, w_qs, w_ks, w_vs, w_fc, plan, geo, keep, float(p_attn), float(p_fc),
-                                 int(n_head_evals))
-    return (xhat, head) if n_head_evals > 0 else xhat
+    xhat, head, sums = _MHAEvals.apply(x_all, w_qs, w_ks, w_vs, w_fc, plan, geo, keep, float(p_attn), float(p_fc),
+                                       int(n_head_evals), bool(want_sums))
+    out = (xhat, head) if n_head_evals > 0 else (xhat,)
+    if want_sums:
+        out = out + (sums,)
+    return out if len(out) > 1 else out[0]
 
 
 class _LinearCM(torch.autograd.Function):

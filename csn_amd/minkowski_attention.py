@@ -70,7 +70,7 @@ class _CrossMHA(torch.autograd.Function):
         rstd = torch.empty((b, lq4), device=dev, dtype=torch.float32)
         w_fc = w_fc.contiguous()
         _lib.check(L.csn_outproj_ln_fwd_f32(CF._ptr(att), D * lq4, CF._ptr(w_fc), CF._ptr(xq_cm), C * lq4, None, CF._ptr(xhat),
-                                            C * lq4, CF._ptr(rstd), b, C, D, lq4, lq4, CF.LN_EPS, p_fc, seed_fc, CF._stream()),
+                                            C * lq4, CF._ptr(rstd), b, C, D, lq4, lq4, CF.LN_EPS, p_fc, seed_fc, None, None, 0, CF._stream()),
                    "csn_outproj_ln_fwd_f32")
         if keep:
             ctx.save_for_backward(xq_cm, xk_cm, xv_cm, w_qs, w_ks, w_vs, w_fc, q, k, v, att, lse, scores, xhat, rstd)

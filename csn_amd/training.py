@@ -180,3 +180,19 @@ def update_knn_graphs(model, train_loader, test_loader, K: int, device, big_cate
         train_g = knn_graph_from_features(model, train_f, train_f, K)
         test_g = knn_graph_from_features(model, test_f, train_f, K)
     return train_g.cpu().numpy().astype(np.int64), test_g.cpu().numpy().astype(np.int64)
+
+
+@torch.no_grad()
+def update_knn_graphs_sharded(model, train_loader_local, test_loader_local, K: int, device, group=None):
+    """update_knn_graphs with the shape collection sharded over the ranks of a torch.distributed job: every rank
+    passes loaders over ITS shapes only (contiguous id ranges in rank order), computes their SSA features, and the train
+    features are all-gathered as the candidate set; each rank scores its own rows.  Returns the whole (S_train, K+1) and
+    (S_test, K+1) int64 tables on every rank — bit-identical to the single-process ones (small-category form; the k-means
+    candidate subset of big categories is CPU code over global descriptors and stays single-process)."""
+    from . import functional as CF
+    from .sharding import knn_graph_sharded
+    train_f = ssa_features(model, train_loader_local, device)
+    test_f = ssa_features(model, test_loader_local, device)
+    train_g = knn_graph_sharded(train_f, K, CF.retrieval_measure, group=group)
+    test_g = knn_graph_sharded(test_f, K, CF.retrieval_measure, cand_local=train_f, group=group)
+    return train_g.cpu().numpy().astype(np.int64), test_g.cpu().numpy().astype(np.int64)

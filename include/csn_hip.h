@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSN_ABI_VERSION 7
+#define CSN_ABI_VERSION 8
 
 #define CSN_E_ARG (-1)     /* null pointer / non-positive size            */
 #define CSN_E_ALIGN (-2)   /* a size or leading dimension is not % 4      */
@@ -154,11 +154,17 @@ int csn_cross_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_ev
  * LayerNorm's affine (gamma, beta), which the caller applies (it is needed un-applied by the backward).
  *   xhat [n_evals][d_model][ld],  rstd [n_evals][n_points].
  * dropout_p / seed: train-mode dropout on the fc output before the residual add (csa_models.py:56,115);
- * mask = function of (seed, position in xhat).  0 = eval mode. */
+ * mask = function of (seed, position in xhat).  0 = eval mode.
+ * xhat_sum (optional) [n_evals][d_model]: sum over the points of every xhat row — n_points * the pooled descriptor
+ * mean_n SSA(x) of csa_models.py:211-212, 218-219 before the affine.  With a workspace sum_ws of
+ * n_evals * ceil(n_points / 256) * d_model floats (sum_ws_floats says how many there are) the 256-channel bf16x3 kernel forms
+ * per-tile partial sums in its epilogue and a small kernel adds them in a fixed order; without one, or on the other kernels,
+ * a streaming pass over xhat follows (dense maps only: xhat_eval_stride == d_model * ld). */
 int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const float* wfc, const float* xres,
                            long long xres_shape_stride, const int* res_index, float* xhat,
                            long long xhat_eval_stride, float* rstd, int n_evals, int d_model, int d_inner, int ld,
-                           int n_points, float eps, float dropout_p, unsigned long long seed, void* stream);
+                           int n_points, float eps, float dropout_p, unsigned long long seed, float* xhat_sum,
+                           float* sum_ws, long long sum_ws_floats, void* stream);
 
 /* ---- (5) output projection + LayerNorm, backward -------------------------------------------------------
  * dz   = dropout-mask * LayerNorm-backward(dxhat; xhat, rstd)   [n_evals][d_model][ld]  (d fc output)

@@ -8,7 +8,7 @@ att = torch.randn((E, D, NP), device="cuda"); w = torch.randn((C, D), device="cu
 ridx = (torch.arange(E, device="cuda", dtype=torch.int32) % 32)
 xhat = torch.empty((E, C, NP), device="cuda"); rstd = torch.empty((E, NP), device="cuda")
 def f(p):
-    _lib.check(L.csn_outproj_ln_fwd_f32(CF._ptr(att), D * NP, CF._ptr(w), CF._ptr(x), C * NP, CF._ptr(ridx), CF._ptr(xhat), C * NP, CF._ptr(rstd), E, C, D, NP, NP, 1e-6, p, 1234, CF._stream()))
+    _lib.check(L.csn_outproj_ln_fwd_f32(CF._ptr(att), D * NP, CF._ptr(w), CF._ptr(x), C * NP, CF._ptr(ridx), CF._ptr(xhat), C * NP, CF._ptr(rstd), E, C, D, NP, NP, 1e-6, p, 1234, None, None, 0, CF._stream()))
 for p in (0.0, 0.1):
     t = timeit(lambda: f(p), n=9)
     print(f"outproj+LN E={E} dropout={p}: {t:6.3f} ms {2*E*C*D*NP/t/1e9:6.1f} TF/s")

@@ -91,7 +91,7 @@ def test_fc_dropout_forward_backward_with_host_mask(E, C, D, NP, p):
     xhat = torch.empty((E, C, NP), device="cuda")
     rstd = torch.empty((E, NP), device="cuda")
     L.check(L.lib().csn_outproj_ln_fwd_f32(attd.data_ptr(), D * NP, wd.data_ptr(), xd.data_ptr(), C * NP, None, xhat.data_ptr(),
-                                           C * NP, rstd.data_ptr(), E, C, D, NP, NP, 1e-6, p, seed, _stream()))
+                                           C * NP, rstd.data_ptr(), E, C, D, NP, NP, 1e-6, p, seed, None, None, 0, _stream()))
     mask = torch.from_numpy(dr.fc_mask(E, C, NP, seed, p)).double()
     a64, w64, x64 = att.double().requires_grad_(True), wfc.double().requires_grad_(True), x.double().requires_grad_(True)
     z = torch.einsum("cd,edn->ecn", w64, a64) * mask / (1 - p) + x64

@@ -318,8 +318,18 @@ def test_outproj_ln_fwd_bwd(L, S, E, C, D, NP):
     attd, wd, xd, rid = att.cuda(), wfc.cuda(), x.cuda(), torch.from_numpy(ridx).cuda()
     xhat = torch.empty((E, C, NP), device=dev)
     rstd = torch.empty((E, NP), device=dev)
+    # point sums of xhat (the pooled descriptors): with a workspace (fused into the epilogue where the kernel can) and without
+    sums = torch.full((E, C), float("nan"), device=dev)
+    sums_nows = torch.full((E, C), float("nan"), device=dev)
+    ws_n = E * ((NP + 255) // 256) * C
+    ws = torch.empty((ws_n,), device=dev)
     L.check(L.lib().csn_outproj_ln_fwd_f32(attd.data_ptr(), D * NP, wd.data_ptr(), xd.data_ptr(), C * NP, rid.data_ptr(),
-                                           xhat.data_ptr(), C * NP, rstd.data_ptr(), E, C, D, NP, NP, 1e-6, 0.0, 0, _stream()))
+                                           xhat.data_ptr(), C * NP, rstd.data_ptr(), E, C, D, NP, NP, 1e-6, 0.0, 0,
+                                           sums_nows.data_ptr(), None, 0, _stream()))
+    xhat.fill_(float("nan"))
+    L.check(L.lib().csn_outproj_ln_fwd_f32(attd.data_ptr(), D * NP, wd.data_ptr(), xd.data_ptr(), C * NP, rid.data_ptr(),
+                                           xhat.data_ptr(), C * NP, rstd.data_ptr(), E, C, D, NP, NP, 1e-6, 0.0, 0,
+                                           sums.data_ptr(), ws.data_ptr(), ws_n, _stream()))
     a64 = att.double().requires_grad_(True)
     w64 = wfc.double().requires_grad_(True)
     z = torch.einsum("cd,edn->ecn", w64, a64) + x.double()[ridx]
@@ -328,6 +338,9 @@ def test_outproj_ln_fwd_bwd(L, S, E, C, D, NP):
     ref = (z - mean) / torch.sqrt(var + 1e-6)
     assert _maxerr(xhat, ref) < tol(5e-6)
     assert _maxerr(rstd, (1 / torch.sqrt(var + 1e-6)).squeeze(1)) < tol(5e-6)
+    ref_sums = ref.sum(dim=2)                                           # O(sqrt(NP)) numbers summing O(1) terms
+    for got in (sums, sums_nows):
+        assert ((got.cpu().double() - ref_sums).abs().max() / NP).item() < tol(2e-6)
 
     dz = torch.empty((E, C, NP), device=dev)
     datt = torch.empty((E, D, NP), device=dev)
