@@ -85,7 +85,7 @@ _SIGNATURES = {
     "csn_outproj_ln_bwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int,
                                        c_int, c_int, c_int, c_float, c_ulonglong, c_int, c_longlong, c_void_p, c_int,
-                                       c_void_p]),
+                                       c_void_p, c_int, c_void_p]),
     "csn_project_wgrad_f32": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_longlong, c_int, c_void_p, c_int, c_int,
                                       c_int, c_int, c_float, c_int, c_void_p, c_longlong, c_void_p]),
     "csn_retrieval_measure_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
@@ -113,7 +113,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.csn_version() != 8:
+        if handle.csn_version() != 9:
             raise CsnError("libcsn_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -84,13 +84,13 @@ class MultiHeadAttention(nn.Module):
         return (self.attention.dropout.p, self.dropout.p) if self.training else (0.0, 0.0)
 
     def evaluate(self, x_all: torch.Tensor, plan: CF.EvalPlan, geo: Optional[CF.MHAGeometry] = None, n_head_evals: int = 0,
-                 want_sums: bool = False):
+                 want_sums: bool = False, link_mix: bool = False):
         """Normalised (pre-affine) outputs (E, C, NP) of a batch of evaluations over shared slots
-        (n_head_evals > 0: also the leading maps as a second tensor; want_sums: also their (E, C) sums over the points,
-        see CF.mha_evals)."""
+        (n_head_evals > 0: also the leading maps as a second result — a tensor, or with link_mix the LinkedMaps that
+        CF.csa_mix takes; want_sums: also their (E, C) sums over the points, see CF.mha_evals)."""
         p_attn, p_fc = self.dropout_rates()
         return CF.mha_evals(x_all, self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight,
-                            plan, geo or self.geometry(), p_attn, p_fc, n_head_evals, want_sums)
+                            plan, geo or self.geometry(), p_attn, p_fc, n_head_evals, want_sums, link_mix)
 
     def plan(self, kind: str, B: int, K1: int, dev) -> CF.EvalPlan:
         """Cached evaluation plans (slot maps live on the device; building one costs a few small H2D copies)."""
@@ -281,7 +281,7 @@ class CrossShapeAt(nn.Module):
         E1, E2 = B * K1, B * K
         # xhat: all (E, C, NP) maps, used only through their means; xhat_mix: the E1 maps that are mixed (same storage)
         xhat, xhat_mix, sums = att.evaluate(x_all, att.plan("csa_train" if train else "csa", B, K1, dev), geo,
-                                            n_head_evals=E1, want_sums=True)
+                                            n_head_evals=E1, want_sums=True, link_mix=True)
         gamma, beta = att.norm.weight, att.norm.bias
         # pooled descriptors y_k = mean_n SSA(x_k)  (:211-212, :218-219); the affine commutes with the mean.  The sums over
         # the points come out of the out-projection's epilogue (no pass over the maps)
@@ -306,7 +306,8 @@ class CrossShapeAt(nn.Module):
         train = any(r > 0 for r in att.dropout_rates())
         xc = xc.contiguous()
         # phase 1 (no neighbour data): [b] mixed self, and in train mode [B + b] the pooled self with its own masks
-        xh1, head1, s1 = att.evaluate(xc, att.plan("self2" if train else "self", B, 1, dev), geo, n_head_evals=B, want_sums=True)
+        xh1, head1, s1 = att.evaluate(xc, att.plan("self2" if train else "self", B, 1, dev), geo, n_head_evals=B, want_sums=True,
+                                       link_mix=True)
         nb = pending.wait()
         if nb.dim() == 5:
             nb = nb.squeeze(-1)
@@ -316,7 +317,8 @@ class CrossShapeAt(nn.Module):
             raise ValueError("a pending neighbour stack must resolve to a contiguous fp32 device tensor (B, K+1, C, n_points)")
         x_all = nb.view(B * K1, C, npts)
         # phase 2: [b*K + k-1] cross evaluations (mixed), [B*K + b*K + k-1] neighbour self-attention (pooled only)
-        xh2, head2, s2 = att.evaluate(x_all, att.plan("csa_cross", B, K1, dev), geo, n_head_evals=B * K, want_sums=True)
+        xh2, head2, s2 = att.evaluate(x_all, att.plan("csa_cross", B, K1, dev), geo, n_head_evals=B * K, want_sums=True,
+                                       link_mix=True)
         gamma, beta = att.norm.weight, att.norm.bias
         m1, m2 = s1 / npts, s2 / npts
         own = m1[B:] if train else m1[:B]

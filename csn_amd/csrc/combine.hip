@@ -88,8 +88,10 @@ __global__ __launch_bounds__(256) void csn_mix_bwd_kernel(const float* __restric
     const long long off = !xhat0 ? ((long long)(b * K1 + k) * C + c) * NP
                                  : (k == 0 ? ((long long)b * C + c) * NP : ((long long)(b * (K1 - 1) + k - 1) * C + c) * NP);
     xk[k] = ((xhat0 && k == 0) ? xhat0 : xhat) + off;
-    ok[k] = ((xhat0 && k == 0) ? dxhat0 : dxhat) + off;
+    float* const o = (xhat0 && k == 0) ? dxhat0 : dxhat;
+    ok[k] = o ? o + off : nullptr;
   }
+  const bool store = xhat0 ? dxhat0 != nullptr : dxhat != nullptr;    // no gradient maps wanted: only the reductions
   double dot[8];
   for (int k = 0; k < 8; ++k) dot[k] = 0.0;
   double sum = 0.0;
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(256) void csn_mix_bwd_kernel(const float* __restric
     for (int k = 0; k < K1; ++k) {
       const f32x4 v = *reinterpret_cast<const f32x4*>(xk[k] + i);
       dot[k] += ((double)g.x * v.x + (double)g.y * v.y) + ((double)g.z * v.z + (double)g.w * v.w);
-      *reinterpret_cast<f32x4*>(ok[k] + i) = g * w[k];
+      if (store) *reinterpret_cast<f32x4*>(ok[k] + i) = g * w[k];
     }
   }
   for (int k = 0; k < K1; ++k) {

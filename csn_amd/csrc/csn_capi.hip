@@ -338,8 +338,10 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
                            float* dctx, float* dwfc, float* ws, long long ws_floats, int n_evals, int d_model,
                            int d_inner, int ld, int n_points, int accumulate, float dropout_p,
                            unsigned long long seed, int dctx_split, long long dctx_plane_stride,
-                           const float* dxhat_rows, int n_dense_evals, void* stream) {
+                           const float* dxhat_rows, int n_dense_evals, const float* dxhat_scale, int dxhat_group,
+                           void* stream) {
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
+  if (dxhat_group < 0) return CSN_E_ARG;
   if (dctx_split && g_math_mode != 1) return CSN_E_ARG;
   if (n_dense_evals < 0 || n_dense_evals > n_evals || (n_dense_evals > 0 && !dxhat)) return CSN_E_ARG;
   if (!xhat || !rstd || !ctx || !wfc_t || !dz || !dctx || !dwfc || !ws) return CSN_E_ARG;
@@ -354,6 +356,7 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
   l.E = n_evals; l.C = d_model; l.ld = ld; l.n_points = n_points;
   l.dropout_p = dropout_p; l.seed = seed;
   l.dxhat_rows = dxhat_rows; l.n_dense = n_dense_evals;
+  l.dxhat_scale = dxhat_scale; l.dxhat_group = dxhat_group > 0 ? dxhat_group : 1;
   int rc = csn_launch_ln_bwd_f32(l, st);
   if (rc) return rc;
   // dctx[e][D][n] = wfc_t[D][c] dz[e][c][n]
@@ -416,8 +419,11 @@ int csn_mix_bwd_f32(const float* dfeats, const float* xhat, const float* comp, c
                     float* rowdot, float* rowsum, int n_shapes, int k1, int channels, int n_points, const float* xhat_self,
                     float* dxhat_self, void* stream) {
   if (!dfeats || !comp || !gamma || !rowdot || !rowsum) return CSN_E_ARG;
-  if ((!xhat || !dxhat) && !(xhat_self && k1 == 1)) return CSN_E_ARG;
-  if ((xhat_self == nullptr) != (dxhat_self == nullptr)) return CSN_E_ARG;
+  if (!xhat && !(xhat_self && k1 == 1)) return CSN_E_ARG;
+  // gradient maps: all of them or none (none = reductions only; csn_outproj_ln_bwd_f32 then rebuilds them from dfeats)
+  const bool want_maps = xhat_self ? dxhat_self != nullptr : dxhat != nullptr;
+  if (want_maps && xhat_self && xhat && !dxhat) return CSN_E_ARG;
+  if (!want_maps && (dxhat || dxhat_self)) return CSN_E_ARG;
   if (n_shapes <= 0 || k1 <= 0 || k1 > 8 || channels <= 0 || n_points <= 0) return CSN_E_ARG;
   if (n_points & 3) return CSN_E_ALIGN;
   if (mis16(dfeats) || mis16(xhat) || mis16(dxhat) || mis16(xhat_self) || mis16(dxhat_self)) return CSN_E_PTR;

@@ -80,6 +80,10 @@ struct CsnLnBwdArgs {
   const float* dxhat; const float* xhat; const float* rstd;   // [e][C][ld], [e][C][ld], [e][n_points]
   const float* dxhat_rows;                                     // optional [e][C]: added to every point of row (e, c)
   int n_dense;                                                 // evaluations e >= n_dense have no dense dxhat (only the row term)
+  // dense part of evaluation e < n_dense = dxhat_scale[e][c] * dxhat[e / dxhat_group][c][n]  (scale null: 1; group 1: map e).
+  // With group = K+1 and scale = comp * gamma the maps are the gradient of the mixed features themselves: the per-evaluation
+  // gradient maps of the mix are never written
+  const float* dxhat_scale; int dxhat_group;
   float* dz;                                                   // [e][C][ld]  gradient w.r.t. the fc output (dropout mask applied)
   float* dz_res;                                               // optional: gradient w.r.t. the residual input (no mask)
   long long eval_stride;

@@ -305,11 +305,20 @@ __global__ __launch_bounds__(256) void csn_ln_bwd_kernel(CsnLnBwdArgs p) {
   constexpr int C = 4 * CPT;
   const long long win = ((long long)(C - 1) * p.ld + p.n_points) * 4;
   const bool dense = e < p.n_dense;
-  const csn_rsrc_t Gr = csn_make_rsrc(dense ? p.dxhat + (long long)e * p.eval_stride : nullptr, dense ? win : 0);
+  const int src = p.dxhat_group > 1 ? e / p.dxhat_group : e;
+  const csn_rsrc_t Gr = csn_make_rsrc(dense ? p.dxhat + (long long)src * p.eval_stride : nullptr, dense ? win : 0);
   const csn_rsrc_t Xr = csn_make_rsrc(p.xhat + (long long)e * p.eval_stride, win);
   const unsigned voff = ok ? (unsigned)n * 4u : CSN_OOB;
   const unsigned ldb = (unsigned)p.ld * 4u;
-  float gx[CPT], xx[CPT], rw[CPT];
+  float gx[CPT], xx[CPT], rw[CPT], sc[CPT];
+  if (p.dxhat_scale && dense) {
+    const float* __restrict__ scl = p.dxhat_scale + (long long)e * C + g * CPT;       // wave-uniform: scalar loads
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) sc[i] = scl[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) sc[i] = 1.f;
+  }
   if (p.dxhat_rows) {
     const float* __restrict__ rows = p.dxhat_rows + (long long)e * C + g * CPT;      // wave-uniform: scalar loads
 #pragma unroll
@@ -326,7 +335,7 @@ __global__ __launch_bounds__(256) void csn_ln_bwd_kernel(CsnLnBwdArgs p) {
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
-    gx[i] += rw[i];
+    gx[i] = fmaf(gx[i], sc[i], rw[i]);
     s1 += gx[i];
     s2 += gx[i] * xx[i];
   }

@@ -26,6 +26,7 @@ LN_EPS = 1e-6         # MID-FC/csa_models.py:57
 RESCALE_THRESHOLD = 8.0
 USE_KV_TILES = True          # fast math: K/V leave the projection as bf16 tile planes (see csn_project_f32, out_split = 2)
 FUSED_POINT_SUMS = os.environ.get("CSN_FUSED_SUMS", "1") != "0"   # 0: pooled sums by a streaming pass (development A/B)
+LINK_MIX = os.environ.get("CSN_LINK_MIX", "1") != "0"             # 0: the mix backward writes per-evaluation gradient maps
 # bench.py sets this to a list to collect (start, end) HIP-event pairs around the fused attention forward launch
 EVENT_SINK = None
 
@@ -175,8 +176,9 @@ class _MHAEvals(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x_all, w_qs, w_ks, w_vs, w_fc, plan: EvalPlan, geo: MHAGeometry, keep_scores: bool,
-                p_attn: float = 0.0, p_fc: float = 0.0, n_head_evals: int = 0, want_sums: bool = False):
+                p_attn: float = 0.0, p_fc: float = 0.0, n_head_evals: int = 0, want_sums: bool = False, link=None):
         _need_cuda(x_all, w_qs, w_ks, w_vs, w_fc)
+        ctx.link = link
         ctx.set_materialize_grads(False)               # an unused output must not cost a zero-filled (E, C, NP) gradient
         # dropout masks are counter-based: two 62-bit seeds from torch's CPU generator (torch.manual_seed reproduces them)
         seed_attn, seed_fc = (torch.randint(0, 2 ** 62, (2,)).tolist() if (p_attn > 0 or p_fc > 0) else (0, 0))
@@ -253,10 +255,13 @@ class _MHAEvals(torch.autograd.Function):
         # constant along the points (the pooled means) and a consumer of the leading maps only (the mix) then hand the
         # backward two cheap gradients instead of one dense (E, C, NP) sum.
         ctx.n_head = n_head_evals
-        return xhat, xhat[:n_head_evals], sums
+        # fourth output: a one-element handle.  A linked mix (csa_mix on LinkedMaps) takes IT as its differentiable input
+        # and leaves the gradient of the mixed features in ctx.link instead of returning per-evaluation gradient maps
+        handle = x_all.new_zeros(1) if link is not None else None
+        return xhat, xhat[:n_head_evals], sums, handle
 
     @staticmethod
-    def backward(ctx, dxhat, dhead, dsums=None):
+    def backward(ctx, dxhat, dhead, dsums=None, dhandle=None):
         x_all, w_qkv, w_fc, qkv, att, lse, scores, xhat, rstd, kv = ctx.saved_tensors
         geo: MHAGeometry = ctx.geo
         plan: EvalPlan = ctx.plan
@@ -281,6 +286,18 @@ class _MHAEvals(torch.autograd.Function):
         dense = dxhat if dxhat is not None else dhead
         n_dense = 0 if dense is None else dense.shape[0]
         dense = None if dense is None else dense.contiguous()
+        # linked mix: the dense term of the leading maps is scale[e][c] * dfeats[e // group] — rebuilt inside the kernel
+        scale, group = None, 1
+        link, ctx.link = ctx.link, None
+        if dhandle is not None and link is not None and link.dfeats is not None:
+            if dense is None:
+                dense, scale, group, n_dense = link.dfeats, link.scale, link.group, ctx.n_head
+            else:                                                        # somebody also used the maps densely: materialise
+                dense = dense.clone() if dense.shape[0] == E else torch.cat(
+                    (dense, dense.new_zeros((E - dense.shape[0],) + tuple(dense.shape[1:]))), dim=0)
+                dense[:ctx.n_head] += link.scale[:, :, None] * link.dfeats.repeat_interleave(link.group, dim=0)[:ctx.n_head]
+                n_dense = E
+            link.dfeats = link.scale = None
         temperature = float(d) ** 0.5
         p_attn, seed_attn, p_fc, seed_fc = ctx.drop
         need_dx = ctx.needs_input_grad[0]
@@ -295,7 +312,8 @@ class _MHAEvals(torch.autograd.Function):
         w_fc_t = w_fc.t().contiguous()
         _lib.check(L.csn_outproj_ln_bwd_f32(_ptr(dense), _ptr(xhat), _ptr(rstd), C * NP, _ptr(att), D * NP,
                                             _ptr(w_fc_t), _ptr(dz), _ptr(dz_res), _ptr(datt), _ptr(dw_fc), _ptr(ws), ws_n,
-                                            E, C, D, NP, NP, 0, p_fc, seed_fc, 0, 0, _ptr(rows), n_dense, _stream()),
+                                            E, C, D, NP, NP, 0, p_fc, seed_fc, 0, 0, _ptr(rows), n_dense, _ptr(scale), group,
+                                            _stream()),
                    "csn_outproj_ln_bwd_f32")
         del ws
 
@@ -348,18 +366,42 @@ class _MHAEvals(torch.autograd.Function):
             dqkv[:, :D] /= temperature
             dx_all = project(dqkv, w_qkv.t().contiguous())
             dx_all.index_add_(0, plan.q_slots.long(), dz if dz_res is None else dz_res)
-        return dx_all, dw_q, dw_k, dw_v, dw_fc, None, None, None, None, None, None, None
+        return dx_all, dw_q, dw_k, dw_v, dw_fc, None, None, None, None, None, None, None, None
+
+
+class MixLink:
+    """What a linked mix leaves for the backward of the evaluations it consumed: the gradient of the mixed features
+    (one map per query shape), the per-(evaluation, channel) factors comp * gamma, and the evaluations mixed per shape."""
+    __slots__ = ("dfeats", "scale", "group")
+
+    def __init__(self):
+        self.dfeats = self.scale = None
+        self.group = 1
+
+
+class LinkedMaps:
+    """The leading maps of an evaluation batch as csa_mix wants them: the data (detached), the handle through which the
+    gradient connection runs, and the link the two backward passes share."""
+    __slots__ = ("maps", "handle", "link")
+
+    def __init__(self, maps, handle, link):
+        self.maps, self.handle, self.link = maps, handle, link
 
 
 def mha_evals(x_all: torch.Tensor, w_qs: torch.Tensor, w_ks: torch.Tensor, w_vs: torch.Tensor, w_fc: torch.Tensor,
               plan: EvalPlan, geo: MHAGeometry, p_attn: float = 0.0, p_fc: float = 0.0, n_head_evals: int = 0,
-              want_sums: bool = False):
+              want_sums: bool = False, link_mix: bool = False):
     """p_attn / p_fc: train-mode dropout probabilities of csa_models.py:141 / :115 (0 in eval mode).
     n_head_evals > 0: returns (xhat, xhat[:n_head_evals]) — use the second for consumers of the leading maps only.
-    want_sums: a further result, the (E, C) sums over the points of every map (differentiable; the pooled descriptors)."""
+    want_sums: a further result, the (E, C) sums over the points of every map (differentiable; the pooled descriptors).
+    link_mix: the second result is a LinkedMaps for csa_mix — the mix's backward then hands this function's backward the
+    gradient of the mixed features and its factors instead of writing one gradient map per evaluation."""
     keep = torch.is_grad_enabled() and any(t.requires_grad for t in (x_all, w_qs, w_ks, w_vs, w_fc))
-    xhat, head, sums = _MHAEvals.apply(x_all, w_qs, w_ks, w_vs, w_fc, plan, geo, keep, float(p_attn), float(p_fc),
-                                       int(n_head_evals), bool(want_sums))
+    link = MixLink() if (link_mix and LINK_MIX and keep and n_head_evals > 0) else None
+    xhat, head, sums, handle = _MHAEvals.apply(x_all, w_qs, w_ks, w_vs, w_fc, plan, geo, keep, float(p_attn), float(p_fc),
+                                               int(n_head_evals), bool(want_sums), link)
+    if link is not None:
+        head = LinkedMaps(head.detach(), handle, link)
     out = (xhat, head) if n_head_evals > 0 else (xhat,)
     if want_sums:
         out = out + (sums,)
@@ -457,6 +499,59 @@ class _CSAMix(torch.autograd.Function):
         return dxhat, dcomp.float(), dgamma.float(), dbeta.float(), None, None, dxself
 
 
-def csa_mix(xhat: torch.Tensor, comp: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B: int, K1: int,
-            xself: Optional[torch.Tensor] = None) -> torch.Tensor:
+class _CSAMixLinked(torch.autograd.Function):
+    """_CSAMix on LinkedMaps: same forward; the backward computes only the reductions (d comp, d gamma, d beta) and leaves
+    dfeats and comp * gamma in the links — csn_outproj_ln_bwd_f32 rebuilds comp_k gamma dfeats inside its LayerNorm backward,
+    so the (B*K1, C, NP) gradient maps are neither written nor read."""
+
+    @staticmethod
+    def forward(ctx, handle, handle_self, comp, gamma, beta, B: int, K1: int, maps: LinkedMaps, maps_self):
+        xhat = maps.maps
+        xself = None if maps_self is None else maps_self.maps
+        _need_cuda(xhat, comp, gamma, beta, xself)
+        E, C, NP = xhat.shape
+        assert xhat.is_contiguous() and E == B * (K1 if xself is None else K1 - 1)
+        assert xself is None or (xself.is_contiguous() and xself.shape == (B, C, NP))
+        comp = comp.contiguous()
+        feats = torch.empty((B, C, NP), device=xhat.device, dtype=torch.float32)
+        _lib.check(_lib.lib().csn_mix_fwd_f32(_ptr(xhat), _ptr(comp), _ptr(gamma), _ptr(beta), _ptr(feats), B, K1, C, NP,
+                                              _ptr(xself), _stream()), "csn_mix_fwd_f32")
+        ctx.save_for_backward(xhat, comp, gamma, beta, xself)
+        ctx.dims = (B, K1)
+        ctx.links = (maps.link, None if maps_self is None else maps_self.link)
+        return feats
+
+    @staticmethod
+    def backward(ctx, dfeats):
+        xhat, comp, gamma, beta, xself = ctx.saved_tensors
+        B, K1 = ctx.dims
+        E, C, NP = xhat.shape
+        dfeats = dfeats.contiguous()
+        rowdot = torch.empty((B, K1, C), device=xhat.device, dtype=torch.float32)
+        rowsum = torch.empty((B, C), device=xhat.device, dtype=torch.float32)
+        _lib.check(_lib.lib().csn_mix_bwd_f32(_ptr(dfeats), _ptr(xhat), _ptr(comp), _ptr(gamma), None, _ptr(rowdot),
+                                              _ptr(rowsum), B, K1, C, NP, _ptr(xself), None, _stream()), "csn_mix_bwd_f32")
+        factors = comp[:, :, None] * gamma                                           # (B, K1, C) = comp_k * gamma
+        link, link_self = ctx.links
+        if link_self is None:
+            link.dfeats, link.scale, link.group = dfeats, factors.reshape(B * K1, C).contiguous(), K1
+        else:
+            link_self.dfeats, link_self.scale, link_self.group = dfeats, factors[:, 0].contiguous(), 1
+            link.dfeats, link.scale, link.group = dfeats, factors[:, 1:].reshape(B * (K1 - 1), C).contiguous(), K1 - 1
+        rd, rs = rowdot.double(), rowsum.double()
+        g64, b64, c64 = gamma.double(), beta.double(), comp.double()
+        dcomp = (rd * g64).sum(dim=2) + (rs * b64).sum(dim=1, keepdim=True)          # (B, K1)
+        dgamma = torch.einsum("bk,bkc->c", c64, rd)
+        dbeta = (c64.sum(dim=1, keepdim=True) * rs).sum(dim=0)
+        one = dfeats.new_ones(1)                     # the handles' "gradient": its arrival is the signal, not its value
+        return one, (one if link_self is not None else None), dcomp.float(), dgamma.float(), dbeta.float(), None, None, None, None
+
+
+def csa_mix(xhat, comp: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B: int, K1: int, xself=None) -> torch.Tensor:
+    """sum_k comp[b,k] * (gamma * xhat[b,k] + beta) over channel-major maps.  xhat / xself: tensors, or the LinkedMaps that
+    mha_evals(link_mix=True) returns (then no per-evaluation gradient maps exist in the backward)."""
+    if isinstance(xhat, LinkedMaps):
+        if xself is not None and not isinstance(xself, LinkedMaps):
+            raise TypeError("csa_mix: xhat and xself must both be LinkedMaps or both tensors")
+        return _CSAMixLinked.apply(xhat.handle, None if xself is None else xself.handle, comp, gamma, beta, B, K1, xhat, xself)
     return _CSAMix.apply(xhat, comp, gamma, beta, B, K1, xself)

@@ -101,7 +101,7 @@ class _CrossMHA(torch.autograd.Function):
         _lib.check(L.csn_outproj_ln_bwd_f32(CF._ptr(dxhat), CF._ptr(xhat), CF._ptr(rstd), C * lq4, CF._ptr(att), D * lq4,
                                             CF._ptr(w_fc.t().contiguous()), CF._ptr(dz), CF._ptr(dz_res), CF._ptr(datt),
                                             CF._ptr(dw_fc), CF._ptr(ws), ws_n, b, C, D, lq4, lq4, 0, p_fc, seed_fc, 0, 0, None,
-                                            b, CF._stream()), "csn_outproj_ln_bwd_f32")
+                                            b, None, 1, CF._stream()), "csn_outproj_ln_bwd_f32")
         # attention backward: gradients to the projected queries, keys and values
         dscores = torch.empty_like(scores)
         delta = torch.empty((b, H, lq4), device=dev, dtype=torch.float32)

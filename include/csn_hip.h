@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSN_ABI_VERSION 8
+#define CSN_ABI_VERSION 9
 
 #define CSN_E_ARG (-1)     /* null pointer / non-positive size            */
 #define CSN_E_ALIGN (-2)   /* a size or leading dimension is not % 4      */
@@ -175,13 +175,19 @@ int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const fl
  * csn_wgrad_workspace_floats(d_model, d_inner, n_evals, n_points) floats.  accumulate != 0 adds into dwfc.
  * The incoming gradient is  dxhat[e][c][n] (evaluations e < n_dense_evals only; the others have none)
  *                         + dxhat_rows[e][c] (optional, NULL = none): a term that is constant along the points — the
- * gradient of the pooled means (csa_models.py:212,219) — so that it never has to be expanded to a full map. */
+ * gradient of the pooled means (csa_models.py:212,219) — so that it never has to be expanded to a full map.
+ * dxhat_scale (optional) [n_dense_evals][d_model] and dxhat_group (>= 1; 0 = 1): the dense term of evaluation e is
+ *   dxhat_scale[e][c] * dxhat[e / dxhat_group][c][n]
+ * — with dxhat = the gradient of the mixed features (dfeats of csn_mix_bwd_f32, one map per query shape), dxhat_group = the
+ * evaluations mixed per shape and dxhat_scale = comp * gamma, the per-evaluation gradient maps of the mix (:233, :238) are
+ * rebuilt on the fly and never travel through HBM. */
 int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* rstd, long long eval_stride,
                            const float* ctx, long long ctx_eval_stride, const float* wfc_t, float* dz, float* dz_res,
                            float* dctx, float* dwfc, float* ws, long long ws_floats, int n_evals, int d_model,
                            int d_inner, int ld, int n_points, int accumulate, float dropout_p,
                            unsigned long long seed, int dctx_split, long long dctx_plane_stride,
-                           const float* dxhat_rows, int n_dense_evals, void* stream);
+                           const float* dxhat_rows, int n_dense_evals, const float* dxhat_scale, int dxhat_group,
+                           void* stream);
 
 /* ---- (6) projection weight gradient ----------------------------------------------------------------------
  * dw[r][c] (+)= scale * sum_{s,n} dout[s][r][n] * x[s][c][n]        (autograd of csa_models.py:103-105) */
@@ -208,6 +214,8 @@ int csn_retrieval_measure_f32(const float* f1, const float* f2, float* out, int 
  * csn_mix_bwd_f32: dxhat[b*k1 + k][c][n] = comp[b][k] gamma[c] dfeats[b][c][n];
  *                  rowdot[b][k][c] = sum_n dfeats[b][c][n] xhat[b*k1+k][c][n];  rowsum[b][c] = sum_n dfeats[b][c][n]
  *                  (fp64 accumulation) from which d comp, d gamma, d beta follow with O(B*k1*C) host-side math.
+ *                  dxhat (and dxhat_self) NULL: the reductions only — the maps are then rebuilt inside
+ *                  csn_outproj_ln_bwd_f32 (dxhat_scale / dxhat_group).
  * xhat_self / dxhat_self != NULL: the k = 0 maps (the shape's own evaluation) live in their own tensors [b][c][n] and
  * xhat / dxhat hold the k1 - 1 others, [b*(k1-1) + k-1] — the form the overlapped multi-GPU path produces (own shapes are
  * evaluated while the neighbour exchange is in flight), so that no concatenation of the two is ever built.

@@ -105,7 +105,7 @@ def test_fc_dropout_forward_backward_with_host_mask(E, C, D, NP, p):
     wt = wd.t().contiguous()
     L.check(L.lib().csn_outproj_ln_bwd_f32(dxd.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), C * NP, attd.data_ptr(), D * NP,
                                            wt.data_ptr(), dz.data_ptr(), dz_res.data_ptr(), datt.data_ptr(), dw.data_ptr(),
-                                           ws.data_ptr(), ws_n, E, C, D, NP, NP, 0, p, seed, 0, 0, None, E, _stream()))
+                                           ws.data_ptr(), ws_n, E, C, D, NP, NP, 0, p, seed, 0, 0, None, E, None, 1, _stream()))
     torch.cuda.synchronize()
     assert _rel(datt, a64.grad) < 2e-5 and _rel(dw, w64.grad) < 2e-5 and _rel(dz_res, x64.grad) < 2e-5
 

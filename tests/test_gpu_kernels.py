@@ -355,10 +355,25 @@ def test_outproj_ln_fwd_bwd(L, S, E, C, D, NP):
     nd = E - 1
     L.check(L.lib().csn_outproj_ln_bwd_f32(dxd.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), C * NP, attd.data_ptr(), D * NP,
                                            wt.data_ptr(), dz.data_ptr(), None, datt.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws_n,
-                                           E, C, D, NP, NP, 0, 0.0, 0, 0, 0, rows_d.data_ptr(), nd, _stream()))
+                                           E, C, D, NP, NP, 0, 0.0, 0, 0, 0, rows_d.data_ptr(), nd, None, 1, _stream()))
     dx_eff = dxhat.double().clone()
     dx_eff[nd:] = 0
     dx_eff += rows.double()[:, :, None]
+    ref.backward(dx_eff, retain_graph=True)
+    assert _maxerr(datt, a64.grad) < tol(2e-5)
+    assert _maxerr(dw, w64.grad) < tol(2e-5)
+    # scaled / grouped dense term: evaluation e < nd takes scale[e][c] * dxhat[e // 2][c][n] (the mix gradient rebuilt on the fly)
+    scale = _rand(rng, E, C)
+    L.check(L.lib().csn_outproj_ln_bwd_f32(dxd.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), C * NP, attd.data_ptr(), D * NP,
+                                           wt.data_ptr(), dz.data_ptr(), None, datt.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws_n,
+                                           E, C, D, NP, NP, 0, 0.0, 0, 0, 0, rows_d.data_ptr(), nd, scale.cuda().data_ptr(), 2,
+                                           _stream()))
+    dx_eff = torch.zeros_like(dx_eff)
+    for e in range(nd):
+        dx_eff[e] = scale[e].double()[:, None] * dxhat[e // 2].double()
+    dx_eff += rows.double()[:, :, None]
+    a64.grad = None
+    w64.grad = None
     ref.backward(dx_eff)
     assert _maxerr(datt, a64.grad) < tol(2e-5)
     assert _maxerr(dw, w64.grad) < tol(2e-5)
