@@ -71,7 +71,8 @@ _SIGNATURES = {
     "csn_block_attn_bwd_dkv_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                            c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_int, c_longlong,
-                                           c_int, c_void_p]),
+                                           c_int, c_void_p, c_int, c_void_p]),
+    "csn_attn_bwd_grouping": (c_int, [c_int, c_int]),
     "csn_cross_attn_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_int, c_int, c_void_p, c_longlong,
                                        c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
                                        c_ulonglong, c_void_p]),
@@ -113,7 +114,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.csn_version() != 9:
+        if handle.csn_version() != 10:
             raise CsnError("libcsn_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -241,7 +241,8 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
                              float* dv, long long dkv_slot_stride, const int* dk_index, const int* dv_index,
                              int accumulate, const int* eval_ids, int n_launch_evals, int n_heads, int d_head,
                              int block, int n_blocks, int score_pitch, int dctx_split, long long dctx_plane_stride,
-                             int q_split, long long q_plane_stride, int probs_tiles, int block_q, int ld_kv, void* stream) {
+                             int q_split, long long q_plane_stride, int probs_tiles, int block_q, int ld_kv,
+                             const int* group_offsets, int n_groups, void* stream) {
   // block_q / ld_kv != 0 (cross-length attention): block counts the keys, block_q (% 4) the queries that are contracted;
   // dk / dv are [d][ld_kv] maps whose columns block .. round-up-4(block) are written as zeros
   if (block_q < 0 || ld_kv < 0 || (ld_kv & 3) || (block_q & 3)) return CSN_E_ARG;
@@ -250,6 +251,7 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   if ((long long)n_blocks * bk4 > lk) return CSN_E_ARG;
   if (probs_tiles && (g_math_mode != 1 || score_pitch < (block + 31) / 32 * 32)) return CSN_E_ARG;
   if (dctx_split || q_split) return CSN_E_ARG;                       // reserved (see header)
+  if (group_offsets && (n_groups <= 0 || !eval_ids || !csn_attn_bwd_grouping(d_head, block))) return CSN_E_ARG;
   if (!dctx || !q || !probs || !dscores || !dk || !dv) return CSN_E_ARG;
   if (n_launch_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
   if (!dim_ok(d_head)) return CSN_E_DIM;
@@ -264,6 +266,8 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   g.M = d_head; g.N = bk4; g.K = bq;
   g.n0 = n_blocks; g.n1 = n_heads; g.k_chunk = 0;
   g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = accumulate; g.eval_ids = eval_ids;
+  if (group_offsets) { g.eval_ids = nullptr; g.grp_off = group_offsets; g.grp_items = eval_ids; }
+  const int n_batch = group_offsets ? n_groups : n_launch_evals;
   g.A = operand(dctx, bq, (long long)d_head * ld, dctx_split ? 2 * ctx_eval_stride : ctx_eval_stride, nullptr, ld);
   g.A.planes = dctx_split; g.A.plane_stride = dctx_plane_stride;
   // tile planes: the same buffers viewed as bf16 (two bf16 per float: strides and pitch double)
@@ -271,14 +275,14 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   g.B = operand(probs, bm * blk_sc, bm * blk_sc * n_blocks, bm * blk_sc * n_blocks * n_heads, nullptr, bm * score_pitch);
   g.B.planes = probs_tiles ? 2 : 0;
   g.C = operand(dv, block, (long long)d_head * lk, dkv_slot_stride, dv_index, lk);
-  int rc = launch_gemm(g, 0, n_blocks * n_heads * n_launch_evals, st);
+  int rc = launch_gemm(g, 0, n_blocks * n_heads * n_batch, st);
   if (rc) return rc;
   g.A = operand(q, bq, (long long)d_head * ld, q_shape_stride, q_index, ld);
   g.A.planes = q_split; g.A.plane_stride = q_plane_stride;
   g.B = operand(dscores, bm * blk_sc, bm * blk_sc * n_blocks, bm * blk_sc * n_blocks * n_heads, nullptr, bm * score_pitch);
   g.B.planes = probs_tiles ? 2 : 0;
   g.C = operand(dk, block, (long long)d_head * lk, dkv_slot_stride, dk_index, lk);
-  return launch_gemm(g, 0, n_blocks * n_heads * n_launch_evals, st);
+  return launch_gemm(g, 0, n_blocks * n_heads * n_batch, st);
 }
 
 int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
@@ -286,10 +290,16 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
                                float* dv, long long dkv_slot_stride, const int* dk_index, const int* dv_index,
                                int accumulate, const int* eval_ids, int n_launch_evals, int n_heads, int d_head,
                                int block, int n_blocks, int score_pitch, int dctx_split, long long dctx_plane_stride,
-                               int q_split, long long q_plane_stride, int probs_tiles, void* stream) {
+                               int q_split, long long q_plane_stride, int probs_tiles, const int* group_offsets,
+                               int n_groups, void* stream) {
   return attn_bwd_dkv_impl(dctx, ctx_eval_stride, q, q_shape_stride, q_index, ld, probs, dscores, dk, dv, dkv_slot_stride,
                            dk_index, dv_index, accumulate, eval_ids, n_launch_evals, n_heads, d_head, block, n_blocks,
-                           score_pitch, dctx_split, dctx_plane_stride, q_split, q_plane_stride, probs_tiles, 0, 0, stream);
+                           score_pitch, dctx_split, dctx_plane_stride, q_split, q_plane_stride, probs_tiles, 0, 0,
+                           group_offsets, n_groups, stream);
+}
+
+int csn_attn_bwd_grouping(int d_head, int block) {
+  return (g_math_mode == 1 && csn_gemm_bf16x3_big_tiles(d_head, (block + 3) / 4 * 4)) ? 1 : 0;
 }
 
 /* cross-length attention backward (MinkowskiNet/models/attention.py: one unchunked block per evaluation, n_queries != n_keys;
@@ -308,7 +318,7 @@ int csn_cross_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_ev
   if (rc) return rc;
   return attn_bwd_dkv_impl(dctx, ctx_eval_stride, q, q_shape_stride, nullptr, ld_q, scores, dscores, dk, dv, dkv_eval_stride,
                            nullptr, nullptr, 0, nullptr, n_evals, n_heads, d_head, n_keys, 1, score_pitch, 0, 0, 0, 0, pt,
-                           n_queries, ld_kv, stream);
+                           n_queries, ld_kv, nullptr, 0, stream);
 }
 
 int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const float* wfc, const float* xres,

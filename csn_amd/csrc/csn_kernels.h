@@ -14,10 +14,16 @@ struct CsnGemmArgs {
   int accumulate;    // C += result
   const int* eval_ids;   // optional: blockIdx.z's slowest index z2 -> evaluation id, applied before the operands' idx2
   int batch;             // number of batch items z (filled in by the launcher)
+  // grouped accumulation (256 x 256 bf16x3 kernel): the slowest batch index z2 counts GROUPS; group g contracts the items
+  // grp_items[grp_off[g] .. grp_off[g+1]) one after the other into the same accumulators (A and B are addressed by the item,
+  // C by the group's first item) and writes once — evaluations that share an output slot need no read-modify-write passes
+  const int* grp_off = nullptr;
+  const int* grp_items = nullptr;
 };
 
 int csn_launch_gemm_f32(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st);
 int csn_launch_gemm_bf16x3(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st);   // gemm_bf16x3.hip, same checks as f32
+int csn_gemm_bf16x3_big_tiles(int M, int N);          // 1: an M x N output takes the 256 x 256 kernel (grouped accumulation available)
 int csn_launch_slab_reduce(const float* slab, float* out, int n_slabs, long long n, float alpha, int accumulate,
                            hipStream_t st);
 

@@ -349,7 +349,10 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
   const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
   const int z0 = z % p.n0; z /= p.n0;
   const int z1 = z % p.n1;
-  const int z2 = p.eval_ids ? p.eval_ids[z / p.n1] : z / p.n1;
+  const int zz = z / p.n1;
+  const int it0 = p.grp_off ? p.grp_off[zz] : zz, it1 = p.grp_off ? p.grp_off[zz + 1] : zz + 1;   // items contracted by this tile
+  auto item_id = [&](int it) { return p.grp_off ? p.grp_items[it] : (p.eval_ids ? p.eval_ids[it] : it); };
+  const int z2 = item_id(it0);
   const int lda = p.A.ld, ldb = p.B.ld, ldc = p.C.ld;
   const int M = p.M, N = p.N;
   int K = p.K;
@@ -359,15 +362,19 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
   const bool c_pl = p.C.planes != 0;
   const bool c_tiles = p.C.planes == 2;
   const int c_es = c_pl ? 2 : 4;
-  const float* a_base = p.A.ptr + p.A.s0 * z0 + p.A.s1 * z1 + p.A.s2 * (long long)(p.A.idx2 ? p.A.idx2[z2] : z2) + (long long)m0 * lda;
-  const long long b_el = p.B.s0 * z0 + p.B.s1 * z1 + p.B.s2 * (long long)(p.B.idx2 ? p.B.idx2[z2] : z2);
-  const float* b_base = BT ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(p.B.ptr) + b_el)
-                           : p.B.ptr + b_el + (B_NK ? (long long)n0 * ldb : (long long)n0);
+  csn_rsrc_t Ar, Br;
+  auto set_item = [&](int zi) {
+    const float* a_base = p.A.ptr + p.A.s0 * z0 + p.A.s1 * z1 + p.A.s2 * (long long)(p.A.idx2 ? p.A.idx2[zi] : zi) + (long long)m0 * lda;
+    const long long b_el = p.B.s0 * z0 + p.B.s1 * z1 + p.B.s2 * (long long)(p.B.idx2 ? p.B.idx2[zi] : zi);
+    const float* b_base = BT ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(p.B.ptr) + b_el)
+                             : p.B.ptr + b_el + (B_NK ? (long long)n0 * ldb : (long long)n0);
+    Ar = csn_make_rsrc(a_base, (long long)BM * lda * 4);
+    Br = csn_make_rsrc(b_base, BT ? (long long)K * ldb * 2
+                                  : (B_NK ? (long long)BN * ldb * 4 : ((long long)(K - 1) * ldb + (N - n0)) * 4));
+  };
+  set_item(z2);
   char* c_base = reinterpret_cast<char*>(p.C.ptr) + (p.C.s0 * z0 + p.C.s1 * z1 + p.C.s2 * (long long)(p.C.idx2 ? p.C.idx2[z2] : z2) + (long long)m0 * ldc + (c_tiles ? 0 : n0)) * c_es;
   const long long c_win = (long long)BM * ldc * c_es;
-  const csn_rsrc_t Ar = csn_make_rsrc(a_base, (long long)BM * lda * 4);
-  const csn_rsrc_t Br = csn_make_rsrc(b_base, BT ? (long long)K * ldb * 2
-                                                 : (B_NK ? (long long)BN * ldb * 4 : ((long long)(K - 1) * ldb + (N - n0)) * 4));
   const csn_rsrc_t Cr = csn_make_rsrc(c_base, c_win), Crl = csn_make_rsrc(c_base + p.C.plane_stride * 2, c_pl ? c_win : 0);
 
   f32x16 acc[MT][NT];
@@ -440,6 +447,11 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
   const int tr_base = (8 * (grp >> 1) + gq) * PN + 16 * (grp & 1) + 4 * gp;
 
   const int nk = (K + BK - 1) / BK;
+  for (int it = it0; it < it1; ++it) {
+  if (it > it0) {
+    __syncthreads();                                    // the previous item's last slab has been read by every wave
+    set_item(item_id(it));
+  }
   if (nk > 0) { load_slab(0); store_slab(0); }
   if (nk > 1) load_slab(BK);
   __syncthreads();
@@ -487,6 +499,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
       if (kt + 2 < nk) load_slab((kt + 2) * BK);
     }
     __syncthreads();
+  }
   }
 
   // per-wave 16 KB of LDS for the epilogues (the tile loop is over; waves 0..3 take As, 4..7 Bs): 32 rows x 128 columns fp32
@@ -686,10 +699,13 @@ int csn_launch_outproj_ln_big(const CsnOutProjArgs& a, hipStream_t st) {
   return csn_launch_rowsum_f32(a.xhat, a.xhat_sum, (long long)a.E * a.C, a.n_points, a.ld, st);
 }
 
+int csn_gemm_bf16x3_big_tiles(int M, int N) { return (csn_gemm_big_tiles && M >= 192 && N >= 224) ? 1 : 0; }
+
 int csn_launch_gemm_bf16x3(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st) {
   if (a.C.planes && a.accumulate) return -1;
   // tiles of 256 x 256 where the output is big enough to fill them (a ragged last tile wastes at most ~3 % here)
   const bool big = csn_gemm_big_tiles && a.M >= 192 && a.N >= 224;
+  if (a.grp_off && !big) return -1;                                 // grouped accumulation: 256 x 256 kernel only
   if (a.B.planes == 2) {                                            // tile-plane B: k-major only
     if (b_is_nk || (a.B.ld & 7)) return -1;
     return big ? launch_big<false, true>(a, batch, st) : launch<128, 128, false, true>(a, batch, st);

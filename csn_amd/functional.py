@@ -27,6 +27,7 @@ RESCALE_THRESHOLD = 8.0
 USE_KV_TILES = True          # fast math: K/V leave the projection as bf16 tile planes (see csn_project_f32, out_split = 2)
 FUSED_POINT_SUMS = os.environ.get("CSN_FUSED_SUMS", "1") != "0"   # 0: pooled sums by a streaming pass (development A/B)
 LINK_MIX = os.environ.get("CSN_LINK_MIX", "1") != "0"             # 0: the mix backward writes per-evaluation gradient maps
+GROUPED_DKV = os.environ.get("CSN_GROUPED_DKV", "1") != "0"       # 0: dK / dV by one read-modify-write launch per colour
 # bench.py sets this to a list to collect (start, end) HIP-event pairs around the fused attention forward launch
 EVENT_SINK = None
 
@@ -87,12 +88,27 @@ class EvalPlan:
         self.q_slots, self.kv_slots, self.v_slots = as_dev(q), as_dev(kv), as_dev(kv + v_shift)
         self.dq_colors = [as_dev(c) for c in self._colors(q)]
         self.dkv_colors = [as_dev(c) for c in self._colors(kv)]
+        # the same sharing as GROUPS: evaluations ordered by key/value slot (biggest groups first: long work-groups start
+        # early), group g = kv_group_items[kv_group_off[g] : kv_group_off[g+1]] — one grouped dK / dV call accumulates a
+        # group's products in registers and writes its slot once (csn_block_attn_bwd_dkv_f32, group_offsets)
+        items, off = self._groups(kv)
+        self.kv_group_items, self.kv_group_off, self.n_kv_groups = as_dev(items), as_dev(off), int(off.size - 1)
         # the first colour of a pass holds the first evaluation of EVERY slot the pass writes, so it may overwrite; only the
         # gradient maps of slots a pass never writes need a zero fill (the weight gradients read all of them)
         all_slots = np.arange(n_slots)
         self.q_unwritten = as_dev(np.setdiff1d(all_slots, q)).long()
         self.k_unwritten = as_dev(np.setdiff1d(all_slots, kv)).long()
         self.v_unwritten = as_dev(np.setdiff1d(all_slots, kv + v_shift)).long()
+
+    @staticmethod
+    def _groups(slots):
+        import numpy as np
+        order = np.argsort(slots, kind="stable")
+        _, start, count = np.unique(slots[order], return_index=True, return_counts=True)
+        by_size = np.argsort(-count, kind="stable")
+        items = np.concatenate([order[start[g]:start[g] + count[g]] for g in by_size])
+        off = np.concatenate(([0], np.cumsum(count[by_size])))
+        return items, off
 
     @staticmethod
     def _colors(slots):
@@ -346,13 +362,22 @@ class _MHAEvals(torch.autograd.Function):
                                                    ids.numel(), H, d, T, nb, Tp, p_attn, seed_attn, 0, 0, kv_flag,
                                                    kv_pitch, pt, _stream()),
                        "csn_block_attn_bwd_dq_f32")
-        for ci, ids in enumerate(plan.dkv_colors):
+        if GROUPED_DKV and L.csn_attn_bwd_grouping(d, T):
+            # one call: the evaluations of a key/value slot are contracted one after the other into the same accumulators
             _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, q_ptr, q_stride, _ptr(plan.q_slots), NP,
                                                     _ptr(scores), _ptr(dscores), gbase + 4 * D * NP, gbase + 8 * D * NP,
-                                                    slot_stride, _ptr(plan.kv_slots), _ptr(plan.v_slots),
-                                                    0 if ci == 0 else 1, _ptr(ids),
-                                                    ids.numel(), H, d, T, nb, Tp, 0, 0, 0, 0, pt, _stream()),
+                                                    slot_stride, _ptr(plan.kv_slots), _ptr(plan.v_slots), 0,
+                                                    _ptr(plan.kv_group_items), E, H, d, T, nb, Tp, 0, 0, 0, 0, pt,
+                                                    _ptr(plan.kv_group_off), plan.n_kv_groups, _stream()),
                        "csn_block_attn_bwd_dkv_f32")
+        else:
+            for ci, ids in enumerate(plan.dkv_colors):
+                _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, q_ptr, q_stride, _ptr(plan.q_slots), NP,
+                                                        _ptr(scores), _ptr(dscores), gbase + 4 * D * NP, gbase + 8 * D * NP,
+                                                        slot_stride, _ptr(plan.kv_slots), _ptr(plan.v_slots),
+                                                        0 if ci == 0 else 1, _ptr(ids),
+                                                        ids.numel(), H, d, T, nb, Tp, 0, 0, 0, 0, pt, None, 0, _stream()),
+                           "csn_block_attn_bwd_dkv_f32")
         del dscores, delta, datt
 
         # ---- projection weight gradients ------------------------------------------------------------------

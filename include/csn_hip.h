@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSN_ABI_VERSION 9
+#define CSN_ABI_VERSION 10
 
 #define CSN_E_ARG (-1)     /* null pointer / non-positive size            */
 #define CSN_E_ALIGN (-2)   /* a size or leading dimension is not % 4      */
@@ -111,7 +111,12 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
  * dq/dk/dv point at row 0 of the [n_heads*d_head][ld] gradient map of slot 0; *_slot_stride in floats.
  * probs_tiles != 0 (math mode 1; score_pitch >= block rounded up to 32): the dq call leaves P_drop and dS as bf16 TILE
  * PLANES — per query row 16 tiles of [hi: 32 keys | lo: 32 keys], the bytes of the fp32 row — and the dkv call must be
- * told the same; the dV / dK products then stage them with plain copies. */
+ * told the same; the dV / dK products then stage them with plain copies.
+ * GROUPED dkv call (group_offsets != NULL; available where csn_attn_bwd_grouping() returns 1): eval_ids lists the
+ * n_launch_evals evaluations ordered so that evaluations sharing an output slot are adjacent, group g = entries
+ * group_offsets[g] .. group_offsets[g+1] (n_groups + 1 offsets); a group's products are accumulated in registers and its
+ * slot is written once — one call for all evaluations instead of one read-modify-write pass per colour. */
+int csn_attn_bwd_grouping(int d_head, int block);
 int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* k,
                               const float* v, long long kv_shape_stride, const int* kv_index, int ld, float* scores,
                               float* dscores, const float* lse, float* delta, float* dq, long long dq_slot_stride,
@@ -124,7 +129,8 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
                                float* dv, long long dkv_slot_stride, const int* dk_index, const int* dv_index,
                                int accumulate, const int* eval_ids, int n_launch_evals, int n_heads, int d_head,
                                int block, int n_blocks, int score_pitch, int dctx_split, long long dctx_plane_stride,
-                               int q_split, long long q_plane_stride, int probs_tiles, void* stream);
+                               int q_split, long long q_plane_stride, int probs_tiles, const int* group_offsets,
+                               int n_groups, void* stream);
 
 /* ---- (3b) cross-length attention: one unchunked block per evaluation, n_queries != n_keys -------------
  * The MinkowskiNet variant of the layer (MinkowskiNet/models/attention.py:31-75, used per shape pair by

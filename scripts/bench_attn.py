@@ -84,7 +84,7 @@ def main():
         gb = dqkv.data_ptr()
         _lib.check(L.csn_block_attn_bwd_dkv_f32(CF._ptr(datt), D * NP, base, 3 * D * NP, CF._ptr(qs), NP, CF._ptr(scores),
                                                 CF._ptr(dscores), gb + 4 * D * NP, gb + 8 * D * NP, 3 * D * NP, None, None,
-                                                0, None, E, H, d, T, nb, Tp, 0, 0, 0, 0, 1 if (a.tiles and L.csn_get_math_mode() == 1) else 0, st), "dkv")
+                                                0, None, E, H, d, T, nb, Tp, 0, 0, 0, 0, 1 if (a.tiles and L.csn_get_math_mode() == 1) else 0, None, 0, st), "dkv")
 
     flops = 4.0 * T * d * NP * E * H
     L.csn_set_math_mode(a.mode)

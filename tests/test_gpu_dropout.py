@@ -64,7 +64,7 @@ def test_attention_dropout_forward_backward_with_host_mask(E, H, d, T, nb, p):
                                               dq.data_ptr(), D * N, None, 0, None, E, H, d, T, nb, Tp, p, seed, 0, 0, 0, 0, 0, _stream()))
     L.check(L.lib().csn_block_attn_bwd_dkv_f32(dd.data_ptr(), D * N, qd.data_ptr(), D * N, None, N, scores.data_ptr(),
                                                dscores.data_ptr(), dk.data_ptr(), dv.data_ptr(), D * N, None, None, 0, None, E, H,
-                                               d, T, nb, Tp, 0, 0, 0, 0, 0, _stream()))
+                                               d, T, nb, Tp, 0, 0, 0, 0, 0, None, 0, _stream()))
     torch.cuda.synchronize()
     assert _rel(dq, q64.grad) < 2e-5 and _rel(dk, k64.grad) < 2e-5 and _rel(dv, v64.grad) < 2e-5
     # the scores buffer now holds the dropped probabilities

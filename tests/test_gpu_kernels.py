@@ -248,7 +248,7 @@ def test_block_attn_bwd(L, S, E, H, d, T, nb):
     L.check(rc, "attn bwd dq")
     rc = L.lib().csn_block_attn_bwd_dkv_f32(dd.data_ptr(), D * N, qd.data_ptr(), D * N, qi.data_ptr(), N, scores.data_ptr(),
                                             dscores.data_ptr(), dk.data_ptr(), dv.data_ptr(), D * N, None, None, 0, None, E,
-                                            H, d, T, nb, Tp, 0, 0, 0, 0, pt, _stream())
+                                            H, d, T, nb, Tp, 0, 0, 0, 0, pt, None, 0, _stream())
     L.check(rc, "attn bwd")
     torch.cuda.synchronize()
     # float64 autograd reference, per evaluation (no sharing: the ABI returns per-evaluation gradients)
@@ -290,9 +290,22 @@ def test_block_attn_bwd(L, S, E, H, d, T, nb):
         L.check(L.lib().csn_block_attn_bwd_dkv_f32(dd.data_ptr(), D * N, qd.data_ptr(), D * N, qi.data_ptr(), N,
                                                    scores2.data_ptr(), dscores.data_ptr(), sk.data_ptr(), sv_.data_ptr(), D * N,
                                                    ki.data_ptr(), ki.data_ptr(), 1, ids.data_ptr(), ids.numel(), H, d, T, nb,
-                                                   Tp, 0, 0, 0, 0, pt, _stream()))
+                                                   Tp, 0, 0, 0, 0, pt, None, 0, _stream()))
     torch.cuda.synchronize()
     assert _maxerr(sq, ref_dq) < tol(2e-5) and _maxerr(sk, ref_dk) < tol(2e-5) and _maxerr(sv_, ref_dv) < tol(2e-5)
+    # grouped form of the dK / dV call: the evaluations of a slot are accumulated in registers, every slot is written once
+    if L.lib().csn_attn_bwd_grouping(d, T):
+        gk, gv = (torch.full((S, D, N), float("nan"), device="cuda") for _ in range(2))
+        L.check(L.lib().csn_block_attn_bwd_dkv_f32(dd.data_ptr(), D * N, qd.data_ptr(), D * N, qi.data_ptr(), N,
+                                                   scores2.data_ptr(), dscores.data_ptr(), gk.data_ptr(), gv.data_ptr(), D * N,
+                                                   ki.data_ptr(), ki.data_ptr(), 0, plan.kv_group_items.data_ptr(), E, H, d, T,
+                                                   nb, Tp, 0, 0, 0, 0, pt, plan.kv_group_off.data_ptr(), plan.n_kv_groups,
+                                                   _stream()))
+        torch.cuda.synchronize()
+        used = torch.from_numpy(np.unique(kv_idx)).long()
+        assert _maxerr(gk[used], ref_dk[used]) < tol(2e-5) and _maxerr(gv[used], ref_dv[used]) < tol(2e-5)
+    else:
+        assert _mode["m"] == 0 or d < 192 or T < 224
 
 
 def _attn_reference_autograd(q, k, v, H, d, T, nb):
