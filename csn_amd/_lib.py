@@ -67,7 +67,7 @@ _SIGNATURES = {
     "csn_block_attn_bwd_dq_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_int,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_int,
                                           c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_ulonglong,
-                                          c_int, c_longlong, c_int, c_longlong, c_int, c_void_p]),
+                                          c_int, c_longlong, c_int, c_longlong, c_int, c_void_p, c_int, c_void_p]),
     "csn_block_attn_bwd_dkv_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                            c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_int, c_longlong,
@@ -114,7 +114,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.csn_version() != 10:
+        if handle.csn_version() != 11:
             raise CsnError("libcsn_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -98,18 +98,39 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   const int L = blockIdx.x, slot = L & 7, jj = L >> 3;
   const int qt = jj % QT, u = (jj / QT) * 8 + slot;
   if (u >= Y * p.E) return;
-  const int e = p.eval_ids ? p.eval_ids[u / Y] : u / Y;
+  // items of this work-group.  Plain launches: the one evaluation eval_ids[u / Y].  Grouped backward (grp_off != null): the
+  // launch index counts GROUPS of evaluations that share the output slot (the query shape's dQ collects K+2 evaluations);
+  // the group's evaluations eval_ids[grp_off[g] .. grp_off[g+1]) run one after the other into the same OUT accumulators,
+  // which leave once — no read-modify-write passes over the gradient maps
+  const int zz = u / Y;
+  const int it0 = (BWD && p.grp_off) ? p.grp_off[zz] : zz;
+  const int it1 = (BWD && p.grp_off) ? p.grp_off[zz + 1] : it0 + 1;     // (forward: always one item — the loop folds away)
+  const int e0 = p.eval_ids ? p.eval_ids[it0] : it0;
   const int hd = (u % Y) % p.H, blk = (u % Y) / p.H;
   const int T = p.T, Tp = p.Tp, ld = p.ld, ldk = p.ld_kv > 0 ? p.ld_kv : p.ld;
   const bool ragged = (T & 3) != 0;                            // keys of the last 4-key group are masked one by one
   const int qrow = qt * 128 + wave * 16 + lq;                  // query index inside the block
   const bool q_ok = qrow < Tq;
-
-  const long long qs = p.q_index ? p.q_index[e] : e;
-  const long long ks = p.kv_index ? p.kv_index[e] : e;
-  const long long os = p.out_index ? p.out_index[e] : e;
   const long long head_off = (long long)hd * D * ld + (long long)blk * Tq;
   const long long win = ((long long)(D - 1) * ld + Tq) * 4;    // bytes spanned by a [D][Tq] window of pitch ld
+  const long long os = p.out_index ? p.out_index[e0] : e0;
+  const csn_rsrc_t Or = csn_make_rsrc(p.out + os * p.out_eval_stride + head_off, win);
+  const long long stat_off0 = ((long long)e0 * p.H + hd) * ((long long)p.n_blocks * Tq) + (long long)blk * Tq;
+  float* xbuf = reinterpret_cast<float*>(&tiles[0][0][0][0]);
+  constexpr int CH_T = D / 16;                                     // 16-byte chunks per thread: D rows x 32 chunks / 512
+  const int cc = tid & 31, crow = tid >> 5;                        // chunk column, first row of this thread (rows + 16 t)
+  const unsigned c_off = (qt * 128 + 4 * cc) < Tq ? (unsigned)(crow * ld + qt * 128 + 4 * cc) * 4u : CSN_OOB;
+  const int col = 16 * wave + lq;                                  // this lane's query column inside the block of 128
+  const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+  f32x4v O[D / 16];
+#pragma unroll
+  for (int c = 0; c < D / 16; ++c) O[c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, m2_run = -INFINITY, l_run = 0.f;   // forward: running max / partial sum of this lane's key quarter
+
+  for (int it = it0; it < it1; ++it) {
+  const int e = p.eval_ids ? p.eval_ids[it] : it;
+  const long long qs = p.q_index ? p.q_index[e] : e;
+  const long long ks = p.kv_index ? p.kv_index[e] : e;
   const long long head_off_kv = (long long)hd * D * ldk + (long long)blk * T;
   const long long win_kv = ((long long)(D - 1) * ldk + (T + 3) / 4 * 4) * 4;
   const csn_rsrc_t Rr = csn_make_rsrc(p.q + qs * p.q_shape_stride + head_off, win);
@@ -141,11 +162,6 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   // use different banks.  Backward: delta_q = sum_d dO[d][q] O[d][q] (the softmax-backward row constant) from a second
   // round with O.
   bf16x8 Rh[D / 32], Rl[D / 32];
-  float* xbuf = reinterpret_cast<float*>(&tiles[0][0][0][0]);
-  constexpr int CH_T = D / 16;                                     // 16-byte chunks per thread: D rows x 32 chunks / 512
-  const int cc = tid & 31, crow = tid >> 5;                        // chunk column, first row of this thread (rows + 16 t)
-  const unsigned c_off = (qt * 128 + 4 * cc) < Tq ? (unsigned)(crow * ld + qt * 128 + 4 * cc) * 4u : CSN_OOB;
-  const int col = 16 * wave + lq;                                  // this lane's query column inside the block of 128
   auto stage_in = [&](const csn_rsrc_t& rs) {
     f32x4 ch[CH_T];
 #pragma unroll
@@ -184,10 +200,6 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   }
   __syncthreads();                                                 // the staging block becomes the tile buffers
 
-  f32x4v O[D / 16];
-#pragma unroll
-  for (int c = 0; c < D / 16; ++c) O[c] = f32x4v{0.f, 0.f, 0.f, 0.f};
-
   // attention-probability dropout (csa_models.py:141): P_drop = mask * P / (1 - p); element index = position in `scores`
   const bool drop = p.dropout_p > 0.f;
   const unsigned thr16 = csn_drop_threshold16(p.dropout_p);
@@ -197,7 +209,6 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
 
   // exponentials run on the hardware exp2: exp(s - m) = exp2(s * log2(e) - m2) with m2 = fl(m * log2(e)), the same m2 for
   // every key of a query, so its rounding cancels in the normalisation; lse is rebuilt from m2 (= m2 ln 2 + ln l)
-  float m_run = -INFINITY, m2_run = -INFINITY, l_run = 0.f;   // forward: running max / partial sum of this lane's key quarter
   float lse2_q = 0.f;                          // backward: per-query constant
   if (BWD) {
     lse2_q = q_ok ? p.lse[stat_off + qrow] * LOG2E : 0.f;
@@ -474,7 +485,6 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   // starts with its vector work, instead of two waves fighting over the same pipe.  With the commits placed as above the
   // shift is hazard-free: a K stage is rewritten in segments 2kt / 2kt+1 (early / late half), last read in 2kt-1 and
   // next read in 2kt+2; a V stage is rewritten in 2kt+1 / 2kt+2, last read in 2kt and next read in 2kt+3.
-  const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
   WGSTAMP(1);
   if (late) __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
@@ -506,15 +516,17 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
 #endif
   }
 
+  if (!late) __syncthreads();                           // pairs with the last barrier of the late half: tiles are idle now
+  }                                                     // next item of the group (its prologue reuses the tiles as staging)
+
   // ---- epilogue -----------------------------------------------------------------------------------
   WGSTAMP(2);
-  if (!late) __syncthreads();                           // pairs with the last barrier of the late half: tiles are idle now
   float inv = 1.f;
   if (!BWD) {
     float l_tot = l_run + __shfl_xor(l_run, 16, 64);
     l_tot += __shfl_xor(l_tot, 32, 64);
     inv = 1.f / l_tot;
-    if (q_ok && kq == 0 && p.lse) p.lse[stat_off + qrow] = m2_run * LN2 + logf(l_tot);
+    if (q_ok && kq == 0 && p.lse) p.lse[stat_off0 + qrow] = m2_run * LN2 + logf(l_tot);
   }
   // OUT leaves through the same [D][128] LDS block as 16-byte rows (chunk c of row r at c ^ 4 ((r >> 2) & 1): the lane
   // quarters write rows 4 apart); when several evaluations share the output slot, the previous partial sums are fetched

@@ -152,7 +152,7 @@ static int attn_fwd_impl(const float* q, const float* k, const float* v, long lo
   a.scores = scores; a.dscores = nullptr; a.lse = lse; a.delta = nullptr; a.ctx = nullptr;
   a.E = n_evals; a.H = n_heads; a.T = block; a.Tp = score_pitch; a.n_blocks = n_blocks;
   a.rescale_threshold = rescale_threshold;
-  a.eval_ids = nullptr; a.out_index = nullptr; a.accumulate = 0;
+  a.eval_ids = nullptr; a.grp_off = nullptr; a.out_index = nullptr; a.accumulate = 0;
   a.dropout_p = dropout_p; a.seed = seed;
   a.r_planes = 0; a.kv_planes = qkv_split; a.r_plane_stride = 0; a.kv_plane_stride = 0; a.sc_tiles = 0;
   return g_math_mode == 1 ? csn_launch_attn_fwd_bf16x3(a, d_head, (hipStream_t)stream)
@@ -186,8 +186,10 @@ static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_e
                             const int* dq_index, int accumulate, const int* eval_ids, int n_launch_evals, int n_heads,
                             int d_head, int block, int n_blocks, int score_pitch, float dropout_p,
                             unsigned long long seed, int dctx_split, long long dctx_plane_stride, int kv_split,
-                            long long kv_plane_stride, int probs_tiles, int block_q, int ld_kv, void* stream) {
+                            long long kv_plane_stride, int probs_tiles, int block_q, int ld_kv, const int* group_offsets,
+                            int n_groups, void* stream) {
   if (block_q < 0 || ld_kv < 0 || (ld_kv & 3)) return CSN_E_ARG;
+  if (group_offsets && (n_groups <= 0 || !eval_ids || !(csn_attn_bwd_grouping(d_head, block) & 1))) return CSN_E_ARG;
   if ((block & 3) && (block_q == 0 || kv_split)) return CSN_E_ALIGN;
   if (probs_tiles && (g_math_mode != 1 || score_pitch < (block + 31) / 32 * 32)) return CSN_E_ARG;
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
@@ -214,9 +216,9 @@ static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_e
   a.q_index = nullptr; a.kv_index = kv_index; a.ld = ld;
   a.out = dq; a.out_eval_stride = dq_slot_stride;
   a.scores = scores; a.dscores = dscores; a.lse = const_cast<float*>(lse); a.delta = delta;
-  a.E = n_launch_evals; a.H = n_heads; a.T = block; a.Tp = score_pitch; a.n_blocks = n_blocks;
+  a.E = group_offsets ? n_groups : n_launch_evals; a.H = n_heads; a.T = block; a.Tp = score_pitch; a.n_blocks = n_blocks;
   a.rescale_threshold = 0.f;
-  a.eval_ids = eval_ids; a.out_index = dq_index; a.accumulate = accumulate;
+  a.eval_ids = eval_ids; a.grp_off = group_offsets; a.out_index = dq_index; a.accumulate = accumulate;
   a.dropout_p = dropout_p; a.seed = seed;
   a.r_planes = 0; a.kv_planes = kv_split; a.r_plane_stride = 0; a.kv_plane_stride = 0; a.kv_ld = (int)kv_plane_stride;
   a.sc_tiles = probs_tiles;
@@ -229,11 +231,12 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
                               const int* dq_index, int accumulate, const int* eval_ids, int n_launch_evals, int n_heads,
                               int d_head, int block, int n_blocks, int score_pitch, float dropout_p,
                               unsigned long long seed, int dctx_split, long long dctx_plane_stride, int kv_split,
-                              long long kv_plane_stride, int probs_tiles, void* stream) {
+                              long long kv_plane_stride, int probs_tiles, const int* group_offsets, int n_groups,
+                              void* stream) {
   return attn_bwd_dq_impl(dctx, ctx, ctx_eval_stride, k, v, kv_shape_stride, kv_index, ld, scores, dscores, lse, delta, dq,
                           dq_slot_stride, dq_index, accumulate, eval_ids, n_launch_evals, n_heads, d_head, block, n_blocks,
                           score_pitch, dropout_p, seed, dctx_split, dctx_plane_stride, kv_split, kv_plane_stride, probs_tiles,
-                          0, 0, stream);
+                          0, 0, group_offsets, n_groups, stream);
 }
 
 static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
@@ -251,7 +254,7 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   if ((long long)n_blocks * bk4 > lk) return CSN_E_ARG;
   if (probs_tiles && (g_math_mode != 1 || score_pitch < (block + 31) / 32 * 32)) return CSN_E_ARG;
   if (dctx_split || q_split) return CSN_E_ARG;                       // reserved (see header)
-  if (group_offsets && (n_groups <= 0 || !eval_ids || !csn_attn_bwd_grouping(d_head, block))) return CSN_E_ARG;
+  if (group_offsets && (n_groups <= 0 || !eval_ids || !(csn_attn_bwd_grouping(d_head, block) & 2))) return CSN_E_ARG;
   if (!dctx || !q || !probs || !dscores || !dk || !dv) return CSN_E_ARG;
   if (n_launch_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
   if (!dim_ok(d_head)) return CSN_E_DIM;
@@ -299,7 +302,8 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
 }
 
 int csn_attn_bwd_grouping(int d_head, int block) {
-  return (g_math_mode == 1 && csn_gemm_bf16x3_big_tiles(d_head, (block + 3) / 4 * 4)) ? 1 : 0;
+  if (g_math_mode != 1) return 0;
+  return 1 | (csn_gemm_bf16x3_big_tiles(d_head, (block + 3) / 4 * 4) ? 2 : 0);
 }
 
 /* cross-length attention backward (MinkowskiNet/models/attention.py: one unchunked block per evaluation, n_queries != n_keys;
@@ -314,7 +318,7 @@ int csn_cross_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_ev
   const int pt = (g_math_mode == 1 && score_pitch >= (n_keys + 31) / 32 * 32) ? 1 : 0;
   int rc = attn_bwd_dq_impl(dctx, ctx, ctx_eval_stride, k, v, kv_shape_stride, nullptr, ld_q, scores, dscores, lse, delta, dq,
                             dq_eval_stride, nullptr, 0, nullptr, n_evals, n_heads, d_head, n_keys, 1, score_pitch, dropout_p,
-                            seed, 0, 0, 0, 0, pt, n_queries, ld_kv, stream);
+                            seed, 0, 0, 0, 0, pt, n_queries, ld_kv, nullptr, 0, stream);
   if (rc) return rc;
   return attn_bwd_dkv_impl(dctx, ctx_eval_stride, q, q_shape_stride, nullptr, ld_q, scores, dscores, dk, dv, dkv_eval_stride,
                            nullptr, nullptr, 0, nullptr, n_evals, n_heads, d_head, n_keys, 1, score_pitch, 0, 0, 0, 0, pt,

@@ -43,6 +43,7 @@ struct CsnAttnArgs {
   int E, H, T, Tp, n_blocks;
   float rescale_threshold;
   const int* eval_ids;                                   // launch z -> evaluation id (nullptr: identity); E = launch size
+  const int* grp_off;                                    // backward, optional: E counts groups; group g = eval_ids[grp_off[g] .. grp_off[g+1])
   const int* out_index;                                  // evaluation -> output slot (nullptr: the evaluation itself)
   int accumulate;                                        // out += result (several evaluations share an output slot)
   float dropout_p;                                       // attention-probability dropout (csa_models.py:141); 0 = off

@@ -28,6 +28,7 @@ USE_KV_TILES = True          # fast math: K/V leave the projection as bf16 tile 
 FUSED_POINT_SUMS = os.environ.get("CSN_FUSED_SUMS", "1") != "0"   # 0: pooled sums by a streaming pass (development A/B)
 LINK_MIX = os.environ.get("CSN_LINK_MIX", "1") != "0"             # 0: the mix backward writes per-evaluation gradient maps
 GROUPED_DKV = os.environ.get("CSN_GROUPED_DKV", "1") != "0"       # 0: dK / dV by one read-modify-write launch per colour
+GROUPED_DQ = os.environ.get("CSN_GROUPED_DQ", "1") != "0"         # 0: dQ likewise
 # bench.py sets this to a list to collect (start, end) HIP-event pairs around the fused attention forward launch
 EVENT_SINK = None
 
@@ -93,6 +94,8 @@ class EvalPlan:
         # group's products in registers and writes its slot once (csn_block_attn_bwd_dkv_f32, group_offsets)
         items, off = self._groups(kv)
         self.kv_group_items, self.kv_group_off, self.n_kv_groups = as_dev(items), as_dev(off), int(off.size - 1)
+        items, off = self._groups(q)
+        self.q_group_items, self.q_group_off, self.n_q_groups = as_dev(items), as_dev(off), int(off.size - 1)
         # the first colour of a pass holds the first evaluation of EVERY slot the pass writes, so it may overwrite; only the
         # gradient maps of slots a pass never writes need a zero fill (the weight gradients read all of them)
         all_slots = np.arange(n_slots)
@@ -354,15 +357,25 @@ class _MHAEvals(torch.autograd.Function):
             k_ptr = q_ptr + 4 * D * NP
             v_ptr = q_ptr + 4 * (2 * D * NP + plan.v_shift * kv_stride)
         pt = 1 if (fast_math() and Tp >= (T + 31) // 32 * 32) else 0    # P / dS travel to the dV / dK products as bf16 tile planes
-        for ci, ids in enumerate(plan.dq_colors):
+        grouping = L.csn_attn_bwd_grouping(d, T)
+        if GROUPED_DQ and (grouping & 1):
+            # one call: the evaluations of a query slot run one after the other into the same dQ accumulators
             _lib.check(L.csn_block_attn_bwd_dq_f32(_ptr(datt), _ptr(att), D * NP, k_ptr, v_ptr, kv_stride,
                                                    _ptr(plan.kv_slots), NP, _ptr(scores), _ptr(dscores), _ptr(lse),
-                                                   _ptr(delta), gbase, slot_stride, _ptr(plan.q_slots),
-                                                   0 if ci == 0 else 1, _ptr(ids),
-                                                   ids.numel(), H, d, T, nb, Tp, p_attn, seed_attn, 0, 0, kv_flag,
-                                                   kv_pitch, pt, _stream()),
+                                                   _ptr(delta), gbase, slot_stride, _ptr(plan.q_slots), 0,
+                                                   _ptr(plan.q_group_items), E, H, d, T, nb, Tp, p_attn, seed_attn, 0, 0,
+                                                   kv_flag, kv_pitch, pt, _ptr(plan.q_group_off), plan.n_q_groups, _stream()),
                        "csn_block_attn_bwd_dq_f32")
-        if GROUPED_DKV and L.csn_attn_bwd_grouping(d, T):
+        else:
+            for ci, ids in enumerate(plan.dq_colors):
+                _lib.check(L.csn_block_attn_bwd_dq_f32(_ptr(datt), _ptr(att), D * NP, k_ptr, v_ptr, kv_stride,
+                                                       _ptr(plan.kv_slots), NP, _ptr(scores), _ptr(dscores), _ptr(lse),
+                                                       _ptr(delta), gbase, slot_stride, _ptr(plan.q_slots),
+                                                       0 if ci == 0 else 1, _ptr(ids),
+                                                       ids.numel(), H, d, T, nb, Tp, p_attn, seed_attn, 0, 0, kv_flag,
+                                                       kv_pitch, pt, None, 0, _stream()),
+                           "csn_block_attn_bwd_dq_f32")
+        if GROUPED_DKV and (grouping & 2):
             # one call: the evaluations of a key/value slot are contracted one after the other into the same accumulators
             _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, q_ptr, q_stride, _ptr(plan.q_slots), NP,
                                                     _ptr(scores), _ptr(dscores), gbase + 4 * D * NP, gbase + 8 * D * NP,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSN_ABI_VERSION 10
+#define CSN_ABI_VERSION 11
 
 #define CSN_E_ARG (-1)     /* null pointer / non-positive size            */
 #define CSN_E_ALIGN (-2)   /* a size or leading dimension is not % 4      */
@@ -112,10 +112,11 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
  * probs_tiles != 0 (math mode 1; score_pitch >= block rounded up to 32): the dq call leaves P_drop and dS as bf16 TILE
  * PLANES — per query row 16 tiles of [hi: 32 keys | lo: 32 keys], the bytes of the fp32 row — and the dkv call must be
  * told the same; the dV / dK products then stage them with plain copies.
- * GROUPED dkv call (group_offsets != NULL; available where csn_attn_bwd_grouping() returns 1): eval_ids lists the
- * n_launch_evals evaluations ordered so that evaluations sharing an output slot are adjacent, group g = entries
- * group_offsets[g] .. group_offsets[g+1] (n_groups + 1 offsets); a group's products are accumulated in registers and its
- * slot is written once — one call for all evaluations instead of one read-modify-write pass per colour. */
+ * GROUPED calls (group_offsets != NULL): eval_ids lists the n_launch_evals evaluations ordered so that evaluations sharing
+ * an output slot are adjacent, group g = entries group_offsets[g] .. group_offsets[g+1] (n_groups + 1 offsets); a group's
+ * results are accumulated in registers and its slot is written once — one call for all evaluations instead of one
+ * read-modify-write pass per colour.  csn_attn_bwd_grouping() says where that is available in the current math mode:
+ * bit 0 = the dq call, bit 1 = the dkv call. */
 int csn_attn_bwd_grouping(int d_head, int block);
 int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* k,
                               const float* v, long long kv_shape_stride, const int* kv_index, int ld, float* scores,
@@ -123,7 +124,8 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
                               const int* dq_index, int accumulate, const int* eval_ids, int n_launch_evals, int n_heads,
                               int d_head, int block, int n_blocks, int score_pitch, float dropout_p,
                               unsigned long long seed, int dctx_split, long long dctx_plane_stride, int kv_split,
-                              long long kv_plane_stride, int probs_tiles, void* stream);
+                              long long kv_plane_stride, int probs_tiles, const int* group_offsets, int n_groups,
+                              void* stream);
 int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
                                const int* q_index, int ld, const float* probs, const float* dscores, float* dk,
                                float* dv, long long dkv_slot_stride, const int* dk_index, const int* dv_index,

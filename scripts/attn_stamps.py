@@ -34,7 +34,7 @@ if os.environ.get("CSN_STAMP_BWD") == "1":       # library built with -DCSN_STAM
     dscores = torch.empty_like(scores); delta = torch.empty((E, H, NP), device="cuda"); dq = torch.empty((E, D, NP), device="cuda")
     _lib.check(L.csn_block_attn_bwd_dq_f32(CF._ptr(datt), CF._ptr(att), D * NP, kp, kp + 2 * D * nb * 1024, 2 * D * nb * 1024,
                                            CF._ptr(ks), NP, CF._ptr(scores), CF._ptr(dscores), CF._ptr(lse), CF._ptr(delta),
-                                           CF._ptr(dq), D * NP, None, 0, None, E, H, d, T, nb, Tp, 0.1, 1234, 0, 0, 1, nb * 1024, 1,
+                                           CF._ptr(dq), D * NP, None, 0, None, E, H, d, T, nb, Tp, 0.1, 1234, 0, 0, 1, nb * 1024, 1, None, 0,
                                            CF._stream()), "dq")
 torch.cuda.synchronize()
 n = 2048 * 8 * 4 * 8

@@ -78,7 +78,7 @@ def main():
                                                v_ptr if tl else base + 8 * D * NP,
                                                kv_stride if tl else 3 * D * NP, CF._ptr(ks), NP, CF._ptr(scores), CF._ptr(dscores), CF._ptr(lse),
                                                CF._ptr(delta), dqkv.data_ptr(), 3 * D * NP, None, 0, None, E, H, d, T, nb,
-                                               Tp, a.drop, seed, 0, 0, kvf if tl else 0, kvp if tl else 0, 1 if tl else 0, st), "dq")
+                                               Tp, a.drop, seed, 0, 0, kvf if tl else 0, kvp if tl else 0, 1 if tl else 0, None, 0, st), "dq")
 
     def dkv():
         gb = dqkv.data_ptr()

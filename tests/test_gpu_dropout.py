@@ -61,7 +61,7 @@ def test_attention_dropout_forward_backward_with_host_mask(E, H, d, T, nb, p):
     dq, dk, dv = (torch.empty((E, D, N), device="cuda") for _ in range(3))
     L.check(L.lib().csn_block_attn_bwd_dq_f32(dd.data_ptr(), ctx.data_ptr(), D * N, kd.data_ptr(), vd.data_ptr(), D * N, None,
                                               N, scores.data_ptr(), dscores.data_ptr(), lse.data_ptr(), delta.data_ptr(),
-                                              dq.data_ptr(), D * N, None, 0, None, E, H, d, T, nb, Tp, p, seed, 0, 0, 0, 0, 0, _stream()))
+                                              dq.data_ptr(), D * N, None, 0, None, E, H, d, T, nb, Tp, p, seed, 0, 0, 0, 0, 0, None, 0, _stream()))
     L.check(L.lib().csn_block_attn_bwd_dkv_f32(dd.data_ptr(), D * N, qd.data_ptr(), D * N, None, N, scores.data_ptr(),
                                                dscores.data_ptr(), dk.data_ptr(), dv.data_ptr(), D * N, None, None, 0, None, E, H,
                                                d, T, nb, Tp, 0, 0, 0, 0, 0, None, 0, _stream()))

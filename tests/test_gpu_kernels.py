@@ -244,7 +244,7 @@ def test_block_attn_bwd(L, S, E, H, d, T, nb):
     rc = L.lib().csn_block_attn_bwd_dq_f32(dd.data_ptr(), ctx.data_ptr(), D * N, kd.data_ptr(), vd.data_ptr(), D * N,
                                            ki.data_ptr(), N, scores.data_ptr(), dscores.data_ptr(), lse.data_ptr(),
                                            delta.data_ptr(), dq.data_ptr(), D * N, None, 0, None, E, H, d, T, nb, Tp, 0.0, 0,
-                                           0, 0, 0, 0, pt, _stream())
+                                           0, 0, 0, 0, pt, None, 0, _stream())
     L.check(rc, "attn bwd dq")
     rc = L.lib().csn_block_attn_bwd_dkv_f32(dd.data_ptr(), D * N, qd.data_ptr(), D * N, qi.data_ptr(), N, scores.data_ptr(),
                                             dscores.data_ptr(), dk.data_ptr(), dv.data_ptr(), D * N, None, None, 0, None, E,
@@ -285,7 +285,7 @@ def test_block_attn_bwd(L, S, E, H, d, T, nb):
         L.check(L.lib().csn_block_attn_bwd_dq_f32(dd.data_ptr(), ctx.data_ptr(), D * N, kd.data_ptr(), vd.data_ptr(), D * N,
                                                   ki.data_ptr(), N, scores2.data_ptr(), dscores.data_ptr(), lse.data_ptr(),
                                                   delta.data_ptr(), sq.data_ptr(), D * N, qi.data_ptr(), 1, ids.data_ptr(),
-                                                  ids.numel(), H, d, T, nb, Tp, 0.0, 0, 0, 0, 0, 0, pt, _stream()))
+                                                  ids.numel(), H, d, T, nb, Tp, 0.0, 0, 0, 0, 0, 0, pt, None, 0, _stream()))
     for ids in plan.dkv_colors:
         L.check(L.lib().csn_block_attn_bwd_dkv_f32(dd.data_ptr(), D * N, qd.data_ptr(), D * N, qi.data_ptr(), N,
                                                    scores2.data_ptr(), dscores.data_ptr(), sk.data_ptr(), sv_.data_ptr(), D * N,
@@ -294,7 +294,21 @@ def test_block_attn_bwd(L, S, E, H, d, T, nb):
     torch.cuda.synchronize()
     assert _maxerr(sq, ref_dq) < tol(2e-5) and _maxerr(sk, ref_dk) < tol(2e-5) and _maxerr(sv_, ref_dv) < tol(2e-5)
     # grouped form of the dK / dV call: the evaluations of a slot are accumulated in registers, every slot is written once
-    if L.lib().csn_attn_bwd_grouping(d, T):
+    grouping = L.lib().csn_attn_bwd_grouping(d, T)
+    assert (grouping & 1) == _mode["m"]
+    if grouping & 1:
+        gq = torch.full((S, D, N), float("nan"), device="cuda")
+        _, _, scores2, _ = _run_attn_fwd(L, q, k, v, q_idx, kv_idx, H, d, T, nb)       # fresh scores: the dq call consumes them
+        dscores.fill_(float("nan"))
+        L.check(L.lib().csn_block_attn_bwd_dq_f32(dd.data_ptr(), ctx.data_ptr(), D * N, kd.data_ptr(), vd.data_ptr(), D * N,
+                                                  ki.data_ptr(), N, scores2.data_ptr(), dscores.data_ptr(), lse.data_ptr(),
+                                                  delta.data_ptr(), gq.data_ptr(), D * N, qi.data_ptr(), 0,
+                                                  plan.q_group_items.data_ptr(), E, H, d, T, nb, Tp, 0.0, 0, 0, 0, 0, 0, pt,
+                                                  plan.q_group_off.data_ptr(), plan.n_q_groups, _stream()))
+        torch.cuda.synchronize()
+        used_q = torch.from_numpy(np.unique(q_idx)).long()
+        assert _maxerr(gq[used_q], ref_dq[used_q]) < tol(2e-5)
+    if grouping & 2:
         gk, gv = (torch.full((S, D, N), float("nan"), device="cuda") for _ in range(2))
         L.check(L.lib().csn_block_attn_bwd_dkv_f32(dd.data_ptr(), D * N, qd.data_ptr(), D * N, qi.data_ptr(), N,
                                                    scores2.data_ptr(), dscores.data_ptr(), gk.data_ptr(), gv.data_ptr(), D * N,
