@@ -33,10 +33,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4, 64 FLOP/clk/SIMD
-# HBM bytes of one fused-attention-forward launch per evaluation, from the PMC passes in profiles/r1m_pmc_hbm_traffic.txt:
-# (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / 256 evaluations = (2 x 3.913e6 + 7.932e6) KB / 256 (gfx950: FETCH_SIZE counts half of
+# HBM bytes of one fused-attention-forward launch per evaluation, from the PMC passes in profiles/r1s_pmc_hbm_traffic.txt:
+# (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / 256 evaluations = (2 x 3.911e6 + 7.631e6) KB / 256 (gfx950: FETCH_SIZE counts half of
 # a 16-byte-per-lane read stream).  Algorithmic: 3 x 10.24 MB of Q/K/V in, 20 MB of scores + 10.24 MB of context out = 61 MB.
-ATTN_FWD_HBM_BYTES_PER_EVAL = (2 * 3.913e6 + 7.932e6) * 1024 / 256
+ATTN_FWD_HBM_BYTES_PER_EVAL = (2 * 3.911e6 + 7.631e6) * 1024 / 256
 PEAK_BF16_MATRIX_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (the bf16x3 mode issues 3 bf16 FLOPs per algorithmic FLOP)
 N_POINTS, C, T, H, D_HEAD, N_CLS = 10000, 256, 500, 1, 256, 39
 
