@@ -85,3 +85,32 @@ def test_oracle_is_not_imported_by_the_product():
             if f.endswith(".py"):
                 txt = open(os.path.join(root, f)).read()
                 assert "oracle" not in txt.replace("no oracle", ""), f
+
+
+def test_eval_plan_colours_and_groups_cover_the_same_sharing():
+    """Host logic of the backward's slot sharing (csn_amd.functional.EvalPlan): colours never repeat a slot inside one
+    launch; groups list every evaluation once, adjacent by slot, biggest groups first."""
+    import numpy as np
+    import torch
+    from csn_amd.functional import EvalPlan
+    B, K1 = 3, 4
+    b, k = np.meshgrid(np.arange(B), np.arange(K1), indexing="ij")
+    q = np.concatenate(((b * K1).reshape(-1), (b * K1 + k)[:, 1:].reshape(-1), (b * K1)[:, 0]))       # csa_train shape
+    kv = np.concatenate(((b * K1 + k).reshape(-1), (b * K1 + k)[:, 1:].reshape(-1), (b * K1)[:, 0]))
+    plan = EvalPlan(q, kv, B * K1, torch.device("cpu"))
+    assert plan.E == q.size
+    for colours, slots in ((plan.dq_colors, q), (plan.dkv_colors, kv)):
+        seen = np.concatenate([c.numpy() for c in colours])
+        assert sorted(seen.tolist()) == list(range(plan.E))
+        for c in colours:
+            assert len(set(slots[c.numpy()].tolist())) == c.numel()
+    for items, off, n, slots in ((plan.q_group_items, plan.q_group_off, plan.n_q_groups, q),
+                                 (plan.kv_group_items, plan.kv_group_off, plan.n_kv_groups, kv)):
+        items, off = items.numpy(), off.numpy()
+        assert sorted(items.tolist()) == list(range(plan.E)) and off[0] == 0 and off[-1] == plan.E and n == off.size - 1
+        sizes = np.diff(off)
+        assert (sizes > 0).all() and (np.diff(sizes) <= 0).all()                    # biggest groups first
+        group_slots = [set(slots[items[off[g]:off[g + 1]]].tolist()) for g in range(n)]
+        assert all(len(s) == 1 for s in group_slots)                                 # one slot per group ...
+        assert len(set.union(*group_slots)) == n == len(set(slots.tolist()))         # ... and one group per slot
+    assert plan.n_q_groups == B * K1 and int(np.diff(plan.q_group_off.numpy()).max()) == K1 + 1    # own slots: K+2 evaluations
