@@ -28,8 +28,11 @@
 __device__ unsigned long long csn_gdbg[65536 * 8];
 extern "C" int csn_gemm_debug_read(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_gdbg), bytes); }
 #define GSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); gst[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+// 256 x 256 kernel: entry, tile loop start, tile loop end, [LN: after the residual pass, after the variance pass], exit
+#define BSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x < 8192) csn_gdbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define GSTAMP(i)
+#define BSTAMP(i)
 #endif
 
 namespace {
@@ -339,6 +342,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
+  BSTAMP(0);
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 128;
 
   const int tiles_n = (p.N + BN - 1) / BN, tiles = tiles_n * ((p.M + BM - 1) / BM);
@@ -447,6 +451,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
   const int tr_base = (8 * (grp >> 1) + gq) * PN + 16 * (grp & 1) + 4 * gp;
 
   const int nk = (K + BK - 1) / BK;
+  BSTAMP(1);
   for (int it = it0; it < it1; ++it) {
   if (it > it0) {
     __syncthreads();                                    // the previous item's last slab has been read by every wave
@@ -502,6 +507,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
   }
   }
 
+  BSTAMP(2);
   // per-wave 16 KB of LDS for the epilogues (the tile loop is over; waves 0..3 take As, 4..7 Bs): 32 rows x 128 columns fp32
   float* wbuf = reinterpret_cast<float*>(wave < 4 ? reinterpret_cast<char*>(&As[0][0][0]) : reinterpret_cast<char*>(&Bs[0][0][0]))
                 + (wave & 3) * 4096;
@@ -511,7 +517,9 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
 
   if constexpr (LN) {
     // ---- fc dropout, + residual, LayerNorm over the 256 channels of each point, write xhat and rstd ------------------
-    // (stays in the accumulator layout: the 16-byte path through LDS of the plain epilogue spills here and measured 20 % slower)
+    // (stays in the accumulator layout: the 16-byte path through the wave's LDS block — residual rows in, transposed reads —
+    //  was built three times and measured 5–20 % slower each time: 40 spilled registers and 128 ds_read_b32 per wave cost
+    //  more than the 96 memory instructions it saves)
     float* red = reinterpret_cast<float*>(&As[0][0][0]);            // [2][4 M-waves][256 points] (the tile loop is over)
     const int wmi = wave >> 1;
     const long long rs = q.res_index ? q.res_index[z2] : z2;
@@ -542,6 +550,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
       if (h == 0) red[wmi * 256 + nl] = s1;
     }
     __syncthreads();
+    BSTAMP(3);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int nl = wn0 + 32 * j + l31;
@@ -558,6 +567,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
       if (h == 0) red[1024 + wmi * 256 + nl] = s2;
     }
     __syncthreads();
+    BSTAMP(4);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int nl = wn0 + 32 * j + l31;
@@ -593,6 +603,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
       s += __shfl_xor(s, 1, 64);
       if ((tid & 1) == 0) q.sum_ws[((long long)z2 * tiles_n + tile_n) * 256 + (tid >> 1)] = s;
     }
+    BSTAMP(5);
     return;
   }
 
@@ -650,6 +661,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
       for (int t = 0; t < 16; ++t) csn_bstore4(vals[t], Cr, off[t]);
     }
   }
+  BSTAMP(5);
 }
 
 template <bool B_NK, bool BT = false, bool LN = false>
