@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: CSA forward + backward query-points/sec (BASELINE.json metric) on N MI355X.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 1 --steps 10 --warmup 3                      # BASELINE.json configs[2] (the metric's config)
+    python bench.py --config 2 | --config 5                             # configs[1] / configs[4] as workloads of their own
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -9,15 +10,19 @@ A "step" = one pass of the hot path over one batch of synthetic shapes, exactly 
 MID-FC/csa_training.py:202-211 does per batch: model(x, neighbours) -> masked cross-entropy -> backward
 (no optimizer step, no data loading; features resident in HBM).
 
-Workload at N = 1: BASELINE.json configs[2] — 32 query shapes x 10000 points x 256 channels, K = 3
-neighbour shapes each (independent synthetic maps), n_heads = 1 (csa_training.py:37 default), 39 classes
-(PartNet Chair).  For N > 1 (configs[3]): every rank owns 32 shapes of a 32*N-shape collection (weak
-scaling), neighbours are drawn from the whole collection, the ranks all-gather the point features over
-RCCL/xGMI inside the timed region, and the 11 weight gradients are all-reduced at the end of the step.
+Workloads (`--config`, numbering of SURVEY.md §8d = BASELINE.json configs[i-1]):
+  3 (default)  32 query shapes x 10000 points x 256 channels, K = 3, 20 blocks of 500 — the configuration the metric is
+               quoted on.  For N > 1 (config 4): every rank owns 32 shapes of a 32*N-shape collection (weak scaling),
+               neighbours are drawn from the whole collection, the ranks exchange the point features over RCCL/xGMI inside the
+               timed region, and the weight gradients are all-reduced at the end of the step.
+  2            4 query shapes x 10000 x 256, K = 2.
+  5            8 query shapes x 50000 points x 96 channels (d_k = d_v = 96), K = 4, 100 blocks of 500.
+n_heads = 1 (csa_training.py:37 default), 39 classes (PartNet Chair), train mode (dropout 0.1 live, csa_training.py:192).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the fused block-attention forward kernel
-(csn_attn_f32_kernel<8,false>), timed live with HIP events on the launch stream; `cpu_baseline` is the
-oracle's faithful op-for-op port of the reference timed on the host cores over a bounded sample.
+Prints ONE JSON line (rank 0).  `roofline` describes the DOMINANT kernel of the step — the longer of the two fused
+block-attention launches (forward: S = Q K^T, softmax, P V; backward: dP = dO V^T, dS, dQ = dS K), each timed live with HIP
+events on the launch stream, mean over the timed steps; the other launch is reported beside it (`roofline_other`).
+`cpu_baseline` is the oracle's faithful op-for-op port of the reference timed on the host cores over a bounded sample.
 """
 import argparse
 import json
@@ -32,23 +37,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4, 64 FLOP/clk/SIMD
-# HBM bytes of one fused-attention-forward launch per evaluation, from the PMC passes in profiles/r1s_pmc_hbm_traffic.txt:
-# (2 x FETCH_SIZE + WRITE_SIZE) x 1024 / 256 evaluations = (2 x 3.911e6 + 7.631e6) KB / 256 (gfx950: FETCH_SIZE counts half of
-# a 16-byte-per-lane read stream).  Algorithmic: 3 x 10.24 MB of Q/K/V in, 20 MB of scores + 10.24 MB of context out = 61 MB.
-ATTN_FWD_HBM_BYTES_PER_EVAL = (2 * 3.911e6 + 7.631e6) * 1024 / 256
-PEAK_BF16_MATRIX_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA (the bf16x3 mode issues 3 bf16 FLOPs per algorithmic FLOP)
-N_POINTS, C, T, H, D_HEAD, N_CLS = 10000, 256, 500, 1, 256, 39
+PEAK_TFLOPS = {"fp32": 157.3,       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4, 64 FLOP/clk/SIMD
+               "bf16x3": 2500.0,    # dense bf16 MFMA; the mode issues 3 bf16 matrix FLOPs per algorithmic FLOP
+               "bf16": 2500.0, "fp16": 2500.0}
+MATH_MODES = {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp16": 3}
+DTYPE_TEXT = {"fp32": "f32", "bf16x3": "bf16x3 (fp32 operands split into 2 bf16, 3 bf16 MFMA per product, fp32 accumulate)",
+              "bf16": "bf16 (one bf16 MFMA per product, fp32 accumulate; outside the 1e-4 contract)",
+              "fp16": "fp16 forward / bf16 backward (one MFMA per product, fp32 accumulate; outside the 1e-4 contract)"}
+H, N_CLS = 1, 39
+CONFIGS = {
+    2: dict(B=4, K=2, N=10000, C=256, d=256, T=500, nb=20, name="BASELINE configs[1]"),
+    3: dict(B=32, K=3, N=10000, C=256, d=256, T=500, nb=20, name="BASELINE configs[2]"),
+    5: dict(B=8, K=4, N=50000, C=96, d=96, T=500, nb=100, name="BASELINE configs[4]"),
+}
+# HBM bytes per launch of the attention kernels, measured by separate rocprofv3 --pmc passes and summarised into this
+# committed file by scripts/pmc_summary.py (never measured by the bench run itself: counters cannot be collected beside
+# the timing); entries are keyed "<config>/<math>/<fwd|bwd>"
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "attn_hbm_traffic.json")
 
 
-def algorithmic_flops_fwd(B, K, N=N_POINTS, Cc=C, Dd=H * D_HEAD, Tt=T):
+def algorithmic_flops_fwd(B, K, N, C, D, T):
     """unique matmul FLOPs of one forward (projections once per shape, 2K+1 evaluations)."""
-    return B * ((K + 1) * 6 * N * Cc * Dd + (2 * K + 1) * (4 * N * Tt * Dd + 2 * N * Dd * Cc))
-
-
-def attn_fwd_flops(B, K, N=N_POINTS, Dd=H * D_HEAD, Tt=T):
-    """QK^T + PV of the fused attention forward launch: (2K+1) evaluations x 4*N*T*D."""
-    return B * (2 * K + 1) * 4 * N * Tt * Dd
+    return B * ((K + 1) * 6 * N * C * D + (2 * K + 1) * (4 * N * T * D + 2 * N * D * C))
 
 
 def masked_ce(logits, label):
@@ -57,25 +67,43 @@ def masked_ce(logits, label):
     return torch.nn.functional.cross_entropy(logits.squeeze(-1), label, ignore_index=0)
 
 
-def cpu_baseline(K, sample_shapes, threads, dropout=True):
-    """Oracle's faithful port (20 x 500 chunk loop, growing cat, 2K+2 MHA calls) on the host, fwd + bwd,
-    in the same mode as the headline run (train mode: both dropouts live, csa_training.py:192)."""
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, sample_shapes, threads, dropout=True):
+    """The oracle's port of the reference on the host, fwd + bwd, in the same mode as the headline run (train mode: both
+    dropouts live, csa_training.py:192).  Reference geometry (20 x 500, d = 256): the faithful op sequence (chunk loop, index
+    gather, growing cat, 2K+2 MHA calls); other geometries: the closed form of the same arithmetic."""
     from oracle import csa_oracle as orc
     torch.set_num_threads(threads)
+    K, N, C, d, T, nb = (cfg[k] for k in ("K", "N", "C", "d", "T", "nb"))
     rng = np.random.default_rng(99)
-    p = {k: v.requires_grad_(True) for k, v in orc.make_params(rng, H, n_cls=N_CLS, csa=True).items()}
-    x = orc.synth_points(rng, (sample_shapes, C, N_POINTS, 1))
-    nb = orc.synth_points(rng, (sample_shapes, K + 1, C, N_POINTS, 1))
-    nb[:, 0] = x
-    lab = orc.synth_labels(rng, sample_shapes, N_POINTS, N_CLS)
+    p = {k: v.requires_grad_(True) for k, v in orc.make_params(rng, H, d_model=C, d_k=d, d_v=d, n_cls=N_CLS, csa=True).items()}
+    x = orc.synth_points(rng, (sample_shapes, C, N, 1))
+    nb_ = orc.synth_points(rng, (sample_shapes, K + 1, C, N, 1))
+    nb_[:, 0] = x
+    lab = orc.synth_labels(rng, sample_shapes, N, N_CLS)
+    pd = 0.1 if dropout else 0.0
+    faithful = (N, C, d, T, nb) == (10000, 256, 256, 500, 20)
+    if faithful:
+        mha = lambda a, b, c, pp, h, **kw: orc.mha_faithful(a, b, c, pp, h, p_attn_drop=pd, p_out_drop=pd)
+        what = "oracle/csa_oracle.py mha_faithful"
+    else:
+        mha = lambda a, b, c, pp, h, **kw: orc.mha_blockdiag(a, b, c, pp, h, d_k=d, d_v=d, block=T, n_blocks=nb)
+        what = "oracle/csa_oracle.py mha_blockdiag (closed form, eval-mode arithmetic)"
 
     def step():
         for v in p.values():
             v.grad = None
-        pd = 0.1 if dropout else 0.0
-        logits = orc.forward_csa(x, nb, p, H, mha=lambda a, b, c, pp, h, **kw: orc.mha_faithful(a, b, c, pp, h, p_attn_drop=pd,
-                                                                                                   p_out_drop=pd))
-        orc.masked_ce_loss(logits, lab).backward()
+        orc.masked_ce_loss(orc.forward_csa(x, nb_, p, H, mha=mha), lab).backward()
 
     step()
     times = []
@@ -84,9 +112,10 @@ def cpu_baseline(K, sample_shapes, threads, dropout=True):
         step()
         times.append(time.perf_counter() - t0)
     t = sorted(times)[1]
-    return {"value": sample_shapes * N_POINTS / t, "unit": "points/s", "cores": threads, "kind": "port",
-            "sample": f"{sample_shapes} of the 32 query shapes (K={K}, {'train mode, dropout 0.1' if dropout else 'eval-mode arithmetic'}, fwd+bwd), median of 3 steps after "
-                      f"1 warm-up, {t:.2f} s/step; oracle/csa_oracle.py mha_faithful"}
+    return {"value": sample_shapes * N / t, "unit": "points/s", "cores": threads, "cpu_model": cpu_model_name(), "kind": "port",
+            "sample": f"{sample_shapes} of the {cfg['B']} query shapes (K={K}, {N} pts x {C} ch, "
+                      f"{'train mode, dropout 0.1' if dropout and faithful else 'eval-mode arithmetic'}, fwd+bwd), median of 3 "
+                      f"steps after 1 warm-up, {t:.2f} s/step; {what}"}
 
 
 def main():
@@ -94,11 +123,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--shapes", type=int, default=32, help="query shapes per GPU")
-    ap.add_argument("--K", type=int, default=3)
+    ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=3,
+                    help="workload: 3 = the metric's configuration (default), 2 / 5 = BASELINE configs[1] / configs[4]")
+    ap.add_argument("--shapes", type=int, default=None, help="query shapes per GPU (default: the configuration's)")
+    ap.add_argument("--K", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--math", choices=["fp32", "bf16x3"], default="bf16x3",
-                    help="arithmetic of the contractions: exact fp32 matrix cores, or three bf16 products per fp32 product")
+    ap.add_argument("--math", choices=sorted(MATH_MODES), default="bf16x3",
+                    help="arithmetic of the contractions: exact fp32 matrix cores; three bf16 products per fp32 product "
+                         "(default: inside the 1e-4 contract); one bf16 / fp16 product (outside it, reported with its error)")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the secondary runs (other math mode, eval-mode arithmetic): what the profiles are taken with")
     args = ap.parse_args()
@@ -106,7 +138,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n_ranks_seen = 1
     if world > 1:
+        # the process group comes up BEFORE anything touches the GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # CSN_BENCH_BACKEND=gloo + CSN_BENCH_ONE_GPU=1 rehearse the N > 1 code path with all ranks on one GPU (no RCCL)
@@ -118,6 +152,7 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
+        n_ranks_seen = dist.get_world_size()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -126,35 +161,43 @@ def main():
     from csn_amd import functional as CF
     from csn_amd.csa_models import get_model
     csn_amd.build()
-    csn_amd._lib.check(csn_amd.lib().csn_set_math_mode(1 if args.math == "bf16x3" else 0))
+    set_math = lambda name: csn_amd._lib.check(csn_amd.lib().csn_set_math_mode(MATH_MODES[name]))
+    set_math(args.math)
 
-    B, K = args.shapes, args.K
+    cfg = dict(CONFIGS[args.config])
+    if args.shapes is not None:
+        cfg["B"] = args.shapes
+    if args.K is not None:
+        cfg["K"] = args.K
+    B, K, N, C, d, T, nb = (cfg[k] for k in ("B", "K", "N", "C", "d", "T", "nb"))
+    D = H * d
     S = B * world
     torch.manual_seed(0)
-    model = get_model("csa", N_CLS, H, K).to(dev)
+    model = get_model("csa", N_CLS, H, K, d_model=C, d_k=d, d_v=d, block=T, n_blocks=nb).to(dev)
     model.trust_neighbor_slot0 = True      # the stack built below has the shape itself in slot 0, like CSADatasetK
     params = [p for n, p in model.named_parameters() if not n.startswith("fc_1")]
 
-    rng = np.random.default_rng(1234 + 2 + 1000 * rank)
-    feats = torch.from_numpy(rng.standard_normal(size=(B, C, N_POINTS)).astype(np.float32)).to(dev)
-    label = torch.from_numpy(np.where(rng.random(size=(B, N_POINTS)) < 0.1, 0,
-                                      rng.integers(0, N_CLS, size=(B, N_POINTS))).astype(np.int64)).to(dev)
+    rng = np.random.default_rng(1234 + (args.config - 1) + 1000 * rank)
+    feats = torch.from_numpy(rng.standard_normal(size=(B, C, N)).astype(np.float32)).to(dev)
+    label = torch.from_numpy(np.where(rng.random(size=(B, N)) < 0.1, 0,
+                                      rng.integers(0, N_CLS, size=(B, N))).astype(np.int64)).to(dev)
     shard = None
     if world == 1:
-        # configs[2]: K independent synthetic neighbour maps per query shape, resident in HBM
-        nbr_maps = torch.from_numpy(rng.standard_normal(size=(B, K, C, N_POINTS)).astype(np.float32)).to(dev)
-        # the neighbour stack (B, K+1, C, N, 1) is an input of the step — what CSADatasetK hands the model, slot 0 = the
-        # shape itself (features_data_loader.py:66-82) — so it is resident in HBM before the timed region
-        x_nb_resident = torch.cat((feats[:, None], nbr_maps), dim=1).unsqueeze(-1).contiguous()
-        del nbr_maps
+        # K independent synthetic neighbour maps per query shape.  The neighbour stack (B, K+1, C, N, 1) is an input of the
+        # step — what CSADatasetK hands the model, slot 0 = the shape itself (features_data_loader.py:66-82) — so it is
+        # resident in HBM before the timed region
+        x_nb_resident = torch.empty((B, K + 1, C, N, 1), device=dev, dtype=torch.float32)
+        x_nb_resident[:, 0, :, :, 0] = feats
+        for k in range(K):
+            x_nb_resident[:, k + 1, :, :, 0] = torch.from_numpy(rng.standard_normal(size=(B, C, N)).astype(np.float32)).to(dev)
     else:
-        # configs[3]: K-regular shape graph over the whole collection (never self), same on every rank
+        # config 4: K-regular shape graph over the whole collection (never self), same on every rank
         from csn_amd.sharding import ShapeGraphShard, regular_graph
         shard = ShapeGraphShard(regular_graph(S, K), B, rank, world, dev)
 
-    attn_events = []
-    exchange_mode = os.environ.get("CSN_EXCHANGE", "allgather")          # "alltoall": neighbour-only exchange (sharding.py)
-    overlap = os.environ.get("CSN_OVERLAP", "1") != "0"                  # all-gather in flight under the self-attention evaluations
+    attn_events = {"fwd": [], "bwd": []}
+    exchange_mode = os.environ.get("CSN_EXCHANGE", "alltoall")           # "allgather": the whole collection to every rank
+    overlap = os.environ.get("CSN_OVERLAP", "1") != "0"                  # exchange in flight under the self-attention evaluations
 
     # CSN_BENCH_SPLIT=1 (N = 1, development aid): run the two-phase evaluation order of the multi-GPU path with the stack
     # already complete, to price its extra work against the single call
@@ -171,10 +214,10 @@ def main():
         for p in params:
             p.grad = None
         if shard is not None:
-            if exchange_mode == "allgather" and overlap:
-                x_nb = shard.exchange_async(feats)                       # the model overlaps its self-attention with it
+            if overlap:
+                x_nb = shard.exchange_async(feats, mode=exchange_mode)   # the model overlaps its self-attention with it
             elif exchange_mode == "alltoall":
-                x_nb = shard.exchange_neighbours(feats)                  # neighbour-only all-to-all (opt-in)
+                x_nb = shard.exchange_neighbours(feats)                  # neighbour-only all-to-all
             else:
                 x_nb = shard.neighbour_stack(feats, shard.exchange(feats))   # all-gather of point features over xGMI
         else:
@@ -184,17 +227,21 @@ def main():
         if record:
             CF.EVENT_SINK = attn_events
         logits = model(feats.unsqueeze(-1), "train", x_nb)
-        CF.EVENT_SINK = None
         loss = masked_ce(logits, label)
         loss.backward()
+        CF.EVENT_SINK = None
         if shard is not None:
             shard.allreduce_grads(params)                                # one 1.6 MB bucket
         return loss
 
     def timed(train_mode):
-        """W warm-up + K timed steps, barrier + synchronize on both sides, max over ranks."""
+        """W warm-up + K timed steps, barrier + synchronize on both sides, max over ranks.  Every run starts from the same
+        generator state, so the dropout masks (pure functions of seed and position) are the same in every math mode and
+        the losses of two modes can be compared."""
         model.train(train_mode)                                          # train: dropout p = 0.1 live (csa_training.py:192)
-        attn_events.clear()
+        torch.manual_seed(1)
+        for v in attn_events.values():
+            v.clear()
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
@@ -213,65 +260,92 @@ def main():
             tmax = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = tmax.item()
-        ms = float(np.mean([a.elapsed_time(b) for a, b in attn_events])) if attn_events else float("nan")
-        return el, float(loss.item()), ms
+        ms = {k: (float(np.mean([a.elapsed_time(b) for a, b in v])) if v else float("nan")) for k, v in attn_events.items()}
+        gnorm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params if p.grad is not None)).item())
+        return el, float(loss.item()), ms, gnorm
 
     # headline first (the training step as the reference runs it), then the secondary runs: eval-mode arithmetic in the
     # headline mode, and the same train-mode step in the other arithmetic mode
-    other = "fp32" if args.math == "bf16x3" else "bf16x3"
-    elapsed, loss_val, attn_ms = timed(True)
+    other = "fp32" if args.math != "fp32" else "bf16x3"
+    elapsed, loss_val, attn_ms, gnorm = timed(True)
     if not args.headline_only:
-        elapsed_eval, loss_eval, _ = timed(False)      # eval-mode arithmetic (dropout off), gradients on
-        csn_amd._lib.check(csn_amd.lib().csn_set_math_mode(1 if other == "bf16x3" else 0))
-        elapsed_other, loss_other, attn_ms_other = timed(True)
-        csn_amd._lib.check(csn_amd.lib().csn_set_math_mode(1 if args.math == "bf16x3" else 0))
+        elapsed_eval, loss_eval, _, _ = timed(False)      # eval-mode arithmetic (dropout off), gradients on
+        set_math(other)
+        elapsed_other, loss_other, attn_ms_other, gnorm_other = timed(True)
+        set_math(args.math)
     n_evals = B * (2 * K + 2)                          # train mode: the pooled and the mixed self evaluation differ
 
     if rank == 0:
-        ms_step = elapsed / args.steps * 1e3
-        value = S * N_POINTS * args.steps / elapsed
-        launch_flops = n_evals * 4 * N_POINTS * T * H * D_HEAD       # QK^T + PV of every evaluation in the launch
+        launch_flops = n_evals * 4 * N * T * D         # forward: QK^T + PV; backward: dO V^T + dS K — the same count
+        traffic_tab = {}
+        if os.path.exists(TRAFFIC_FILE):
+            with open(TRAFFIC_FILE) as fh:
+                traffic_tab = json.load(fh)
 
-        def roof(math, ms):
-            fast = math == "bf16x3"
+        def roof(math, which, ms):
+            fast = math != "fp32"
             ach = launch_flops / (ms * 1e-3) / 1e12
-            peak = PEAK_BF16_MATRIX_TFLOPS if fast else PEAK_F32_MATRIX_TFLOPS
-            r = {"bound": "mfma", "kernel": ("csn_attn_bf16x3_kernel<8,false,true>" if fast else "csn_attn_f32_kernel<8,false>")
-                                            + " (fused block attention forward)",
+            peak = PEAK_TFLOPS[math]
+            tmpl = f"<{d // 32},{'true' if which == 'bwd' else 'false'}{',true' if fast else ''}>"
+            entry = traffic_tab.get(f"{args.config}/{math}/{which}") if (B, K) == (CONFIGS[args.config]["B"], CONFIGS[args.config]["K"]) else None
+            r = {"bound": "mfma",
+                 "kernel": ("csn_attn_bf16x3_kernel" if fast else "csn_attn_f32_kernel") + tmpl
+                           + (" (fused block attention backward: dP, dS, dQ)" if which == "bwd" else " (fused block attention forward)"),
                  "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                 "traffic": ATTN_FWD_HBM_BYTES_PER_EVAL * n_evals, "launch_ms": ms,
+                 "traffic": entry["bytes_per_launch"] if entry else None,
+                 "traffic_source": (entry["source"] + " (rocprofv3 --pmc passes of this command, not measured in this run)") if entry else None,
+                 "launch_ms": ms, "launch_ms_is": f"mean of {args.steps} timed launches (HIP events on the launch stream)",
                  "flops_per_launch": launch_flops,
-                 "note": "algorithmic FLOPs: 512 kFLOP per query point per evaluation x 10000 points x evaluations in the launch"}
-            if fast:
+                 "note": f"algorithmic FLOPs: 4*T*d = {4 * T * d // 1000} kFLOP per query point per evaluation x {N} points x "
+                         f"{n_evals} evaluations in the launch"}
+            if math == "bf16x3":
                 r["note"] += "; this mode issues 3 bf16 matrix FLOPs per algorithmic FLOP, so the matrix pipe sees 3x `achieved`"
             return r
 
+        def roofs(math, ms):
+            dom = "bwd" if not (ms["bwd"] < ms["fwd"]) else "fwd"     # NaN-safe: backward unless the forward is longer
+            oth = "fwd" if dom == "bwd" else "bwd"
+            return roof(math, dom, ms[dom]), roof(math, oth, ms[oth])
+
+        dominant, second = roofs(args.math, attn_ms)
         out = {
-            "metric": "CSA fwd+bwd points/sec (10k pts x 256 ch, K=3)", "value": S * N_POINTS * args.steps / elapsed,
-            "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "CSA fwd+bwd points/sec (10k pts x 256 ch, K=3)" if args.config == 3 else
+                      f"CSA fwd+bwd points/sec ({N // 1000}k pts x {C} ch, K={K})",
+            "value": S * N * args.steps / elapsed,
+            "unit": "points/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3 (fp32 operands split into 2 bf16, 3 bf16 MFMA per product, fp32 accumulate)" if args.math == "bf16x3"
-                     else "f32",
+            "dtype": DTYPE_TEXT[args.math],
             "data": "synthetic",
-            "config": {"workload": f"CSA K={K}, {B} query shapes/GPU x {N_POINTS} pts x {C} ch, n_heads={H}, d_k=d_v={D_HEAD}, "
-                                   f"20 blocks of {T}, {N_CLS} classes, fwd + masked CE + bwd, train mode (dropout 0.1 live, "
+            "config": {"workload": f"{cfg['name']}: CSA K={K}, {B} query shapes/GPU x {N} pts x {C} ch, n_heads={H}, d_k=d_v={d}, "
+                                   f"{nb} blocks of {T}, {N_CLS} classes, fwd + masked CE + bwd, train mode (dropout 0.1 live, "
                                    f"2K+2 evaluations/shape), math mode {args.math}",
-                       "shapes_total": S, "K": K, "parallelism": f"shape-graph sharded x{world}" if world > 1 else "single GPU",
-                       "loss": loss_val,
-                       "step_tflops_algorithmic": 3 * algorithmic_flops_fwd(S, K) / (elapsed / args.steps) / 1e12},
-            "roofline": roof(args.math, attn_ms),
+                       "shapes_total": S, "K": K,
+                       "parallelism": (f"shape-graph sharded x{world}, exchange {exchange_mode}" + (" overlapped" if overlap else "")) if world > 1 else "single GPU",
+                       "loss": loss_val, "grad_norm": gnorm,
+                       "step_tflops_algorithmic": 3 * algorithmic_flops_fwd(S, K, N, C, D, T) / (elapsed / args.steps) / 1e12},
+            "roofline": dominant, "roofline_other": second,
         }
         if not args.headline_only:
-            out["config"]["dropout_off"] = {"points_per_s": S * N_POINTS * args.steps / elapsed_eval,
+            out["config"]["dropout_off"] = {"points_per_s": S * N * args.steps / elapsed_eval,
                                             "ms_per_step": elapsed_eval / args.steps * 1e3, "loss": loss_eval,
                                             "note": "same step with eval-mode arithmetic (2K+1 evaluations/shape), gradients on"}
-            out["config"][f"math_{other}"] = {"points_per_s": S * N_POINTS * args.steps / elapsed_other,
+            d_o, s_o = roofs(other, attn_ms_other)
+            out["config"][f"math_{other}"] = {"points_per_s": S * N * args.steps / elapsed_other,
                                               "ms_per_step": elapsed_other / args.steps * 1e3, "loss": loss_other,
-                                              "roofline": roof(other, attn_ms_other),
-                                              "note": "the same train-mode step in the other arithmetic mode"}
+                                              "grad_norm": gnorm_other, "roofline": d_o, "roofline_other": s_o,
+                                              "note": "the same train-mode step (same dropout masks) in the other arithmetic mode"}
+            # the timed step is also a checked step: same masks, two arithmetic modes — loss and gradient norm must agree
+            tol = 1e-4 if {args.math, other} <= {"fp32", "bf16x3"} else 5e-2
+            ok = abs(loss_val - loss_other) <= tol * max(1.0, abs(loss_other)) and abs(gnorm - gnorm_other) <= max(tol, 1e-3) * gnorm_other
+            out["config"]["cross_mode_check"] = {"loss_abs_diff": abs(loss_val - loss_other),
+                                                 "grad_norm_rel_diff": abs(gnorm - gnorm_other) / gnorm_other, "tolerance": tol,
+                                                 "ok": bool(ok)}
+            if not ok:
+                print(f"bench: WARNING the {args.math} step disagrees with the {other} step beyond {tol}: "
+                      f"loss {loss_val} vs {loss_other}, |grad| {gnorm} vs {gnorm_other}", file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             cores = min(len(os.sched_getaffinity(0)), 16)          # the GPU box gives one GPU a 16-core share
-            out["cpu_baseline"] = cpu_baseline(K, 4, cores)
+            out["cpu_baseline"] = cpu_baseline(cfg, 4 if args.config == 3 else (2 if args.config == 2 else 1), cores)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -7,6 +7,7 @@ current HIP stream.  There is NO fallback: if the library cannot be built/loaded
 from __future__ import annotations
 
 import ctypes
+import hashlib
 import os
 import subprocess
 from ctypes import c_char_p, c_float, c_int, c_longlong, c_ulonglong, c_void_p
@@ -18,6 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libcsn_hip.so")
 SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "attn_f32.hip", "attn_bf16x3.hip", "outproj_ln.hip", "retrieval.hip", "combine.hip", "csn_capi.hip"]
 HEADERS = ["csn_common.h", "csn_kernels.h", os.path.join("..", "..", "include", "csn_hip.h")]
 ARCH = "gfx950"
+BUILD_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared"]
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -26,11 +28,26 @@ class CsnError(RuntimeError):
     pass
 
 
+STAMP_PATH = LIB_PATH + ".sha256"
+
+
+def _source_digest() -> str:
+    """sha256 over the names and bytes of every source and header the library is built from (and the build flags)."""
+    h = hashlib.sha256(" ".join(BUILD_FLAGS).encode())
+    for f in SOURCES + HEADERS:
+        h.update(f.encode())
+        with open(os.path.join(_CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _stale() -> bool:
-    if not os.path.exists(LIB_PATH):
+    """The library is current iff the digest recorded beside it at build time equals the digest of the sources now
+    (content, not modification times: a snapshot copy or a checkout changes mtimes without changing a byte)."""
+    if not (os.path.exists(LIB_PATH) and os.path.exists(STAMP_PATH)):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(os.path.join(_CSRC, f)) > t for f in SOURCES + HEADERS)
+    with open(STAMP_PATH) as fh:
+        return fh.read().strip() != _source_digest()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -40,7 +57,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH + ".tmp"]
+    cmd = [hipcc] + BUILD_FLAGS + ["-o", LIB_PATH + ".tmp"]
     cmd += [os.path.join(_CSRC, f) for f in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -48,6 +65,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if res.returncode != 0:
         raise CsnError("hipcc failed:\n" + res.stdout + res.stderr)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    with open(STAMP_PATH, "w") as fh:
+        fh.write(_source_digest() + "\n")
     global _lib
     _lib = None
     return LIB_PATH

@@ -129,6 +129,13 @@ class MultiHeadAttention(nn.Module):
                 nbr = (b * K1 + k)[:, 1:].reshape(-1)
                 own = (b * K1)[:, 1:].reshape(-1)
                 cache[key] = CF.EvalPlan(np.concatenate((own, nbr)), np.concatenate((nbr, nbr)), B * K1, dev)
+            elif kind == "cross_only":
+                # descriptor reuse (multi-GPU): only [b*K + k-1] MHA(x_b, x_bk, x_bk) — the neighbours' own self-attention is
+                # their owners' work (csn_amd.sharding.PendingStack.gather_pooled); slots as in "csa"
+                b, k = np.meshgrid(ar, np.arange(K1), indexing="ij")
+                nbr = (b * K1 + k)[:, 1:].reshape(-1)
+                own = (b * K1)[:, 1:].reshape(-1)
+                cache[key] = CF.EvalPlan(own, nbr, B * K1, dev)
             else:
                 raise ValueError(kind)
         return cache[key]
@@ -179,11 +186,16 @@ class CrossShapeAt(nn.Module):
     """csa_models.py:146-404."""
 
     def __init__(self, num_classes, d_model, n_heads, K=None, d_k=256, d_v=256, attention_type='ssa',
-                 after_fc=False, device=None):
+                 after_fc=False, device=None, block=CF.REF_BLOCK, n_blocks=CF.REF_NBLOCKS):
+        """Arguments as the reference's (csa_models.py:147).  The reference hard-codes 256 for the widths of ``fc_1``,
+        ``logit`` and the compatibility head (:150-151, :160-161) and 20 x 500 for the chunking (:83-84): here they follow
+        ``d_model`` / ``block`` / ``n_blocks`` (identical for the defaults), so that the other BASELINE configurations —
+        e.g. 8 x 50000 points x 96 channels in 100 blocks — run through the same module."""
         super().__init__()
-        self.fc_1 = self._conv1x1_bn_relu(928, 256)            # never executed when after_fc=True; kept for checkpoints
-        self.logit = self._conv1x1(256, num_classes)
-        self.attention = MultiHeadAttention(n_heads, d_model, d_k, d_v)
+        self.d_model = d_model
+        self.fc_1 = self._conv1x1_bn_relu(928, d_model)        # never executed when after_fc=True; kept for checkpoints
+        self.logit = self._conv1x1(d_model, num_classes)
+        self.attention = MultiHeadAttention(n_heads, d_model, d_k, d_v, block=block, n_blocks=n_blocks)
         self.attention_type = attention_type
         self.after_fc = after_fc
         self.device = device
@@ -194,8 +206,8 @@ class CrossShapeAt(nn.Module):
         self.trust_neighbor_slot0 = False
         if 'csa' in self.attention_type:
             self.K = K
-            self.compatibility_q = nn.Linear(256, 256)
-            self.compatibility_k = nn.Linear(256, 256)
+            self.compatibility_q = nn.Linear(d_model, d_model)
+            self.compatibility_k = nn.Linear(d_model, d_model)
 
     @staticmethod
     def _conv1x1(nin, nout, use_bias=False):
@@ -316,13 +328,20 @@ class CrossShapeAt(nn.Module):
         if not (nb.is_cuda and nb.dtype == torch.float32 and nb.is_contiguous() and nb.shape[-1] == npts):
             raise ValueError("a pending neighbour stack must resolve to a contiguous fp32 device tensor (B, K+1, C, n_points)")
         x_all = nb.view(B * K1, C, npts)
-        # phase 2: [b*K + k-1] cross evaluations (mixed), [B*K + b*K + k-1] neighbour self-attention (pooled only)
-        xh2, head2, s2 = att.evaluate(x_all, att.plan("csa_cross", B, K1, dev), geo, n_head_evals=B * K, want_sums=True,
-                                       link_mix=True)
         gamma, beta = att.norm.weight, att.norm.bias
-        m1, m2 = s1 / npts, s2 / npts
+        m1 = s1 / npts
         own = m1[B:] if train else m1[:B]
-        pooled_hat = torch.cat((own.view(B, 1, C), m2[B * K:].view(B, K, C)), dim=1)
+        if getattr(pending, "reuse_descriptors", False) and K > 0:
+            # descriptor reuse: the pooled SSA descriptor of a neighbour is its OWNER's own descriptor, fetched through one small
+            # differentiable all-gather — the K neighbour self-attention evaluations per shape (:214-220) are not run here
+            xh2, head2 = att.evaluate(x_all, att.plan("cross_only", B, K1, dev), geo, n_head_evals=B * K, link_mix=True)
+            nbr_hat = pending.gather_pooled(own)                                        # (B, K, C), pre-affine means
+        else:
+            # phase 2: [b*K + k-1] cross evaluations (mixed), [B*K + b*K + k-1] neighbour self-attention (pooled only)
+            xh2, head2, s2 = att.evaluate(x_all, att.plan("csa_cross", B, K1, dev), geo, n_head_evals=B * K, want_sums=True,
+                                           link_mix=True)
+            nbr_hat = (s2 / npts)[B * K:].view(B, K, C)
+        pooled_hat = torch.cat((own.view(B, 1, C), nbr_hat), dim=1)
         pooled = pooled_hat * gamma + beta
         comp = self._compatibility(pooled)
         feats = CF.csa_mix(head2, comp, gamma, beta, B, K1, xself=head1)   # own maps and cross maps stay where they are
@@ -406,18 +425,23 @@ class CrossShapeAt(nn.Module):
         return knn_graph
 
 
-def backbone_fc_ssa_logit(num_classes, n_heads):
-    return CrossShapeAt(num_classes, 256, n_heads, attention_type='ssa', after_fc=True)
+def backbone_fc_ssa_logit(num_classes, n_heads, **geometry):
+    return CrossShapeAt(num_classes, geometry.pop("d_model", 256), n_heads, attention_type='ssa', after_fc=True, **geometry)
 
 
-def backbone_fc_csa_logit(num_classes, n_heads, K):
-    return CrossShapeAt(num_classes, 256, n_heads, K, attention_type='csa', after_fc=True)
+def backbone_fc_csa_logit(num_classes, n_heads, K, **geometry):
+    return CrossShapeAt(num_classes, geometry.pop("d_model", 256), n_heads, K, attention_type='csa', after_fc=True, **geometry)
 
 
-def get_model(attention_type, num_classes, n_heads, K=None):
-    """csa_models.py:426-432."""
+def get_model(attention_type, num_classes, n_heads, K=None, **geometry):
+    """csa_models.py:426-432.  ``geometry`` (all optional, the defaults are the reference's constants): d_model=256,
+    d_k=256, d_v=256, block=500, n_blocks=20 — e.g. ``get_model('csa', 39, 1, 4, d_model=96, d_k=96, d_v=96,
+    n_blocks=100)`` is BASELINE.json's 50000-point, 96-channel configuration."""
+    unknown = set(geometry) - {"d_model", "d_k", "d_v", "block", "n_blocks"}
+    if unknown:
+        raise TypeError(f"get_model: unexpected arguments {sorted(unknown)}")
     if attention_type == 'ssa':
-        return backbone_fc_ssa_logit(num_classes, n_heads)
+        return backbone_fc_ssa_logit(num_classes, n_heads, **geometry)
     if attention_type == 'csa':
-        return backbone_fc_csa_logit(num_classes, n_heads, K)
+        return backbone_fc_csa_logit(num_classes, n_heads, K, **geometry)
     raise AttributeError(f'{attention_type} not supported')

@@ -16,9 +16,10 @@
 //   "tile planes"    — written by the projection (csn_project_f32, out_split = 2): per row and 500-point block, 16 tiles of
 //                      [hi: 32 keys | lo: 32 keys] bf16 (block pitch 1024, padding zero).  A tile row is then 128
 //                      contiguous, 128-byte aligned bytes, and staging is a plain copy — no conversion work per tile.
-// LDS images (conflict-free): tileA swaps the two 8-byte chunks of every 16-byte unit on rows with bit 3 set (the
-// transposing read of a 32-lane group touches rows r and r + 8 together); tileB XORs the 16-byte unit index with
-// (-(row >> 2)) & 3; the hi and lo planes are 128 bytes out of phase so that one staging store hits both without conflict.
+// LDS images (conflict-free): tileA swaps the two 8-byte chunks of every 16-byte unit on rows with bit 3 ^ bit 0 set (the
+// transposing read of a 32-lane group touches rows r and r + 8 together, a staging store rows r and r + 1); tileB XORs the
+// 16-byte unit index with (-(row >> 2)) & 3; the hi and lo planes are 64 bytes out of phase so that one staging store (whose
+// banks repeat every 128 bytes) hits both without conflict.
 // Schedule: LDS fragment reads run 4 steps ahead of their matrix instructions (explicit register ring); a tile is two barrier
 // segments and waves 4..7 run one segment behind waves 0..3; the register operand, the delta inputs and the output travel
 // as 16-byte rows through an LDS transpose (a wave-level memory instruction costs ~100 cycles whatever its width).
@@ -77,7 +78,14 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   constexpr int D = 32 * DT;
   constexpr int PIECES = D * 8;                         // 16-byte pieces per streamed tile
   constexpr int NP_T = (PIECES + 511) / 512;            // pieces per thread per tile
-  constexpr int PLANE = D * KT + 64;                    // plane pitch: 128 bytes of phase between hi and lo
+  // plane pitch: 64 bytes of phase between hi and lo.  LDS STORES bank on 32 dwords (128 bytes): a staging instruction of the
+  // tile-plane path writes the hi and the lo unit of a row together (lanes u and u + 4), and with the planes a multiple of
+  // 128 bytes apart the two would land on the same banks (measured: SQ_LDS_BANK_CONFLICT = 15 % of the LDS cycles of both
+  // attention kernels, all of it these stores).  CSN_LDS_V=0 rebuilds the old image (128 bytes of phase) for A/B timing.
+#ifndef CSN_LDS_V
+#define CSN_LDS_V 1
+#endif
+  constexpr int PLANE = D * KT + (CSN_LDS_V ? 32 : 64);
   // [A | B][stage][plane hi/lo][row][32 keys] — one array, so that the prologue / epilogue can use all of it as a
   // [D rows][128 queries] fp32 staging block for 16-byte global accesses
   __shared__ __attribute__((aligned(16))) __bf16 tiles[2][2][2][PLANE];
@@ -205,7 +213,8 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   const unsigned thr16 = csn_drop_threshold16(p.dropout_p);
   const float keep_scale = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
   const unsigned salt = csn_block_salt((unsigned long long)(((long long)e * p.H + hd) * p.n_blocks + blk), p.seed);
-  const unsigned pw_base = (unsigned)(4 * kq * Tp + qrow);       // pair index of this lane's keys 8 kq, 8 kq + 1
+  const int mp = Tq > Tp ? Tq : Tp;                               // mask pitch: pair index = key pair * mp + query stays unique when n_queries > score_pitch
+  const unsigned pw_base = (unsigned)(4 * kq * mp + qrow);       // pair index of this lane's keys 8 kq, 8 kq + 1
 
   // exponentials run on the hardware exp2: exp(s - m) = exp2(s * log2(e) - m2) with m2 = fl(m * log2(e)), the same m2 for
   // every key of a query, so its rounding cancels in the normalisation; lse is rebuilt from m2 (= m2 ln 2 + ln l)
@@ -223,7 +232,9 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   // unit tid % 8 of the row's 128 bytes (units 0..3: hi plane keys 8 u .. 8 u + 7, units 4..7: lo plane).  Everything that
   // depends on i is wave-uniform (scalar offset of the load, immediate offset of the LDS store): rows 64 apart share the swizzles.
   const int t_c = tid & 7, t_row = tid >> 3;
-  const int t_sw = (t_row >> 3) & 1, t_swz = (-((t_row >> 2) & 3)) & 3;
+  // tileA chunk swap: rows r and r + 8 are read together by the transposing read, and the 8-byte stores of a 16-lane group
+  // cover rows r, r + 1 of both planes — so the swap bit is (r >> 3) ^ r: both pairs then sit on complementary banks
+  const int t_sw = (CSN_LDS_V ? ((t_row >> 3) ^ t_row) : (t_row >> 3)) & 1, t_swz = (-((t_row >> 2) & 3)) & 3;
   const unsigned t_off = KVP ? (unsigned)(t_row * kld * 2 + t_c * 16) : (unsigned)(t_row * ldk + 4 * t_c) * 4u;
   const bool t_last_ok = tid + 512 * (NP_T - 1) < PIECES;         // only the last piece can fall beyond the tile
   // fp32: 8-byte chunk c -> tileA chunk c ^ sw;  tileB unit (c >> 1) ^ swz, half c & 1
@@ -284,7 +295,8 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   // row 8 kq + q' and the 4-key chunk that feeds score rows 4 p .. 4 p + 3: keys 8 p .. 8 p + 3 for S0, 8 p + 4 .. for S1
   // (chunks swapped inside their 16-byte unit when (row >> 3) & 1 = kq & 1 is set)
   const int tr_row = 8 * kq + (lq >> 2);
-  const int a_pos0 = tr_row * KT + 8 * (lq & 3) + 4 * (kq & 1), a_pos1 = tr_row * KT + 8 * (lq & 3) + 4 * ((kq & 1) ^ 1);
+  const int tr_sw = (CSN_LDS_V ? (kq ^ (lq >> 2)) : kq) & 1;      // = the store side's swap bit of row tr_row (and of tr_row + 4)
+  const int a_pos0 = tr_row * KT + 8 * (lq & 3) + 4 * tr_sw, a_pos1 = tr_row * KT + 8 * (lq & 3) + 4 * (tr_sw ^ 1);
   // tileB: row lq of the 16-channel tile, 16-byte unit kq ^ ((-(lq >> 2)) & 3): keys 8 kq .. 8 kq + 7
   const int b_pos = lq * KT + 8 * (kq ^ ((-((lq >> 2) & 3)) & 3));
 
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     if (drop) {
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        const unsigned h = csn_pair_hash(pw_base + (unsigned)((kt * (KT / 2) + w) * Tp), salt);
+        const unsigned h = csn_pair_hash(pw_base + (unsigned)((kt * (KT / 2) + w) * mp), salt);
         keep[2 * w] = (h & 0xffffu) >= thr16;
         keep[2 * w + 1] = (h >> 16) >= thr16;
       }

@@ -138,7 +138,8 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
   const unsigned thr16 = csn_drop_threshold16(p.dropout_p);
   const float keep_scale = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
   const unsigned salt = csn_block_salt((unsigned long long)(((long long)e * p.H + hd) * p.n_blocks + blk), p.seed);
-  const unsigned pw_base = (unsigned)(2 * kq * Tp + qrow);       // pair index of this lane's keys 4 kq, 4 kq + 1
+  const int mp = Tq > Tp ? Tq : Tp;                               // mask pitch: pair index = key pair * mp + query stays unique when n_queries > score_pitch
+  const unsigned pw_base = (unsigned)(2 * kq * mp + qrow);       // pair index of this lane's keys 4 kq, 4 kq + 1
 
   float m_run = -INFINITY, l_run = 0.f;       // forward: running max / partial sum of this lane's key quarter
   float lse_q = 0.f;                           // backward: per-query constant
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int w = 0; w < 2; ++w) {
-          const unsigned h = csn_pair_hash(pw_base + (unsigned)((kt * (KT / 2) + 8 * j + w) * Tp), salt);
+          const unsigned h = csn_pair_hash(pw_base + (unsigned)((kt * (KT / 2) + 8 * j + w) * mp), salt);
           keep[4 * j + 2 * w] = (h & 0xffffu) >= thr16;
           keep[4 * j + 2 * w + 1] = (h >> 16) >= thr16;
         }

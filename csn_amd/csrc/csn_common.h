@@ -115,7 +115,7 @@ CSN_DEVINL unsigned csn_drop_threshold(float p) { return (unsigned)(p * 16777216
 // Attention-probability masks (the bulk of all mask decisions: T*T per block) use a cheaper form of the same idea:
 // a score block (evaluation, head, block) draws a 32-bit salt from (seed, block id) with the two-round hash above —
 // wave-uniform, scalar unit — and ONE mixer round over (pair index ^ salt) decides two elements at once: the
-// keys 2w and 2w+1 of query q have pair index w * pitch + q and take the low / high 16 bits;
+// keys 2w and 2w+1 of query q have pair index w * max(score pitch, queries per block) + q and take the low / high 16 bits;
 // keep  <=>  16-bit field >= p * 2^16.
 CSN_DEVINL unsigned csn_block_salt(unsigned long long block_id, unsigned long long seed) {
   const unsigned h = csn_mix32((unsigned)block_id ^ (unsigned)seed);

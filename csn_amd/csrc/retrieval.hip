@@ -39,8 +39,10 @@ __global__ __launch_bounds__(256, 2) void csn_retrieval_rowmax_kernel(const floa
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-  const int pair = blockIdx.y, i = pair / s2, j = pair % s2;
-  const int nq0 = blockIdx.x * 128;
+  // 1-D grid, pair-major: blockIdx.x = pair * tiles + tile (a y dimension would cap the pair count at 65535)
+  const int tiles = (n1 + 127) / 128;
+  const int pair = blockIdx.x / tiles, i = pair / s2, j = pair % s2;
+  const int nq0 = (blockIdx.x % tiles) * 128;
 
   const csn_rsrc_t Qr = csn_make_rsrc(f1 + ((long long)i * n1 + nq0) * C, (long long)min(128, n1 - nq0) * C * 4);
   const int pr = tid >> 3, pc = (tid & 7) * 4;
@@ -151,7 +153,9 @@ int csn_launch_retrieval_f32(const float* f1, const float* f2, float* out, int s
   const long long r1 = (long long)s1 * n1, r2 = (long long)s2 * n2;
   hipLaunchKernelGGL(csn_row_inv_norm_kernel, dim3((unsigned)((r1 + 3) / 4)), dim3(256), 0, st, f1, inv1, r1, C, 1e-12f);
   hipLaunchKernelGGL(csn_row_inv_norm_kernel, dim3((unsigned)((r2 + 3) / 4)), dim3(256), 0, st, f2, inv2, r2, C, 1e-12f);
-  hipLaunchKernelGGL(csn_retrieval_rowmax_kernel, dim3((n1 + 127) / 128, s1 * s2), dim3(256), 0, st, f1, f2, inv1, inv2,
+  const long long blocks = (long long)((n1 + 127) / 128) * s1 * s2;
+  if (blocks > 0x7fffffffLL) return -1;                    // CSN_E_ARG: score fewer query shapes per call
+  hipLaunchKernelGGL(csn_retrieval_rowmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, f1, f2, inv1, inv2,
                      rowmax, s2, n1, n2, C);
   hipLaunchKernelGGL(csn_row_mean_kernel, dim3(s1 * s2), dim3(256), 0, st, rowmax, out, n1);
   return (int)hipGetLastError();

@@ -32,10 +32,11 @@ def pad_points(feats: np.ndarray, label: Optional[np.ndarray] = None, n_points: 
 class FeaturesDataset(Dataset):
     """(feats (1, 256, N, 1), label (N,)) per shape (features_data_loader.py:9-48)."""
 
-    def __init__(self, dataroot: str, attention_type: str = "backbone_fc_ssa_logit"):
+    def __init__(self, dataroot: str, attention_type: str = "backbone_fc_ssa_logit", n_points: int = N_POINTS):
         self.features_dir = os.path.join(dataroot, "fc_1")
         self.labels_dir = os.path.join(dataroot, "point_labels")
         self.files = os.listdir(self.features_dir)
+        self.n_points = n_points                 # the reference pads to 10000 (features_data_loader.py:37); other geometries differ
 
     def __len__(self):
         return len(self.files)
@@ -43,7 +44,7 @@ class FeaturesDataset(Dataset):
     def load(self, name: str):
         feats = np.load(os.path.join(self.features_dir, name))
         label = np.load(os.path.join(self.labels_dir, name)).astype(int)
-        return pad_points(feats, label)
+        return pad_points(feats, label, self.n_points)
 
     def __getitem__(self, idx):
         feats, label = self.load(self.files[idx])
@@ -54,9 +55,9 @@ class CSADatasetK(Dataset):
     """(feats (256, N, 1), label (N,), neighbor_feats (K+1, 256, N, 1)); neighbours come from ``dataroot_K`` in kNN-graph
     order, skipping the shape itself, slot 0 = the shape (features_data_loader.py:79-140)."""
 
-    def __init__(self, dataroot: str, dataroot_K: str, knn_graph, K: int):
-        self.own = FeaturesDataset(dataroot)
-        self.nbr = FeaturesDataset(dataroot_K)
+    def __init__(self, dataroot: str, dataroot_K: str, knn_graph, K: int, n_points: int = N_POINTS):
+        self.own = FeaturesDataset(dataroot, n_points=n_points)
+        self.nbr = FeaturesDataset(dataroot_K, n_points=n_points)
         self.K = K
         self.knn_graph = np.copy(knn_graph)
 
@@ -68,7 +69,7 @@ class CSADatasetK(Dataset):
         stack = [feats]
         for kidx in self.knn_graph[idx]:
             if kidx != idx:
-                stack.append(pad_points(np.load(os.path.join(self.nbr.features_dir, self.nbr.files[kidx])))[0])
+                stack.append(pad_points(np.load(os.path.join(self.nbr.features_dir, self.nbr.files[kidx])), None, self.nbr.n_points)[0])
             if len(stack) == self.K + 1:
                 break
         nb = torch.from_numpy(np.array(stack))
@@ -105,3 +106,114 @@ class SyntheticShapes(Dataset):
             if len(stack) == self.K + 1:
                 break
         return f, l, torch.stack(stack)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# device-resident feature cache: the K np.load's per item of CSADatasetK become index arithmetic
+# ---------------------------------------------------------------------------------------------------------
+def neighbour_table(knn_graph, K: int) -> np.ndarray:
+    """(S, K) int64 neighbour ids per shape out of a kNN graph (S, >= K+1) exactly as CSADatasetK.__getitem__ picks them
+    (features_data_loader.py:124-135): walk the graph row in order, skip the shape itself, stop at K neighbours."""
+    g = np.asarray(knn_graph)
+    out = np.empty((g.shape[0], K), dtype=np.int64)
+    for idx, row in enumerate(g):
+        picked = [int(k) for k in row if int(k) != idx][:K]
+        if len(picked) < K:
+            raise ValueError(f"graph row {idx} holds fewer than {K} neighbours besides the shape itself")
+        out[idx] = picked
+    return out
+
+
+class DeviceFeatureCache:
+    """All shapes of a feature dataset resident in device memory, keyed by shape id: ``feats`` (S_local, C, N) fp32 and
+    ``labels`` (S_local, N) int64 for the ids [first, first + S_local) this process owns (the whole dataset by default; one
+    contiguous range per rank when the collection is sharded, the same ranges ShapeGraphShard uses).
+
+    The reference's CSADatasetK re-reads K neighbour files from disk for EVERY item of EVERY epoch
+    (features_data_loader.py:124-135: ``np.load`` per neighbour) and stacks them on the host; here every file is read once
+    (wrap-around padded like features_data_loader.py:37-43), and a batch's (B, K+1, C, N, 1) neighbour stack is one indexed
+    gather out of HBM — or, sharded, the input of the neighbour exchange (``shard()``), so the exchange of SURVEY §8e is fed
+    straight from the cache.  288 GB of HBM hold ~28000 shapes of 10000 x 256 fp32: every PartNet category fits one GPU."""
+
+    def __init__(self, source, device, first: int = 0, count: Optional[int] = None, n_points: int = N_POINTS):
+        n_total = len(source)
+        count = n_total - first if count is None else count
+        if first < 0 or count < 0 or first + count > n_total:
+            raise ValueError(f"owned range [{first}, {first + count}) outside the {n_total} shapes of the dataset")
+        self.first, self.n_total, self.device = first, n_total, torch.device(device)
+        feats, labels = [], []
+        for idx in range(first, first + count):
+            f, lab = self._load(source, idx, n_points)
+            feats.append(f)
+            labels.append(lab)
+        self.feats = torch.stack(feats).to(self.device) if feats else torch.empty((0, 0, n_points), device=self.device)
+        self.labels = torch.stack(labels).to(self.device) if labels else torch.empty((0, n_points), dtype=torch.int64, device=self.device)
+
+    @staticmethod
+    def _load(source, idx: int, n_points: int):
+        """One shape as ((C, N) fp32, (N,) int64), from a FeaturesDataset (files), a CSADatasetK (its own shapes) or any
+        dataset with the FeaturesDataset item contract."""
+        if isinstance(source, CSADatasetK):
+            source = source.own
+        if isinstance(source, FeaturesDataset):
+            f, lab = source.load(source.files[idx])                   # (1, C, N, 1), padded
+            return torch.from_numpy(f[0, :, :n_points, 0].astype(np.float32)), torch.from_numpy(lab[:n_points].astype(np.int64))
+        item = source[idx]
+        f, lab = item[0], item[1]
+        f = f.reshape(f.shape[-3], f.shape[-2])                       # (1, C, N, 1) or (C, N, 1) -> (C, N)
+        return f[:, :n_points].float().contiguous(), lab[:n_points].long()
+
+    def __len__(self):
+        return self.feats.shape[0]
+
+    def _local(self, ids) -> torch.Tensor:
+        ids = torch.as_tensor(ids, dtype=torch.int64, device=self.device).reshape(-1)
+        if ids.numel() and (int(ids.min()) < self.first or int(ids.max()) >= self.first + len(self)):
+            raise IndexError("shape id outside this cache's owned range: fetch it through the exchange of csn_amd.sharding")
+        return ids - self.first
+
+    def batch(self, ids):
+        """(feats (B, C, N, 1), labels (B, N)) of the given shape ids — what FeaturesDataset / the first two items of
+        CSADatasetK hand the model."""
+        loc = self._local(ids)
+        return self.feats.index_select(0, loc).unsqueeze(-1), self.labels.index_select(0, loc)
+
+    def neighbour_stack(self, ids, nbr_table, neighbour_cache: "Optional[DeviceFeatureCache]" = None) -> torch.Tensor:
+        """(B, K+1, C, N, 1): slot 0 = the shape itself, slots 1..K = its neighbours in graph order — bit for bit the tensor
+        a DataLoader over CSADatasetK collates (features_data_loader.py:124-140), built by one indexed gather.  ``nbr_table``
+        = neighbour_table(knn_graph, K); ``neighbour_cache``: where the neighbours live when they come from another set
+        (test shapes take their neighbours from the training set, csa_training.py:288-290)."""
+        src = self if neighbour_cache is None else neighbour_cache
+        ids_t = torch.as_tensor(ids, dtype=torch.int64).reshape(-1)
+        nbr = torch.as_tensor(np.asarray(nbr_table)[ids_t.numpy()], dtype=torch.int64)            # (B, K)
+        B, K = nbr.shape
+        own = self.feats.index_select(0, self._local(ids_t))                                        # (B, C, N)
+        out = torch.empty((B, K + 1) + tuple(own.shape[1:]), device=self.device, dtype=own.dtype)
+        out[:, 0] = own
+        if K:
+            out[:, 1:] = src.feats.index_select(0, src._local(nbr.reshape(-1))).view((B, K) + tuple(own.shape[1:]))
+        return out.unsqueeze(-1)
+
+    def batches(self, batch_size: int, nbr_table=None, neighbour_cache: "Optional[DeviceFeatureCache]" = None):
+        """Iterate the owned shapes in id order like ``DataLoader(dataset, batch_size, shuffle=False)``: yields
+        (feats, label) or, with a neighbour table, (feats (B, C, N, 1), label, neighbour stack) — all on the device."""
+        for lo in range(self.first, self.first + len(self), batch_size):
+            ids = np.arange(lo, min(lo + batch_size, self.first + len(self)))
+            f, lab = self.batch(ids)
+            yield (f, lab) if nbr_table is None else (f, lab, self.neighbour_stack(ids, nbr_table, neighbour_cache))
+
+    # -- sharded collections -------------------------------------------------------------------------------------
+    @classmethod
+    def for_rank(cls, source, device, rank: int, world: int, n_points: int = N_POINTS) -> "DeviceFeatureCache":
+        """The cache of rank ``rank``'s share of the collection: shapes [rank * S/world, (rank + 1) * S/world)."""
+        S = len(source)
+        if S % world:
+            raise ValueError(f"{S} shapes do not split evenly over {world} ranks")
+        per = S // world
+        return cls(source, device, first=rank * per, count=per, n_points=n_points)
+
+    def shard(self, nbr_table, rank: int, world: int):
+        """The ShapeGraphShard whose exchange this cache feeds: ``shard.exchange_async(cache.feats)`` (or
+        ``exchange_neighbours``) yields the neighbour stack of every owned shape without touching the host."""
+        from .sharding import ShapeGraphShard
+        return ShapeGraphShard(np.asarray(nbr_table), len(self), rank, world, self.device)

@@ -12,7 +12,6 @@ evaluations over K+1 slots (csa_models.py:209-242); each slot is projected to Q/
 from __future__ import annotations
 
 import math
-import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -25,12 +24,24 @@ REF_NBLOCKS = 20      # MID-FC/csa_models.py:83
 LN_EPS = 1e-6         # MID-FC/csa_models.py:57
 RESCALE_THRESHOLD = 8.0
 USE_KV_TILES = True          # fast math: K/V leave the projection as bf16 tile planes (see csn_project_f32, out_split = 2)
-FUSED_POINT_SUMS = os.environ.get("CSN_FUSED_SUMS", "1") != "0"   # 0: pooled sums by a streaming pass (development A/B)
-LINK_MIX = os.environ.get("CSN_LINK_MIX", "1") != "0"             # 0: the mix backward writes per-evaluation gradient maps
-GROUPED_DKV = os.environ.get("CSN_GROUPED_DKV", "1") != "0"       # 0: dK / dV by one read-modify-write launch per colour
-GROUPED_DQ = os.environ.get("CSN_GROUPED_DQ", "1") != "0"         # 0: dQ likewise
-# bench.py sets this to a list to collect (start, end) HIP-event pairs around the fused attention forward launch
+# The fused data flow of the step, and the plain forms of the same arithmetic it replaced.  Only
+# tests/test_gpu_module.py::test_fused_data_flow_equals_the_unfused_one flips these (monkeypatch) to check one against the other.
+FUSED_POINT_SUMS = True      # False: pooled sums by a streaming pass over the maps
+LINK_MIX = True              # False: the mix backward writes per-evaluation gradient maps
+GROUPED_DKV = True           # False: dK / dV by one read-modify-write launch per colour
+GROUPED_DQ = True            # False: dQ likewise
+# bench.py sets this to a dict {"fwd": [], "bwd": []} to collect (start, end) HIP-event pairs around the two fused attention launches
 EVENT_SINK = None
+
+
+def draw_seeds(n: int):
+    """n 62-bit dropout seeds from torch's CPU generator (``torch.manual_seed`` reproduces a step).  In a torch.distributed
+    job the rank is folded in, so ranks seeded alike (``torch.manual_seed(0)`` everywhere) still draw different masks."""
+    seeds = torch.randint(0, 2 ** 62, (n,)).tolist()
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        salt = (torch.distributed.get_rank() * 0x9E3779B97F4A7C15) & (2 ** 62 - 1)
+        seeds = [s ^ salt for s in seeds]
+    return seeds
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -165,19 +176,25 @@ def project_wgrad(dout: torch.Tensor, x: torch.Tensor, scale: float = 1.0) -> to
     return dw
 
 
-def retrieval_measure(f1: torch.Tensor, f2: torch.Tensor) -> torch.Tensor:
+def retrieval_measure(f1: torch.Tensor, f2: torch.Tensor, pair_budget: int = 2 ** 28) -> torch.Tensor:
     """f1 (S1, N1, C), f2 (S2, N2, C) point-major SSA features -> (S1, S2) mean-of-max cosine
-    (get_retrieval_measure, MID-FC/csa_models.py:244-267)."""
+    (get_retrieval_measure, MID-FC/csa_models.py:244-267).  The per-point maxima scratch is S1*S2*N1 floats — O(S^2) — so
+    the query shapes are scored in row chunks of at most ``pair_budget`` scratch floats (1 GiB by default; Vase, 741 x 741
+    shapes of 10000 points, would otherwise ask for 22 GB).  Every (query, candidate) score is the same arithmetic whatever
+    the chunking."""
     _need_cuda(f1, f2)
     f1 = f1.contiguous()
     f2 = f2.contiguous()
     S1, N1, C = f1.shape
     S2, N2, _ = f2.shape
     out = torch.empty((S1, S2), device=f1.device, dtype=torch.float32)
-    ws_n = S1 * N1 + S2 * N2 + S1 * S2 * N1
+    rows = max(1, min(S1, pair_budget // max(1, S2 * N1)))
+    ws_n = rows * N1 + S2 * N2 + rows * S2 * N1
     ws = torch.empty((ws_n,), device=f1.device, dtype=torch.float32)
-    _lib.check(_lib.lib().csn_retrieval_measure_f32(_ptr(f1), _ptr(f2), _ptr(out), S1, N1, S2, N2, C, _ptr(ws), ws_n,
-                                                    _stream()), "csn_retrieval_measure_f32")
+    for i in range(0, S1, rows):
+        r = min(rows, S1 - i)
+        _lib.check(_lib.lib().csn_retrieval_measure_f32(_ptr(f1[i:i + r]), _ptr(f2), _ptr(out[i:i + r]), r, N1, S2, N2, C,
+                                                        _ptr(ws), ws_n, _stream()), "csn_retrieval_measure_f32")
     return out
 
 
@@ -200,7 +217,7 @@ class _MHAEvals(torch.autograd.Function):
         ctx.link = link
         ctx.set_materialize_grads(False)               # an unused output must not cost a zero-filled (E, C, NP) gradient
         # dropout masks are counter-based: two 62-bit seeds from torch's CPU generator (torch.manual_seed reproduces them)
-        seed_attn, seed_fc = (torch.randint(0, 2 ** 62, (2,)).tolist() if (p_attn > 0 or p_fc > 0) else (0, 0))
+        seed_attn, seed_fc = draw_seeds(2) if (p_attn > 0 or p_fc > 0) else (0, 0)
         q_slots, kv_slots, v_shift = plan.q_slots, plan.kv_slots, plan.v_shift
         L = _lib.lib()
         S, C, NP = x_all.shape
@@ -250,7 +267,7 @@ class _MHAEvals(torch.autograd.Function):
         if EVENT_SINK is not None:
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record()
-            EVENT_SINK.append((ev0, ev1))
+            EVENT_SINK["fwd"].append((ev0, ev1))
         xhat = torch.empty((E, C, NP), device=dev, dtype=torch.float32)
         rstd = torch.empty((E, NP), device=dev, dtype=torch.float32)
         w_fc = w_fc.contiguous()
@@ -358,6 +375,9 @@ class _MHAEvals(torch.autograd.Function):
             v_ptr = q_ptr + 4 * (2 * D * NP + plan.v_shift * kv_stride)
         pt = 1 if (fast_math() and Tp >= (T + 31) // 32 * 32) else 0    # P / dS travel to the dV / dK products as bf16 tile planes
         grouping = L.csn_attn_bwd_grouping(d, T)
+        if EVENT_SINK is not None:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record()
         if GROUPED_DQ and (grouping & 1):
             # one call: the evaluations of a query slot run one after the other into the same dQ accumulators
             _lib.check(L.csn_block_attn_bwd_dq_f32(_ptr(datt), _ptr(att), D * NP, k_ptr, v_ptr, kv_stride,
@@ -375,6 +395,10 @@ class _MHAEvals(torch.autograd.Function):
                                                        ids.numel(), H, d, T, nb, Tp, p_attn, seed_attn, 0, 0, kv_flag,
                                                        kv_pitch, pt, None, 0, _stream()),
                            "csn_block_attn_bwd_dq_f32")
+        if EVENT_SINK is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            EVENT_SINK["bwd"].append((ev0, ev1))
         if GROUPED_DKV and (grouping & 2):
             # one call: the evaluations of a key/value slot are contracted one after the other into the same accumulators
             _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, q_ptr, q_stride, _ptr(plan.q_slots), NP,

@@ -55,7 +55,7 @@ class _CrossMHA(torch.autograd.Function):
         q = CF.project(xq_cm, w_qs.contiguous(), div_rows=D, temperature=temperature)     # (b, D, lq4), pre-scaled
         k = CF.project(xk_cm, w_ks.contiguous())
         v = CF.project(xv_cm, w_vs.contiguous())
-        seed_attn, seed_fc = (torch.randint(0, 2 ** 62, (2,)).tolist() if (p_attn > 0 or p_fc > 0) else (0, 0))
+        seed_attn, seed_fc = CF.draw_seeds(2) if (p_attn > 0 or p_fc > 0) else (0, 0)
         att = torch.empty((b, D, lq4), device=dev, dtype=torch.float32)
         lse = torch.empty((b, H, lq4), device=dev, dtype=torch.float32)
         scores = torch.empty((b, H, lq4, Tp), device=dev, dtype=torch.float32) if (keep or want_attn) else None

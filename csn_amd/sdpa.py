@@ -14,6 +14,35 @@ def _up(n: int, m: int) -> int:
     return (n + m - 1) // m * m
 
 
+_M32 = 0xFFFFFFFF
+
+
+def _mix32(h: torch.Tensor) -> torch.Tensor:
+    """csn_mix32 (csrc/csn_common.h) on int64 tensors holding 32-bit values."""
+    h = h ^ (h >> 16)
+    h = (h * 0x85EBCA6B) & _M32
+    h = h ^ (h >> 13)
+    h = (h * 0xC2B2AE35) & _M32
+    return h ^ (h >> 16)
+
+
+def attention_keep_mask(n_evals: int, n_queries: int, n_keys: int, score_pitch: int, seed: int, p: float, device) -> torch.Tensor:
+    """The keep mask the attention kernels apply to the probabilities of ``n_evals`` single-block evaluations
+    (csn_block_salt / csn_pair_hash of csrc/csn_common.h, restated with torch integer ops on the device): bool
+    (n_evals, n_queries, n_keys).  Only used to hand a caller the DROPPED probabilities the reference returns in train mode
+    (csa_models.py:141-144); the kernels regenerate the mask themselves."""
+    e = torch.arange(n_evals, device=device, dtype=torch.int64)
+    s0, s1 = seed & _M32, (seed >> 32) & _M32
+    salt = _mix32((_mix32((e & _M32) ^ s0) + ((e >> 32) ^ s1) + 0x9E3779B9) & _M32).view(n_evals, 1, 1)
+    q = torch.arange(n_queries, device=device, dtype=torch.int64).view(1, n_queries, 1)
+    key = torch.arange(n_keys, device=device, dtype=torch.int64).view(1, 1, n_keys)
+    pair = ((key >> 1) * max(score_pitch, n_queries) + q) & _M32
+    h = _mix32(pair ^ salt)
+    field = torch.where((key & 1) == 1, h >> 16, h & 0xFFFF)
+    # (the threshold is formed in fp32 like csn_drop_threshold16)
+    return field >= int(torch.tensor(p, dtype=torch.float32).mul(65536.0).item())
+
+
 class _SDPA(torch.autograd.Function):
     """softmax(q k^T / temperature) v for (B, H, Tq, d) x (B, H, Tk, d) x (B, H, Tk, d): every (batch, head) pair is one
     evaluation of the cross-length entry points (csn_cross_attn_fwd_f32 / _bwd_f32); Tq and Tk are arbitrary."""
@@ -39,13 +68,16 @@ class _SDPA(torch.autograd.Function):
         lse = torch.empty((S, 1, Tq4), device=q.device, dtype=torch.float32)
         scores = torch.empty((S, 1, Tq4, Tp), device=q.device, dtype=torch.float32)
         L = _lib.lib()
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if p_drop > 0 else 0
+        seed = CF.draw_seeds(1)[0] if p_drop > 0 else 0
         _lib.check(L.csn_cross_attn_fwd_f32(CF._ptr(qm), CF._ptr(km), CF._ptr(vm), d * Tq4, d * Tk4, Tq4, Tk4, CF._ptr(att),
                                             d * Tq4, CF._ptr(scores), CF._ptr(lse), S, 1, d, Tq4, Tk, Tp, CF.RESCALE_THRESHOLD,
                                             p_drop, seed, CF._stream()), "csn_cross_attn_fwd_f32")
-        # P[q][key] = exp(S[q][key] - lse[q])   (the un-dropped probabilities; with dropout the reference returns the
-        # dropped ones — every caller in the reference discards this tensor)
-        prob = torch.exp(scores[:, 0, :Tq, :Tk] - lse[:, 0, :Tq, None]).reshape(B, H, Tq, Tk)
+        # P[q][key] = exp(S[q][key] - lse[q]); in train mode the reference returns the DROPPED probabilities
+        # (attn = dropout(softmax(..)), csa_models.py:141-144): the kernel's mask is rebuilt here, outside the hot path
+        prob = torch.exp(scores[:, 0, :Tq, :Tk] - lse[:, 0, :Tq, None])
+        if p_drop > 0:
+            prob = prob * attention_keep_mask(S, Tq, Tk, Tp, seed, p_drop, q.device) / (1.0 - p_drop)
+        prob = prob.reshape(B, H, Tq, Tk)
         ctx.save_for_backward(qm, km, vm, att, lse, scores)
         ctx.temperature = temperature
         ctx.drop = (p_drop, seed)
@@ -83,20 +115,24 @@ sdpa_cross = sdpa_block        # same entry: query and key counts may differ (Mi
 
 
 def last_block_probabilities(mha, Q, K):
-    """Probabilities of the last block, (B, H, T, T), as the reference returns them (csa_models.py:125)."""
+    """Probabilities of the last block, (B, H, T, T), as the reference returns them (csa_models.py:125): the last block is
+    projected again (HIP GEMM, csn_project_f32) and scored by the stand-alone entry.  In train mode these are dropped
+    probabilities under a mask of their own draw (the hot path does not keep its masks)."""
     geo = mha.geometry()
     lo, hi = (geo.n_blocks - 1) * geo.block, geo.n_blocks * geo.block
 
     def chunk(x):
         if x.dim() == 4:
             x = x.squeeze(-1)
-        return x[:, :, lo:hi].to(CF_device(), torch.float32).permute(0, 2, 1)      # (B, T, C)
+        return x[:, :, lo:hi].to(CF_device(), torch.float32).contiguous()         # (B, C, T) channel-major
 
     with torch.no_grad():
         B = Q.shape[0]
-        q = mha.w_qs(chunk(Q)).view(B, geo.block, geo.n_head, geo.d_head).transpose(1, 2)
-        k = mha.w_ks(chunk(K)).view(B, geo.block, geo.n_head, geo.d_head).transpose(1, 2)
-        return sdpa_block(q.contiguous(), k.contiguous(), k.contiguous(), float(geo.d_head) ** 0.5)[1]
+        heads = lambda m: m.view(B, geo.n_head, geo.d_head, geo.block).transpose(2, 3).contiguous()   # (B, H, T, d)
+        q = heads(CF.project(chunk(Q), mha.w_qs.weight.contiguous()))
+        k = heads(CF.project(chunk(K), mha.w_ks.weight.contiguous()))
+        p_drop = mha.attention.dropout.p if mha.training else 0.0
+        return sdpa_block(q, k, k, float(geo.d_head) ** 0.5, p_drop)[1]
 
 
 def CF_device():

@@ -84,33 +84,50 @@ class ShapeGraphShard:
     def exchange_neighbours(self, feats: torch.Tensor) -> torch.Tensor:
         """Neighbour-only form of exchange + neighbour_stack: every rank sends each other rank only the shapes that rank's
         graph rows reference (one all-to-all with uneven splits: at 8 ranks and K = 3 at most 96 of the 224 remote shapes),
-        and the (B, K+1, C, N, 1) stack is gathered out of [received ; own].  Opt-in (bench: CSN_EXCHANGE=alltoall)."""
+        and the (B, K+1, C, N, 1) stack is gathered out of [received ; own].  The default exchange of bench.py and of
+        exchange_async."""
         if self.world == 1:
             raise ValueError("exchange_neighbours needs world > 1")
+        self._start_alltoall(feats.contiguous()).wait()
+        return self._finish_alltoall(feats)
+
+    def exchange_async(self, feats: torch.Tensor, mode: str = "alltoall", reuse_descriptors: bool = True) -> "PendingStack":
+        """Start the exchange and return at once: ``wait()`` on the result yields the neighbour stack.  A model that is handed
+        the pending object (CrossShapeAt accepts it in place of the neighbour tensor) runs the evaluations that need no
+        neighbour data — the self-attention of its own shapes — while the exchange is in flight.
+        mode "alltoall" (default): neighbour-only exchange, every rank receives just the shapes its graph rows name (one
+        all_to_all_single with uneven splits; at 8 ranks and K = 3 at most 96 of the 224 remote shapes); "allgather": the
+        whole collection to every rank (RCCL's stock all-gather), kept as the fallback.
+        reuse_descriptors: the pending object also offers ``gather_pooled`` (see PendingStack), with which the model takes
+        the neighbours' pooled SSA descriptors from their owners instead of recomputing SSA(x_k) for every use."""
+        if self.world == 1:
+            raise ValueError("exchange_async needs world > 1")
+        feats = feats.contiguous()
+        if mode == "allgather":
+            if self._gathered is None or self._gathered.shape[1:] != feats.shape[1:]:
+                self._gathered = torch.empty((self.S,) + tuple(feats.shape[1:]), device=feats.device, dtype=feats.dtype)
+            work = dist.all_gather_into_tensor(self._gathered, feats, async_op=True)
+        elif mode == "alltoall":
+            work = self._start_alltoall(feats)
+        else:
+            raise ValueError(f"unknown exchange mode {mode!r}")
+        return PendingStack(self, feats, work, mode, reuse_descriptors)
+
+    def _start_alltoall(self, feats: torch.Tensor):
         tail = tuple(feats.shape[1:])
         if self._pool is None or self._pool.shape[1:] != tail or self._pool.dtype != feats.dtype:
             self._pool = torch.empty((self._n_recv + self.B,) + tail, device=feats.device, dtype=feats.dtype)
-        send = feats.index_select(0, self._send_ids) if self._send_ids.numel() else feats[:0]
-        recv = self._pool[:self._n_recv]
-        dist.all_to_all_single(recv, send.contiguous(), self._recv_splits, self._send_splits)
+        self._send = (feats.index_select(0, self._send_ids) if self._send_ids.numel() else feats[:0]).contiguous()
+        return dist.all_to_all_single(self._pool[:self._n_recv], self._send, self._recv_splits, self._send_splits, async_op=True)
+
+    def _finish_alltoall(self, feats: torch.Tensor) -> torch.Tensor:
+        tail = tuple(feats.shape[1:])
         self._pool[self._n_recv:].copy_(feats)
         shape = (self.B * (self.K + 1),) + tail
         if self._stack is None or self._stack.shape != shape or self._stack.dtype != feats.dtype:
             self._stack = torch.empty(shape, device=feats.device, dtype=feats.dtype)
         torch.index_select(self._pool, 0, self._pool_rows, out=self._stack)
         return self._stack.view((self.B, self.K + 1) + tail).unsqueeze(-1)
-
-    def exchange_async(self, feats: torch.Tensor) -> "PendingStack":
-        """Start the all-gather and return at once: ``wait()`` on the result yields the neighbour stack.  A model that is
-        handed the pending object (CrossShapeAt accepts it in place of the neighbour tensor) runs the evaluations that
-        need no neighbour data — the self-attention of its own shapes — while the exchange is in flight."""
-        if self.world == 1:
-            raise ValueError("exchange_async needs world > 1")
-        if self._gathered is None or self._gathered.shape[1:] != feats.shape[1:]:
-            self._gathered = torch.empty((self.S,) + tuple(feats.shape[1:]), device=feats.device, dtype=feats.dtype)
-        feats = feats.contiguous()
-        work = dist.all_gather_into_tensor(self._gathered, feats, async_op=True)
-        return PendingStack(self, feats, work)
 
     def neighbour_stack(self, feats: torch.Tensor, collection: torch.Tensor) -> torch.Tensor:
         """(B, K+1, C, N, 1) exactly as CSADatasetK hands it to the model (features_data_loader.py:124-140):
@@ -142,18 +159,51 @@ class ShapeGraphShard:
             off += p.numel()
 
 
+class _GatherDescriptors(torch.autograd.Function):
+    """(B, C) per-rank rows -> (S, C) table of all ranks' rows (all-gather, rank order).  Backward: the table's gradient is
+    summed over the ranks (every consumer's contribution to a descriptor goes back to its owner) and the own rows returned
+    — the "descriptor-gradient reduce-scatter" of SURVEY §8e (2), as one all-reduce of S*C floats (256 KB at 256 shapes)."""
+
+    @staticmethod
+    def forward(ctx, own: torch.Tensor, first: int, n_shapes: int):
+        ctx.first, ctx.rows = first, own.shape[0]
+        table = own.new_empty((n_shapes,) + tuple(own.shape[1:]))
+        dist.all_gather_into_tensor(table, own.contiguous())
+        return table
+
+    @staticmethod
+    def backward(ctx, dtable):
+        dtable = dtable.contiguous().clone()
+        dist.all_reduce(dtable)
+        return dtable[ctx.first:ctx.first + ctx.rows], None, None
+
+
 class PendingStack:
     """A neighbour stack whose exchange is still in flight (ShapeGraphShard.exchange_async)."""
 
-    def __init__(self, shard: ShapeGraphShard, feats: torch.Tensor, work):
-        self._shard, self._feats, self._work = shard, feats, work
+    def __init__(self, shard: ShapeGraphShard, feats: torch.Tensor, work, mode: str = "allgather", reuse_descriptors: bool = False):
+        self._shard, self._feats, self._work, self._mode = shard, feats, work, mode
         self._stack: Optional[torch.Tensor] = None
+        self.reuse_descriptors = reuse_descriptors
 
     def wait(self) -> torch.Tensor:
         if self._stack is None:
             self._work.wait()                                  # orders the compute stream behind the collective
-            self._stack = self._shard.neighbour_stack(self._feats, self._shard._gathered)
+            if self._mode == "alltoall":
+                self._stack = self._shard._finish_alltoall(self._feats)
+            else:
+                self._stack = self._shard.neighbour_stack(self._feats, self._shard._gathered)
         return self._stack
+
+    def gather_pooled(self, own_pooled: torch.Tensor) -> torch.Tensor:
+        """own_pooled (B, C): the pooled SSA descriptors of the rank's own shapes (mean over the points of SSA(x),
+        csa_models.py:211-212).  Returns (B, K, C): the descriptors of every shape's K neighbours, taken from the neighbours'
+        OWNERS through one small all-gather (differentiable: the gradient a consumer puts on a neighbour's descriptor is
+        summed back into the owner's evaluation).  A shape's descriptor is thus computed once in the whole job instead of
+        once per use (csa_models.py:214-220 recomputes SSA(x_k) for every (shape, neighbour) pair: K of the 2K+2
+        evaluations per shape)."""
+        table = _GatherDescriptors.apply(own_pooled, self._shard.first, self._shard.S)
+        return table[self._shard.local_graph]
 
 
 # -- kNN shape graph, rows of the retrieval matrix sharded by query shape (SURVEY.md §8e, collective 4) --------------------

@@ -85,9 +85,16 @@ def _unpack(batch):
 
 
 def train_layers(model, dataloader: Iterable, optimizer, num_class: int, device, accumulation_steps: int = 1,
-                 max_batches: Optional[int] = None) -> float:
-    """One pass over the loader in train mode with gradient accumulation (csa_training.py:191-222).
-    Returns the mean (accumulation-scaled) loss, accumulated on the device and read back once."""
+                 max_batches: Optional[int] = None, reference_semantics: bool = True) -> float:
+    """One pass over the loader in train mode (csa_training.py:191-222).  Returns the mean (accumulation-scaled) loss,
+    accumulated on the device and read back once.
+
+    ``reference_semantics=True`` (default) reproduces the reference's loop AS WRITTEN, including two things that look like
+    slips: ``optimizer.zero_grad()`` runs at the top of EVERY iteration (:196), so with ``gradient_accumulation_steps`` > 1
+    only the last micro-batch's (1/steps-scaled) gradient reaches ``optimizer.step()`` (:213-215); and a NaN loss is
+    multiplied by 0 (:206-207), which leaves it NaN, so its backward poisons that step.  ``False`` is the repaired loop:
+    gradients really accumulate between steps and a NaN loss contributes a zero gradient.  tests/test_training_host.py pins
+    both behaviours."""
     model.train()
     total = torch.zeros((), device=device, dtype=torch.float64)
     n = 0
@@ -95,14 +102,20 @@ def train_layers(model, dataloader: Iterable, optimizer, num_class: int, device,
     n_batches = len(batches)
     optimizer.zero_grad()
     for i, batch in enumerate(batches):
+        if reference_semantics:
+            optimizer.zero_grad()                                                        # :196
         feats, label, nbrs = _unpack(batch)
         feats, label = feats.to(device), label.to(device)
         out = model(feats, "test", nbrs) if nbrs is not None else model(feats, "train")
         loss, _ = loss_functions_seg(out, label, num_class)
         loss = loss / accumulation_steps
-        loss = torch.where(torch.isnan(loss), torch.zeros_like(loss), loss)              # NaN guard (:206-207)
-        total += loss.detach().double()
-        loss.backward()
+        bad = torch.isnan(loss)
+        total += torch.where(bad, torch.zeros_like(loss), loss).detach().double()        # running loss skips NaN (:206-209)
+        if reference_semantics:
+            loss = torch.where(bad, loss * 0.0, loss)             # :206-207 — NaN * 0 is NaN: the guard does not guard
+            loss.backward()
+        elif not bool(bad):                                       # repaired: a NaN micro-batch contributes nothing
+            loss.backward()
         n += 1
         if (i + 1) % accumulation_steps == 0 or (i + 1) == n_batches:
             optimizer.step()
@@ -125,11 +138,11 @@ def validate_layers(model, dataloader: Iterable, class_num: int, device, max_bat
         feats, label = feats.to(device), label.to(device)
         out = model(feats, "test", nbrs.to(device)) if nbrs is not None else model(feats, "test")
         loss, _ = loss_functions_seg(out, label, class_num)
-        if not torch.isnan(loss):
-            total += loss.double()
+        ok = (~torch.isnan(loss)).double()                       # a NaN batch is skipped altogether (:239-240), no host sync
+        total += torch.where(torch.isnan(loss), torch.zeros_like(loss), loss).double()
         i_b, u_b = IoU_per_shape(out, label, class_num)
-        intsc += i_b.double()
-        union += u_b.double()
+        intsc += i_b.double() * ok
+        union += u_b.double() * ok
         n += 1
         if max_batches is not None and n >= max_batches:
             break

@@ -210,7 +210,9 @@ long long csn_wgrad_workspace_floats(int rows, int cols, int n_maps, int n_point
 /* ---- (7) retrieval measure for the shape kNN graph (csa_models.py:244-267) ------------------------------
  * r[i][j] = mean_n max_m cos(f1[i][n][:], f2[j][m][:]) over L2-normalised rows (eps 1e-12), for
  * POINT-MAJOR features f1 [s1][n1][channels], f2 [s2][n2][channels] as get_all_feats returns them
- * (csa_models.py:299).  ws: at least (s1*n1 + s2*n2) floats (inverse row norms) + s1*s2*n1 floats. */
+ * (csa_models.py:299).  ws: at least (s1*n1 + s2*n2) floats (inverse row norms) + s1*s2*n1 floats (per-point maxima): O(s1*s2),
+ * so a caller with many shapes scores the query shapes in row chunks (csn_amd.functional.retrieval_measure does).  Any pair
+ * count is accepted up to ceil(n1/128)*s1*s2 < 2^31 work-groups (CSN_E_ARG beyond). */
 int csn_retrieval_measure_f32(const float* f1, const float* f2, float* out, int s1, int n1, int s2, int n2,
                               int channels, float* ws, long long ws_floats, void* stream);
 

@@ -33,14 +33,16 @@ def _hash2(idx, seed: int):
     return _mix32((h + (hi ^ s1) + np.uint64(0x9e3779b9)) & np.uint64(0xffffffff))
 
 
-def attention_mask(E, H, nb, T, Tp, seed, p):
-    """mask[e][h][blk][key][query] for the scores buffer geometry [E][H][nb][T][Tp]  (csn_block_salt / csn_pair_hash):
+def attention_mask(E, H, nb, T, Tp, seed, p, Tq=None):
+    """mask[e][h][blk][key][query] for the scores buffer geometry [E][H][nb][Tq][Tp]  (csn_block_salt / csn_pair_hash):
     every score block draws a salt from (seed, block id); one mixer round over (pair index ^ salt) decides the keys 2w
-    (low 16 bits) and 2w+1 (high 16 bits) of query q, pair index = w * Tp + q; keep <=> field >= p * 2^16."""
+    (low 16 bits) and 2w+1 (high 16 bits) of query q, pair index = w * max(Tp, Tq) + q; keep <=> field >= p * 2^16.
+    T keys, Tq queries per block (None: = T, the MID-FC layer)."""
+    Tq = T if Tq is None else Tq
     salt = _hash2(np.arange(E * H * nb, dtype=np.uint64), seed).reshape(E, H, nb, 1, 1)
     key = np.arange(T, dtype=np.uint64).reshape(1, 1, 1, T, 1)
-    q = np.arange(T, dtype=np.uint64).reshape(1, 1, 1, 1, T)
-    pair = ((key >> np.uint64(1)) * np.uint64(Tp) + q) & np.uint64(0xffffffff)
+    q = np.arange(Tq, dtype=np.uint64).reshape(1, 1, 1, 1, Tq)
+    pair = ((key >> np.uint64(1)) * np.uint64(max(Tp, Tq)) + q) & np.uint64(0xffffffff)
     h = _mix32(pair ^ salt)
     field = np.where((key & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xffff))
     thr = np.uint64(int(np.float32(p) * np.float32(65536.0)))

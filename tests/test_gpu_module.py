@@ -176,12 +176,9 @@ def test_overlapped_path_matches_single_call():
     from csn_amd.csa_models import get_model
     rng = np.random.default_rng(31)
     B, K, H, n_cls = 2, 3, 1, 7
-    p = orc.make_params(rng, H, n_cls=n_cls, csa=True)
-    x = orc.synth_points(rng, (B, 256, 10000, 1)).cuda()
-    nb = orc.synth_points(rng, (B, K + 1, 256, 10000, 1))
-    nb[:, 0] = x.cpu()
-    nb = nb.cuda().contiguous()
-    lab = orc.synth_labels(rng, B, 10000, n_cls).cuda()
+    # well-conditioned inputs (oracle.conditioned_csa_case): the compatibility-head gradients are held to the same 2e-4
+    p, x, nb, lab = orc.conditioned_csa_case(rng, B, K, H, n_cls, 4.0, 3.0, 1.0)
+    x, nb, lab = x.cuda(), nb.cuda().contiguous(), lab.cuda()
     outs = []
     for overlapped in (False, True):
         m = get_model("csa", n_cls, H, K)
@@ -196,7 +193,7 @@ def test_overlapped_path_matches_single_call():
     assert set(g0) == set(g1) and len(g0) == 11
     for n in g0:
         scale = g0[n].abs().max().item()
-        tol_n = 3e-2 if n.startswith("compatibility") else 2e-4       # compat-head gradients: differences of O(1) sums, see below
+        tol_n = 2e-4
         assert (g0[n] - g1[n]).abs().max().item() <= tol_n * scale + 1e-9, n
     # train mode: both dropouts live, masks drawn in a different order -> statistically equal, finite, different
     m = get_model("csa", n_cls, H, K)
@@ -215,12 +212,9 @@ def test_fused_data_flow_equals_the_unfused_one(monkeypatch):
     from csn_amd.csa_models import get_model
     rng = np.random.default_rng(41)
     B, K, H, n_cls = 2, 3, 1, 7
-    p = orc.make_params(rng, H, n_cls=n_cls, csa=True)
-    x = orc.synth_points(rng, (B, 256, 10000, 1)).cuda()
-    nb = orc.synth_points(rng, (B, K + 1, 256, 10000, 1))
-    nb[:, 0] = x.cpu()
-    nb = nb.cuda().contiguous()
-    lab = orc.synth_labels(rng, B, 10000, n_cls).cuda()
+    # well-conditioned inputs (oracle.conditioned_csa_case): the compatibility-head gradients are held to the same 2e-4
+    p, x, nb, lab = orc.conditioned_csa_case(rng, B, K, H, n_cls, 4.0, 3.0, 1.0)
+    x, nb, lab = x.cuda(), nb.cuda().contiguous(), lab.cuda()
     outs = []
     for fused in (True, False):
         for knob in ("FUSED_POINT_SUMS", "LINK_MIX", "GROUPED_DKV", "GROUPED_DQ"):
@@ -237,7 +231,7 @@ def test_fused_data_flow_equals_the_unfused_one(monkeypatch):
     assert set(g0) == set(g1) and len(g0) == 11
     for n in g0:
         scale = g0[n].abs().max().item()
-        tol_n = 3e-2 if n.startswith("compatibility") else 2e-4       # compat-head gradients: differences of O(1) sums
+        tol_n = 2e-4
         assert (g0[n] - g1[n]).abs().max().item() <= tol_n * scale + 1e-9, n
 
 
@@ -255,7 +249,9 @@ def _grad_check(model, g, key, expect):
         # oracle, recorded by make_golden.py): the compatibility-head gradients are ~1e-7 differences of O(1) sums
         # (a 256-long MFMA fp32 accumulation chain is a plain fmaf chain: its rounding error is a few times that of
         #  the blocked CPU GEMM the reference ran on, hence the factor 10 on the noise term)
-        noise = float(g[f"{key}_gnoise_{name}"][0])
+        # ... and ONLY for those four tensors: every other tensor is held to the plain 1e-4 (the compatibility head itself is
+        # held to 1e-4 on the well-conditioned G7 cases, test_g7_conditioned_csa_holds_all_11_gradients_to_1e4)
+        noise = float(g[f"{key}_gnoise_{name}"][0]) if name.startswith("compatibility") else 0.0
         assert np.abs(got - ref).max() <= 1e-4 * scale + 10.0 * noise, (name, np.abs(got - ref).max(), scale, noise)
         st = g[f"{key}_gstats_{name}"]
         assert abs(gr.double().norm().item() - st[1]) <= 1e-4 * st[1] + 10.0 * noise * np.sqrt(gr.numel()), name
@@ -286,6 +282,42 @@ def test_g4_csa_forward_backward_against_reference_goldens(golden_dir):
         assert np.abs(feats.cpu().permute(0, 2, 1)[:, ::ROW_STRIDE].numpy() - g[f"g4_{i}_feat_rows"]).max() < ATOL
         assert np.abs(comp.cpu().numpy() - g[f"g4_{i}_comp_oracle"]).max() < 1e-5
         _grad_check(model, g, f"g4_{i}", 11)
+
+
+def test_g7_conditioned_csa_holds_all_11_gradients_to_1e4(golden_dir):
+    """The compatibility head on a WELL-CONDITIONED problem (oracle.conditioned_csa_case: per-shape channel offsets, scaled
+    fc / w_qs — the reference's own fp32 noise on these gradients is ~1e-6 relative, recorded in the goldens): every one of
+    the 11 trained tensors, compatibility_{q,k}.{weight,bias} included, within 1e-4 relative of the reference's gradients,
+    no noise allowance, in both math modes; and within 1e-4 of the float64 oracle's as well."""
+    g = _load(golden_dir, "g7_csa_conditioned")
+    for i in range(2):
+        B, K, H, n_cls, seed = (int(v) for v in g[f"g7_{i}_cfg"])
+        fc_s, q_s, off = (float(v) for v in g[f"g7_{i}_scales"])
+        p, x, nb, lab = orc.conditioned_csa_case(np.random.default_rng(seed), B, K, H, n_cls, fc_s, q_s, off)
+        model = _model("csa", p, H, n_cls, K)
+        logits = model(x.cuda(), "test", nb)
+        loss = orc.masked_ce_loss(logits, lab.cuda())
+        loss.backward()
+        rows = logits.detach().cpu().squeeze(-1).permute(0, 2, 1)[:, ::ROW_STRIDE].numpy()
+        assert np.abs(rows - g[f"g7_{i}_logit_rows"]).max() < ATOL
+        assert abs(loss.item() - g[f"g7_{i}_loss"][0]) < 1e-5
+        with torch.no_grad():
+            _, comp, _ = model._csa_cm(x.cuda(), nb.cuda(), return_parts=True)
+        assert np.abs(comp.cpu().numpy() - g[f"g7_{i}_comp_oracle"]).max() < 1e-5
+        seen = 0
+        for name, prm in model.named_parameters():
+            if name.startswith("fc_1"):
+                assert prm.grad is None
+                continue
+            ref = g[f"g7_{i}_grad_{name}"]
+            gr = prm.grad.detach().cpu()
+            got = gr.numpy() if gr.numel() <= 10000 else gr.reshape(gr.shape[0], -1)[::17, ::13].contiguous().numpy()
+            scale = np.abs(ref).max()
+            assert np.abs(got - ref).max() <= 1e-4 * scale, (name, np.abs(got - ref).max() / scale)
+            st = g[f"g7_{i}_gstats_{name}"]
+            assert abs(gr.double().norm().item() - st[1]) <= 1e-4 * st[1], name
+            seen += 1
+        assert seen == 11
 
 
 def test_g5_ssa_forward_backward_against_reference_goldens(golden_dir):

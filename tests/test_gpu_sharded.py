@@ -58,3 +58,94 @@ def test_knn_graph_sharded_two_ranks_bit_exact(tmp_path):
         got = torch.load(os.path.join(tmp_path, f"g{r}.pt"))
         assert got.dtype == torch.int64 and got.shape == (sum(SHARDS), K + 1)
         assert torch.equal(got, single)
+
+
+# ---- the CSA step itself, sharded by query shape: neighbour-only exchange, overlapped evaluation, descriptor reuse -------
+CSA_B, CSA_K, CSA_N, CSA_CLS = 2, 2, 400, 6
+CSA_GEO = dict(block=100, n_blocks=4)
+
+
+def _csa_collection(world):
+    """A small collection with per-shape channel offsets (well-conditioned compatibility gradients, see
+    oracle.conditioned_csa_case) + one set of weights."""
+    rng = np.random.default_rng(23)
+    S = CSA_B * world
+    p = orc.make_params(rng, 1, n_cls=CSA_CLS, csa=True)
+    p["attention.fc.weight"] = p["attention.fc.weight"] * 4.0
+    feats = orc.synth_points(rng, (S, 256, CSA_N)) + orc.synth_points(rng, (S, 256, 1))
+    labels = orc.synth_labels(rng, S, CSA_N, CSA_CLS)
+    return p, feats, labels
+
+
+def _csa_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from csn_amd import _lib
+    from csn_amd.csa_models import get_model
+    from csn_amd.sharding import ShapeGraphShard, regular_graph
+    _lib.check(_lib.lib().csn_set_math_mode(1))
+    p, feats, labels = _csa_collection(world)
+    shard = ShapeGraphShard(regular_graph(CSA_B * world, CSA_K), CSA_B, rank, world, torch.device("cuda"))
+    lo, hi = shard.first, shard.first + CSA_B
+    mine, lab = feats[lo:hi].cuda(), labels[lo:hi].cuda()
+    out = {}
+    for tag, kw in (("reuse", dict(mode="alltoall", reuse_descriptors=True)),
+                    ("a2a", dict(mode="alltoall", reuse_descriptors=False)),
+                    ("gather", dict(mode="allgather", reuse_descriptors=False))):
+        model = get_model("csa", CSA_CLS, 1, CSA_K, **CSA_GEO)
+        model.load_state_dict(p, strict=False)
+        model = model.cuda().eval()
+        logits = model(mine.unsqueeze(-1), "test", shard.exchange_async(mine, **kw))
+        loss = orc.masked_ce_loss(logits, lab)
+        loss.backward()
+        params = [q for n, q in model.named_parameters() if q.grad is not None]
+        shard.allreduce_grads(params)
+        out[tag] = {"logits": logits.detach().cpu(), "loss": loss.item(),
+                    "grads": {n: q.grad.cpu() for n, q in model.named_parameters() if q.grad is not None}}
+    torch.save(out, os.path.join(out_dir, f"csa{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_csa_step_with_descriptor_reuse_equals_single_process(tmp_path):
+    """Two ranks (sharing the test box's GPU) run the CSA step on their halves of a 4-shape collection three ways —
+    neighbour-only all-to-all with the neighbours' pooled descriptors taken from their owners, the same without reuse, and
+    the all-gather fallback — and each must reproduce the single-process module on the whole collection: logits, loss and,
+    after the gradient all-reduce, all 11 weight gradients (eval mode: the arithmetic is deterministic)."""
+    from csn_amd import _lib
+    from csn_amd.csa_models import get_model
+    from csn_amd.sharding import ShapeGraphShard, regular_graph
+    world = 2
+    mp.spawn(_csa_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(tmp_path, f"csa{r}.pt")) for r in range(world)]
+    _lib.check(_lib.lib().csn_set_math_mode(1))
+    try:
+        p, feats, labels = _csa_collection(world)
+        graph = regular_graph(CSA_B * world, CSA_K)
+        model = get_model("csa", CSA_CLS, 1, CSA_K, **CSA_GEO)
+        model.load_state_dict(p, strict=False)
+        model = model.cuda().eval()
+        total, ref_logits = 0.0, []
+        for r in range(world):
+            sh = ShapeGraphShard(graph, CSA_B, r, world, torch.device("cpu"))
+            lo, hi = sh.first, sh.first + CSA_B
+            stack = sh.neighbour_stack(feats[lo:hi], feats)
+            logits = model(feats[lo:hi].cuda().unsqueeze(-1), "test", stack.cuda())
+            loss = orc.masked_ce_loss(logits, labels[lo:hi].cuda())
+            ref_logits.append((logits.detach().cpu(), loss.item()))
+            total = total + loss / world
+        total.backward()
+        ref_grads = {n: q.grad.cpu() for n, q in model.named_parameters() if q.grad is not None}
+        assert len(ref_grads) == 11
+        for tag in ("reuse", "a2a", "gather"):
+            for r in range(world):
+                got = res[r][tag]
+                assert (got["logits"] - ref_logits[r][0]).abs().max().item() < 2e-5, tag
+                assert abs(got["loss"] - ref_logits[r][1]) < 1e-5, tag
+                assert set(got["grads"]) == set(ref_grads)
+                for n, g in ref_grads.items():
+                    assert (got["grads"][n] - g).abs().max().item() <= 2e-4 * g.abs().max().item(), (tag, n)
+    finally:
+        _lib.lib().csn_set_math_mode(0)

@@ -131,6 +131,29 @@ def test_g4_csa(golden_dir):
         assert _check_grads(g, f"g4_{i}", grads) == 11
 
 
+def test_g7_conditioned_csa_all_gradients_at_1e4(golden_dir):
+    """G7: the compatibility-head gradients are well-conditioned here (oracle.conditioned_csa_case), so the oracle must
+    reproduce all 11 of the reference's gradients to 1e-4 relative with NO noise allowance."""
+    g = _load(golden_dir, "g7_csa_conditioned")
+    for i in range(1 if os.environ.get("CSN_SLOW", "0") != "1" else 2):       # case 1 (B = 2, K = 3): CSN_SLOW=1
+        B, K, H, n_cls, seed = (int(v) for v in g[f"g7_{i}_cfg"])
+        fc_s, q_s, off = (float(v) for v in g[f"g7_{i}_scales"])
+        p, x, nb, lab = orc.conditioned_csa_case(np.random.default_rng(seed), B, K, H, n_cls, fc_s, q_s, off)
+        logits, loss, grads = _run_model(p, lambda q: orc.forward_csa(x, nb, q, H), lab)
+        _close(logits.squeeze(-1).permute(0, 2, 1)[:, ::ROW_STRIDE].numpy(), g[f"g7_{i}_logit_rows"])
+        assert abs(loss - g[f"g7_{i}_loss"][0]) < 1e-5
+        seen = 0
+        for name, gr in grads.items():
+            if gr is None:
+                continue
+            ref = g[f"g7_{i}_grad_{name}"]
+            got = gr.numpy() if gr.numel() <= 10000 else gr.reshape(gr.shape[0], -1)[::17, ::13].contiguous().numpy()
+            assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), name
+            assert float(g[f"g7_{i}_gnoise_{name}"][0]) <= 5e-5 * float(g[f"g7_{i}_gstats_{name}"][2]), name   # the case IS conditioned
+            seen += 1
+        assert seen == 11
+
+
 def test_g5_ssa(golden_dir):
     g = _load(golden_dir, "g5_ssa")
     for i in range(2):

@@ -26,8 +26,8 @@ def _collection(world):
     return p, feats, labels
 
 
-def _loss(p, x_stack, feats, labels):
-    logits = orc.forward_csa(feats.unsqueeze(-1), x_stack, p, 1, **KW)
+def _loss(p, x_stack, feats, labels, neighbour_pooled=None):
+    logits = orc.forward_csa(feats.unsqueeze(-1), x_stack, p, 1, neighbour_pooled=neighbour_pooled, **KW)
     return orc.masked_ce_loss(logits, labels)
 
 
@@ -52,12 +52,24 @@ def _worker(rank, world, port, out_dir):
         for k in range(K):
             assert torch.equal(stack[b, k + 1, :, :, 0], feats[graph[lo + b, k]])
     assert torch.equal(shard.exchange_neighbours(mine), stack)             # neighbour-only all-to-all builds the same stack
-    pending = shard.exchange_async(mine)                                   # the overlapped form: the model calls wait() late
-    assert torch.equal(pending.wait(), stack) and pending.wait() is pending.wait()
+    for mode in ("alltoall", "allgather"):                                 # the overlapped forms: the model calls wait() late
+        pending = shard.exchange_async(mine, mode=mode)
+        assert torch.equal(pending.wait(), stack) and pending.wait() is pending.wait()
     loss = _loss(params, stack, mine, labels[lo:hi])
     loss.backward()
     shard.allreduce_grads(params.values(), average=True)
-    torch.save({"loss": loss.item(), "grads": {k: v.grad for k, v in params.items()}}, os.path.join(out_dir, f"r{rank}.pt"))
+    out = {"loss": loss.item(), "grads": {k: v.grad.clone() for k, v in params.items()}}
+    # descriptor reuse: every shape's pooled SSA descriptor comes from its owner (differentiable all-gather) — same loss,
+    # and after the gradient all-reduce the same weight gradients, with K fewer evaluations per shape on every rank
+    for v in params.values():
+        v.grad = None
+    pending = shard.exchange_async(mine, reuse_descriptors=True)
+    loss_r = _loss(params, pending.wait(), mine, labels[lo:hi], neighbour_pooled=pending.gather_pooled)
+    loss_r.backward()
+    shard.allreduce_grads(params.values(), average=True)
+    out["loss_reuse"] = loss_r.item()
+    out["grads_reuse"] = {k: v.grad.clone() for k, v in params.items()}
+    torch.save(out, os.path.join(out_dir, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -91,6 +103,10 @@ def test_two_rank_sharded_step_equals_single_process(tmp_path):
             got = res[r]["grads"][k]
             assert torch.allclose(got, v.grad, rtol=1e-4, atol=1e-7), k
         assert torch.equal(res[0]["grads"][k], res[1]["grads"][k])         # ranks agree bit-for-bit after the all-reduce
+        for r in range(world):                                             # descriptor reuse: same averaged gradients
+            assert torch.allclose(res[r]["grads_reuse"][k], v.grad, rtol=2e-4, atol=2e-7), k
+    for r in range(world):
+        assert abs(res[r]["loss_reuse"] - res[r]["loss"]) < 1e-6
 
 
 def _a2a_worker(rank, world, port):

@@ -1,6 +1,8 @@
 """Host-side caller logic (csn_amd/training.py, csn_amd/data.py) — CPU tests of the pure functions."""
 import os
 
+import pytest
+
 import numpy as np
 import torch
 
@@ -83,3 +85,109 @@ def test_optimizer_and_warm_start_follow_the_reference():
     T.load_trained_ssa_layers(csa, ssa.state_dict())                                         # utils.py:29-39
     for k, v in ssa.state_dict().items():
         assert torch.equal(csa.state_dict()[k], v)
+
+
+class _TinySeg(torch.nn.Module):
+    """model(feats, mode, neighbours) -> logits (B, n_cls, N, 1): a 1x1 convolution, enough to watch the optimizer."""
+
+    def __init__(self, C, n_cls):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(n_cls, C))
+
+    def forward(self, feats, mode=None, neighbor_feats=None):
+        return torch.einsum("kc,bcn->bkn", self.w, feats.squeeze(-1)).unsqueeze(-1)
+
+
+def _micro_batches(rng, n, C=8, N=32, n_cls=4):
+    out = []
+    for _ in range(n):
+        f = torch.from_numpy(rng.standard_normal((2, C, N, 1)).astype(np.float32))
+        lab = torch.from_numpy(rng.integers(1, n_cls, size=(2, N)).astype(np.int64))
+        out.append((f, lab, torch.zeros(2, 1, C, N, 1)))
+    return out
+
+
+def test_train_layers_reference_order_versus_repaired_accumulation():
+    """csa_training.py:196 zeroes the gradients at the top of EVERY iteration, so with gradient_accumulation_steps = 2 only
+    the second micro-batch's half-scaled gradient reaches optimizer.step() (:213-215).  reference_semantics=True (default)
+    reproduces exactly that; False accumulates both."""
+    rng = np.random.default_rng(3)
+    batches = _micro_batches(rng, 2)
+    grads = []
+    for f, lab, _ in batches:
+        m = _TinySeg(8, 4)
+        loss, _ = T.loss_functions_seg(m(f), lab, 4)
+        (loss / 2).backward()
+        grads.append(m.w.grad.clone())
+    for ref_mode, want in ((True, grads[1]), (False, grads[0] + grads[1])):
+        m = _TinySeg(8, 4)
+        opt = torch.optim.SGD(m.parameters(), lr=1.0)
+        T.train_layers(m, batches, opt, 4, torch.device("cpu"), accumulation_steps=2, reference_semantics=ref_mode)
+        assert torch.allclose(m.w.detach(), -want, atol=1e-7), ref_mode
+
+
+def test_train_layers_nan_loss_guard_as_written_and_repaired():
+    """:206-207 multiplies a NaN loss by 0 — still NaN — so the reference's step is poisoned; the repaired loop skips it."""
+    rng = np.random.default_rng(4)
+    good, bad = _micro_batches(rng, 2)
+    bad = (bad[0] * float("nan"), bad[1], bad[2])
+    for ref_mode in (True, False):
+        m = _TinySeg(8, 4)
+        opt = torch.optim.SGD(m.parameters(), lr=1.0)
+        mean_loss = T.train_layers(m, [good, bad], opt, 4, torch.device("cpu"), accumulation_steps=1, reference_semantics=ref_mode)
+        assert np.isfinite(mean_loss) and mean_loss > 0              # the running loss skips the NaN batch in both
+        assert torch.isnan(m.w).any().item() == ref_mode
+
+
+def test_validate_layers_skips_nan_batches_entirely():
+    """csa_training.py:239-240: a NaN batch is `continue`d — neither its loss nor its IoU counts are accumulated."""
+    rng = np.random.default_rng(5)
+    good, bad = _micro_batches(rng, 2)
+    bad = (bad[0] * float("nan"), bad[1], bad[2])
+    m = _TinySeg(8, 4)
+    with torch.no_grad():
+        m.w.copy_(torch.from_numpy(rng.standard_normal((4, 8)).astype(np.float32)))
+    iou_both, loss_both = T.validate_layers(m, [good, bad], 4, torch.device("cpu"))
+    iou_good, loss_good = T.validate_layers(m, [good], 4, torch.device("cpu"))
+    assert abs(iou_both - iou_good) < 1e-12 and abs(loss_both * 2 - loss_good) < 1e-9
+
+
+def _write_feature_files(root, n_shapes, rng, sizes):
+    os.makedirs(os.path.join(root, "fc_1"))
+    os.makedirs(os.path.join(root, "point_labels"))
+    for i in range(n_shapes):
+        n = sizes[i % len(sizes)]
+        np.save(os.path.join(root, "fc_1", f"s{i:02d}.npy"), rng.standard_normal((1, 256, n, 1)).astype(np.float32))
+        np.save(os.path.join(root, "point_labels", f"s{i:02d}.npy"), rng.integers(0, 5, size=(n,)))
+
+
+def test_device_feature_cache_builds_the_same_neighbour_stacks_as_csadatasetk(tmp_path, monkeypatch):
+    """the cache (every file read once, stacks by indexed gather) against a DataLoader over the restated
+    CSADatasetK (K np.load's per item, features_data_loader.py:124-140): features, labels and neighbour stacks bit for bit,
+    including wrap-around padded shapes, self-skipping graph rows, and test shapes whose neighbours live in the train set."""
+    from torch.utils.data import DataLoader
+    monkeypatch.setattr(os, "listdir", lambda p, _ls=os.listdir: sorted(_ls(p)))       # a fixed file order for both readers
+    rng = np.random.default_rng(12)
+    tr, te = str(tmp_path / "train"), str(tmp_path / "test")
+    _write_feature_files(tr, 6, rng, sizes=(64, 40, 64, 51))
+    _write_feature_files(te, 3, rng, sizes=(64, 33))
+    K = 2
+    g_train = np.array([[0, 3, 5], [1, 0, 2], [4, 2, 1], [3, 1, 0], [4, 5, 0], [5, 2, 3]])     # self first, third or absent
+    g_test = np.array([[2, 4, 0], [5, 1, 3], [0, 1, 2]])                                        # ids into the TRAIN set
+    ds_train = D.CSADatasetK(tr, tr, g_train, K, n_points=64)
+    ds_test = D.CSADatasetK(te, tr, g_test, K, n_points=64)
+    cache_tr = D.DeviceFeatureCache(ds_train, "cpu", n_points=64)
+    cache_te = D.DeviceFeatureCache(ds_test, "cpu", n_points=64)
+    assert len(cache_tr) == 6 and cache_tr.feats.shape == (6, 256, 64) and cache_tr.labels.dtype == torch.int64
+    tab_tr = D.neighbour_table(g_train, K)
+    assert tab_tr.tolist() == [[3, 5], [0, 2], [4, 1], [1, 0], [5, 0], [2, 3]]                 # self skipped, graph order kept
+    for (f, lab, nb), (cf, cl, cnb) in zip(DataLoader(ds_train, 4, shuffle=False), cache_tr.batches(4, tab_tr)):
+        assert torch.equal(f, cf) and torch.equal(lab, cl) and torch.equal(nb, cnb)
+    # test shapes: the reference compares graph entries with the TEST index (features_data_loader.py:127), so a train id that
+    # happens to equal the test shape's own index is skipped — neighbour_table reproduces that rule
+    tab_te = D.neighbour_table(g_test, K)
+    assert tab_te.tolist() == [[2, 4], [5, 3], [0, 1]]
+    for (f, lab, nb), (cf, cl, cnb) in zip(DataLoader(ds_test, 2, shuffle=False), cache_te.batches(2, tab_te, cache_tr)):
+        assert torch.equal(f, cf) and torch.equal(lab, cl) and torch.equal(nb, cnb)
+    with pytest.raises(IndexError):
+        D.DeviceFeatureCache(ds_train, "cpu", first=2, count=2, n_points=64).batch([0])
