@@ -19,6 +19,10 @@
 //
 // MFMA fragment maps (32x32x16 bf16): A lane l holds A[l & 31][8 (l >> 5) + j], B lane l holds
 // B[8 (l >> 5) + j][l & 31], j = 0..7; C/D as for the fp32 shape.
+// SINGLE-PRODUCT MODES (math modes 2 and 3): the same kernels with the lo planes dropped — every operand is rounded once to
+// bf16 (mode 2) or fp16 (mode 3) and a product is ONE matrix instruction (~2^-9 / 2^-11 relative error per operand: outside
+// the 1e-4 contract, reported with its measured error).  Tile planes then hold one plane: per row and block 16 tiles of
+// 32 elements (block pitch 512 instead of 1024).  Template parameter PR = csn_mode::{Bf16x3, Bf16, F16} (csn_common.h).
 #include "csn_common.h"
 #include "csn_kernels.h"
 
@@ -37,38 +41,36 @@ extern "C" int csn_gemm_debug_read(void* dst, long long bytes) { return (int)hip
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
+using namespace csn_mode;
 
 constexpr int BK = 32;                 // two MFMA k-steps of 16
-constexpr int PK = BK + 8;             // pitch of k-contiguous planes (bf16): 80-byte rows, conflict-free b128 reads
+constexpr int PK = BK + 8;             // pitch of k-contiguous planes (16-bit elements): 80-byte rows, conflict-free b128 reads
 
-CSN_DEVINL f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
-
-// split 4 floats into 4 hi and 4 lo bf16 (round-to-nearest-even both times)
-CSN_DEVINL void split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    hi[i] = (__bf16)v[i];
-    lo[i] = (__bf16)(v[i] - (float)hi[i]);
+// acc += a * b on the 32x32x16 matrix instruction: three products of the hi / lo terms (small terms first), or one
+template <typename PR>
+CSN_DEVINL f32x16 mma32(s16x8 ah, s16x8 al, s16x8 bh, s16x8 bl, f32x16 c) {
+  if constexpr (PR::NT == 3) {
+    c = mfma32<PR::F16>(al, bh, c);
+    c = mfma32<PR::F16>(ah, bl, c);
   }
+  return mfma32<PR::F16>(ah, bh, c);
 }
 
 // BT: the k-major B operand arrives as bf16 "tile planes" (see attn_bf16x3.hip): per k row, consecutive 32-column tiles of
 // [hi 32 | lo 32] (B.ld = row pitch in bf16 elements, B strides in bf16 elements; padding columns inside a tile are zero).
 // Its staging is then a plain copy — 16-byte loads, 16-byte LDS stores, no conversion work.  This is how the attention
 // backward hands the probabilities P and the score gradients dS to the dV / dK products.
-template <int BM, int BN, bool B_NK, bool BT = false>
+template <typename PR, int BM, int BN, bool B_NK, bool BT = false>
 __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) {
+  constexpr int NPL = PR::NPL;                          // planes per operand: hi (+ lo)
   static_assert(!BT || (!B_NK && BN == 128), "tile-plane B: k-major, 128-column tiles");
   constexpr int MT = BM / 64, NT = BN / 64;
   constexpr int A_PASS = BM / 32, B_PASS = BN / 32;
   constexpr int TPR = BN / 4, RPP = 256 / TPR;          // KN staging: threads per k row, k rows per pass
   constexpr int PN = BN + 32;                           // pitch of the k-major B planes: rows 64 B apart mod 256
   constexpr int A_EL = BM * PK, B_EL = B_NK ? BN * PK : BK * PN;
-  __shared__ __attribute__((aligned(16))) __bf16 As[2][2][A_EL];   // [stage][plane][row][k]
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][2][B_EL];   // NK: [stage][plane][col][k]   KN: [stage][plane][k][col]
+  __shared__ __attribute__((aligned(16))) short As[2][NPL][A_EL];   // [stage][plane][row][k]
+  __shared__ __attribute__((aligned(16))) short Bs[2][NPL][B_EL];   // NK: [stage][plane][col][k]   KN: [stage][plane][k][col]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #ifdef CSN_STAMPS
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   const int c_es = c_pl ? 2 : 4;
   const float* a_base = p.A.ptr + p.A.s0 * z0 + p.A.s1 * z1 + p.A.s2 * (long long)(p.A.idx2 ? p.A.idx2[z2] : z2) + (long long)m0 * lda;
   const long long b_el = p.B.s0 * z0 + p.B.s1 * z1 + p.B.s2 * (long long)(p.B.idx2 ? p.B.idx2[z2] : z2);
-  const float* b_base = BT ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(p.B.ptr) + b_el)
+  const float* b_base = BT ? reinterpret_cast<const float*>(reinterpret_cast<const short*>(p.B.ptr) + b_el)
                            : p.B.ptr + b_el + (B_NK ? (long long)n0 * ldb : (long long)n0);
   char* c_base = reinterpret_cast<char*>(p.C.ptr) + (p.C.s0 * z0 + p.C.s1 * z1 + p.C.s2 * (long long)(p.C.idx2 ? p.C.idx2[z2] : z2) + (long long)m0 * ldc + (c_tiles ? 0 : n0)) * c_es;
   const long long c_win = (long long)BM * ldc * c_es;
@@ -119,14 +121,21 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
 
   const int pr = tid >> 3, pc = (tid & 7) * 4;
   const int kr = tid / TPR, kc = (tid % TPR) * 4;
+  // tile-plane B: a k row of the tile is B_PASS * NPL / 2 ... contiguous 16-byte units w = (tid & 7) + 8 i of NPL * 64-byte
+  // tiles; unit w sits in tile w / (4 NPL), plane (w % (4 NPL)) / 4, keys 8 (w % 4) .. + 7 of the tile
+  constexpr int BT_PASS = B_PASS * NPL / 2;             // 16-byte units per thread and slab
   unsigned a_off[A_PASS], b_off[B_PASS];
+  int bt_dst[B_PASS];
 #pragma unroll
   for (int i = 0; i < A_PASS; ++i) a_off[i] = (m0 + pr + 32 * i) < M ? (unsigned)((pr + 32 * i) * lda + pc) * 4u : CSN_OOB;
-  const int t_u8 = tid & 7, t_u = t_u8 & 3, t_pl = t_u8 >> 2;       // tile planes: 16-byte unit of a 128-byte tile row
 #pragma unroll
   for (int i = 0; i < B_PASS; ++i) {
-    if (BT) b_off[i] = (n0 + 32 * i + 8 * t_u) < N ? (unsigned)(pr * ldb) * 2u + (unsigned)((n0 >> 5) + i) * 128u + (unsigned)t_u8 * 16u : CSN_OOB;
-    else if (B_NK) b_off[i] = (n0 + pr + 32 * i) < N ? (unsigned)((pr + 32 * i) * ldb + pc) * 4u : CSN_OOB;
+    if (BT) {
+      const int w = (tid & 7) + 8 * i, tile = w / (4 * NPL), within = w % (4 * NPL), t_u = within & 3;
+      b_off[i] = (i < BT_PASS && (n0 + 32 * tile + 8 * t_u) < N)
+                     ? (unsigned)(pr * ldb) * 2u + (unsigned)(n0 >> 5) * (unsigned)(64 * NPL) + (unsigned)w * 16u : CSN_OOB;
+      bt_dst[i] = (within >> 2) * B_EL + pr * PN + 32 * tile + 8 * t_u;
+    } else if (B_NK) b_off[i] = (n0 + pr + 32 * i) < N ? (unsigned)((pr + 32 * i) * ldb + pc) * 4u : CSN_OOB;
     else b_off[i] = (n0 + kc) < N ? (unsigned)((kr + RPP * i) * ldb + kc) * 4u : CSN_OOB;
   }
 
@@ -136,9 +145,9 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) ra[i] = csn_bload4(Ar, a_off[i] | kp, (unsigned)k0 * 4u);
     if (BT) {
-      const unsigned kb = (k0 + pr) < K ? 0u : CSN_OOB;               // k row pr of the slab, tile i of the 128 columns
+      const unsigned kb = (k0 + pr) < K ? 0u : CSN_OOB;               // k row pr of the slab
 #pragma unroll
-      for (int i = 0; i < B_PASS; ++i) rb[i] = csn_bload4(Br, b_off[i] | kb, (unsigned)k0 * (unsigned)ldb * 2u);
+      for (int i = 0; i < BT_PASS; ++i) rb[i] = csn_bload4(Br, b_off[i] | kb, (unsigned)k0 * (unsigned)ldb * 2u);
     } else if (B_NK) {
 #pragma unroll
       for (int i = 0; i < B_PASS; ++i) rb[i] = csn_bload4(Br, b_off[i] | kp, (unsigned)k0 * 4u);
@@ -151,24 +160,24 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
     }
   };
   auto store_slab = [&](int st) {
-    bf16x4 hi, lo;
+    s16x4 hi, lo;
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
-      split4(ra[i], hi, lo);
-      *reinterpret_cast<bf16x4*>(&As[st][0][(pr + 32 * i) * PK + pc]) = hi;
-      *reinterpret_cast<bf16x4*>(&As[st][1][(pr + 32 * i) * PK + pc]) = lo;
+      split4<PR>(ra[i], hi, lo);
+      *reinterpret_cast<s16x4*>(&As[st][0][(pr + 32 * i) * PK + pc]) = hi;
+      if constexpr (NPL == 2) *reinterpret_cast<s16x4*>(&As[st][NPL - 1][(pr + 32 * i) * PK + pc]) = lo;
     }
     if (BT) {
 #pragma unroll
-      for (int i = 0; i < B_PASS; ++i) *reinterpret_cast<f32x4*>(&Bs[st][t_pl][pr * PN + 32 * i + 8 * t_u]) = rb[i];
+      for (int i = 0; i < BT_PASS; ++i) *reinterpret_cast<f32x4*>(&Bs[st][0][bt_dst[i]]) = rb[i];
       return;
     }
 #pragma unroll
     for (int i = 0; i < B_PASS; ++i) {
-      split4(rb[i], hi, lo);
+      split4<PR>(rb[i], hi, lo);
       const int dst = B_NK ? (pr + 32 * i) * PK + pc : (kr + RPP * i) * PN + kc;
-      *reinterpret_cast<bf16x4*>(&Bs[st][0][dst]) = hi;
-      *reinterpret_cast<bf16x4*>(&Bs[st][1][dst]) = lo;
+      *reinterpret_cast<s16x4*>(&Bs[st][0][dst]) = hi;
+      if constexpr (NPL == 2) *reinterpret_cast<s16x4*>(&Bs[st][NPL - 1][dst]) = lo;
     }
   };
 

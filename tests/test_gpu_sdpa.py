@@ -40,7 +40,7 @@ def test_g1_goldens_through_the_drop_in_class(golden_dir, math_mode):
 
 
 @pytest.mark.parametrize("Tq,Tk", [(700, 100), (64, 64), (37, 301)])
-def test_train_mode_returns_the_dropped_probabilities(Tq, Tk):
+def test_train_mode_returns_the_dropped_probabilities(Tq, Tk, math_mode):
     """attn = dropout(softmax(q k^T / t)) and out = attn v (csa_models.py:141-142): the returned probabilities carry the
     kernel's own mask — rebuilt on the host from (seed, position) — and the output is their product with v.  (700, 100):
     more queries than the score pitch (128), where the pair index must still be unique."""
@@ -61,7 +61,7 @@ def test_train_mode_returns_the_dropped_probabilities(Tq, Tk):
     soft = torch.softmax((q.double() / d ** 0.5) @ k.double().transpose(2, 3), dim=-1)
     want = soft * mask / (1.0 - p)
     assert abs(mask.mean().item() - (1.0 - p)) < 0.01
-    assert (pr.cpu().double() - want).abs().max().item() < 2e-6
+    assert (pr.cpu().double() - want).abs().max().item() < (1e-5 if math_mode else 2e-6)      # bf16x3: measured 3.3e-6
     assert (o.cpu().double() - want @ v.double()).abs().max().item() < 1e-4
     if Tq > Tp:
         # the old pair index (key pair * pitch + query) gave query Tp + a, pair w the mask of query a, pair w + 1
