@@ -51,19 +51,37 @@ def _stale() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP source for gfx950 into csn_amd/libcsn_hip.so (in-tree, so it travels to the GPU box)."""
+    """Compile every HIP source for gfx950 into csn_amd/libcsn_hip.so (in-tree, so it travels to the GPU box): one object
+    per translation unit, compiled side by side, then one link."""
     if not force and not _stale():
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
-    cmd = [hipcc] + BUILD_FLAGS + ["-o", LIB_PATH + ".tmp"]
-    cmd += [os.path.join(_CSRC, f) for f in SOURCES]
+    obj_dir = os.path.join(_HERE, "_obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    compile_flags = [f for f in BUILD_FLAGS if f != "-shared"]
+    jobs = []
+    for f in SOURCES:
+        obj = os.path.join(obj_dir, f.replace(".hip", ".o"))
+        cmd = [hipcc] + compile_flags + ["-c", os.path.join(_CSRC, f), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        jobs.append((f, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    objs, errors = [], []
+    for f, obj, proc in jobs:
+        out, _ = proc.communicate()
+        if proc.returncode != 0:
+            errors.append(f"{f}:\n{out}")
+        objs.append(obj)
+    if errors:
+        raise CsnError("hipcc failed:\n" + "\n".join(errors))
+    link = [hipcc] + BUILD_FLAGS + ["-o", LIB_PATH + ".tmp"] + objs
     if verbose:
-        print(" ".join(cmd), flush=True)
-    res = subprocess.run(cmd, capture_output=True, text=True)
+        print(" ".join(link), flush=True)
+    res = subprocess.run(link, capture_output=True, text=True)
     if res.returncode != 0:
-        raise CsnError("hipcc failed:\n" + res.stdout + res.stderr)
+        raise CsnError("hipcc link failed:\n" + res.stdout + res.stderr)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     with open(STAMP_PATH, "w") as fh:
         fh.write(_source_digest() + "\n")
@@ -75,6 +93,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 _SIGNATURES = {
     "csn_version": (c_int, []),
     "csn_set_math_mode": (c_int, [c_int]),
+    "csn_set_thread_math_mode": (c_int, [c_int]),
     "csn_get_math_mode": (c_int, []),
     "csn_status_string": (c_char_p, [c_int]),
     "csn_wgrad_workspace_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
@@ -133,7 +152,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.csn_version() != 11:
+        if handle.csn_version() != 12:
             raise CsnError("libcsn_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -60,8 +60,11 @@ class ScaledDotProductAttention(nn.Module):
 class MultiHeadAttention(nn.Module):
     """Block-diagonal multi-head attention (csa_models.py:37-125)."""
 
-    def __init__(self, n_head, d_model, d_k, d_v, dropout=0.1, block=CF.REF_BLOCK, n_blocks=CF.REF_NBLOCKS):
+    def __init__(self, n_head, d_model, d_k, d_v, dropout=0.1, block=CF.REF_BLOCK, n_blocks=CF.REF_NBLOCKS, math=None):
         super().__init__()
+        # arithmetic of this module's contractions: None = the library's process default (bf16x3 unless csn_set_math_mode
+        # changed it), or 'fp32' | 'bf16x3' | 'bf16' | 'fp16' (include/csn_hip.h, CSN_MATH_*) for this module only
+        self.math_mode = CF.mode_id(math)
         if d_k != d_v:
             raise ValueError("the HIP attention kernels need d_k == d_v (the reference always uses 256/256)")
         self.n_head, self.d_k, self.d_v = n_head, d_k, d_v
@@ -89,8 +92,9 @@ class MultiHeadAttention(nn.Module):
         (n_head_evals > 0: also the leading maps as a second result — a tensor, or with link_mix the LinkedMaps that
         CF.csa_mix takes; want_sums: also their (E, C) sums over the points, see CF.mha_evals)."""
         p_attn, p_fc = self.dropout_rates()
-        return CF.mha_evals(x_all, self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight,
-                            plan, geo or self.geometry(), p_attn, p_fc, n_head_evals, want_sums, link_mix)
+        with CF.math_mode(self.math_mode):
+            return CF.mha_evals(x_all, self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight,
+                                plan, geo or self.geometry(), p_attn, p_fc, n_head_evals, want_sums, link_mix)
 
     def plan(self, kind: str, B: int, K1: int, dev) -> CF.EvalPlan:
         """Cached evaluation plans (slot maps live on the device; building one costs a few small H2D copies)."""
@@ -186,7 +190,7 @@ class CrossShapeAt(nn.Module):
     """csa_models.py:146-404."""
 
     def __init__(self, num_classes, d_model, n_heads, K=None, d_k=256, d_v=256, attention_type='ssa',
-                 after_fc=False, device=None, block=CF.REF_BLOCK, n_blocks=CF.REF_NBLOCKS):
+                 after_fc=False, device=None, block=CF.REF_BLOCK, n_blocks=CF.REF_NBLOCKS, math=None):
         """Arguments as the reference's (csa_models.py:147).  The reference hard-codes 256 for the widths of ``fc_1``,
         ``logit`` and the compatibility head (:150-151, :160-161) and 20 x 500 for the chunking (:83-84): here they follow
         ``d_model`` / ``block`` / ``n_blocks`` (identical for the defaults), so that the other BASELINE configurations —
@@ -195,7 +199,7 @@ class CrossShapeAt(nn.Module):
         self.d_model = d_model
         self.fc_1 = self._conv1x1_bn_relu(928, d_model)        # never executed when after_fc=True; kept for checkpoints
         self.logit = self._conv1x1(d_model, num_classes)
-        self.attention = MultiHeadAttention(n_heads, d_model, d_k, d_v, block=block, n_blocks=n_blocks)
+        self.attention = MultiHeadAttention(n_heads, d_model, d_k, d_v, block=block, n_blocks=n_blocks, math=math)
         self.attention_type = attention_type
         self.after_fc = after_fc
         self.device = device
@@ -221,10 +225,11 @@ class CrossShapeAt(nn.Module):
 
     # -- forward ----------------------------------------------------------------------------------------------
     def forward(self, x, mode=None, neighbor_feats=None):
-        if self.attention_type == 'ssa':
-            return self.forward_ssa(x, mode)
-        if self.attention_type == 'csa':
-            return self.forward_csa(x, neighbor_feats, mode)
+        with CF.math_mode(self.attention.math_mode):       # the logit layer and the mix run in the module's mode too
+            if self.attention_type == 'ssa':
+                return self.forward_ssa(x, mode)
+            if self.attention_type == 'csa':
+                return self.forward_csa(x, neighbor_feats, mode)
         return x                                                               # csa_models.py:182-189 falls through
 
     def _logits(self, feats_cm: torch.Tensor) -> torch.Tensor:
@@ -436,8 +441,9 @@ def backbone_fc_csa_logit(num_classes, n_heads, K, **geometry):
 def get_model(attention_type, num_classes, n_heads, K=None, **geometry):
     """csa_models.py:426-432.  ``geometry`` (all optional, the defaults are the reference's constants): d_model=256,
     d_k=256, d_v=256, block=500, n_blocks=20 — e.g. ``get_model('csa', 39, 1, 4, d_model=96, d_k=96, d_v=96,
-    n_blocks=100)`` is BASELINE.json's 50000-point, 96-channel configuration."""
-    unknown = set(geometry) - {"d_model", "d_k", "d_v", "block", "n_blocks"}
+    n_blocks=100)`` is BASELINE.json's 50000-point, 96-channel configuration — and ``math`` = 'fp32' | 'bf16x3' | 'bf16' |
+    'fp16' (default: the library's process default, bf16x3): the arithmetic of this model's contractions."""
+    unknown = set(geometry) - {"d_model", "d_k", "d_v", "block", "n_blocks", "math"}
     if unknown:
         raise TypeError(f"get_model: unexpected arguments {sorted(unknown)}")
     if attention_type == 'ssa':

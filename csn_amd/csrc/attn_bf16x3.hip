@@ -44,39 +44,31 @@ namespace {
 constexpr int KT = 32;               // keys per streamed tile
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
-typedef float f32x4v __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
+using namespace csn_mode;
+typedef f32x4m f32x4v;
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
 
-CSN_DEVINL f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-
-// acc += a * b with a = ah + al, b = bh + bl (small terms first)
-CSN_DEVINL f32x4v mfma3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x4v c) {
-  c = mfma16(al, bh, c);
-  c = mfma16(ah, bl, c);
-  return mfma16(ah, bh, c);
-}
-
-CSN_DEVINL bf16x8 join8(s16x4 a, s16x4 b) {
-  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-  return __builtin_bit_cast(bf16x8, v);
-}
-
-CSN_DEVINL void split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    hi[i] = (__bf16)v[i];
-    lo[i] = (__bf16)(v[i] - (float)hi[i]);
+// acc += a * b on the 16x16x32 matrix instruction: a = ah + al, b = bh + bl as three products (small terms first), or one
+template <typename PR>
+CSN_DEVINL f32x4v mma16(s16x8 ah, s16x8 al, s16x8 bh, s16x8 bl, f32x4v c) {
+  if constexpr (PR::NT == 3) {
+    c = mfma16<PR::HALF>(al, bh, c);
+    c = mfma16<PR::HALF>(ah, bl, c);
   }
+  return mfma16<PR::HALF>(ah, bh, c);
 }
 
-template <int DT, bool BWD, bool KVP>
+// PR = csn_mode::Bf16x3 (math mode 1: hi / lo planes, three products), Bf16 / F16 (modes 2 / 3: one plane, one product;
+// tile-plane K/V only, F16 forward only).  The single-product modes drop every "lo" object of this file: the LDS planes, the
+// fragment reads, the conversions, two of the three matrix instructions, and half of the bytes of every tile plane.
+template <typename PR, int DT, bool BWD, bool KVP>
 __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) {
+  static_assert(PR::NT == 3 || KVP, "single-product modes take K / V as tile planes");
+  constexpr int NPL = PR::NPL;                          // planes: hi (+ lo)
   constexpr int D = 32 * DT;
-  constexpr int PIECES = D * 8;                         // 16-byte pieces per streamed tile
+  constexpr int UPR = KVP ? 4 * NPL : 8;                // 16-byte pieces per tile row (tile planes: 4 per plane; fp32: 8)
+  constexpr int RPP = 512 / UPR;                        // tile rows staged per pass of the 512 threads
+  constexpr int PIECES = D * UPR;                       // 16-byte pieces per streamed tile
   constexpr int NP_T = (PIECES + 511) / 512;            // pieces per thread per tile
   // plane pitch: 64 bytes of phase between hi and lo.  LDS STORES bank on 32 dwords (128 bytes): a staging instruction of the
   // tile-plane path writes the hi and the lo unit of a row together (lanes u and u + 4), and with the planes a multiple of
@@ -87,11 +79,11 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
 #endif
   constexpr int PLANE = D * KT + (CSN_LDS_V ? 32 : 64);
   // [A | B][stage][plane hi/lo][row][32 keys] — one array, so that the prologue / epilogue can use all of it as a
-  // [D rows][128 queries] fp32 staging block for 16-byte global accesses
-  __shared__ __attribute__((aligned(16))) __bf16 tiles[2][2][2][PLANE];
-  auto& tileA = tiles[0];
-  auto& tileB = tiles[1];
-  static_assert(sizeof(tiles) >= D * 128 * 4, "staging block");
+  // [D rows][128 queries] fp32 staging block for 16-byte global accesses (which sets the size in the one-plane modes)
+  constexpr int TILE_EL = 2 * 2 * NPL * PLANE, STAGE_EL = D * 128 * 2;
+  __shared__ __attribute__((aligned(16))) short tiles[TILE_EL > STAGE_EL ? TILE_EL : STAGE_EL];
+  auto tileA = [&](int st, int pl) -> short* { return tiles + (st * NPL + pl) * PLANE; };
+  auto tileB = [&](int st, int pl) -> short* { return tiles + ((2 + st) * NPL + pl) * PLANE; };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, kq = lane >> 4;
@@ -124,7 +116,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   const long long os = p.out_index ? p.out_index[e0] : e0;
   const csn_rsrc_t Or = csn_make_rsrc(p.out + os * p.out_eval_stride + head_off, win);
   const long long stat_off0 = ((long long)e0 * p.H + hd) * ((long long)p.n_blocks * Tq) + (long long)blk * Tq;
-  float* xbuf = reinterpret_cast<float*>(&tiles[0][0][0][0]);
+  float* xbuf = reinterpret_cast<float*>(tiles);
   constexpr int CH_T = D / 16;                                     // 16-byte chunks per thread: D rows x 32 chunks / 512
   const int cc = tid & 31, crow = tid >> 5;                        // chunk column, first row of this thread (rows + 16 t)
   const unsigned c_off = (qt * 128 + 4 * cc) < Tq ? (unsigned)(crow * ld + qt * 128 + 4 * cc) * 4u : CSN_OOB;
@@ -142,12 +134,12 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   const long long head_off_kv = (long long)hd * D * ldk + (long long)blk * T;
   const long long win_kv = ((long long)(D - 1) * ldk + (T + 3) / 4 * 4) * 4;
   const csn_rsrc_t Rr = csn_make_rsrc(p.q + qs * p.q_shape_stride + head_off, win);
-  // tile planes: bf16 elements, row pitch kv_ld = n_blocks * 1024, this block's 16 tiles start at blk * 1024
+  // tile planes: 16-bit elements, row pitch kv_ld = n_blocks * 512 NPL, this block's 16 tiles start at blk * 512 NPL
   const int kld = p.kv_ld;
-  const long long kv_off = KVP ? ks * p.kv_shape_stride + (long long)hd * D * kld + (long long)blk * 1024 : 0;
-  const long long kv_win = ((long long)(D - 1) * kld + 1024) * 2;
-  const __bf16* kpl = reinterpret_cast<const __bf16*>(BWD ? p.v : p.k);
-  const __bf16* vpl = reinterpret_cast<const __bf16*>(BWD ? p.k : p.v);
+  const long long kv_off = KVP ? ks * p.kv_shape_stride + (long long)hd * D * kld + (long long)blk * (512 * NPL) : 0;
+  const long long kv_win = ((long long)(D - 1) * kld + 512 * NPL) * 2;
+  const short* kpl = reinterpret_cast<const short*>(BWD ? p.v : p.k);
+  const short* vpl = reinterpret_cast<const short*>(BWD ? p.k : p.v);
   const csn_rsrc_t Ar = KVP ? csn_make_rsrc(kpl + kv_off, kv_win)
                             : csn_make_rsrc((BWD ? p.v : p.k) + ks * p.kv_shape_stride + head_off_kv, win_kv);
   const csn_rsrc_t Br = KVP ? csn_make_rsrc(vpl + kv_off, kv_win)
@@ -169,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   // lane picks its values from there.  Chunk c of row r sits at c ^ 4 ((r >> 3) & 1): rows 8 apart (lane quarters kq, kq+1)
   // use different banks.  Backward: delta_q = sum_d dO[d][q] O[d][q] (the softmax-backward row constant) from a second
   // round with O.
-  bf16x8 Rh[D / 32], Rl[D / 32];
+  s16x8 Rh[D / 32], Rl[D / 32];
   auto stage_in = [&](const csn_rsrc_t& rs) {
     f32x4 ch[CH_T];
 #pragma unroll
@@ -190,8 +182,8 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     for (int j = 0; j < 8; ++j) {
       const float v = pick(32 * s + 8 * kq + j);
       rv[8 * s + j] = v;
-      Rh[s][j] = (__bf16)v;
-      Rl[s][j] = (__bf16)(v - (float)Rh[s][j]);
+      Rh[s][j] = to16<PR::HALF>(v);
+      Rl[s][j] = PR::NT == 3 ? to16<PR::HALF>(v - from16<PR::HALF>(Rh[s][j])) : Rh[s][j];
     }
   float delta_q = 0.f;
   if (BWD) {
@@ -228,15 +220,18 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   const unsigned s_base = (unsigned)(qrow * Tp + 8 * kq) * 4u;
 
   // ---- streamed tiles: global -> registers -> LDS (swizzled) ---------------------------------------
-  // piece idx = tid + 512 i  ->  row (tid >> 3) + 64 i.  fp32 input: keys 4 c .. 4 c + 3, c = tid % 8.  Tile planes: 16-byte
-  // unit tid % 8 of the row's 128 bytes (units 0..3: hi plane keys 8 u .. 8 u + 7, units 4..7: lo plane).  Everything that
+  // piece idx = tid + 512 i  ->  row tid / UPR + RPP i.  fp32 input: keys 4 c .. 4 c + 3, c = tid % 8.  Tile planes: 16-byte
+  // unit tid % UPR of the row's 64 NPL bytes (units 0..3: hi plane keys 8 u .. 8 u + 7, units 4..7: lo plane).  Everything that
   // depends on i is wave-uniform (scalar offset of the load, immediate offset of the LDS store): rows 64 apart share the swizzles.
-  const int t_c = tid & 7, t_row = tid >> 3;
+  const int t_c = tid & (UPR - 1), t_row = tid / UPR;
+  constexpr int SWB = (KVP && NPL == 1) ? 1 : 0;        // one plane: a 16-lane store group covers rows r .. r + 3 — swap on bit 1
   // tileA chunk swap: rows r and r + 8 are read together by the transposing read, and the 8-byte stores of a 16-lane group
   // cover rows r, r + 1 of both planes — so the swap bit is (r >> 3) ^ r: both pairs then sit on complementary banks
-  const int t_sw = (CSN_LDS_V ? ((t_row >> 3) ^ t_row) : (t_row >> 3)) & 1, t_swz = (-((t_row >> 2) & 3)) & 3;
+  const int t_sw = (CSN_LDS_V ? ((t_row >> 3) ^ (t_row >> SWB)) : (t_row >> 3)) & 1, t_swz = (-((t_row >> 2) & 3)) & 3;
   const unsigned t_off = KVP ? (unsigned)(t_row * kld * 2 + t_c * 16) : (unsigned)(t_row * ldk + 4 * t_c) * 4u;
-  const bool t_last_ok = tid + 512 * (NP_T - 1) < PIECES;         // only the last piece can fall beyond the tile
+  // only the last piece can fall beyond the tile — and not even that one when the pieces fill the passes (compile-time: the
+  // guards around the last piece's stores fold away)
+  const bool t_last_ok = (PIECES % 512 == 0) || (tid + 512 * (NP_T - 1) < PIECES);
   // fp32: 8-byte chunk c -> tileA chunk c ^ sw;  tileB unit (c >> 1) ^ swz, half c & 1
   // planes: unit u = c & 3 of plane c >> 2 -> tileA chunks (2 u) ^ sw and (2 u + 1) ^ sw;  tileB unit u ^ swz
   const int t_u = t_c & 3, t_pl = t_c >> 2;
@@ -249,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
       const unsigned off = (kt * KT + 8 * t_u) < T ? t_off : CSN_OOB;
 #pragma unroll
       for (int i = 0; i < NP_T; ++i)
-        g[i] = csn_bload4(rs, (i == NP_T - 1 && !t_last_ok) ? CSN_OOB : off, (unsigned)(kt * 128 + 64 * i * kld * 2));
+        g[i] = csn_bload4(rs, (i == NP_T - 1 && !t_last_ok) ? CSN_OOB : off, (unsigned)(kt * (64 * NPL) + RPP * i * kld * 2));
     } else {
       const int k0 = kt * KT;
       // T % 4 == 0: a 16-byte piece is all in or all out; pieces past the block end are switched off
@@ -264,15 +259,15 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     for (int i = 0; i < NP_T; ++i)
       if (i < NP_T - 1 || t_last_ok) {
         if (KVP) {
-          __bf16* base = &tileA[st][0][a_dst + 64 * KT * i];
-          const bf16x8 v = __builtin_bit_cast(bf16x8, g[i]);
-          *reinterpret_cast<bf16x4*>(base + 4 * t_sw) = bf16x4{v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<bf16x4*>(base + 4 * (t_sw ^ 1)) = bf16x4{v[4], v[5], v[6], v[7]};
+          short* base = tileA(st, 0) + a_dst + RPP * KT * i;
+          const s16x8 v = __builtin_bit_cast(s16x8, g[i]);
+          *reinterpret_cast<s16x4*>(base + 4 * t_sw) = s16x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<s16x4*>(base + 4 * (t_sw ^ 1)) = s16x4{v[4], v[5], v[6], v[7]};
         } else {
-          bf16x4 hi, lo;
-          split4(g[i], hi, lo);
-          *reinterpret_cast<bf16x4*>(&tileA[st][0][a_dst + 64 * KT * i]) = hi;
-          *reinterpret_cast<bf16x4*>(&tileA[st][1][a_dst + 64 * KT * i]) = lo;
+          s16x4 hi, lo;
+          split4<PR>(g[i], hi, lo);
+          *reinterpret_cast<s16x4*>(tileA(st, 0) + a_dst + RPP * KT * i) = hi;
+          *reinterpret_cast<s16x4*>(tileA(st, NPL - 1) + a_dst + RPP * KT * i) = lo;
         }
       }
   };
@@ -281,12 +276,12 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     for (int i = 0; i < NP_T; ++i)
       if (i < NP_T - 1 || t_last_ok) {
         if (KVP) {
-          *reinterpret_cast<f32x4*>(&tileB[st][0][b_dst + 64 * KT * i]) = g[i];
+          *reinterpret_cast<f32x4*>(tileB(st, 0) + b_dst + RPP * KT * i) = g[i];
         } else {
-          bf16x4 hi, lo;
-          split4(g[i], hi, lo);
-          *reinterpret_cast<bf16x4*>(&tileB[st][0][b_dst + 64 * KT * i]) = hi;
-          *reinterpret_cast<bf16x4*>(&tileB[st][1][b_dst + 64 * KT * i]) = lo;
+          s16x4 hi, lo;
+          split4<PR>(g[i], hi, lo);
+          *reinterpret_cast<s16x4*>(tileB(st, 0) + b_dst + RPP * KT * i) = hi;
+          *reinterpret_cast<s16x4*>(tileB(st, NPL - 1) + b_dst + RPP * KT * i) = lo;
         }
       }
   };
@@ -295,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   // row 8 kq + q' and the 4-key chunk that feeds score rows 4 p .. 4 p + 3: keys 8 p .. 8 p + 3 for S0, 8 p + 4 .. for S1
   // (chunks swapped inside their 16-byte unit when (row >> 3) & 1 = kq & 1 is set)
   const int tr_row = 8 * kq + (lq >> 2);
-  const int tr_sw = (CSN_LDS_V ? (kq ^ (lq >> 2)) : kq) & 1;      // = the store side's swap bit of row tr_row (and of tr_row + 4)
+  const int tr_sw = (CSN_LDS_V ? (kq ^ (lq >> (2 + SWB))) : kq) & 1;      // = the store side's swap bit of row tr_row (and of tr_row + 4)
   const int a_pos0 = tr_row * KT + 8 * (lq & 3) + 4 * tr_sw, a_pos1 = tr_row * KT + 8 * (lq & 3) + 4 * (tr_sw ^ 1);
   // tileB: row lq of the 16-channel tile, 16-byte unit kq ^ ((-(lq >> 2)) & 3): keys 8 kq .. 8 kq + 7
   const int b_pos = lq * KT + 8 * (kq ^ ((-((lq >> 2) & 3)) & 3));
@@ -307,7 +302,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   bool j_ok[2];
   float sv[8];
   f32x4v S0, S1;
-  bf16x8 ph, pl;                                        // T1 as a 32-key B fragment, split into bf16 hi / lo
+  s16x8 ph, pl;                                         // T1 as a 32-key B fragment, split into hi / lo
   auto score_pos = [&](int kt) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -335,35 +330,42 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   auto phase1 = [&](int st) {
     S0 = f32x4v{0.f, 0.f, 0.f, 0.f};
     S1 = f32x4v{0.f, 0.f, 0.f, 0.f};
-    const __bf16* __restrict__ tAh = tileA[st][0];
-    const __bf16* __restrict__ tAl = tileA[st][1];
+    const short* __restrict__ tAh = tileA(st, 0);
+    const short* __restrict__ tAl = tileA(st, NPL - 1);
     constexpr int NH = 2 * (D / 32);                    // half steps: (s, 16-key tile t)
-    bf16x8 ah[PD], al[PD];
-    auto rd = [&](int h, bf16x8& fh, bf16x8& fl) {
+    s16x8 ah[PD], al[PD];
+    auto rd = [&](int h, s16x8& fh, s16x8& fl) {
       const int o = 32 * (h >> 1) * KT + ((h & 1) ? a_pos1 : a_pos0);
       fh = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAh + o)),
                  __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAh + o + 4 * KT)));
-      fl = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAl + o)),
-                 __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAl + o + 4 * KT)));
+      if constexpr (NPL == 2)
+        fl = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAl + o)),
+                   __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAl + o + 4 * KT)));
+      else fl = fh;
     };
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int h = 0; h < PD && h < NH; ++h) rd(h, ah[h], al[h]);
-    __builtin_amdgcn_sched_group_barrier(0x100, 4 * (PD < NH ? PD : NH), 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * NPL * (PD < NH ? PD : NH), 0);
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int r = h % PD, sidx = h >> 1;
-      if (h & 1) S1 = mfma3(ah[r], al[r], Rh[sidx], Rl[sidx], S1);
-      else S0 = mfma3(ah[r], al[r], Rh[sidx], Rl[sidx], S0);
+      if (h & 1) S1 = mma16<PR>(ah[r], al[r], Rh[sidx], Rl[sidx], S1);
+      else S0 = mma16<PR>(ah[r], al[r], Rh[sidx], Rl[sidx], S0);
       if (h + PD < NH) rd(h + PD, ah[r], al[r]);
-      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, PR::NT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NPL, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
   // pointwise: softmax / dropout (forward), dS (backward); leaves T1 in (ph, pl)
   auto pointwise = [&](int kt) {
     score_pos(kt);
+    // keys beyond the block end exist only in the LAST tile: the masking below is one wave-uniform branch per tile and
+    // selects inside it (the per-element form compiled to sixteen exec-mask branches in every tile's vector segment).
+    // nv = valid keys among this lane's 8 (queries beyond the block need no mask: their rows are zeros and are never stored)
+    const bool last_tile = kt == nkt - 1;
+    const int nv = T - (kt * KT + 8 * kq);
     float t1[8] = {S0[0], S0[1], S0[2], S0[3], S1[0], S1[1], S1[2], S1[3]};
     // keep decisions of this lane's 8 elements: one hash per key pair (csn_common.h)
     bool keep[8];
@@ -376,12 +378,11 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
       }
     }
     if (!BWD) {
-      float mx = -INFINITY;
+      if (last_tile) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {
-        if (!j_ok[r >> 2] || (ragged && kt * KT + 8 * kq + r >= T)) t1[r] = -INFINITY;
-        mx = fmaxf(mx, t1[r]);
+        for (int r = 0; r < 8; ++r) t1[r] = r < nv ? t1[r] : -INFINITY;
       }
+      float mx = fmaxf(fmaxf(fmaxf(t1[0], t1[1]), fmaxf(t1[2], t1[3])), fmaxf(fmaxf(t1[4], t1[5]), fmaxf(t1[6], t1[7])));
 #pragma unroll
       for (int j = 0; j < 2; ++j)                              // (zero-sized window when scores are not kept)
         csn_bstore4(f32x4{t1[4 * j], t1[4 * j + 1], t1[4 * j + 2], t1[4 * j + 3]}, Sr, s_voff[j]);
@@ -411,10 +412,16 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
         for (int r = 0; r < 8; ++r) t1[r] = keep[r] ? t1[r] * keep_scale : 0.f;
       }
     } else {
+      float pvs[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) pvs[r] = __builtin_amdgcn_exp2f(fmaf(sv[r], LOG2E, -lse2_q));   // softmax probability (csa_models.py:141)
+      if (last_tile) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pvs[r] = r < nv ? pvs[r] : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const bool ok = s_voff[r >> 2] != CSN_OOB && !(ragged && kt * KT + 8 * kq + r >= T);
-        const float pv = ok ? __builtin_amdgcn_exp2f(fmaf(sv[r], LOG2E, -lse2_q)) : 0.f;   // softmax probability (csa_models.py:141)
+        const float pv = pvs[r];
         const float md = (!drop || keep[r]) ? keep_scale : 0.f;    // d P_drop / d P
         const float ds = pv * (t1[r] * md - delta_q);              // d softmax (delta = rowsum(dO * O) already has the mask)
         sv[r] = pv * md;                                           // what the dV product needs: the dropped probabilities
@@ -430,49 +437,59 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      ph[r] = (__bf16)t1[r];
-      pl[r] = (__bf16)(t1[r] - (float)ph[r]);
+      ph[r] = to16<PR::HALF>(t1[r]);
+      pl[r] = PR::NT == 3 ? to16<PR::HALF>(t1[r] - from16<PR::HALF>(ph[r])) : ph[r];
     }
     if (BWD && p.sc_tiles) {
-      // P and dS leave as bf16 tile planes, per query row 16 tiles of [hi: 32 keys | lo: 32 keys] — the k-major operand
-      // the dV / dK products stage without conversion work.  P overwrites exactly the bytes of the scores of this tile
-      // (already consumed by this wave); keys beyond the block end are written as zeros.
-      const unsigned tv = q_ok ? (unsigned)(qrow * Tp) * 4u + (unsigned)(kt * 128 + 16 * kq) : CSN_OOB;
-      bf16x8 qh, ql;
+      // P and dS leave as tile planes, per query row 16 tiles of [hi: 32 keys | lo: 32 keys] — the k-major operand
+      // the dV / dK products stage without conversion work; keys beyond the block end are written as zeros.
+      s16x8 qh, ql;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        qh[r] = (__bf16)sv[r];
-        ql[r] = (__bf16)(sv[r] - (float)qh[r]);
+        qh[r] = to16<PR::HALF>(sv[r]);
+        ql[r] = PR::NT == 3 ? to16<PR::HALF>(sv[r] - from16<PR::HALF>(qh[r])) : qh[r];
       }
-      csn_bstore4(__builtin_bit_cast(f32x4, qh), Sr, tv);
-      csn_bstore4(__builtin_bit_cast(f32x4, ql), Sr, tv, 64u);
-      csn_bstore4(__builtin_bit_cast(f32x4, ph), dSr, tv);
-      csn_bstore4(__builtin_bit_cast(f32x4, pl), dSr, tv, 64u);
+      if constexpr (NPL == 2) {
+        // two planes: a row of 16 tiles is exactly the bytes of the fp32 score row — P overwrites the scores of this tile
+        // (already consumed by this wave) in place, dS takes the same place in `dscores`
+        const unsigned tv = q_ok ? (unsigned)(qrow * Tp) * 4u + (unsigned)(kt * 128 + 16 * kq) : CSN_OOB;
+        csn_bstore4(__builtin_bit_cast(f32x4, qh), Sr, tv);
+        csn_bstore4(__builtin_bit_cast(f32x4, ql), Sr, tv, 64u);
+        csn_bstore4(__builtin_bit_cast(f32x4, ph), dSr, tv);
+        csn_bstore4(__builtin_bit_cast(f32x4, pl), dSr, tv, 64u);
+      } else {
+        // one plane: a row is half the bytes, so compact rows cannot overwrite the scores in place (they would run over the
+        // rows of other work-groups).  Both go to this block's region of `dscores`: [P: Tq rows | dS: Tq rows] of pitch Tp
+        // 16-bit elements; the scores stay untouched
+        const unsigned tv = q_ok ? (unsigned)(qrow * Tp) * 2u + (unsigned)(kt * 64 + 16 * kq) : CSN_OOB;
+        csn_bstore4(__builtin_bit_cast(f32x4, qh), dSr, tv);
+        csn_bstore4(__builtin_bit_cast(f32x4, ph), dSr, tv, (unsigned)(Tq * Tp) * 2u);
+      }
     }
   };
   // phase 2: OUT[c][q] += sum_key tileB[c][key] T1[key][q]
   auto phase2 = [&](int st) {
-    const __bf16* __restrict__ tBh = tileB[st][0];
-    const __bf16* __restrict__ tBl = tileB[st][1];
+    const short* __restrict__ tBh = tileB(st, 0);
+    const short* __restrict__ tBl = tileB(st, NPL - 1);
     constexpr int NC = D / 16;
-    bf16x8 vh[PD], vl[PD];
+    s16x8 vh[PD], vl[PD];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < PD && c < NC; ++c) {
-      vh[c] = *reinterpret_cast<const bf16x8*>(tBh + c * 16 * KT + b_pos);
-      vl[c] = *reinterpret_cast<const bf16x8*>(tBl + c * 16 * KT + b_pos);
+      vh[c] = *reinterpret_cast<const s16x8*>(tBh + c * 16 * KT + b_pos);
+      vl[c] = *reinterpret_cast<const s16x8*>(tBl + c * 16 * KT + b_pos);
     }
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (PD < NC ? PD : NC), 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, NPL * (PD < NC ? PD : NC), 0);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int r = c % PD;
-      O[c] = mfma3(vh[r], vl[r], ph, pl, O[c]);
+      O[c] = mma16<PR>(vh[r], vl[r], ph, pl, O[c]);
       if (c + PD < NC) {
-        vh[r] = *reinterpret_cast<const bf16x8*>(tBh + (c + PD) * 16 * KT + b_pos);
-        vl[r] = *reinterpret_cast<const bf16x8*>(tBl + (c + PD) * 16 * KT + b_pos);
+        vh[r] = *reinterpret_cast<const s16x8*>(tBh + (c + PD) * 16 * KT + b_pos);
+        vl[r] = *reinterpret_cast<const s16x8*>(tBl + (c + PD) * 16 * KT + b_pos);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, PR::NT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -571,20 +588,25 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   WGSTAMP(3);
 }
 
-template <int DT>
+template <typename PR, int DT>
 int launch_dt(const CsnAttnArgs& a, bool bwd, hipStream_t st) {
   const long long units = (long long)a.n_blocks * a.H * a.E;
   dim3 grid((unsigned)(((units + 7) / 8) * 8 * (((a.Tq > 0 ? a.Tq : a.T) + 127) / 128)));
   if (a.kv_planes) {
-    if (bwd) hipLaunchKernelGGL((csn_attn_bf16x3_kernel<DT, true, true>), grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((csn_attn_bf16x3_kernel<DT, false, true>), grid, dim3(512), 0, st, a);
+    if (bwd) {
+      if constexpr (!PR::HALF) hipLaunchKernelGGL((csn_attn_bf16x3_kernel<PR, DT, true, true>), grid, dim3(512), 0, st, a);
+      else return -1;                                               // fp16: forward only (gradients underflow fp16)
+    } else hipLaunchKernelGGL((csn_attn_bf16x3_kernel<PR, DT, false, true>), grid, dim3(512), 0, st, a);
   } else {
-    if (bwd) hipLaunchKernelGGL((csn_attn_bf16x3_kernel<DT, true, false>), grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((csn_attn_bf16x3_kernel<DT, false, false>), grid, dim3(512), 0, st, a);
+    if constexpr (PR::NT == 3) {
+      if (bwd) hipLaunchKernelGGL((csn_attn_bf16x3_kernel<PR, DT, true, false>), grid, dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((csn_attn_bf16x3_kernel<PR, DT, false, false>), grid, dim3(512), 0, st, a);
+    } else return -1;                                               // single-product modes: tile-plane K / V only
   }
   return (int)hipGetLastError();
 }
 
+template <typename PR>
 int launch_any(const CsnAttnArgs& a, int d, bool bwd, hipStream_t st) {
   if (a.E <= 0 || a.n_blocks <= 0) return 0;
   if ((a.ld & 3) || (a.Tp & 3) || (a.ld_kv & 3)) return -2;
@@ -593,16 +615,25 @@ int launch_any(const CsnAttnArgs& a, int d, bool bwd, hipStream_t st) {
   if (a.sc_tiles && a.Tp < (a.T + 31) / 32 * 32) return -2;
   if (a.kv_planes && (a.T > 512 || (a.kv_ld & 7) || (a.kv_shape_stride & 7))) return -2;    // 16 tiles of 32 keys per block
   switch (d) {
-    case 32: return launch_dt<1>(a, bwd, st);
-    case 64: return launch_dt<2>(a, bwd, st);
-    case 96: return launch_dt<3>(a, bwd, st);
-    case 128: return launch_dt<4>(a, bwd, st);
-    case 256: return launch_dt<8>(a, bwd, st);
+    case 32: return launch_dt<PR, 1>(a, bwd, st);
+    case 64: return launch_dt<PR, 2>(a, bwd, st);
+    case 96: return launch_dt<PR, 3>(a, bwd, st);
+    case 128: return launch_dt<PR, 4>(a, bwd, st);
+    case 256: return launch_dt<PR, 8>(a, bwd, st);
     default: return -5;
+  }
+}
+
+int launch_mode(const CsnAttnArgs& a, int d, int mode, bool bwd, hipStream_t st) {
+  switch (mode) {
+    case 1: return launch_any<Bf16x3>(a, d, bwd, st);
+    case 2: return launch_any<Bf16>(a, d, bwd, st);
+    case 3: return launch_any<F16>(a, d, bwd, st);
+    default: return -1;
   }
 }
 
 }  // namespace
 
-int csn_launch_attn_fwd_bf16x3(const CsnAttnArgs& a, int d, hipStream_t st) { return launch_any(a, d, false, st); }
-int csn_launch_attn_bwd_bf16x3(const CsnAttnArgs& a, int d, hipStream_t st) { return launch_any(a, d, true, st); }
+int csn_launch_attn_fwd_bf16x3(const CsnAttnArgs& a, int d, int mode, hipStream_t st) { return launch_mode(a, d, mode, false, st); }
+int csn_launch_attn_bwd_bf16x3(const CsnAttnArgs& a, int d, int mode, hipStream_t st) { return launch_mode(a, d, mode, true, st); }

@@ -5,14 +5,26 @@
 
 namespace {
 
-int g_math_mode = 0;       // 0: exact fp32 matrix cores; 1: three bf16 products per fp32 product (plain contractions)
+// 0: exact fp32 matrix cores; 1: bf16x3 (three bf16 products per fp32 product); 2: bf16; 3: fp16 (one product)
+int g_math_mode = CSN_MATH_BF16X3;          // process default (csn_set_math_mode)
+thread_local int t_math_mode = -1;          // per-thread override (csn_set_thread_math_mode); -1 = none
+
+inline int mode() { return t_math_mode >= 0 ? t_math_mode : g_math_mode; }
+inline int planes_of(int m) { return m == 1 ? 2 : 1; }          // tile-plane / split-tensor planes of a 16-bit mode
+
+// the cross-length entry points (fp32 K / V maps) have no single-product kernels: in modes 2 / 3 they run as mode 1
+struct ModeGuard {
+  int saved;
+  explicit ModeGuard(int m) : saved(t_math_mode) { t_math_mode = m; }
+  ~ModeGuard() { t_math_mode = saved; }
+};
 
 int launch_gemm(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st) {
-  if (g_math_mode == 1) {
+  if (mode() != 0) {
     if (a.M <= 0 || a.N <= 0 || batch <= 0) return 0;
     if ((a.A.ld & 3) || (a.B.ld & 3) || (a.K & 3) || (a.k_chunk & 3)) return CSN_E_ALIGN;
     if (!b_is_nk && (a.N & 3)) return CSN_E_ALIGN;
-    return csn_launch_gemm_bf16x3(a, b_is_nk, batch, st);
+    return csn_launch_gemm_bf16x3(a, b_is_nk, batch, mode(), st);
   }
   return csn_launch_gemm_f32(a, b_is_nk, batch, st);
 }
@@ -67,12 +79,17 @@ extern "C" {
 
 int csn_version(void) { return CSN_ABI_VERSION; }
 
-int csn_set_math_mode(int mode) {
-  if (mode != 0 && mode != 1) return CSN_E_ARG;
-  g_math_mode = mode;
+int csn_set_math_mode(int m) {
+  if (m < 0 || m > 3) return CSN_E_ARG;
+  g_math_mode = m;
   return 0;
 }
-int csn_get_math_mode(void) { return g_math_mode; }
+int csn_set_thread_math_mode(int m) {
+  if (m < -1 || m > 3) return CSN_E_ARG;
+  t_math_mode = m;
+  return 0;
+}
+int csn_get_math_mode(void) { return mode(); }
 
 const char* csn_status_string(int status) {
   switch (status) {
@@ -97,15 +114,17 @@ long long csn_wgrad_workspace_floats(int rows, int cols, int n_maps, int n_point
 int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const float* w, int rows, int channels,
                     float* out, long long out_shape_stride, int ld_out, int n_shapes, int n_points, int div_rows,
                     float temperature, int out_split, long long out_plane_stride, void* stream) {
-  if (out_split && g_math_mode != 1) return CSN_E_ARG;
+  if (out_split && mode() == 0) return CSN_E_ARG;
   if (out_split < 0 || out_split > 2) return CSN_E_ARG;
   if (!x || !w || !out || rows <= 0 || channels <= 0 || n_shapes <= 0 || n_points <= 0) return CSN_E_ARG;
   if (out_split == 2) {
-    // tile planes: out_plane_stride = points per attention block (<= 512), ld_out = row pitch = n_blocks * 1024 bf16
-    if (out_plane_stride <= 0 || out_plane_stride > 512 || (out_plane_stride & 3) || (ld_out & 1023)) return CSN_E_ARG;
-    if (((long long)n_points + out_plane_stride - 1) / out_plane_stride * 1024 > ld_out) return CSN_E_ARG;
+    // tile planes: out_plane_stride = points per attention block (<= 512), ld_out = row pitch = n_blocks * 512 * planes
+    const int bp = 512 * planes_of(mode());
+    if (out_plane_stride <= 0 || out_plane_stride > 512 || (out_plane_stride & 3) || (ld_out % bp)) return CSN_E_ARG;
+    if (((long long)n_points + out_plane_stride - 1) / out_plane_stride * bp > ld_out) return CSN_E_ARG;
     if (out_shape_stride & 7) return CSN_E_STRIDE;
   }
+  if (out_split == 1 && mode() != 1) return CSN_E_ARG;              // whole hi / lo planes: mode 1 only
   if ((ld_x & 3) || (ld_out & 3) || (n_points & 3) || (channels & 3)) return CSN_E_ALIGN;
   if (mis16(x) || mis16(w) || mis16(out)) return CSN_E_PTR;
   if ((x_shape_stride & 3) || (out_shape_stride & 3)) return CSN_E_STRIDE;
@@ -132,8 +151,10 @@ static int attn_fwd_impl(const float* q, const float* k, const float* v, long lo
   if (block_q < 0 || ld_kv < 0 || (ld_kv & 3) || (long long)n_blocks * ((block + 3) / 4 * 4) > lk) return CSN_E_ARG;
   if ((block & 3) && (block_q == 0 || qkv_split)) return CSN_E_ALIGN;
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
-  if (qkv_split && g_math_mode != 1) return CSN_E_ARG;
-  if (qkv_split && (qkv_plane_stride <= 0 || (qkv_plane_stride & 1023) || qkv_plane_stride < (long long)n_blocks * 1024 ||
+  if (qkv_split && mode() == 0) return CSN_E_ARG;
+  if (!qkv_split && mode() >= 2) return CSN_E_ARG;                   // single-product modes take K / V as tile planes
+  const int bp = 512 * planes_of(mode());
+  if (qkv_split && (qkv_plane_stride <= 0 || (qkv_plane_stride % bp) || qkv_plane_stride < (long long)n_blocks * bp ||
                     block > 512 || (kv_shape_stride & 7)))
     return CSN_E_ARG;
   if (!q || !k || !v || !ctx || n_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
@@ -155,8 +176,8 @@ static int attn_fwd_impl(const float* q, const float* k, const float* v, long lo
   a.eval_ids = nullptr; a.grp_off = nullptr; a.out_index = nullptr; a.accumulate = 0;
   a.dropout_p = dropout_p; a.seed = seed;
   a.r_planes = 0; a.kv_planes = qkv_split; a.r_plane_stride = 0; a.kv_plane_stride = 0; a.sc_tiles = 0;
-  return g_math_mode == 1 ? csn_launch_attn_fwd_bf16x3(a, d_head, (hipStream_t)stream)
-                          : csn_launch_attn_fwd_f32(a, d_head, (hipStream_t)stream);
+  return mode() != 0 ? csn_launch_attn_fwd_bf16x3(a, d_head, mode(), (hipStream_t)stream)
+                     : csn_launch_attn_fwd_f32(a, d_head, (hipStream_t)stream);
 }
 
 int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
@@ -175,6 +196,7 @@ int csn_cross_attn_fwd_f32(const float* q, const float* k, const float* v, long 
                            float* scores, float* lse, int n_evals, int n_heads, int d_head, int n_queries, int n_keys,
                            int score_pitch, float rescale_threshold, float dropout_p, unsigned long long seed, void* stream) {
   if (n_queries <= 0 || n_keys <= 0 || (n_queries & 3)) return CSN_E_ARG;
+  ModeGuard guard(mode() >= 2 ? 1 : mode());
   return attn_fwd_impl(q, k, v, q_shape_stride, kv_shape_stride, nullptr, nullptr, ld_q, ctx, ctx_eval_stride, scores, lse,
                        n_evals, n_heads, d_head, n_keys, 1, score_pitch, rescale_threshold, dropout_p, seed, 0, 0, n_queries,
                        ld_kv, stream);
@@ -191,11 +213,14 @@ static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_e
   if (block_q < 0 || ld_kv < 0 || (ld_kv & 3)) return CSN_E_ARG;
   if (group_offsets && (n_groups <= 0 || !eval_ids || !(csn_attn_bwd_grouping(d_head, block) & 1))) return CSN_E_ARG;
   if ((block & 3) && (block_q == 0 || kv_split)) return CSN_E_ALIGN;
-  if (probs_tiles && (g_math_mode != 1 || score_pitch < (block + 31) / 32 * 32)) return CSN_E_ARG;
+  if (probs_tiles && (mode() == 0 || score_pitch < (block + 31) / 32 * 32)) return CSN_E_ARG;
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
   if (dctx_split) return CSN_E_ARG;                                  // reserved (see header)
-  if (kv_split && g_math_mode != 1) return CSN_E_ARG;
-  if (kv_split && (kv_plane_stride <= 0 || (kv_plane_stride & 1023) || kv_plane_stride < (long long)n_blocks * 1024 ||
+  if (kv_split && mode() == 0) return CSN_E_ARG;
+  if (mode() == 3) return CSN_E_ARG;                                 // fp16: forward only — run the backward in mode 2
+  if (mode() == 2 && !(kv_split && probs_tiles)) return CSN_E_ARG;   // single-product mode: tile planes in and out
+  const int bp = 512 * planes_of(mode());
+  if (kv_split && (kv_plane_stride <= 0 || (kv_plane_stride % bp) || kv_plane_stride < (long long)n_blocks * bp ||
                    block > 512 || (kv_shape_stride & 7)))
     return CSN_E_ARG;
   if (!dctx || !ctx || !k || !v || !scores || !dscores || !lse || !delta || !dq) return CSN_E_ARG;
@@ -222,7 +247,7 @@ static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_e
   a.dropout_p = dropout_p; a.seed = seed;
   a.r_planes = 0; a.kv_planes = kv_split; a.r_plane_stride = 0; a.kv_plane_stride = 0; a.kv_ld = (int)kv_plane_stride;
   a.sc_tiles = probs_tiles;
-  return g_math_mode == 1 ? csn_launch_attn_bwd_bf16x3(a, d_head, st) : csn_launch_attn_bwd_f32(a, d_head, st);
+  return mode() != 0 ? csn_launch_attn_bwd_bf16x3(a, d_head, mode(), st) : csn_launch_attn_bwd_f32(a, d_head, st);
 }
 
 int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* k,
@@ -252,7 +277,8 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   if ((block & 3) && block_q == 0) return CSN_E_ALIGN;
   const int bq = block_q > 0 ? block_q : block, lk = ld_kv > 0 ? ld_kv : ld, bk4 = (block + 3) / 4 * 4;
   if ((long long)n_blocks * bk4 > lk) return CSN_E_ARG;
-  if (probs_tiles && (g_math_mode != 1 || score_pitch < (block + 31) / 32 * 32)) return CSN_E_ARG;
+  if (probs_tiles && (mode() == 0 || score_pitch < (block + 31) / 32 * 32)) return CSN_E_ARG;
+  if (mode() == 3 || (mode() == 2 && !probs_tiles)) return CSN_E_ARG;
   if (dctx_split || q_split) return CSN_E_ARG;                       // reserved (see header)
   if (group_offsets && (n_groups <= 0 || !eval_ids || !(csn_attn_bwd_grouping(d_head, block) & 2))) return CSN_E_ARG;
   if (!dctx || !q || !probs || !dscores || !dk || !dv) return CSN_E_ARG;
@@ -273,16 +299,22 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   const int n_batch = group_offsets ? n_groups : n_launch_evals;
   g.A = operand(dctx, bq, (long long)d_head * ld, dctx_split ? 2 * ctx_eval_stride : ctx_eval_stride, nullptr, ld);
   g.A.planes = dctx_split; g.A.plane_stride = dctx_plane_stride;
-  // tile planes: the same buffers viewed as bf16 (two bf16 per float: strides and pitch double)
+  // tile planes: the same buffers viewed as 16-bit elements (two per float: block strides double).  Two planes (mode 1): a
+  // row of 16 tiles [hi | lo] is the fp32 row, pitch 2 * score_pitch, P in `probs`, dS in `dscores`.  One plane (mode 2):
+  // compact rows of pitch score_pitch, both in `dscores` — per block [P: bq rows | dS: bq rows] (`probs` is not read)
   const int bm = probs_tiles ? 2 : 1;
-  g.B = operand(probs, bm * blk_sc, bm * blk_sc * n_blocks, bm * blk_sc * n_blocks * n_heads, nullptr, bm * score_pitch);
+  const bool one_plane = probs_tiles && mode() == 2;
+  const int ldb = one_plane ? score_pitch : bm * score_pitch;
+  const float* p_src = one_plane ? dscores : probs;
+  const float* ds_src = one_plane ? reinterpret_cast<const float*>(reinterpret_cast<const short*>(dscores) + blk_sc) : dscores;
+  g.B = operand(p_src, bm * blk_sc, bm * blk_sc * n_blocks, bm * blk_sc * n_blocks * n_heads, nullptr, ldb);
   g.B.planes = probs_tiles ? 2 : 0;
   g.C = operand(dv, block, (long long)d_head * lk, dkv_slot_stride, dv_index, lk);
   int rc = launch_gemm(g, 0, n_blocks * n_heads * n_batch, st);
   if (rc) return rc;
   g.A = operand(q, bq, (long long)d_head * ld, q_shape_stride, q_index, ld);
   g.A.planes = q_split; g.A.plane_stride = q_plane_stride;
-  g.B = operand(dscores, bm * blk_sc, bm * blk_sc * n_blocks, bm * blk_sc * n_blocks * n_heads, nullptr, bm * score_pitch);
+  g.B = operand(ds_src, bm * blk_sc, bm * blk_sc * n_blocks, bm * blk_sc * n_blocks * n_heads, nullptr, ldb);
   g.B.planes = probs_tiles ? 2 : 0;
   g.C = operand(dk, block, (long long)d_head * lk, dkv_slot_stride, dk_index, lk);
   return launch_gemm(g, 0, n_blocks * n_heads * n_batch, st);
@@ -302,7 +334,7 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
 }
 
 int csn_attn_bwd_grouping(int d_head, int block) {
-  if (g_math_mode != 1) return 0;
+  if (mode() == 0) return 0;
   return 1 | (csn_gemm_bf16x3_big_tiles(d_head, (block + 3) / 4 * 4) ? 2 : 0);
 }
 
@@ -315,7 +347,8 @@ int csn_cross_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_ev
                            int n_queries, int n_keys, int score_pitch, float dropout_p, unsigned long long seed,
                            void* stream) {
   if (n_queries <= 0 || n_keys <= 0 || (n_queries & 3)) return CSN_E_ARG;
-  const int pt = (g_math_mode == 1 && score_pitch >= (n_keys + 31) / 32 * 32) ? 1 : 0;
+  ModeGuard guard(mode() >= 2 ? 1 : mode());
+  const int pt = (mode() != 0 && score_pitch >= (n_keys + 31) / 32 * 32) ? 1 : 0;
   int rc = attn_bwd_dq_impl(dctx, ctx, ctx_eval_stride, k, v, kv_shape_stride, nullptr, ld_q, scores, dscores, lse, delta, dq,
                             dq_eval_stride, nullptr, 0, nullptr, n_evals, n_heads, d_head, n_keys, 1, score_pitch, dropout_p,
                             seed, 0, 0, 0, 0, pt, n_queries, ld_kv, nullptr, 0, stream);
@@ -344,7 +377,7 @@ int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const fl
   a.E = n_evals; a.C = d_model; a.D = d_inner; a.ld = ld; a.n_points = n_points; a.eps = eps;
   a.dropout_p = dropout_p; a.seed = seed;
   a.xhat_sum = xhat_sum; a.sum_ws = sum_ws; a.sum_ws_floats = sum_ws ? sum_ws_floats : 0;
-  return csn_launch_outproj_ln_fwd_f32(a, g_math_mode == 1, (hipStream_t)stream);
+  return csn_launch_outproj_ln_fwd_f32(a, mode(), (hipStream_t)stream);
 }
 
 int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* rstd, long long eval_stride,
@@ -356,7 +389,7 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
                            void* stream) {
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
   if (dxhat_group < 0) return CSN_E_ARG;
-  if (dctx_split && g_math_mode != 1) return CSN_E_ARG;
+  if (dctx_split && mode() == 0) return CSN_E_ARG;
   if (n_dense_evals < 0 || n_dense_evals > n_evals || (n_dense_evals > 0 && !dxhat)) return CSN_E_ARG;
   if (!xhat || !rstd || !ctx || !wfc_t || !dz || !dctx || !dwfc || !ws) return CSN_E_ARG;
   if (n_evals <= 0 || n_points <= 0 || d_inner <= 0 || d_model <= 0) return CSN_E_ARG;

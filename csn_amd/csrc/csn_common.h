@@ -61,6 +61,9 @@ CSN_DEVINL u32x2 csn_bload2(csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
 CSN_DEVINL void csn_bstore_bf16(__bf16 v, csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
   __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, v), r, voff, soff, 0);
 }
+CSN_DEVINL void csn_bstore16(short v, csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
+  __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, r, voff, soff, 0);
+}
 
 // Guarded 16-byte load of 4 consecutive floats row[c..c+3]; elements at index >= clim read as 0.
 // row + c must be 16-byte aligned when c + 3 < clim (hosts check ld % 4 == 0 and offsets % 4 == 0).
@@ -123,6 +126,58 @@ CSN_DEVINL unsigned csn_block_salt(unsigned long long block_id, unsigned long lo
 }
 CSN_DEVINL unsigned csn_pair_hash(unsigned pair_index, unsigned salt) { return csn_mix32(pair_index ^ salt); }
 CSN_DEVINL unsigned csn_drop_threshold16(float p) { return (unsigned)(p * 65536.0f); }
+
+// ---- 16-bit matrix-core arithmetic: math modes 1..3 -----------------------------------------------------------------
+// A mode is a compile-time policy of the 16-bit kernels (gemm_bf16x3.hip, attn_bf16x3.hip, outproj_ln.hip):
+//   Bf16x3 (mode 1)  x = hi + lo (two bf16), product = hi*hi + hi*lo + lo*hi: NT = 3 matrix instructions, NPL = 2 planes
+//   Bf16   (mode 2)  x = bf16(x), one product, one plane
+//   F16    (mode 3)  x = fp16(x), one product, one plane (forward kernels only: gradients underflow fp16)
+// 16-bit data is carried as raw shorts (LDS images, fragments, tile planes) and reinterpreted at the matrix instruction.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 csn_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 csn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 csn_f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 csn_f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+namespace csn_mode {
+struct Bf16x3 { static constexpr int NT = 3, NPL = 2; static constexpr bool HALF = false; };
+struct Bf16 { static constexpr int NT = 1, NPL = 1; static constexpr bool HALF = false; };
+struct F16 { static constexpr int NT = 1, NPL = 1; static constexpr bool HALF = true; };
+
+template <bool H16> CSN_DEVINL short to16(float v) {
+  if constexpr (H16) return __builtin_bit_cast(short, (_Float16)v);
+  else return __builtin_bit_cast(short, (__bf16)v);
+}
+template <bool H16> CSN_DEVINL float from16(short v) {
+  if constexpr (H16) return (float)__builtin_bit_cast(_Float16, v);
+  else return (float)__builtin_bit_cast(__bf16, v);
+}
+template <bool H16> CSN_DEVINL s16x4 to16x4(const f32x4 v) {
+  if constexpr (H16) return __builtin_bit_cast(s16x4, __builtin_convertvector(v, csn_f16x4));
+  else return __builtin_bit_cast(s16x4, __builtin_convertvector(v, csn_bf16x4));
+}
+template <bool H16> CSN_DEVINL f32x4 from16x4(const s16x4 v) {
+  if constexpr (H16) return __builtin_convertvector(__builtin_bit_cast(csn_f16x4, v), f32x4);
+  else return __builtin_convertvector(__builtin_bit_cast(csn_bf16x4, v), f32x4);
+}
+// 4 floats -> 4 hi (round to nearest even) and, in the three-product mode, 4 lo = round(v - hi)
+template <typename PR> CSN_DEVINL void split4(const f32x4 v, s16x4& hi, s16x4& lo) {
+  hi = to16x4<PR::HALF>(v);
+  if constexpr (PR::NT == 3) lo = to16x4<PR::HALF>(v - from16x4<PR::HALF>(hi));
+  else lo = hi;
+}
+template <bool H16> CSN_DEVINL f32x16 mfma32(s16x8 a, s16x8 b, f32x16 c) {          // v_mfma_f32_32x32x16_{bf16,f16}
+  if constexpr (H16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(csn_f16x8, a), __builtin_bit_cast(csn_f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(csn_bf16x8, a), __builtin_bit_cast(csn_bf16x8, b), c, 0, 0, 0);
+}
+template <bool H16> CSN_DEVINL f32x4m mfma16(s16x8 a, s16x8 b, f32x4m c) {           // v_mfma_f32_16x16x32_{bf16,f16}
+  if constexpr (H16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(csn_f16x8, a), __builtin_bit_cast(csn_f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(csn_bf16x8, a), __builtin_bit_cast(csn_bf16x8, b), c, 0, 0, 0);
+}
+CSN_DEVINL s16x8 join8(s16x4 a, s16x4 b) { return s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+}  // namespace csn_mode
 
 // sum / max across the two 32-lane halves of a wave (lane l <-> lane l ^ 32)
 CSN_DEVINL float csn_xhalf(float v) { return __shfl_xor(v, 32, 64); }

@@ -22,7 +22,7 @@ struct CsnGemmArgs {
 };
 
 int csn_launch_gemm_f32(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st);
-int csn_launch_gemm_bf16x3(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st);   // gemm_bf16x3.hip, same checks as f32
+int csn_launch_gemm_bf16x3(const CsnGemmArgs& a, int b_is_nk, int batch, int mode, hipStream_t st);   // gemm_bf16x3.hip; mode 1 bf16x3, 2 bf16, 3 fp16
 int csn_gemm_bf16x3_big_tiles(int M, int N);          // 1: an M x N output takes the 256 x 256 kernel (grouped accumulation available)
 int csn_launch_slab_reduce(const float* slab, float* out, int n_slabs, long long n, float alpha, int accumulate,
                            hipStream_t st);
@@ -60,8 +60,8 @@ struct CsnAttnArgs {
 };
 int csn_launch_attn_fwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
 int csn_launch_attn_bwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
-int csn_launch_attn_fwd_bf16x3(const CsnAttnArgs& a, int d, hipStream_t st);     // attn_bf16x3.hip
-int csn_launch_attn_bwd_bf16x3(const CsnAttnArgs& a, int d, hipStream_t st);
+int csn_launch_attn_fwd_bf16x3(const CsnAttnArgs& a, int d, int mode, hipStream_t st);     // attn_bf16x3.hip; mode 1..3 (2, 3: tile-plane K/V only)
+int csn_launch_attn_bwd_bf16x3(const CsnAttnArgs& a, int d, int mode, hipStream_t st);     // mode 1, 2
 
 // ---- output projection + residual + LayerNorm (outproj_ln.hip) --------------------------------
 struct CsnOutProjArgs {
@@ -80,8 +80,8 @@ struct CsnOutProjArgs {
   float* xhat_sum; float* sum_ws; long long sum_ws_floats;
 };
 int csn_launch_partial_sums_f32(const float* ws, float* out, long long rows_outer, int tiles, int C, hipStream_t st);
-int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, int fast, hipStream_t st);   // fast: bf16x3 contraction
-int csn_launch_outproj_ln_big(const CsnOutProjArgs& a, hipStream_t st);                 // gemm_bf16x3.hip: C = 256, 256 x 256 tiles
+int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, int mode, hipStream_t st);   // mode 0: fp32, 1..3: 16-bit matrix-core contraction
+int csn_launch_outproj_ln_big(const CsnOutProjArgs& a, int mode, hipStream_t st);       // gemm_bf16x3.hip: C = 256, 256 x 256 tiles
 
 struct CsnLnBwdArgs {
   const float* dxhat; const float* xhat; const float* rstd;   // [e][C][ld], [e][C][ld], [e][n_points]

@@ -50,10 +50,10 @@ constexpr int PK = BK + 8;             // pitch of k-contiguous planes (16-bit e
 template <typename PR>
 CSN_DEVINL f32x16 mma32(s16x8 ah, s16x8 al, s16x8 bh, s16x8 bl, f32x16 c) {
   if constexpr (PR::NT == 3) {
-    c = mfma32<PR::F16>(al, bh, c);
-    c = mfma32<PR::F16>(ah, bl, c);
+    c = mfma32<PR::HALF>(al, bh, c);
+    c = mfma32<PR::HALF>(ah, bl, c);
   }
-  return mfma32<PR::F16>(ah, bh, c);
+  return mfma32<PR::HALF>(ah, bh, c);
 }
 
 // BT: the k-major B operand arrives as bf16 "tile planes" (see attn_bf16x3.hip): per k row, consecutive 32-column tiles of
@@ -203,41 +203,34 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
 #endif
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+      s16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int o = (wm0 + 32 * i + l31) * PK + 16 * s + 8 * h;
-        ah[i] = *reinterpret_cast<const bf16x8*>(&As[cur][0][o]);
-        al[i] = *reinterpret_cast<const bf16x8*>(&As[cur][1][o]);
+        ah[i] = *reinterpret_cast<const s16x8*>(&As[cur][0][o]);
+        al[i] = *reinterpret_cast<const s16x8*>(&As[cur][NPL - 1][o]);          // (one plane: al = ah, unused)
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         if (B_NK) {
           const int o = (wn0 + 32 * j + l31) * PK + 16 * s + 8 * h;
-          bh[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur][0][o]);
-          bl[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur][1][o]);
+          bh[j] = *reinterpret_cast<const s16x8*>(&Bs[cur][0][o]);
+          bl[j] = *reinterpret_cast<const s16x8*>(&Bs[cur][NPL - 1][o]);
         } else {
           const int o = tr_base + (16 * s) * PN + wn0 + 32 * j;
           typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
-          const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][0][o]));
-          const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][0][o + 4 * PN]));
-          const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][1][o]));
-          const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][1][o + 4 * PN]));
-          typedef short s16x8 __attribute__((ext_vector_type(8)));
-          const s16x8 hv = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-          const s16x8 lv = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-          bh[j] = __builtin_bit_cast(bf16x8, hv);
-          bl[j] = __builtin_bit_cast(bf16x8, lv);
+          bh[j] = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][0][o])),
+                        __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][0][o + 4 * PN])));
+          if constexpr (NPL == 2)
+            bl[j] = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][1][o])),
+                          __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][1][o + 4 * PN])));
+          else bl[j] = bh[j];
         }
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          acc[i][j] = mfma_bf16(al[i], bh[j], acc[i][j]);      // small terms first
-          acc[i][j] = mfma_bf16(ah[i], bl[j], acc[i][j]);
-          acc[i][j] = mfma_bf16(ah[i], bh[j], acc[i][j]);
-        }
+        for (int j = 0; j < NT; ++j) acc[i][j] = mma32<PR>(ah[i], al[i], bh[j], bl[j], acc[i][j]);
     }
     // slab kt + 1 (loaded one iteration ago) is split and written into the other stage while the matrix pipe drains;
     // slab kt + 2 starts its trip from HBM
@@ -277,16 +270,16 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
     for (int j = 0; j < NT; ++j) {
       const int n = n0 + wn0 + 32 * j + l31;
       const int blk = n / Tb, kib = n - blk * Tb;
-      const unsigned col = (unsigned)(blk * 1024 + (kib >> 5) * 64 + (kib & 31));
+      const unsigned col = (unsigned)(blk * (512 * NPL) + (kib >> 5) * (32 * NPL) + (kib & 31));
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ml = wm0 + 32 * i + csn_acc_row(r, h);
           const unsigned off = ((m0 + ml) < M && n < N) ? ((unsigned)(ml * ldc) + col) * 2u : CSN_OOB;
-          const __bf16 hi = (__bf16)acc[i][j][r];
-          csn_bstore_bf16(hi, Cr, off);
-          csn_bstore_bf16((__bf16)(acc[i][j][r] - (float)hi), Cr, off, 64u);
+          const short hi = to16<PR::HALF>(acc[i][j][r]);
+          csn_bstore16(hi, Cr, off);
+          if constexpr (NPL == 2) csn_bstore16(to16<PR::HALF>(acc[i][j][r] - from16<PR::HALF>(hi)), Cr, off, 64u);
         }
     }
     return;
@@ -299,9 +292,9 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const __bf16 hi = (__bf16)acc[i][j][r];
-          csn_bstore_bf16(hi, Cr, c_off[i][j][r]);
-          csn_bstore_bf16((__bf16)(acc[i][j][r] - (float)hi), Crl, c_off[i][j][r]);
+          const short hi = to16<PR::HALF>(acc[i][j][r]);
+          csn_bstore16(hi, Cr, c_off[i][j][r]);
+          if constexpr (NPL == 2) csn_bstore16(to16<PR::HALF>(acc[i][j][r] - from16<PR::HALF>(hi)), Crl, c_off[i][j][r]);
         }
     return;
   }
@@ -339,15 +332,21 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
 // LN: the out-projection of the attention layer (csa_models.py:114-118) — M = d_model = 256 is exactly one tile, so the
 // epilogue can apply the fc dropout, add the residual and LayerNorm every point over its 256 channels (per-point sums are
 // combined across the four M-waves through LDS) before anything is written: C = xhat, q carries the epilogue's operands.
-template <bool B_NK, bool BT, bool LN = false>
+template <typename PR, bool B_NK, bool BT, bool LN = false>
 __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs p, CsnOutProjArgs q) {
   static_assert(!BT || !B_NK, "tile-plane B is k-major");
   static_assert(!LN || (!B_NK && !BT), "LayerNorm epilogue: W_fc (MK) x Ctx^T (KN)");
+  constexpr int NPL = PR::NPL;
   constexpr int BM = 256, BN = 256, MT = 2, NT = 4;
   constexpr int PN = BN + 32;                           // pitch of the k-major B planes
   constexpr int A_EL = BM * BK, B_EL = B_NK ? BN * BK : BK * PN;
-  __shared__ __attribute__((aligned(16))) __bf16 As[2][2][A_EL];   // [stage][plane][row][k ^ swizzle]
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][2][B_EL];   // NK: like A   KN: [stage][plane][k][col]
+  // two planes: 128 KB (136 KB with a k-major B); one plane: half of that, but never less than the 128 KB the epilogues
+  // use as per-wave fp32 transpose blocks (8 x 16 KB) and the LayerNorm epilogue as its reduction / partial-sum scratch
+  constexpr int A_ST = NPL == 2 ? 2 * A_EL : 16384, B_ST = NPL == 2 ? 2 * B_EL : (B_EL > 16384 ? B_EL : 16384);
+  __shared__ __attribute__((aligned(16))) short As_raw[2 * A_ST];   // [stage][plane][row][k ^ swizzle]
+  __shared__ __attribute__((aligned(16))) short Bs_raw[2 * B_ST];   // NK: like A   KN: [stage][plane][k][col]
+  auto As = [&](int st, int pl) -> short* { return As_raw + st * A_ST + pl * A_EL; };
+  auto Bs = [&](int st, int pl) -> short* { return Bs_raw + st * B_ST + pl * B_EL; };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
@@ -379,7 +378,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
   auto set_item = [&](int zi) {
     const float* a_base = p.A.ptr + p.A.s0 * z0 + p.A.s1 * z1 + p.A.s2 * (long long)(p.A.idx2 ? p.A.idx2[zi] : zi) + (long long)m0 * lda;
     const long long b_el = p.B.s0 * z0 + p.B.s1 * z1 + p.B.s2 * (long long)(p.B.idx2 ? p.B.idx2[zi] : zi);
-    const float* b_base = BT ? reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(p.B.ptr) + b_el)
+    const float* b_base = BT ? reinterpret_cast<const float*>(reinterpret_cast<const short*>(p.B.ptr) + b_el)
                              : p.B.ptr + b_el + (B_NK ? (long long)n0 * ldb : (long long)n0);
     Ar = csn_make_rsrc(a_base, (long long)BM * lda * 4);
     Br = csn_make_rsrc(b_base, BT ? (long long)K * ldb * 2
@@ -401,15 +400,22 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
   // staging: 4 A pieces + 4 B pieces of 16 bytes per thread and slab
   const int pr = tid >> 3, pc = (tid & 7) * 4;          // k-contiguous operands: row pr + 64 i, k = pc .. pc + 3
   const int kr = tid >> 6, kc = (tid & 63) * 4;         // k-major B: k row kr + 8 i, columns kc .. kc + 3
-  const int t_u8 = tid & 7, t_u = t_u8 & 3, t_pl = t_u8 >> 2, t_kr = (tid >> 3) & 31, t_tg = tid >> 8;   // tile-plane B
+  // tile-plane B: k row t_kr of the slab; its 256 columns are 8 tiles of NPL x 64 bytes = 32 NPL contiguous 16-byte units,
+  // unit w = t_j + 16 i (t_j = this thread's place among the 16 threads of the row) -> tile w / (4 NPL), plane, 8 keys
+  const int t_kr = (tid >> 3) & 31, t_j = (tid & 7) + 8 * (tid >> 8);
+  constexpr int BT_PASS = 2 * NPL;
   const int sw_dst = pr * BK + ((((pc >> 3) ^ ((pr >> 2) & 3)) << 3) | (pc & 4));     // rows 64 apart share the swizzle
   unsigned a_off[4], b_off[4];
+  int bt_dst[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     a_off[i] = (m0 + pr + 64 * i) < M ? (unsigned)((pr + 64 * i) * lda + pc) * 4u : CSN_OOB;
-    if (BT) b_off[i] = (n0 + 32 * (t_tg + 2 * i) + 8 * t_u) < N
-                           ? (unsigned)(t_kr * ldb) * 2u + (unsigned)((n0 >> 5) + t_tg + 2 * i) * 128u + (unsigned)t_u8 * 16u : CSN_OOB;
-    else if (B_NK) b_off[i] = (n0 + pr + 64 * i) < N ? (unsigned)((pr + 64 * i) * ldb + pc) * 4u : CSN_OOB;
+    if (BT) {
+      const int w = t_j + 16 * i, tile = w / (4 * NPL), within = w % (4 * NPL), t_u = within & 3;
+      b_off[i] = (i < BT_PASS && (n0 + 32 * tile + 8 * t_u) < N)
+                     ? (unsigned)(t_kr * ldb) * 2u + (unsigned)(n0 >> 5) * (unsigned)(64 * NPL) + (unsigned)w * 16u : CSN_OOB;
+      bt_dst[i] = (within >> 2) * B_EL + t_kr * PN + 32 * tile + 8 * t_u;
+    } else if (B_NK) b_off[i] = (n0 + pr + 64 * i) < N ? (unsigned)((pr + 64 * i) * ldb + pc) * 4u : CSN_OOB;
     else b_off[i] = (n0 + kc) < N ? (unsigned)((kr + 8 * i) * ldb + kc) * 4u : CSN_OOB;
   }
   f32x4 ra[4], rb[4];
@@ -420,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
     if (BT) {
       const unsigned kb = (k0 + t_kr) < K ? 0u : CSN_OOB;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rb[i] = csn_bload4(Br, b_off[i] | kb, (unsigned)k0 * (unsigned)ldb * 2u);
+      for (int i = 0; i < BT_PASS; ++i) rb[i] = csn_bload4(Br, b_off[i] | kb, (unsigned)k0 * (unsigned)ldb * 2u);
     } else if (B_NK) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) rb[i] = csn_bload4(Br, b_off[i] | kp, (unsigned)k0 * 4u);
@@ -433,24 +439,24 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
     }
   };
   auto store_slab = [&](int st) {
-    bf16x4 hi, lo;
+    s16x4 hi, lo;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      split4(ra[i], hi, lo);
-      *reinterpret_cast<bf16x4*>(&As[st][0][sw_dst + 64 * BK * i]) = hi;
-      *reinterpret_cast<bf16x4*>(&As[st][1][sw_dst + 64 * BK * i]) = lo;
+      split4<PR>(ra[i], hi, lo);
+      *reinterpret_cast<s16x4*>(As(st, 0) + sw_dst + 64 * BK * i) = hi;
+      if constexpr (NPL == 2) *reinterpret_cast<s16x4*>(As(st, 1) + sw_dst + 64 * BK * i) = lo;
     }
     if (BT) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(&Bs[st][t_pl][t_kr * PN + 32 * (t_tg + 2 * i) + 8 * t_u]) = rb[i];
+      for (int i = 0; i < BT_PASS; ++i) *reinterpret_cast<f32x4*>(Bs(st, 0) + bt_dst[i]) = rb[i];
       return;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      split4(rb[i], hi, lo);
+      split4<PR>(rb[i], hi, lo);
       const int dst = B_NK ? sw_dst + 64 * BK * i : (kr + 8 * i) * PN + kc;
-      *reinterpret_cast<bf16x4*>(&Bs[st][0][dst]) = hi;
-      *reinterpret_cast<bf16x4*>(&Bs[st][1][dst]) = lo;
+      *reinterpret_cast<s16x4*>(Bs(st, 0) + dst) = hi;
+      if constexpr (NPL == 2) *reinterpret_cast<s16x4*>(Bs(st, 1) + dst) = lo;
     }
   };
 
@@ -473,39 +479,32 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
     const int cur = kt & 1;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 ah[MT], al[MT];
+      s16x8 ah[MT], al[MT];
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         const int o = (wm0 + 32 * i + l31) * BK + (((2 * s + h) ^ fr_sw) << 3);
-        ah[i] = *reinterpret_cast<const bf16x8*>(&As[cur][0][o]);
-        al[i] = *reinterpret_cast<const bf16x8*>(&As[cur][1][o]);
+        ah[i] = *reinterpret_cast<const s16x8*>(As(cur, 0) + o);
+        al[i] = *reinterpret_cast<const s16x8*>(As(cur, NPL - 1) + o);           // (one plane: al = ah, unused)
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        bf16x8 bh, bl;
+        s16x8 bh, bl;
         if (B_NK) {
           const int o = (wn0 + 32 * j + l31) * BK + (((2 * s + h) ^ fr_sw) << 3);
-          bh = *reinterpret_cast<const bf16x8*>(&Bs[cur][0][o]);
-          bl = *reinterpret_cast<const bf16x8*>(&Bs[cur][1][o]);
+          bh = *reinterpret_cast<const s16x8*>(Bs(cur, 0) + o);
+          bl = *reinterpret_cast<const s16x8*>(Bs(cur, NPL - 1) + o);
         } else {
           const int o = tr_base + (16 * s) * PN + wn0 + 32 * j;
           typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
-          const s16x4 h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][0][o]));
-          const s16x4 h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][0][o + 4 * PN]));
-          const s16x4 l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][1][o]));
-          const s16x4 l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[cur][1][o + 4 * PN]));
-          typedef short s16x8 __attribute__((ext_vector_type(8)));
-          const s16x8 hv = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-          const s16x8 lv = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-          bh = __builtin_bit_cast(bf16x8, hv);
-          bl = __builtin_bit_cast(bf16x8, lv);
+          bh = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Bs(cur, 0) + o)),
+                     __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Bs(cur, 0) + o + 4 * PN)));
+          if constexpr (NPL == 2)
+            bl = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Bs(cur, 1) + o)),
+                       __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Bs(cur, 1) + o + 4 * PN)));
+          else bl = bh;
         }
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          acc[i][j] = mfma_bf16(al[i], bh, acc[i][j]);        // small terms first
-          acc[i][j] = mfma_bf16(ah[i], bl, acc[i][j]);
-          acc[i][j] = mfma_bf16(ah[i], bh, acc[i][j]);
-        }
+        for (int i = 0; i < MT; ++i) acc[i][j] = mma32<PR>(ah[i], al[i], bh, bl, acc[i][j]);
       }
     }
     if (kt + 1 < nk) {
@@ -518,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
 
   BSTAMP(2);
   // per-wave 16 KB of LDS for the epilogues (the tile loop is over; waves 0..3 take As, 4..7 Bs): 32 rows x 128 columns fp32
-  float* wbuf = reinterpret_cast<float*>(wave < 4 ? reinterpret_cast<char*>(&As[0][0][0]) : reinterpret_cast<char*>(&Bs[0][0][0]))
+  float* wbuf = reinterpret_cast<float*>(wave < 4 ? reinterpret_cast<char*>(As_raw) : reinterpret_cast<char*>(Bs_raw))
                 + (wave & 3) * 4096;
   const int cc = lane & 31, rsub = lane >> 5;                         // chunk column (4 floats) and row parity of this lane
   const int col = wn0 + 4 * cc, n = n0 + col;
@@ -529,7 +528,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
     // (stays in the accumulator layout: the 16-byte path through the wave's LDS block — residual rows in, transposed reads —
     //  was built three times and measured 5–20 % slower each time: 40 spilled registers and 128 ds_read_b32 per wave cost
     //  more than the 96 memory instructions it saves)
-    float* red = reinterpret_cast<float*>(&As[0][0][0]);            // [2][4 M-waves][256 points] (the tile loop is over)
+    float* red = reinterpret_cast<float*>(As_raw);                  // [2][4 M-waves][256 points] (the tile loop is over)
     const int wmi = wave >> 1;
     const long long rs = q.res_index ? q.res_index[z2] : z2;
     const csn_rsrc_t Rr = csn_make_rsrc(q.xres + rs * q.xres_shape_stride + n0, ((long long)(BM - 1) * ldc + (N - n0)) * 4);
@@ -596,7 +595,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
       // per-channel sums of xhat over this tile's points (the pooled descriptor needs mean_n xhat): lane partials over the
       // wave's 4 column tiles go to LDS as psum[row][wn][32 lanes]; thread (row, wn) adds its 32 (conflict-free rotation),
       // the pair is combined and one float per row leaves for sum_ws[e][tile_n][row]
-      float* psum = reinterpret_cast<float*>(&Bs[0][0][0]);         // 64 KB; `red` lives in As
+      float* psum = reinterpret_cast<float*>(Bs_raw);               // 64 KB; `red` lives in As
       const int wn = wave & 1;
 #pragma unroll
       for (int i = 0; i < MT; ++i)
@@ -626,7 +625,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
   if (c_tiles) {
     const int Tb = (int)p.C.plane_stride;
     const int blk = n / Tb, kib = n - blk * Tb;                        // Tb % 4 == 0: the 4 points share block and tile
-    tcol = (unsigned)(blk * 1024 + (kib >> 5) * 64 + (kib & 31));
+    tcol = (unsigned)(blk * (512 * NPL) + (kib >> 5) * (32 * NPL) + (kib & 31));
   }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -651,12 +650,14 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
     if (c_pl) {
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
-        bf16x4 hi, lo;
-        split4(vals[t], hi, lo);
+        s16x4 hi, lo;
+        split4<PR>(vals[t], hi, lo);
         const u32x2 h2 = __builtin_bit_cast(u32x2, hi), l2 = __builtin_bit_cast(u32x2, lo);
         __builtin_amdgcn_raw_buffer_store_b64(h2, Cr, off[t], 0, 0);
-        if (c_tiles) __builtin_amdgcn_raw_buffer_store_b64(l2, Cr, off[t], 64, 0);
-        else __builtin_amdgcn_raw_buffer_store_b64(l2, Crl, off[t], 0, 0);
+        if constexpr (NPL == 2) {
+          if (c_tiles) __builtin_amdgcn_raw_buffer_store_b64(l2, Cr, off[t], 64, 0);
+          else __builtin_amdgcn_raw_buffer_store_b64(l2, Crl, off[t], 0, 0);
+        }
       }
     } else {
       if (p.accumulate) {
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
   BSTAMP(5);
 }
 
-template <bool B_NK, bool BT = false, bool LN = false>
+template <typename PR, bool B_NK, bool BT = false, bool LN = false>
 int launch_big(const CsnGemmArgs& a, int batch, hipStream_t st, const CsnOutProjArgs* ln = nullptr) {
   CsnGemmArgs b = a;
   b.batch = batch;
@@ -681,17 +682,17 @@ int launch_big(const CsnGemmArgs& a, int batch, hipStream_t st, const CsnOutProj
   dim3 grid((unsigned)(((batch + 7) / 8) * 8 * tiles));
   CsnOutProjArgs q{};
   if (ln) q = *ln;
-  hipLaunchKernelGGL((csn_gemm_bf16x3_big_kernel<B_NK, BT, LN>), grid, dim3(512), 0, st, b, q);
+  hipLaunchKernelGGL((csn_gemm_bf16x3_big_kernel<PR, B_NK, BT, LN>), grid, dim3(512), 0, st, b, q);
   return (int)hipGetLastError();
 }
 
-template <int BM, int BN, bool B_NK, bool BT = false>
+template <typename PR, int BM, int BN, bool B_NK, bool BT = false>
 int launch(const CsnGemmArgs& a, int batch, hipStream_t st) {
   CsnGemmArgs b = a;
   b.batch = batch;
   const long long tiles = (long long)((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
   dim3 grid((unsigned)(((batch + 7) / 8) * 8 * tiles));
-  hipLaunchKernelGGL((csn_gemm_bf16x3_kernel<BM, BN, B_NK, BT>), grid, dim3(256), 0, st, b);
+  hipLaunchKernelGGL((csn_gemm_bf16x3_kernel<PR, BM, BN, B_NK, BT>), grid, dim3(256), 0, st, b);
   return (int)hipGetLastError();
 }
 
@@ -700,8 +701,8 @@ int launch(const CsnGemmArgs& a, int batch, hipStream_t st) {
 int csn_gemm_big_tiles = 1;      // development switch (csn_debug_set_big_tiles)
 extern "C" void csn_debug_set_big_tiles(int on) { csn_gemm_big_tiles = on; }
 
-// out-projection + residual + LayerNorm for d_model = 256 on the 256 x 256 tiles (math mode 1): xhat = LN(W_fc Ctx^T (+drop) + x)
-int csn_launch_outproj_ln_big(const CsnOutProjArgs& a, hipStream_t st) {
+// out-projection + residual + LayerNorm for d_model = 256 on the 256 x 256 tiles (math modes 1..3): xhat = LN(W_fc Ctx^T (+drop) + x)
+int csn_launch_outproj_ln_big(const CsnOutProjArgs& a, int mode, hipStream_t st) {
   if (a.C != 256 || (a.D & 3) || (a.ld & 3) || (a.n_points & 3)) return -5;
   CsnGemmArgs g;
   g.A = CsnOperand{const_cast<float*>(a.wfc), 0, 0, 0, nullptr, a.D, 0, 0};
@@ -714,7 +715,9 @@ int csn_launch_outproj_ln_big(const CsnOutProjArgs& a, hipStream_t st) {
   CsnOutProjArgs b = a;
   const bool fused_sums = a.xhat_sum && a.sum_ws && a.sum_ws_floats >= (long long)a.E * tiles_n * 256;
   if (!fused_sums) b.sum_ws = nullptr;
-  int rc = launch_big<false, false, true>(g, a.E, st, &b);
+  int rc = mode == 3   ? launch_big<F16, false, false, true>(g, a.E, st, &b)
+           : mode == 2 ? launch_big<Bf16, false, false, true>(g, a.E, st, &b)
+                       : launch_big<Bf16x3, false, false, true>(g, a.E, st, &b);
   if (rc || !a.xhat_sum) return rc;
   if (fused_sums) return csn_launch_partial_sums_f32(a.sum_ws, a.xhat_sum, a.E, tiles_n, 256, st);
   return csn_launch_rowsum_f32(a.xhat, a.xhat_sum, (long long)a.E * a.C, a.n_points, a.ld, st);
@@ -722,16 +725,29 @@ int csn_launch_outproj_ln_big(const CsnOutProjArgs& a, hipStream_t st) {
 
 int csn_gemm_bf16x3_big_tiles(int M, int N) { return (csn_gemm_big_tiles && M >= 192 && N >= 224) ? 1 : 0; }
 
-int csn_launch_gemm_bf16x3(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st) {
-  if (a.C.planes && a.accumulate) return -1;
+namespace {
+template <typename PR>
+int launch_mode(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st) {
   // tiles of 256 x 256 where the output is big enough to fill them (a ragged last tile wastes at most ~3 % here)
   const bool big = csn_gemm_big_tiles && a.M >= 192 && a.N >= 224;
   if (a.grp_off && !big) return -1;                                 // grouped accumulation: 256 x 256 kernel only
   if (a.B.planes == 2) {                                            // tile-plane B: k-major only
     if (b_is_nk || (a.B.ld & 7)) return -1;
-    return big ? launch_big<false, true>(a, batch, st) : launch<128, 128, false, true>(a, batch, st);
+    return big ? launch_big<PR, false, true>(a, batch, st) : launch<PR, 128, 128, false, true>(a, batch, st);
   }
-  if (big) return b_is_nk ? launch_big<true>(a, batch, st) : launch_big<false>(a, batch, st);
-  if (a.M <= 64) return b_is_nk ? launch<64, 128, true>(a, batch, st) : launch<64, 128, false>(a, batch, st);
-  return b_is_nk ? launch<128, 128, true>(a, batch, st) : launch<128, 128, false>(a, batch, st);
+  if (big) return b_is_nk ? launch_big<PR, true>(a, batch, st) : launch_big<PR, false>(a, batch, st);
+  if (a.M <= 64) return b_is_nk ? launch<PR, 64, 128, true>(a, batch, st) : launch<PR, 64, 128, false>(a, batch, st);
+  return b_is_nk ? launch<PR, 128, 128, true>(a, batch, st) : launch<PR, 128, 128, false>(a, batch, st);
+}
+}  // namespace
+
+// mode: 1 = bf16x3, 2 = bf16, 3 = fp16 (csn_set_math_mode)
+int csn_launch_gemm_bf16x3(const CsnGemmArgs& a, int b_is_nk, int batch, int mode, hipStream_t st) {
+  if (a.C.planes && a.accumulate) return -1;
+  switch (mode) {
+    case 1: return launch_mode<Bf16x3>(a, b_is_nk, batch, st);
+    case 2: return launch_mode<Bf16>(a, b_is_nk, batch, st);
+    case 3: return launch_mode<F16>(a, b_is_nk, batch, st);
+    default: return -1;
+  }
 }

@@ -137,30 +137,18 @@ __global__ __launch_bounds__(256, 2) void csn_outproj_ln_fwd_kernel(CsnOutProjAr
 // ---- bf16x3 variant (math mode 1): the contraction runs as three bf16 matrix-core products per fp32 product; the
 // residual add, dropout and LayerNorm epilogue are the fp32 code of the exact kernel, unchanged.  Operand split and
 // fragment maps: see gemm_bf16x3.hip.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
+using namespace csn_mode;
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
-CSN_DEVINL bf16x8 join8(s16x4 a, s16x4 b) {
-  const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-  return __builtin_bit_cast(bf16x8, v);
-}
-CSN_DEVINL void split4(const f32x4 v, bf16x4& hi, bf16x4& lo) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    hi[i] = (__bf16)v[i];
-    lo[i] = (__bf16)(v[i] - (float)hi[i]);
-  }
-}
 
-template <int CT>
+// PR = csn_mode::Bf16x3 / Bf16 / F16 (math modes 1 / 2 / 3): three products of hi / lo planes, or one product of one plane
+template <typename PR, int CT>
 __global__ __launch_bounds__(256, 2) void csn_outproj_ln_fwd_bf16x3_kernel(CsnOutProjArgs p) {
+  constexpr int NPL = PR::NPL;
   constexpr int C = 32 * CT;
   constexpr int PK = BK + 8;                                      // k-contiguous planes: 80-byte rows (conflict-free b128)
   constexpr int PN = BN + 32;                                     // k-major planes: rows 64 B apart mod 256 (conflict-free tr reads)
-  __shared__ __attribute__((aligned(16))) __bf16 As[2][C * PK];   // [plane][c][k]   W_fc[c][k0..k0+31] split into bf16 hi / lo
-  __shared__ __attribute__((aligned(16))) __bf16 Bs[2][BK * PN];  // [plane][k][n]   Ctx^T[k0..k0+31][n0..n0+127]
+  __shared__ __attribute__((aligned(16))) short As[NPL][C * PK];   // [plane][c][k]   W_fc[c][k0..k0+31] split into hi / lo
+  __shared__ __attribute__((aligned(16))) short Bs[NPL][BK * PN];  // [plane][k][n]   Ctx^T[k0..k0+31][n0..n0+127]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
@@ -199,18 +187,18 @@ __global__ __launch_bounds__(256, 2) void csn_outproj_ln_fwd_bf16x3_kernel(CsnOu
     }
   };
   auto store_slab = [&]() {
-    bf16x4 hi, lo;
+    s16x4 hi, lo;
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
-      split4(ra[i], hi, lo);
-      *reinterpret_cast<bf16x4*>(&As[0][(pr + 32 * i) * PK + pc]) = hi;
-      *reinterpret_cast<bf16x4*>(&As[1][(pr + 32 * i) * PK + pc]) = lo;
+      split4<PR>(ra[i], hi, lo);
+      *reinterpret_cast<s16x4*>(&As[0][(pr + 32 * i) * PK + pc]) = hi;
+      if constexpr (NPL == 2) *reinterpret_cast<s16x4*>(&As[NPL - 1][(pr + 32 * i) * PK + pc]) = lo;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      split4(rb[i], hi, lo);
-      *reinterpret_cast<bf16x4*>(&Bs[0][(kr + 8 * i) * PN + kc]) = hi;
-      *reinterpret_cast<bf16x4*>(&Bs[1][(kr + 8 * i) * PN + kc]) = lo;
+      split4<PR>(rb[i], hi, lo);
+      *reinterpret_cast<s16x4*>(&Bs[0][(kr + 8 * i) * PN + kc]) = hi;
+      if constexpr (NPL == 2) *reinterpret_cast<s16x4*>(&Bs[NPL - 1][(kr + 8 * i) * PN + kc]) = lo;
     }
   };
   // transposing read of the k-major Ctx planes: lane group g = lane >> 4 covers points 16 (g & 1) .. +15 of this wave's 32
@@ -226,18 +214,22 @@ __global__ __launch_bounds__(256, 2) void csn_outproj_ln_fwd_bf16x3_kernel(CsnOu
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const int o = tr_base + 16 * s * PN;
-      const bf16x8 bh = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[0][o])),
-                              __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[0][o + 4 * PN])));
-      const bf16x8 bl = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[1][o])),
-                              __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[1][o + 4 * PN])));
+      const s16x8 bh = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[0][o])),
+                             __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[0][o + 4 * PN])));
+      s16x8 bl = bh;
+      if constexpr (NPL == 2)
+        bl = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[1][o])),
+                   __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(&Bs[1][o + 4 * PN])));
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         const int a = (c * 32 + l31) * PK + 16 * s + 8 * h;
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&As[0][a]);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(&As[1][a]);
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[c], 0, 0, 0);      // small terms first
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[c], 0, 0, 0);
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[c], 0, 0, 0);
+        const s16x8 ah = *reinterpret_cast<const s16x8*>(&As[0][a]);
+        const s16x8 al = *reinterpret_cast<const s16x8*>(&As[NPL - 1][a]);
+        if constexpr (PR::NT == 3) {
+          acc[c] = mfma32<PR::HALF>(al, bh, acc[c]);                                     // small terms first
+          acc[c] = mfma32<PR::HALF>(ah, bl, acc[c]);
+        }
+        acc[c] = mfma32<PR::HALF>(ah, bh, acc[c]);
       }
     }
     __syncthreads();
@@ -392,27 +384,29 @@ __global__ __launch_bounds__(256) void csn_rowdot_kernel(const float* __restrict
 }
 
 template <int CT>
-int launch_fwd(const CsnOutProjArgs& a, int fast, hipStream_t st) {
+int launch_fwd(const CsnOutProjArgs& a, int mode, hipStream_t st) {
   dim3 grid((a.n_points + BN - 1) / BN, a.E);
-  if (fast) hipLaunchKernelGGL((csn_outproj_ln_fwd_bf16x3_kernel<CT>), grid, dim3(256), 0, st, a);
+  if (mode == 1) hipLaunchKernelGGL((csn_outproj_ln_fwd_bf16x3_kernel<Bf16x3, CT>), grid, dim3(256), 0, st, a);
+  else if (mode == 2) hipLaunchKernelGGL((csn_outproj_ln_fwd_bf16x3_kernel<Bf16, CT>), grid, dim3(256), 0, st, a);
+  else if (mode == 3) hipLaunchKernelGGL((csn_outproj_ln_fwd_bf16x3_kernel<F16, CT>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((csn_outproj_ln_fwd_kernel<CT>), grid, dim3(256), 0, st, a);
   return (int)hipGetLastError();
 }
 
 }  // namespace
 
-int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, int fast, hipStream_t st) {
+int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, int mode, hipStream_t st) {
   if (a.E <= 0 || a.n_points <= 0) return 0;
   if ((a.ld & 3) || (a.D & 3) || (a.n_points & 3)) return -2;
   if ((a.ctx_eval_stride & 3) || (a.xres_shape_stride & 3) || (a.xhat_eval_stride & 3)) return -4;
-  if (fast && a.C == 256 && a.n_points >= 224) return csn_launch_outproj_ln_big(a, st);     // 256 x 256 tiles (gemm_bf16x3.hip)
+  if (mode && a.C == 256 && a.n_points >= 224) return csn_launch_outproj_ln_big(a, mode, st);     // 256 x 256 tiles (gemm_bf16x3.hip)
   int rc;
   switch (a.C) {
-    case 32: rc = launch_fwd<1>(a, fast, st); break;
-    case 64: rc = launch_fwd<2>(a, fast, st); break;
-    case 96: rc = launch_fwd<3>(a, fast, st); break;
-    case 128: rc = launch_fwd<4>(a, fast, st); break;
-    case 256: rc = launch_fwd<8>(a, fast, st); break;
+    case 32: rc = launch_fwd<1>(a, mode, st); break;
+    case 64: rc = launch_fwd<2>(a, mode, st); break;
+    case 96: rc = launch_fwd<3>(a, mode, st); break;
+    case 128: rc = launch_fwd<4>(a, mode, st); break;
+    case 256: rc = launch_fwd<8>(a, mode, st); break;
     default: return -5;
   }
   if (rc || !a.xhat_sum) return rc;

@@ -15,9 +15,13 @@ import math
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
+import threading
+
 import torch
 
 from . import _lib
+
+_tls = threading.local()
 
 REF_BLOCK = 500       # MID-FC/csa_models.py:84
 REF_NBLOCKS = 20      # MID-FC/csa_models.py:83
@@ -137,9 +141,62 @@ class EvalPlan:
 # ------------------------------------------------------------------------------------------------------
 # raw (non-differentiable) calls — thin, typed views of the C ABI
 # ------------------------------------------------------------------------------------------------------
+MATH_MODES = {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp16": 3}      # CSN_MATH_* of include/csn_hip.h
+
+
+def mode_id(mode) -> Optional[int]:
+    """'fp32' | 'bf16x3' | 'bf16' | 'fp16' | 0..3 | None -> the library's mode number (None stays None = no override)."""
+    if mode is None:
+        return None
+    m = MATH_MODES[mode] if isinstance(mode, str) else int(mode)
+    if m not in (0, 1, 2, 3):
+        raise ValueError(f"unknown math mode {mode!r}")
+    return m
+
+
+def current_mode() -> int:
+    """The math mode in effect for the calling thread (process default unless a ``math_mode`` block is open)."""
+    return _lib.lib().csn_get_math_mode()
+
+
+def backward_mode(mode: int) -> int:
+    """The mode a backward pass runs in: fp16 is forward-only (gradients of this path reach 1e-7 and underflow fp16), its
+    backward runs in bf16."""
+    return 2 if mode == 3 else mode
+
+
+class math_mode:
+    """``with math_mode(m):`` — the calling thread's library calls run in mode ``m`` inside the block (csn_set_thread_math_mode;
+    other threads are untouched; None = leave as is).  The autograd functions of this file record the mode of their forward and
+    open the same block (in ``backward_mode``) in their backward, which runs on autograd's own threads."""
+
+    def __init__(self, mode):
+        self.mode = mode_id(mode)
+
+    def __enter__(self):
+        if self.mode is not None:
+            L = _lib.lib()
+            self.prev = L.csn_get_math_mode()
+            self.had = getattr(_tls, "depth", 0)
+            _tls.depth = self.had + 1
+            _lib.check(L.csn_set_thread_math_mode(self.mode))
+        return self
+
+    def __exit__(self, *exc):
+        if self.mode is not None:
+            _tls.depth = self.had
+            _lib.lib().csn_set_thread_math_mode(self.prev if self.had else -1)
+        return False
+
+
 def fast_math() -> bool:
-    """True when the contractions run as three bf16 matrix-core products per fp32 product (csn_set_math_mode(1))."""
-    return _lib.lib().csn_get_math_mode() == 1
+    """True when the contractions run on the 16-bit matrix-core kernels (math modes 1..3)."""
+    return current_mode() != 0
+
+
+def planes() -> int:
+    """Planes of a tile-plane tensor in the current mode: hi + lo in bf16x3, one in the single-product modes."""
+    return 2 if current_mode() == 1 else 1
 
 
 def project(x: torch.Tensor, w: torch.Tensor, div_rows: int = 0, temperature: float = 1.0,
@@ -216,6 +273,16 @@ class _MHAEvals(torch.autograd.Function):
         _need_cuda(x_all, w_qs, w_ks, w_vs, w_fc)
         ctx.link = link
         ctx.set_materialize_grads(False)               # an unused output must not cost a zero-filled (E, C, NP) gradient
+        mode = current_mode()
+        if mode >= 2 and geo.block > 512:
+            mode = 1                                   # the single-product kernels take K / V as tile planes (blocks <= 512 keys)
+        ctx.mode = mode
+        with math_mode(mode):
+            return _MHAEvals._forward(ctx, x_all, w_qs, w_ks, w_vs, w_fc, plan, geo, keep_scores, p_attn, p_fc, n_head_evals,
+                                      want_sums, link)
+
+    @staticmethod
+    def _forward(ctx, x_all, w_qs, w_ks, w_vs, w_fc, plan, geo, keep_scores, p_attn, p_fc, n_head_evals, want_sums, link):
         # dropout masks are counter-based: two 62-bit seeds from torch's CPU generator (torch.manual_seed reproduces them)
         seed_attn, seed_fc = draw_seeds(2) if (p_attn > 0 or p_fc > 0) else (0, 0)
         q_slots, kv_slots, v_shift = plan.q_slots, plan.kv_slots, plan.v_shift
@@ -236,13 +303,15 @@ class _MHAEvals(torch.autograd.Function):
         # MultiHeadAttention.forward(Q, K, V) with three distinct inputs uses that
         tiles = fast_math() and USE_KV_TILES and T <= 512
         if tiles:
-            # fast math: K and V leave the projection as bf16 "tile planes" (per row and block 16 tiles of [hi 32 | lo 32],
-            # 128-byte aligned), which the attention kernels stage with plain copies; Q (pre-scaled) stays fp32
-            ldp = nb * 1024
+            # 16-bit modes: K and V leave the projection as "tile planes" (per row and block 16 tiles of [hi 32 | lo 32] bf16 in
+            # bf16x3, of [32] bf16 / fp16 in the single-product modes), which the attention kernels stage with plain copies; Q
+            # (pre-scaled) stays fp32
+            npl = planes()
+            ldp = nb * 512 * npl
             qkv = project(x_all, w_qkv[:D], div_rows=D, temperature=temperature)              # (S, D, NP) = Qs
-            kv = torch.empty((S, 2 * D, ldp), device=dev, dtype=torch.bfloat16)
+            kv = torch.empty((S, 2 * D, ldp), device=dev, dtype=torch.float16 if ctx.mode == 3 else torch.bfloat16)
             if T % 32:
-                kv.view(S, 2 * D, nb, 16, 2, 32)[:, :, :, (T - 1) // 32, :, T % 32:] = 0       # padding keys of the last tile
+                kv.view(S, 2 * D, nb, 16, npl, 32)[:, :, :, (T - 1) // 32, :, T % 32:] = 0     # padding keys of the last tile
             _lib.check(L.csn_project_f32(_ptr(x_all), x_all.stride(0), NP, _ptr(w_qkv[D:]), 2 * D, C, _ptr(kv), 2 * D * ldp,
                                          ldp, S, NP, 0, 1.0, 2, T, _stream()), "csn_project_f32")
             q_ptr, q_stride = qkv.data_ptr(), D * NP
@@ -298,6 +367,11 @@ class _MHAEvals(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dxhat, dhead, dsums=None, dhandle=None):
+        with math_mode(backward_mode(ctx.mode)):
+            return _MHAEvals._backward(ctx, dxhat, dhead, dsums, dhandle)
+
+    @staticmethod
+    def _backward(ctx, dxhat, dhead, dsums=None, dhandle=None):
         x_all, w_qkv, w_fc, qkv, att, lse, scores, xhat, rstd, kv = ctx.saved_tensors
         geo: MHAGeometry = ctx.geo
         plan: EvalPlan = ctx.plan
@@ -368,12 +442,22 @@ class _MHAEvals(torch.autograd.Function):
         q_stride, kv_stride, kv_flag, kv_pitch = ctx.ptrs
         gbase, q_ptr = dqkv.data_ptr(), qkv.data_ptr()
         if kv_flag:
+            if ctx.mode == 3:
+                # fp16 forward / bf16 backward: the forward's K / V planes hold fp16 bits — project them again as bf16 planes
+                # (one GEMM over the slots; the alternative, fp16 gradient products, underflows)
+                kv = torch.empty_like(kv, dtype=torch.bfloat16)
+                if T % 32:
+                    kv.view(S, 2 * D, nb, 16, 1, 32)[:, :, :, (T - 1) // 32, :, T % 32:] = 0
+                _lib.check(L.csn_project_f32(_ptr(x_all), x_all.stride(0), NP, _ptr(w_qkv[D:]), 2 * D, C, _ptr(kv), kv_stride,
+                                             kv_pitch, S, NP, 0, 1.0, 2, T, _stream()), "csn_project_f32")
             k_ptr = kv.data_ptr()
             v_ptr = k_ptr + 2 * (D * kv_pitch + plan.v_shift * kv_stride)
         else:
             k_ptr = q_ptr + 4 * D * NP
             v_ptr = q_ptr + 4 * (2 * D * NP + plan.v_shift * kv_stride)
-        pt = 1 if (fast_math() and Tp >= (T + 31) // 32 * 32) else 0    # P / dS travel to the dV / dK products as bf16 tile planes
+        pt = 1 if (fast_math() and Tp >= (T + 31) // 32 * 32) else 0    # P / dS travel to the dV / dK products as tile planes
+        # (bf16x3: P overwrites the scores in place, dS fills `dscores`; bf16: both go to `dscores` as compact rows and the
+        #  dK / dV call reads them there — csn_hip.h (3))
         grouping = L.csn_attn_bwd_grouping(d, T)
         if EVENT_SINK is not None:
             ev0 = torch.cuda.Event(enable_timing=True)
@@ -477,14 +561,16 @@ class _LinearCM(torch.autograd.Function):
     def forward(ctx, x, w):
         _need_cuda(x, w)
         ctx.save_for_backward(x, w)
+        ctx.mode = current_mode()
         return project(x, w.contiguous())
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = project(dy, w.t().contiguous()) if ctx.needs_input_grad[0] else None
-        dw = project_wgrad(dy, x) if ctx.needs_input_grad[1] else None
+        with math_mode(backward_mode(ctx.mode)):
+            dx = project(dy, w.t().contiguous()) if ctx.needs_input_grad[0] else None
+            dw = project_wgrad(dy, x) if ctx.needs_input_grad[1] else None
         return dx, dw
 
 

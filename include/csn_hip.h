@@ -27,7 +27,13 @@
 extern "C" {
 #endif
 
-#define CSN_ABI_VERSION 11
+#define CSN_ABI_VERSION 12
+
+/* math modes (csn_set_math_mode / csn_set_thread_math_mode) */
+#define CSN_MATH_FP32 0
+#define CSN_MATH_BF16X3 1
+#define CSN_MATH_BF16 2
+#define CSN_MATH_FP16 3
 
 #define CSN_E_ARG (-1)     /* null pointer / non-positive size            */
 #define CSN_E_ALIGN (-2)   /* a size or leading dimension is not % 4      */
@@ -38,19 +44,32 @@ extern "C" {
 
 /* ABI version of the loaded library (== CSN_ABI_VERSION). */
 int csn_version(void);
-/* Arithmetic of the plain contractions (projections, their weight gradients, dCtx, dK, dV):
- *   0 = exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32; the parity-bearing default),
- *   1 = "bf16x3": every fp32 operand is split into two bf16 terms and a product is three bf16 MFMAs
- *       (hi*hi + hi*lo + lo*hi, fp32 accumulate): ~1e-5 relative error per product, 5.3x the matrix-core rate.
- * Process-wide setting, not thread-safe; returns CSN_E_ARG for any other value. */
-/* SPLIT TENSORS (math mode 1 only).  Arguments named *_split / *_plane_stride let a kernel write, or read, an fp32
+/* Arithmetic of the contractions (projections, attention products, out-projection, every gradient product):
+ *   0 CSN_MATH_FP32    exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4: bit-identical to an fmaf chain);
+ *   1 CSN_MATH_BF16X3  every fp32 operand is split into two bf16 terms and a product is three bf16 MFMAs
+ *                      (hi*hi + hi*lo + lo*hi, fp32 accumulate): ~1e-5 relative error per product, 5.3x the fp32 matrix rate.
+ *                      THE DEFAULT: like mode 0 it is inside the 1e-4 contract of the path (every parity test runs in both);
+ *   2 CSN_MATH_BF16    every operand rounded once to bf16, one MFMA per product, fp32 accumulate; tile planes hold one
+ *                      plane (half the bytes).  OUTSIDE the 1e-4 contract: ~1e-2 relative on outputs (reported by the tests);
+ *   3 CSN_MATH_FP16    the same with fp16 operands — FORWARD entry points only (gradients of this path reach 1e-7 and
+ *                      underflow fp16): the backward entry points return CSN_E_ARG in this mode; callers run them in mode 2
+ *                      (csn_amd does: "fp16 forward / bf16 backward").
+ * The retrieval measure (7) always runs in exact fp32 (bit-exact kNN indices).  The cross-length entry points (3b) have no
+ * single-product kernels: in modes 2 / 3 they run as mode 1.
+ * csn_set_math_mode sets the PROCESS default; csn_set_thread_math_mode overrides it for the calling thread only (-1 clears the
+ * override), which is how a module selects its own mode per call without touching other threads (csn_amd brackets every
+ * forward / backward with it; autograd's backward threads set their own).  csn_get_math_mode returns the mode in effect for
+ * the calling thread.  Both setters return CSN_E_ARG for an unknown value. */
+/* SPLIT TENSORS (math mode 1).  Arguments named *_split / *_plane_stride let a kernel write, or read, an fp32
  * tensor as two bf16 planes x = hi + lo (hi = bf16(x), lo = bf16(x - hi)): the pointer then addresses the HIGH
  * plane (bf16 elements, cast to float* for the ABI), the LOW plane starts `plane_stride` bf16 elements later, and
  * every stride / leading dimension of that tensor counts bf16 elements (same numbers as for the fp32 tensor).
  * The producer's epilogue splits once; consumers stage the planes into LDS with plain copies (no conversion work per
  * tile).  A split dctx (attention-output gradient) is laid out [evaluation][2 planes][n_heads*d_head][ld]: its
  * evaluation stride is 2 * ctx_eval_stride and dctx_plane_stride = ctx_eval_stride.
- * TILE PLANES (math mode 1 only): the form in which keys and values travel from the projection to the attention kernels.
+ * TILE PLANES (math modes 1..3): the form in which keys and values travel from the projection to the attention kernels
+ * (described for mode 1, two planes; in modes 2 / 3 there is ONE plane of bf16 / fp16 elements: a tile is [32 keys], the block
+ * pitch 512, ld_out = n_blocks * 512, and a probs_tiles backward leaves P and dS as compact rows — see (3)).
  * csn_project_f32 with out_split = 2 writes, per output row and per attention block of `out_plane_stride` (<= 512) points,
  * 16 tiles of [hi: 32 keys | lo: 32 keys] bf16 — block pitch 1024, row pitch ld_out = n_blocks * 1024, out_shape_stride in
  * bf16 elements; the padding keys of a block's last tile are not written and must be zero.  Every 32-key tile row is then
@@ -61,6 +80,7 @@ int csn_version(void);
  * k/v tile planes of csn_block_attn_fwd_f32 / csn_block_attn_bwd_dq_f32; dctx_split / q_split INPUTS are reserved
  * (CSN_E_ARG).  Passing *_split != 0 in math mode 0 returns CSN_E_ARG. */
 int csn_set_math_mode(int mode);
+int csn_set_thread_math_mode(int mode);
 int csn_get_math_mode(void);
 /* Human-readable text for a status code returned by any function below. Host pointer, static storage. */
 const char* csn_status_string(int status);
@@ -109,9 +129,13 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
  * csn_block_attn_bwd_dkv_f32: in  dctx, q + q_index as in forward, probs (= scores after the dq call), dscores;
  *                             out dv[dv_index[e]] (+)= P^T dctx,  dk[dk_index[e]] (+)= dS^T Qs.
  * dq/dk/dv point at row 0 of the [n_heads*d_head][ld] gradient map of slot 0; *_slot_stride in floats.
- * probs_tiles != 0 (math mode 1; score_pitch >= block rounded up to 32): the dq call leaves P_drop and dS as bf16 TILE
- * PLANES — per query row 16 tiles of [hi: 32 keys | lo: 32 keys], the bytes of the fp32 row — and the dkv call must be
- * told the same; the dV / dK products then stage them with plain copies.
+ * probs_tiles != 0 (math modes 1, 2; score_pitch >= block rounded up to 32): the dq call leaves P_drop and dS as TILE
+ * PLANES and the dkv call must be told the same; the dV / dK products then stage them with plain copies.  Mode 1: per query
+ * row 16 tiles of [hi: 32 keys | lo: 32 keys] bf16 — the bytes of the fp32 row — P in place over `scores`, dS in `dscores`.
+ * Mode 2 (one plane): rows of 16 tiles of [32 keys] are half the bytes, so both go to `dscores` — per (evaluation, head,
+ * block) region of block * score_pitch floats: [P: block rows | dS: block rows] of pitch score_pitch bf16 elements — and
+ * `scores` is left untouched; the dkv call reads both from its `dscores` argument (`probs` is ignored).  Mode 2 REQUIRES
+ * kv_split and probs_tiles.
  * GROUPED calls (group_offsets != NULL): eval_ids lists the n_launch_evals evaluations ordered so that evaluations sharing
  * an output slot are adjacent, group g = entries group_offsets[g] .. group_offsets[g+1] (n_groups + 1 offsets); a group's
  * results are accumulated in registers and its slot is written once — one call for all evaluations instead of one

@@ -24,7 +24,7 @@ def _set_mode(mode):
 @pytest.fixture(autouse=True)
 def _restore_mode():
     yield
-    _set_mode(0)
+    _set_mode(1)
 
 
 def _module(p, n_cls, K, **geo):

@@ -14,6 +14,17 @@ from tests import dropout_ref as dr
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def exact_fp32_mode():
+    """The element-wise checks against a float64 reference with the very same mask use fp32-rounding tolerances: they run in
+    the exact-fp32 math mode (the masks themselves do not depend on the mode)."""
+    from csn_amd import _lib
+    _lib.build()
+    _lib.check(_lib.lib().csn_set_math_mode(0))
+    yield
+    _lib.lib().csn_set_math_mode(1)
+
+
 def _rand(rng, *shape):
     return torch.from_numpy(rng.standard_normal(size=shape).astype(np.float32))
 

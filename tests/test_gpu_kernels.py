@@ -27,7 +27,7 @@ def math_mode(request, L):
     L.check(L.lib().csn_set_math_mode(request.param))
     _mode["m"] = request.param
     yield request.param
-    L.lib().csn_set_math_mode(0)
+    L.lib().csn_set_math_mode(1)
 
 
 def tol(x):

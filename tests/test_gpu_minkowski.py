@@ -22,7 +22,7 @@ def L():
 def math_mode(request, L):
     L.check(L.lib().csn_set_math_mode(request.param))
     yield request.param
-    L.lib().csn_set_math_mode(0)
+    L.lib().csn_set_math_mode(1)
 
 
 def _params(rng, H, C, d):

@@ -23,7 +23,7 @@ def math_mode(request):
     _lib.build()
     _lib.check(_lib.lib().csn_set_math_mode(request.param))
     yield request.param
-    _lib.lib().csn_set_math_mode(0)
+    _lib.lib().csn_set_math_mode(1)
 
 
 def _load(golden_dir, name):

@@ -17,7 +17,7 @@ def math_mode(request):
     _lib.build()
     _lib.check(_lib.lib().csn_set_math_mode(request.param))
     yield request.param
-    _lib.lib().csn_set_math_mode(0)
+    _lib.lib().csn_set_math_mode(1)
 
 
 def test_g1_goldens_through_the_drop_in_class(golden_dir, math_mode):

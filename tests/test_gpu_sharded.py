@@ -148,4 +148,4 @@ def test_sharded_csa_step_with_descriptor_reuse_equals_single_process(tmp_path):
                 for n, g in ref_grads.items():
                     assert (got["grads"][n] - g).abs().max().item() <= 2e-4 * g.abs().max().item(), (tag, n)
     finally:
-        _lib.lib().csn_set_math_mode(0)
+        _lib.lib().csn_set_math_mode(1)
