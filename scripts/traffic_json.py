@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Turn the HBM counter summary of scripts/run_profile.sh (hbm.txt: mean FETCH_SIZE / WRITE_SIZE per launch, KB) into
+profiles/attn_hbm_traffic.json, which bench.py reads for `roofline.traffic`:
+    python scripts/traffic_json.py <hbm.txt> <config> <math> [<source label>]
+gfx950: HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md §HBM: FETCH_SIZE counts half of a 16-byte-per-lane
+read stream)."""
+import json, os, re, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    path, config, math = sys.argv[1], sys.argv[2], sys.argv[3]
+    label = sys.argv[4] if len(sys.argv) > 4 else os.path.relpath(path, ROOT)
+    vals = {}
+    for line in open(path):
+        m = re.match(r"csn_attn_\w+<(.*?)>.*?(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+\s+mean=\s*([0-9.]+)", line)
+        if m:
+            args = [a.strip() for a in m.group(1).split(",")]          # <mode, DT, BWD, KVP>
+            which = "bwd" if args[-2] == "true" else "fwd"
+            vals.setdefault(which, {})[m.group(2)] = float(m.group(3))
+    out_path = os.path.join(ROOT, "profiles", "attn_hbm_traffic.json")
+    tab = json.load(open(out_path)) if os.path.exists(out_path) else {}
+    for which, v in vals.items():
+        tab[f"{config}/{math}/{which}"] = {"bytes_per_launch": (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024,
+                                           "fetch_size_kb": v["FETCH_SIZE"], "write_size_kb": v["WRITE_SIZE"], "source": label}
+    json.dump(tab, open(out_path, "w"), indent=1, sort_keys=True)
+    print(json.dumps(tab, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
