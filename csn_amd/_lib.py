@@ -118,6 +118,13 @@ _SIGNATURES = {
                                        c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_longlong, c_longlong, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                        c_ulonglong, c_void_p]),
+    "csn_varlen_attn_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_int, c_int, c_void_p, c_longlong,
+                                        c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_float,
+                                        c_float, c_ulonglong, c_void_p]),
+    "csn_varlen_attn_bwd_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p, c_longlong, c_longlong,
+                                        c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_longlong, c_longlong, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                        c_float, c_ulonglong, c_void_p]),
     "csn_outproj_ln_fwd_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p,
                                        c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
                                        c_ulonglong, c_void_p, c_void_p, c_longlong, c_void_p]),

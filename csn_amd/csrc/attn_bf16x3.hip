@@ -47,6 +47,18 @@ constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 using namespace csn_mode;
 typedef f32x4m f32x4v;
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+typedef short __attribute__((address_space(3))) lds_s16;
+typedef s16x8 __attribute__((address_space(3))) lds_s16x8;
+
+// An LDS address the compiler cannot fold into its constant arithmetic.  The V^T / K^T tile array starts 64 KB into the LDS
+// block, beyond the 16-bit immediate of a DS instruction: left to itself the compiler rebuilt the address of every one of the
+// 2 x D/16 fragment reads of phase 2 with a vector add (26 per tile at d = 256).  With the stage's base made opaque once per
+// phase, every read is that register plus an immediate.
+CSN_DEVINL const lds_s16* opaque_lds(const short* p) {
+  const lds_s16* q = (const lds_s16*)p;
+  asm volatile("" : "+v"(q));
+  return q;
+}
 
 // acc += a * b on the 16x16x32 matrix instruction: a = ah + al, b = bh + bl as three products (small terms first), or one
 template <typename PR>
@@ -107,10 +119,13 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   const int it1 = (BWD && p.grp_off) ? p.grp_off[zz + 1] : it0 + 1;     // (forward: always one item — the loop folds away)
   const int e0 = p.eval_ids ? p.eval_ids[it0] : it0;
   const int hd = (u % Y) % p.H, blk = (u % Y) / p.H;
-  const int T = p.T, Tp = p.Tp, ld = p.ld, ldk = p.ld_kv > 0 ? p.ld_kv : p.ld;
+  // ragged batches: this evaluation's own query / key counts (Tq, p.T stay the maxima that lay out the buffers)
+  const int Tq_e = p.tq_arr ? p.tq_arr[e0] : Tq;
+  if (qt * 128 >= Tq_e) return;                                // a query tile beyond a short evaluation (whole work-group)
+  const int T = p.t_arr ? p.t_arr[e0] : p.T, Tp = p.Tp, ld = p.ld, ldk = p.ld_kv > 0 ? p.ld_kv : p.ld;
   const bool ragged = (T & 3) != 0;                            // keys of the last 4-key group are masked one by one
   const int qrow = qt * 128 + wave * 16 + lq;                  // query index inside the block
-  const bool q_ok = qrow < Tq;
+  const bool q_ok = qrow < Tq_e;
   const long long head_off = (long long)hd * D * ld + (long long)blk * Tq;
   const long long win = ((long long)(D - 1) * ld + Tq) * 4;    // bytes spanned by a [D][Tq] window of pitch ld
   const long long os = p.out_index ? p.out_index[e0] : e0;
@@ -119,7 +134,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   float* xbuf = reinterpret_cast<float*>(tiles);
   constexpr int CH_T = D / 16;                                     // 16-byte chunks per thread: D rows x 32 chunks / 512
   const int cc = tid & 31, crow = tid >> 5;                        // chunk column, first row of this thread (rows + 16 t)
-  const unsigned c_off = (qt * 128 + 4 * cc) < Tq ? (unsigned)(crow * ld + qt * 128 + 4 * cc) * 4u : CSN_OOB;
+  const unsigned c_off = (qt * 128 + 4 * cc) < Tq_e ? (unsigned)(crow * ld + qt * 128 + 4 * cc) * 4u : CSN_OOB;
   const int col = 16 * wave + lq;                                  // this lane's query column inside the block of 128
   const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
   f32x4v O[D / 16];
@@ -469,15 +484,15 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   };
   // phase 2: OUT[c][q] += sum_key tileB[c][key] T1[key][q]
   auto phase2 = [&](int st) {
-    const short* __restrict__ tBh = tileB(st, 0);
-    const short* __restrict__ tBl = tileB(st, NPL - 1);
+    const lds_s16* tBh = opaque_lds(tileB(st, 0) + b_pos);
+    const lds_s16* tBl = tBh + (NPL - 1) * PLANE;
     constexpr int NC = D / 16;
     s16x8 vh[PD], vl[PD];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < PD && c < NC; ++c) {
-      vh[c] = *reinterpret_cast<const s16x8*>(tBh + c * 16 * KT + b_pos);
-      vl[c] = *reinterpret_cast<const s16x8*>(tBl + c * 16 * KT + b_pos);
+      vh[c] = *reinterpret_cast<const lds_s16x8*>(tBh + c * 16 * KT);
+      vl[c] = *reinterpret_cast<const lds_s16x8*>(tBl + c * 16 * KT);
     }
     __builtin_amdgcn_sched_group_barrier(0x100, NPL * (PD < NC ? PD : NC), 0);
 #pragma unroll
@@ -485,8 +500,8 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
       const int r = c % PD;
       O[c] = mma16<PR>(vh[r], vl[r], ph, pl, O[c]);
       if (c + PD < NC) {
-        vh[r] = *reinterpret_cast<const s16x8*>(tBh + (c + PD) * 16 * KT + b_pos);
-        vl[r] = *reinterpret_cast<const s16x8*>(tBl + (c + PD) * 16 * KT + b_pos);
+        vh[r] = *reinterpret_cast<const lds_s16x8*>(tBh + (c + PD) * 16 * KT);
+        vl[r] = *reinterpret_cast<const lds_s16x8*>(tBl + (c + PD) * 16 * KT);
       }
       __builtin_amdgcn_sched_group_barrier(0x008, PR::NT, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
@@ -516,6 +531,8 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   // next read in 2kt+2; a V stage is rewritten in 2kt+1 / 2kt+2, last read in 2kt and next read in 2kt+3.
   WGSTAMP(1);
   if (late) __syncthreads();
+  // (a two-tiles-per-trip form of this loop, with the LDS stage a compile-time constant, was built and dropped: at d = 256 it
+  //  spilled 28 registers in the forward and 82 in the backward kernel)
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1, nxt = cur ^ 1;
     const bool more = kt + 1 < nkt;

@@ -67,9 +67,12 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
   if (u >= Y * p.E) return;
   const int e = p.eval_ids ? p.eval_ids[u / Y] : u / Y;
   const int hd = (u % Y) % p.H, blk = (u % Y) / p.H;
-  const int T = p.T, Tp = p.Tp, ld = p.ld, ldk = p.ld_kv > 0 ? p.ld_kv : p.ld;
+  // ragged batches: this evaluation's own query / key counts (Tq, p.T stay the maxima that lay out the buffers)
+  const int Tq_e = p.tq_arr ? p.tq_arr[e] : Tq;
+  if (qt * 128 >= Tq_e) return;                                // a query tile beyond a short evaluation (whole work-group)
+  const int T = p.t_arr ? p.t_arr[e] : p.T, Tp = p.Tp, ld = p.ld, ldk = p.ld_kv > 0 ? p.ld_kv : p.ld;
   const int qrow = qt * 128 + wave * 16 + lq;                  // query index inside the block
-  const bool q_ok = qrow < Tq;
+  const bool q_ok = qrow < Tq_e;
 
   const long long qs = p.q_index ? p.q_index[e] : e;
   const long long ks = p.kv_index ? p.kv_index[e] : e;
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
   float* xbuf = &tiles[0][0][0];
   constexpr int CH_T = D / 16;                                     // 16-byte chunks per thread: D rows x 32 chunks / 512
   const int cc = tid & 31, crow = tid >> 5;
-  const unsigned c_off = (qt * 128 + 4 * cc) < Tq ? (unsigned)(crow * ld + qt * 128 + 4 * cc) * 4u : CSN_OOB;
+  const unsigned c_off = (qt * 128 + 4 * cc) < Tq_e ? (unsigned)(crow * ld + qt * 128 + 4 * cc) * 4u : CSN_OOB;
   const int col = 16 * wave + lq;
   auto stage_in = [&](const csn_rsrc_t& rs) {
     f32x4 ch[CH_T];

@@ -144,9 +144,10 @@ static int attn_fwd_impl(const float* q, const float* k, const float* v, long lo
                          long long ctx_eval_stride, float* scores, float* lse, int n_evals, int n_heads,
                          int d_head, int block, int n_blocks, int score_pitch, float rescale_threshold,
                          float dropout_p, unsigned long long seed, int qkv_split, long long qkv_plane_stride,
-                         int block_q, int ld_kv, void* stream) {
+                         int block_q, int ld_kv, void* stream, const int* tq_arr = nullptr, const int* t_arr = nullptr) {
   // block_q / ld_kv != 0: the queries of a block are counted separately from its keys (block = keys) and K/V maps have
-  // their own leading dimension; key counts need not be multiples of 4 then (fp32 K/V maps only)
+  // their own leading dimension; key counts need not be multiples of 4 then (fp32 K/V maps only).  tq_arr / t_arr: the
+  // per-evaluation counts of a ragged batch (block_q / block are then the maxima)
   const int bq = block_q > 0 ? block_q : block, lk = ld_kv > 0 ? ld_kv : ld;
   if (block_q < 0 || ld_kv < 0 || (ld_kv & 3) || (long long)n_blocks * ((block + 3) / 4 * 4) > lk) return CSN_E_ARG;
   if ((block & 3) && (block_q == 0 || qkv_split)) return CSN_E_ALIGN;
@@ -176,6 +177,7 @@ static int attn_fwd_impl(const float* q, const float* k, const float* v, long lo
   a.eval_ids = nullptr; a.grp_off = nullptr; a.out_index = nullptr; a.accumulate = 0;
   a.dropout_p = dropout_p; a.seed = seed;
   a.r_planes = 0; a.kv_planes = qkv_split; a.r_plane_stride = 0; a.kv_plane_stride = 0; a.sc_tiles = 0;
+  a.tq_arr = tq_arr; a.t_arr = t_arr;
   return mode() != 0 ? csn_launch_attn_fwd_bf16x3(a, d_head, mode(), (hipStream_t)stream)
                      : csn_launch_attn_fwd_f32(a, d_head, (hipStream_t)stream);
 }
@@ -209,8 +211,9 @@ static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_e
                             int d_head, int block, int n_blocks, int score_pitch, float dropout_p,
                             unsigned long long seed, int dctx_split, long long dctx_plane_stride, int kv_split,
                             long long kv_plane_stride, int probs_tiles, int block_q, int ld_kv, const int* group_offsets,
-                            int n_groups, void* stream) {
+                            int n_groups, void* stream, const int* tq_arr = nullptr, const int* t_arr = nullptr) {
   if (block_q < 0 || ld_kv < 0 || (ld_kv & 3)) return CSN_E_ARG;
+  if ((tq_arr || t_arr) && (group_offsets || n_blocks != 1)) return CSN_E_ARG;
   if (group_offsets && (n_groups <= 0 || !eval_ids || !(csn_attn_bwd_grouping(d_head, block) & 1))) return CSN_E_ARG;
   if ((block & 3) && (block_q == 0 || kv_split)) return CSN_E_ALIGN;
   if (probs_tiles && (mode() == 0 || score_pitch < (block + 31) / 32 * 32)) return CSN_E_ARG;
@@ -247,6 +250,7 @@ static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_e
   a.dropout_p = dropout_p; a.seed = seed;
   a.r_planes = 0; a.kv_planes = kv_split; a.r_plane_stride = 0; a.kv_plane_stride = 0; a.kv_ld = (int)kv_plane_stride;
   a.sc_tiles = probs_tiles;
+  a.tq_arr = tq_arr; a.t_arr = t_arr;
   return mode() != 0 ? csn_launch_attn_bwd_bf16x3(a, d_head, mode(), st) : csn_launch_attn_bwd_f32(a, d_head, st);
 }
 
@@ -270,7 +274,8 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
                              int accumulate, const int* eval_ids, int n_launch_evals, int n_heads, int d_head,
                              int block, int n_blocks, int score_pitch, int dctx_split, long long dctx_plane_stride,
                              int q_split, long long q_plane_stride, int probs_tiles, int block_q, int ld_kv,
-                             const int* group_offsets, int n_groups, void* stream) {
+                             const int* group_offsets, int n_groups, void* stream, const int* tq_arr = nullptr,
+                             const int* t_arr = nullptr) {
   // block_q / ld_kv != 0 (cross-length attention): block counts the keys, block_q (% 4) the queries that are contracted;
   // dk / dv are [d][ld_kv] maps whose columns block .. round-up-4(block) are written as zeros
   if (block_q < 0 || ld_kv < 0 || (ld_kv & 3) || (block_q & 3)) return CSN_E_ARG;
@@ -296,6 +301,7 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   g.n0 = n_blocks; g.n1 = n_heads; g.k_chunk = 0;
   g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = accumulate; g.eval_ids = eval_ids;
   if (group_offsets) { g.eval_ids = nullptr; g.grp_off = group_offsets; g.grp_items = eval_ids; }
+  g.n_arr = t_arr; g.k_arr = tq_arr;            // ragged batch: keys (rounded up to 4 by the kernel) / queries of every evaluation
   const int n_batch = group_offsets ? n_groups : n_launch_evals;
   g.A = operand(dctx, bq, (long long)d_head * ld, dctx_split ? 2 * ctx_eval_stride : ctx_eval_stride, nullptr, ld);
   g.A.planes = dctx_split; g.A.plane_stride = dctx_plane_stride;
@@ -356,6 +362,37 @@ int csn_cross_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_ev
   return attn_bwd_dkv_impl(dctx, ctx_eval_stride, q, q_shape_stride, nullptr, ld_q, scores, dscores, dk, dv, dkv_eval_stride,
                            nullptr, nullptr, 0, nullptr, n_evals, n_heads, d_head, n_keys, 1, score_pitch, 0, 0, 0, 0, pt,
                            n_queries, ld_kv, nullptr, 0, stream);
+}
+
+/* ragged batches of the cross-length attention: the same kernels with per-evaluation query / key counts (device arrays) */
+int csn_varlen_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
+                            long long kv_shape_stride, int ld_q, int ld_kv, float* ctx, long long ctx_eval_stride,
+                            float* scores, float* lse, int n_evals, int n_heads, int d_head, int max_queries, int max_keys,
+                            const int* n_queries, const int* n_keys, int score_pitch, float rescale_threshold,
+                            float dropout_p, unsigned long long seed, void* stream) {
+  if (max_queries <= 0 || max_keys <= 0 || (max_queries & 3) || !n_queries || !n_keys) return CSN_E_ARG;
+  ModeGuard guard(mode() >= 2 ? 1 : mode());
+  return attn_fwd_impl(q, k, v, q_shape_stride, kv_shape_stride, nullptr, nullptr, ld_q, ctx, ctx_eval_stride, scores, lse,
+                       n_evals, n_heads, d_head, max_keys, 1, score_pitch, rescale_threshold, dropout_p, seed, 0, 0, max_queries,
+                       ld_kv, stream, n_queries, n_keys);
+}
+
+int csn_varlen_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* q, const float* k,
+                            const float* v, long long q_shape_stride, long long kv_shape_stride, int ld_q, int ld_kv,
+                            float* scores, float* dscores, const float* lse, float* delta, float* dq, float* dk, float* dv,
+                            long long dq_eval_stride, long long dkv_eval_stride, int n_evals, int n_heads, int d_head,
+                            int max_queries, int max_keys, const int* n_queries, const int* n_keys, int score_pitch,
+                            float dropout_p, unsigned long long seed, void* stream) {
+  if (max_queries <= 0 || max_keys <= 0 || (max_queries & 3) || !n_queries || !n_keys) return CSN_E_ARG;
+  ModeGuard guard(mode() >= 2 ? 1 : mode());
+  const int pt = (mode() != 0 && score_pitch >= (max_keys + 31) / 32 * 32) ? 1 : 0;
+  int rc = attn_bwd_dq_impl(dctx, ctx, ctx_eval_stride, k, v, kv_shape_stride, nullptr, ld_q, scores, dscores, lse, delta, dq,
+                            dq_eval_stride, nullptr, 0, nullptr, n_evals, n_heads, d_head, max_keys, 1, score_pitch, dropout_p,
+                            seed, 0, 0, 0, 0, pt, max_queries, ld_kv, nullptr, 0, stream, n_queries, n_keys);
+  if (rc) return rc;
+  return attn_bwd_dkv_impl(dctx, ctx_eval_stride, q, q_shape_stride, nullptr, ld_q, scores, dscores, dk, dv, dkv_eval_stride,
+                           nullptr, nullptr, 0, nullptr, n_evals, n_heads, d_head, max_keys, 1, score_pitch, 0, 0, 0, 0, pt,
+                           max_queries, ld_kv, nullptr, 0, stream, n_queries, n_keys);
 }
 
 int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const float* wfc, const float* xres,

@@ -19,6 +19,10 @@ struct CsnGemmArgs {
   // C by the group's first item) and writes once — evaluations that share an output slot need no read-modify-write passes
   const int* grp_off = nullptr;
   const int* grp_items = nullptr;
+  // ragged batches (varlen attention backward): per-item column / contraction counts, indexed by the slowest batch index
+  // z2 (after eval_ids); N and K above are then the maxima that size the grid.  n_arr[z] is rounded up to 4; k_arr[z] % 4 == 0.
+  const int* n_arr = nullptr;
+  const int* k_arr = nullptr;
 };
 
 int csn_launch_gemm_f32(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st);
@@ -57,6 +61,10 @@ struct CsnAttnArgs {
   int Tq;                                                // queries per block (0: = T); T counts the keys
   int ld_kv;                                             // leading dimension of the fp32 K/V maps (0: = ld)
   int sc_tiles;                                          // backward (bf16x3): P and dS leave as bf16 tile planes [query][tile: hi 32 | lo 32]
+  // ragged batches (n_blocks = 1): per-evaluation query / key counts (device arrays; null = Tq / T for every evaluation).
+  // Tq and T are then the maxima: they size the grid, the score pitch and the buffers; tq_arr[e] % 4 == 0.
+  const int* tq_arr;
+  const int* t_arr;
 };
 int csn_launch_attn_fwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
 int csn_launch_attn_bwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);

@@ -180,6 +180,30 @@ int csn_cross_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_ev
                            int n_queries, int n_keys, int score_pitch, float dropout_p, unsigned long long seed,
                            void* stream);
 
+/* ---- (3c) ragged batches of the cross-length attention ("varlen") -------------------------------------------
+ * ONE launch chain for a batch of shape pairs whose query and key counts all differ — MinkowskiNet/models/hrnet.py:378-410,
+ * 456-470 calls the layer once per shape / per shape pair, with 1..5 k voxels each.  The entry points of (3b) with length
+ * arrays: n_queries[e] and n_keys[e] are DEVICE int arrays of n_evals entries (the cu_seqlens of a padded layout); max_queries
+ * (% 4) and max_keys bound them and size the grid, score_pitch and the buffers, which are PADDED to common leading dimensions:
+ *   q, ctx, dctx, dq [n_evals][n_heads*d_head][ld_q],  k, v, dk, dv [n_evals][n_heads*d_head][ld_kv],
+ *   scores, dscores [n_evals][n_heads][max_queries][score_pitch],  lse, delta [n_evals][n_heads][max_queries].
+ * n_queries[e] % 4 == 0 (round a shape's point count up: its zero points cost little and contribute nothing); n_keys[e] is
+ * arbitrary (>= 1).  Work-groups of query tiles beyond n_queries[e] exit at once and key tiles beyond n_keys[e] are never
+ * visited, so a short evaluation costs its own size.  Rows / columns beyond an evaluation's own counts are neither read as
+ * data nor written: the caller zero-fills ctx, dq, dk, dv where it goes on to use the padding (csn_amd does), and the padding
+ * points of the input maps must be finite (zeros).  Dropout masks are indexed with the launch's max_queries / score_pitch. */
+int csn_varlen_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
+                            long long kv_shape_stride, int ld_q, int ld_kv, float* ctx, long long ctx_eval_stride,
+                            float* scores, float* lse, int n_evals, int n_heads, int d_head, int max_queries, int max_keys,
+                            const int* n_queries, const int* n_keys, int score_pitch, float rescale_threshold,
+                            float dropout_p, unsigned long long seed, void* stream);
+int csn_varlen_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* q, const float* k,
+                            const float* v, long long q_shape_stride, long long kv_shape_stride, int ld_q, int ld_kv,
+                            float* scores, float* dscores, const float* lse, float* delta, float* dq, float* dk, float* dv,
+                            long long dq_eval_stride, long long dkv_eval_stride, int n_evals, int n_heads, int d_head,
+                            int max_queries, int max_keys, const int* n_queries, const int* n_keys, int score_pitch,
+                            float dropout_p, unsigned long long seed, void* stream);
+
 /* ---- (4) output projection + residual + LayerNorm, forward -------------------------------------------
  * z[c][n] = sum_D wfc[c][D] ctx[e][D][n] + xres[res_index[e]][c][n];  xhat = (z - mean_c z) * rstd,
  * rstd = 1/sqrt(var_c z + eps).   Replaces fc + residual + LayerNorm (csa_models.py:52,57,114-118) up to the
