@@ -38,13 +38,17 @@ class _CrossMHA(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xq, xk, xv, w_qs, w_ks, w_vs, w_fc, n_head: int, d_head: int, p_attn: float, p_fc: float,
-                want_attn: bool, keep: bool):
+                want_attn: bool, keep: bool, q_lens=None, k_lens=None):
+        """q_lens / k_lens (int32 device tensors, one entry per batch item; q_lens % 4 == 0): a RAGGED batch — item i uses
+        the first q_lens[i] query points and k_lens[i] key points of its zero-padded rows, in one launch chain
+        (csn_varlen_attn_fwd_f32 / _bwd_f32)."""
         CF._need_cuda(xq, xk, xv, w_qs, w_ks, w_vs, w_fc)
         L = _lib.lib()
         b, lq, C = xq.shape
         lk = xk.shape[1]
         if xv.shape[1] != lk:
             raise ValueError("keys and values must have the same length")
+        varlen = q_lens is not None
         H, d, D = n_head, d_head, n_head * d_head
         lq4, lk4 = _up(lq, 4), _up(lk, 4)
         Tp = _up(lk, 32)
@@ -56,12 +60,20 @@ class _CrossMHA(torch.autograd.Function):
         k = CF.project(xk_cm, w_ks.contiguous())
         v = CF.project(xv_cm, w_vs.contiguous())
         seed_attn, seed_fc = CF.draw_seeds(2) if (p_attn > 0 or p_fc > 0) else (0, 0)
-        att = torch.empty((b, D, lq4), device=dev, dtype=torch.float32)
+        # ragged batch: the context of padding queries is never written — it must read as zero downstream (fc + LayerNorm of
+        # a zero row is a finite zero row, and nothing flows back from it)
+        att = (torch.zeros if varlen else torch.empty)((b, D, lq4), device=dev, dtype=torch.float32)
         lse = torch.empty((b, H, lq4), device=dev, dtype=torch.float32)
         scores = torch.empty((b, H, lq4, Tp), device=dev, dtype=torch.float32) if (keep or want_attn) else None
-        _lib.check(L.csn_cross_attn_fwd_f32(CF._ptr(q), CF._ptr(k), CF._ptr(v), D * lq4, D * lk4, lq4, lk4, CF._ptr(att),
-                                            D * lq4, CF._ptr(scores), CF._ptr(lse), b, H, d, lq4, lk, Tp,
-                                            CF.RESCALE_THRESHOLD, p_attn, seed_attn, CF._stream()), "csn_cross_attn_fwd_f32")
+        if varlen:
+            _lib.check(L.csn_varlen_attn_fwd_f32(CF._ptr(q), CF._ptr(k), CF._ptr(v), D * lq4, D * lk4, lq4, lk4, CF._ptr(att),
+                                                 D * lq4, CF._ptr(scores), CF._ptr(lse), b, H, d, lq4, lk, CF._ptr(q_lens),
+                                                 CF._ptr(k_lens), Tp, CF.RESCALE_THRESHOLD, p_attn, seed_attn, CF._stream()),
+                       "csn_varlen_attn_fwd_f32")
+        else:
+            _lib.check(L.csn_cross_attn_fwd_f32(CF._ptr(q), CF._ptr(k), CF._ptr(v), D * lq4, D * lk4, lq4, lk4, CF._ptr(att),
+                                                D * lq4, CF._ptr(scores), CF._ptr(lse), b, H, d, lq4, lk, Tp,
+                                                CF.RESCALE_THRESHOLD, p_attn, seed_attn, CF._stream()), "csn_cross_attn_fwd_f32")
         attn = None
         if want_attn:
             # the un-dropped probabilities (the reference returns the dropped ones in train mode; hrnet.py discards them)
@@ -76,6 +88,7 @@ class _CrossMHA(torch.autograd.Function):
             ctx.save_for_backward(xq_cm, xk_cm, xv_cm, w_qs, w_ks, w_vs, w_fc, q, k, v, att, lse, scores, xhat, rstd)
             ctx.dims = (b, lq, lk, C, H, d, Tp)
             ctx.drop = (p_attn, seed_attn, p_fc, seed_fc)
+            ctx.lens = (q_lens, k_lens)
         if attn is not None:
             ctx.mark_non_differentiable(attn)
         return xhat, attn
@@ -105,14 +118,24 @@ class _CrossMHA(torch.autograd.Function):
         # attention backward: gradients to the projected queries, keys and values
         dscores = torch.empty_like(scores)
         delta = torch.empty((b, H, lq4), device=dev, dtype=torch.float32)
-        dq = torch.empty((b, D, lq4), device=dev, dtype=torch.float32)
-        dk = torch.empty((b, D, lk4), device=dev, dtype=torch.float32)
-        dv = torch.empty((b, D, lk4), device=dev, dtype=torch.float32)
+        q_lens, k_lens = ctx.lens
+        varlen = q_lens is not None
+        alloc = torch.zeros if varlen else torch.empty               # ragged batch: rows / columns of the padding stay zero
+        dq = alloc((b, D, lq4), device=dev, dtype=torch.float32)
+        dk = alloc((b, D, lk4), device=dev, dtype=torch.float32)
+        dv = alloc((b, D, lk4), device=dev, dtype=torch.float32)
         work = scores.clone()                                        # the backward turns the scores into probabilities in place
-        _lib.check(L.csn_cross_attn_bwd_f32(CF._ptr(datt), CF._ptr(att), D * lq4, CF._ptr(q), CF._ptr(k), CF._ptr(v), D * lq4,
-                                            D * lk4, lq4, lk4, CF._ptr(work), CF._ptr(dscores), CF._ptr(lse), CF._ptr(delta),
-                                            CF._ptr(dq), CF._ptr(dk), CF._ptr(dv), D * lq4, D * lk4, b, H, d, lq4, lk, Tp,
-                                            p_attn, seed_attn, CF._stream()), "csn_cross_attn_bwd_f32")
+        if varlen:
+            _lib.check(L.csn_varlen_attn_bwd_f32(CF._ptr(datt), CF._ptr(att), D * lq4, CF._ptr(q), CF._ptr(k), CF._ptr(v), D * lq4,
+                                                 D * lk4, lq4, lk4, CF._ptr(work), CF._ptr(dscores), CF._ptr(lse), CF._ptr(delta),
+                                                 CF._ptr(dq), CF._ptr(dk), CF._ptr(dv), D * lq4, D * lk4, b, H, d, lq4, lk,
+                                                 CF._ptr(q_lens), CF._ptr(k_lens), Tp, p_attn, seed_attn, CF._stream()),
+                       "csn_varlen_attn_bwd_f32")
+        else:
+            _lib.check(L.csn_cross_attn_bwd_f32(CF._ptr(datt), CF._ptr(att), D * lq4, CF._ptr(q), CF._ptr(k), CF._ptr(v), D * lq4,
+                                                D * lk4, lq4, lk4, CF._ptr(work), CF._ptr(dscores), CF._ptr(lse), CF._ptr(delta),
+                                                CF._ptr(dq), CF._ptr(dk), CF._ptr(dv), D * lq4, D * lk4, b, H, d, lq4, lk, Tp,
+                                                p_attn, seed_attn, CF._stream()), "csn_cross_attn_bwd_f32")
         del work, dscores
         need = ctx.needs_input_grad
         dq /= temperature                                            # Qs = (xq Wq^T) / sqrt(d)
@@ -127,7 +150,7 @@ class _CrossMHA(torch.autograd.Function):
             dxk = CF.project(dk, w_ks.t().contiguous())[:, :, :lk].transpose(1, 2)
         if need[2]:
             dxv = CF.project(dv, w_vs.t().contiguous())[:, :, :lk].transpose(1, 2)
-        return dxq, dxk, dxv, dw_q, dw_k, dw_v, dw_fc, None, None, None, None, None, None
+        return dxq, dxk, dxv, dw_q, dw_k, dw_v, dw_fc, None, None, None, None, None, None, None, None
 
 
 class ScaledDotProductAttention(nn.Module):
@@ -194,3 +217,32 @@ class MultiHeadAttention(nn.Module):
                                      self.return_attention, keep)
         out = xhat[:, :, :lq].transpose(1, 2) * self.norm.weight + self.norm.bias
         return out, attn
+
+    def forward_varlen(self, qs, ks, vs=None):
+        """A RAGGED batch in one launch chain: ``qs[i]`` (n_i, d_model), ``ks[i]`` / ``vs[i]`` (m_i, d_model) point-major features
+        of shape pair i (``vs=None``: values = keys), every n_i and m_i different — what MinkowskiNet/models/hrnet.py:378-410,
+        456-470 does with one ``forward`` call per shape / shape pair.  Returns the list of outputs (n_i, d_model), equal to
+        ``[self(q[None], k[None], v[None])[0][0] for ...]`` (in train mode: other dropout masks).  The pairs are zero-padded to
+        the longest one (query counts rounded up to 4) and carried with their length arrays (csn_varlen_attn_*_f32): a short
+        pair costs its own size in the attention kernels; only the projections and the LayerNorm see the padding."""
+        vs = ks if vs is None else vs
+        if not (len(qs) == len(ks) == len(vs)) or not qs:
+            raise ValueError("forward_varlen needs equally long, non-empty lists")
+        if not qs[0].is_cuda:
+            raise _lib.CsnError("csn_amd ops need tensors on the MI355X (cuda) device; there is no CPU path")
+        dev, C = qs[0].device, qs[0].shape[-1]
+        nq, nk = [int(t.shape[0]) for t in qs], [int(t.shape[0]) for t in ks]
+        if any(int(v.shape[0]) != m for v, m in zip(vs, nk)) or min(nq) < 1 or min(nk) < 1:
+            raise ValueError("keys and values of a pair must have the same, non-zero length")
+        pad = lambda ts, n: torch.stack([torch.nn.functional.pad(t.float(), (0, 0, 0, n - t.shape[0])) for t in ts])
+        Lq, Lk = max(nq), max(nk)
+        q, k = pad(qs, Lq), pad(ks, Lk)
+        v = k if vs is ks else pad(vs, Lk)
+        q_lens = torch.tensor([_up(n, 4) for n in nq], dtype=torch.int32, device=dev)
+        k_lens = torch.tensor(nk, dtype=torch.int32, device=dev)
+        p_attn, p_fc = (self.attention.dropout.p, self.dropout.p) if self.training else (0.0, 0.0)
+        ws = (self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight)
+        keep = torch.is_grad_enabled() and any(t.requires_grad for t in tuple(qs) + tuple(ks) + tuple(vs) + ws)
+        xhat, _ = _CrossMHA.apply(q, k, v, *ws, self.n_head, self.d_k, float(p_attn), float(p_fc), False, keep, q_lens, k_lens)
+        out = xhat.transpose(1, 2) * self.norm.weight + self.norm.bias                     # (b, Lq4, C)
+        return [out[i, :n] for i, n in enumerate(nq)]
