@@ -215,7 +215,8 @@ def main():
             p.grad = None
         if shard is not None:
             if overlap:
-                x_nb = shard.exchange_async(feats, mode=exchange_mode)   # the model overlaps its self-attention with it
+                x_nb = shard.exchange_async(feats, mode=exchange_mode,   # the model overlaps its self-attention with it
+                                            reuse_descriptors=os.environ.get("CSN_REUSE", "1") != "0")
             elif exchange_mode == "alltoall":
                 x_nb = shard.exchange_neighbours(feats)                  # neighbour-only all-to-all
             else:
@@ -260,7 +261,9 @@ def main():
             tmax = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = tmax.item()
-        ms = {k: (float(np.mean([a.elapsed_time(b) for a, b in v])) if v else float("nan")) for k, v in attn_events.items()}
+        # per STEP: the attention launches of one step summed (N = 1: one forward and one backward launch; the overlapped
+        # multi-GPU path: two of each — own shapes first, the evaluations that need neighbour data after the exchange)
+        ms = {k: (float(np.sum([a.elapsed_time(b) for a, b in v])) / args.steps if v else float("nan")) for k, v in attn_events.items()}
         gnorm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params if p.grad is not None)).item())
         return el, float(loss.item()), ms, gnorm
 
@@ -273,7 +276,10 @@ def main():
         set_math(other)
         elapsed_other, loss_other, attn_ms_other, gnorm_other = timed(True)
         set_math(args.math)
-    n_evals = B * (2 * K + 2)                          # train mode: the pooled and the mixed self evaluation differ
+    reuse = world > 1 and overlap and os.environ.get("CSN_REUSE", "1") != "0"
+    # train mode: the pooled and the mixed self evaluation differ (2K+2 per shape); with descriptor reuse (N > 1) the K
+    # neighbour self-attention evaluations per shape are their owners' work: K+2 per shape
+    n_evals = B * ((K + 2) if reuse else (2 * K + 2))
 
     if rank == 0:
         launch_flops = n_evals * 4 * N * T * D         # forward: QK^T + PV; backward: dO V^T + dS K — the same count
@@ -294,7 +300,7 @@ def main():
                  "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                  "traffic": entry["bytes_per_launch"] if entry else None,
                  "traffic_source": (entry["source"] + " (rocprofv3 --pmc passes of this command, not measured in this run)") if entry else None,
-                 "launch_ms": ms, "launch_ms_is": f"mean of {args.steps} timed launches (HIP events on the launch stream)",
+                 "launch_ms": ms, "launch_ms_is": f"mean over {args.steps} timed steps of the step's launches of this kernel (HIP events on the launch stream)",
                  "flops_per_launch": launch_flops,
                  "note": f"algorithmic FLOPs: 4*T*d = {4 * T * d // 1000} kFLOP per query point per evaluation x {N} points x "
                          f"{n_evals} evaluations in the launch"}
@@ -318,9 +324,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{cfg['name']}: CSA K={K}, {B} query shapes/GPU x {N} pts x {C} ch, n_heads={H}, d_k=d_v={d}, "
                                    f"{nb} blocks of {T}, {N_CLS} classes, fwd + masked CE + bwd, train mode (dropout 0.1 live, "
-                                   f"2K+2 evaluations/shape), math mode {args.math}",
+                                   + ("K+2 evaluations/shape: every shape's pooled SSA descriptor is computed once, by its owner"
+                                      if reuse else "2K+2 evaluations/shape") + f"), math mode {args.math}",
+                       "evaluations_per_shape": n_evals // B,
                        "shapes_total": S, "K": K,
-                       "parallelism": (f"shape-graph sharded x{world}, exchange {exchange_mode}" + (" overlapped" if overlap else "")) if world > 1 else "single GPU",
+                       "parallelism": (f"shape-graph sharded x{world}, exchange {exchange_mode}" + (" overlapped" if overlap else "")
+                                       + (", descriptor reuse" if reuse else "")) if world > 1 else "single GPU",
                        "loss": loss_val, "grad_norm": gnorm,
                        "step_tflops_algorithmic": 3 * algorithmic_flops_fwd(S, K, N, C, D, T) / (elapsed / args.steps) / 1e12},
             "roofline": dominant, "roofline_other": second,
