@@ -204,11 +204,27 @@ def main():
     split_probe = world == 1 and os.environ.get("CSN_BENCH_SPLIT") == "1"
 
     class _ReadyStack:
-        def __init__(self, stack):
-            self.stack = stack
+        """stands in for csn_amd.sharding.PendingStack with the exchange already complete (development aids below)"""
+        reuse_descriptors = False
+
+        def __init__(self, stack, graph=None):
+            self.stack, self.graph = stack, graph
+            self.reuse_descriptors = graph is not None
 
         def wait(self):
             return self.stack
+
+        def gather_pooled(self, own_pooled):
+            return own_pooled[self.graph]            # every neighbour is one of this process's own shapes
+
+    # CSN_BENCH_SPLIT=2 (N = 1, development aid): the per-GPU compute of the N > 1 path without any exchange — the 32 shapes
+    # are their own collection (K-regular graph among them), neighbour descriptors are taken from their "owners" (K+2
+    # evaluations per shape)
+    local_graph = None
+    if world == 1 and os.environ.get("CSN_BENCH_SPLIT") == "2":
+        from csn_amd.sharding import regular_graph
+        local_graph = torch.from_numpy(regular_graph(B, K)).to(dev)
+        x_nb_resident[:, 1:, :, :, 0] = feats[local_graph]
 
     def step(record=False):
         for p in params:
@@ -225,6 +241,8 @@ def main():
             x_nb = x_nb_resident                                         # (B, K+1, C, N, 1), slot 0 = self
             if split_probe:
                 x_nb = _ReadyStack(x_nb)
+            elif local_graph is not None:
+                x_nb = _ReadyStack(x_nb, local_graph)
         if record:
             CF.EVENT_SINK = attn_events
         logits = model(feats.unsqueeze(-1), "train", x_nb)
@@ -276,7 +294,7 @@ def main():
         set_math(other)
         elapsed_other, loss_other, attn_ms_other, gnorm_other = timed(True)
         set_math(args.math)
-    reuse = world > 1 and overlap and os.environ.get("CSN_REUSE", "1") != "0"
+    reuse = (world > 1 and overlap and os.environ.get("CSN_REUSE", "1") != "0") or local_graph is not None
     # train mode: the pooled and the mixed self evaluation differ (2K+2 per shape); with descriptor reuse (N > 1) the K
     # neighbour self-attention evaluations per shape are their owners' work: K+2 per shape
     n_evals = B * ((K + 2) if reuse else (2 * K + 2))

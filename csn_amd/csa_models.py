@@ -139,7 +139,9 @@ class MultiHeadAttention(nn.Module):
                 b, k = np.meshgrid(ar, np.arange(K1), indexing="ij")
                 nbr = (b * K1 + k)[:, 1:].reshape(-1)
                 own = (b * K1)[:, 1:].reshape(-1)
-                cache[key] = CF.EvalPlan(own, nbr, B * K1, dev)
+                # Q is read of the own slots b*K1 only, K / V of the neighbour slots b*K1 + k only
+                cache[key] = CF.EvalPlan(own, nbr, B * K1, dev, q_ranges=[(0, K1, B)],
+                                         kv_ranges=[(k_, K1, B) for k_ in range(1, K1)])
             else:
                 raise ValueError(kind)
         return cache[key]

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
       score_pos(kt);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const f32x4 v = csn_bload4(Sr, s_voff[j]);
+        const f32x4 v = csn_bload4_stream(Sr, s_voff[j]);
         sv[4 * j] = v[0]; sv[4 * j + 1] = v[1]; sv[4 * j + 2] = v[2]; sv[4 * j + 3] = v[3];
       }
     }
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
       float mx = fmaxf(fmaxf(fmaxf(t1[0], t1[1]), fmaxf(t1[2], t1[3])), fmaxf(fmaxf(t1[4], t1[5]), fmaxf(t1[6], t1[7])));
 #pragma unroll
       for (int j = 0; j < 2; ++j)                              // (zero-sized window when scores are not kept)
-        csn_bstore4(f32x4{t1[4 * j], t1[4 * j + 1], t1[4 * j + 2], t1[4 * j + 3]}, Sr, s_voff[j]);
+        csn_bstore4_stream(f32x4{t1[4 * j], t1[4 * j + 1], t1[4 * j + 2], t1[4 * j + 3]}, Sr, s_voff[j]);
       // lazy rescale: only when some query's running maximum would grow by more than the threshold.  The four lanes
       // of a query share m_run, so the cross-lane maximum is only needed inside the (rare) branch.
       if (__any(mx > m_run + p.rescale_threshold)) {
@@ -445,8 +445,8 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
       if (!p.sc_tiles) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          csn_bstore4(f32x4{sv[4 * j], sv[4 * j + 1], sv[4 * j + 2], sv[4 * j + 3]}, Sr, s_voff[j]);
-          csn_bstore4(f32x4{t1[4 * j], t1[4 * j + 1], t1[4 * j + 2], t1[4 * j + 3]}, dSr, s_voff[j]);
+          csn_bstore4_stream(f32x4{sv[4 * j], sv[4 * j + 1], sv[4 * j + 2], sv[4 * j + 3]}, Sr, s_voff[j]);
+          csn_bstore4_stream(f32x4{t1[4 * j], t1[4 * j + 1], t1[4 * j + 2], t1[4 * j + 3]}, dSr, s_voff[j]);
         }
       }
     }
@@ -468,17 +468,17 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
         // two planes: a row of 16 tiles is exactly the bytes of the fp32 score row — P overwrites the scores of this tile
         // (already consumed by this wave) in place, dS takes the same place in `dscores`
         const unsigned tv = q_ok ? (unsigned)(qrow * Tp) * 4u + (unsigned)(kt * 128 + 16 * kq) : CSN_OOB;
-        csn_bstore4(__builtin_bit_cast(f32x4, qh), Sr, tv);
-        csn_bstore4(__builtin_bit_cast(f32x4, ql), Sr, tv, 64u);
-        csn_bstore4(__builtin_bit_cast(f32x4, ph), dSr, tv);
-        csn_bstore4(__builtin_bit_cast(f32x4, pl), dSr, tv, 64u);
+        csn_bstore4_stream(__builtin_bit_cast(f32x4, qh), Sr, tv);
+        csn_bstore4_stream(__builtin_bit_cast(f32x4, ql), Sr, tv, 64u);
+        csn_bstore4_stream(__builtin_bit_cast(f32x4, ph), dSr, tv);
+        csn_bstore4_stream(__builtin_bit_cast(f32x4, pl), dSr, tv, 64u);
       } else {
         // one plane: a row is half the bytes, so compact rows cannot overwrite the scores in place (they would run over the
         // rows of other work-groups).  Both go to this block's region of `dscores`: [P: Tq rows | dS: Tq rows] of pitch Tp
         // 16-bit elements; the scores stay untouched
         const unsigned tv = q_ok ? (unsigned)(qrow * Tp) * 2u + (unsigned)(kt * 64 + 16 * kq) : CSN_OOB;
-        csn_bstore4(__builtin_bit_cast(f32x4, qh), dSr, tv);
-        csn_bstore4(__builtin_bit_cast(f32x4, ph), dSr, tv, (unsigned)(Tq * Tp) * 2u);
+        csn_bstore4_stream(__builtin_bit_cast(f32x4, qh), dSr, tv);
+        csn_bstore4_stream(__builtin_bit_cast(f32x4, ph), dSr, tv, (unsigned)(Tq * Tp) * 2u);
       }
     }
   };

@@ -53,6 +53,17 @@ CSN_DEVINL void csn_bstore(float v, csn_rsrc_t r, unsigned voff, unsigned soff =
 CSN_DEVINL void csn_bstore4(f32x4 v, csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
 }
+// streaming forms (cache policy nt, aux bit 1): bytes that are written once and read once much later — the saved scores,
+// the P / dS planes — should not push the K / V tiles that four query-tile work-groups re-read out of the XCD's L2
+#ifndef CSN_NT
+#define CSN_NT 1
+#endif
+CSN_DEVINL f32x4 csn_bload4_stream(csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, CSN_NT ? 2 : 0));
+}
+CSN_DEVINL void csn_bstore4_stream(f32x4 v, csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, CSN_NT ? 2 : 0);
+}
 // 8-byte (4 x bf16) and 2-byte (1 x bf16) accesses for split-bf16 planes
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 CSN_DEVINL u32x2 csn_bload2(csn_rsrc_t r, unsigned voff, unsigned soff = 0) {

@@ -93,13 +93,21 @@ class EvalPlan:
     a colour every output slot occurs once, so a colour is one launch that adds into the per-slot gradient
     maps without atomics and without per-evaluation temporaries."""
 
-    def __init__(self, q_slots, kv_slots, n_slots: int, device, v_shift: int = 0):
+    def __init__(self, q_slots, kv_slots, n_slots: int, device, v_shift: int = 0, q_ranges=None, kv_ranges=None):
+        """q_ranges / kv_ranges (optional): the slots whose Q / K,V projections the evaluations actually read, as arithmetic
+        progressions [(first, step, count), ...] — a plan that reads Q of every (K+1)-th slot only (descriptor reuse: the own
+        shapes) and K / V of the others then projects, and contracts weight gradients over, just those.  None = every slot."""
         import numpy as np
         q = np.asarray(q_slots, dtype=np.int64).reshape(-1)
         kv = np.asarray(kv_slots, dtype=np.int64).reshape(-1)
         assert q.shape == kv.shape and q.size > 0
         assert q.min() >= 0 and max(q.max(), kv.max() + v_shift) < n_slots
         self.E, self.S, self.v_shift = int(q.size), int(n_slots), int(v_shift)
+        self.q_ranges, self.kv_ranges = q_ranges, kv_ranges
+        if q_ranges is not None or kv_ranges is not None:
+            assert v_shift == 0 and q_ranges is not None and kv_ranges is not None
+            cover = lambda rs: set(int(f + st * i) for f, st, c in rs for i in range(c))
+            assert set(q.tolist()) <= cover(q_ranges) and set(kv.tolist()) <= cover(kv_ranges), "slot ranges must cover the plan"
         as_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
         self.q_slots, self.kv_slots, self.v_slots = as_dev(q), as_dev(kv), as_dev(kv + v_shift)
         self.dq_colors = [as_dev(c) for c in self._colors(q)]
@@ -308,19 +316,34 @@ class _MHAEvals(torch.autograd.Function):
             # (pre-scaled) stays fp32
             npl = planes()
             ldp = nb * 512 * npl
-            qkv = project(x_all, w_qkv[:D], div_rows=D, temperature=temperature)              # (S, D, NP) = Qs
+            qkv = torch.empty((S, D, NP), device=dev, dtype=torch.float32)                    # Qs
             kv = torch.empty((S, 2 * D, ldp), device=dev, dtype=torch.float16 if ctx.mode == 3 else torch.bfloat16)
             if T % 32:
                 kv.view(S, 2 * D, nb, 16, npl, 32)[:, :, :, (T - 1) // 32, :, T % 32:] = 0     # padding keys of the last tile
-            _lib.check(L.csn_project_f32(_ptr(x_all), x_all.stride(0), NP, _ptr(w_qkv[D:]), 2 * D, C, _ptr(kv), 2 * D * ldp,
-                                         ldp, S, NP, 0, 1.0, 2, T, _stream()), "csn_project_f32")
+            for first, step, count in (plan.q_ranges or [(0, 1, S)]):
+                _lib.check(L.csn_project_f32(x_all.data_ptr() + 4 * first * C * NP, step * C * NP, NP, _ptr(w_qkv), D, C,
+                                             qkv.data_ptr() + 4 * first * D * NP, step * D * NP, NP, count, NP, D, temperature,
+                                             0, 0, _stream()), "csn_project_f32")
+            for first, step, count in (plan.kv_ranges or [(0, 1, S)]):
+                _lib.check(L.csn_project_f32(x_all.data_ptr() + 4 * first * C * NP, step * C * NP, NP, _ptr(w_qkv[D:]), 2 * D, C,
+                                             kv.data_ptr() + 2 * first * 2 * D * ldp, step * 2 * D * ldp, ldp, count, NP, 0, 1.0, 2,
+                                             T, _stream()), "csn_project_f32")
             q_ptr, q_stride = qkv.data_ptr(), D * NP
             k_ptr, kv_stride = kv.data_ptr(), 2 * D * ldp
             v_ptr = k_ptr + 2 * (D * ldp + v_shift * kv_stride)
             kv_flag, kv_pitch = 1, ldp
         else:
             kv = None
-            qkv = project(x_all, w_qkv, div_rows=D, temperature=temperature)                  # (S, 3D, NP); Q rows pre-scaled
+            if plan.q_ranges is None:
+                qkv = project(x_all, w_qkv, div_rows=D, temperature=temperature)              # (S, 3D, NP); Q rows pre-scaled
+            else:
+                qkv = torch.empty((S, 3 * D, NP), device=dev, dtype=torch.float32)
+                for rows0, nrows, ranges in ((0, D, plan.q_ranges), (D, 2 * D, plan.kv_ranges)):
+                    for first, step, count in ranges:
+                        _lib.check(L.csn_project_f32(x_all.data_ptr() + 4 * first * C * NP, step * C * NP, NP, _ptr(w_qkv[rows0:]),
+                                                     nrows, C, qkv.data_ptr() + 4 * (first * 3 * D + rows0) * NP, step * 3 * D * NP, NP,
+                                                     count, NP, D if rows0 == 0 else 0, temperature, 0, 0, _stream()),
+                                   "csn_project_f32")
             q_ptr, q_stride = qkv.data_ptr(), 3 * D * NP
             k_ptr, kv_stride = q_ptr + 4 * D * NP, 3 * D * NP
             v_ptr = q_ptr + 4 * (2 * D * NP + v_shift * kv_stride)
@@ -432,12 +455,16 @@ class _MHAEvals(torch.autograd.Function):
         dscores = torch.empty_like(scores)
         delta = torch.empty((E, H, NP), device=dev, dtype=torch.float32)
         dqkv = torch.empty((S, 3 * D, NP), device=dev, dtype=torch.float32)
-        if plan.q_unwritten.numel():
-            dqkv[:, :D].index_fill_(0, plan.q_unwritten, 0.0)
-        if plan.k_unwritten.numel():
-            dqkv[:, D:2 * D].index_fill_(0, plan.k_unwritten, 0.0)
-        if plan.v_unwritten.numel():
-            dqkv[:, 2 * D:].index_fill_(0, plan.v_unwritten, 0.0)
+        # the weight gradients contract every slot's gradient maps — or, for a plan with slot ranges (and no input gradients
+        # wanted), only the ranges: the maps of the other (slot, projection) pairs are then neither cleared nor read
+        ranged = plan.q_ranges is not None and not need_dx
+        if not ranged:
+            if plan.q_unwritten.numel():
+                dqkv[:, :D].index_fill_(0, plan.q_unwritten, 0.0)
+            if plan.k_unwritten.numel():
+                dqkv[:, D:2 * D].index_fill_(0, plan.k_unwritten, 0.0)
+            if plan.v_unwritten.numel():
+                dqkv[:, 2 * D:].index_fill_(0, plan.v_unwritten, 0.0)
         slot_stride = 3 * D * NP                                   # of the fp32 gradient maps
         q_stride, kv_stride, kv_flag, kv_pitch = ctx.ptrs
         gbase, q_ptr = dqkv.data_ptr(), qkv.data_ptr()
@@ -502,7 +529,18 @@ class _MHAEvals(torch.autograd.Function):
         del dscores, delta, datt
 
         # ---- projection weight gradients ------------------------------------------------------------------
-        dw_qkv = project_wgrad(dqkv, x_all)
+        if ranged:
+            dw_qkv = torch.empty((3 * D, C), device=dev, dtype=torch.float32)
+            for rows0, nrows, ranges in ((0, D, plan.q_ranges), (D, 2 * D, plan.kv_ranges)):
+                for i, (first, step, count) in enumerate(ranges):
+                    ws_n = L.csn_wgrad_workspace_floats(nrows, C, count, NP)
+                    ws = torch.empty((ws_n,), device=dev, dtype=torch.float32)
+                    _lib.check(L.csn_project_wgrad_f32(dqkv.data_ptr() + 4 * (first * 3 * D + rows0) * NP, step * 3 * D * NP, NP,
+                                                       x_all.data_ptr() + 4 * first * C * NP, step * C * NP, NP,
+                                                       dw_qkv.data_ptr() + 4 * rows0 * C, nrows, C, count, NP, 1.0,
+                                                       0 if i == 0 else 1, _ptr(ws), ws_n, _stream()), "csn_project_wgrad_f32")
+        else:
+            dw_qkv = project_wgrad(dqkv, x_all)
         dw_q = dw_qkv[:D] / temperature               # Qs = (x Wq^T) / sqrt(d)  (csa_models.py:139)
         dw_k, dw_v = dw_qkv[D:2 * D], dw_qkv[2 * D:]
 

@@ -77,7 +77,7 @@ def _csa_collection(world):
     return p, feats, labels
 
 
-def _csa_worker(rank, world, port, out_dir):
+def _csa_worker(rank, world, port, out_dir, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -85,7 +85,7 @@ def _csa_worker(rank, world, port, out_dir):
     from csn_amd import _lib
     from csn_amd.csa_models import get_model
     from csn_amd.sharding import ShapeGraphShard, regular_graph
-    _lib.check(_lib.lib().csn_set_math_mode(1))
+    _lib.check(_lib.lib().csn_set_math_mode(mode))
     p, feats, labels = _csa_collection(world)
     shard = ShapeGraphShard(regular_graph(CSA_B * world, CSA_K), CSA_B, rank, world, torch.device("cuda"))
     lo, hi = shard.first, shard.first + CSA_B
@@ -109,7 +109,8 @@ def _csa_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_sharded_csa_step_with_descriptor_reuse_equals_single_process(tmp_path):
+@pytest.mark.parametrize("mode", [0, 1], ids=["fp32", "bf16x3"])
+def test_sharded_csa_step_with_descriptor_reuse_equals_single_process(tmp_path, mode):
     """Two ranks (sharing the test box's GPU) run the CSA step on their halves of a 4-shape collection three ways —
     neighbour-only all-to-all with the neighbours' pooled descriptors taken from their owners, the same without reuse, and
     the all-gather fallback — and each must reproduce the single-process module on the whole collection: logits, loss and,
@@ -118,9 +119,9 @@ def test_sharded_csa_step_with_descriptor_reuse_equals_single_process(tmp_path):
     from csn_amd.csa_models import get_model
     from csn_amd.sharding import ShapeGraphShard, regular_graph
     world = 2
-    mp.spawn(_csa_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_csa_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
     res = [torch.load(os.path.join(tmp_path, f"csa{r}.pt")) for r in range(world)]
-    _lib.check(_lib.lib().csn_set_math_mode(1))
+    _lib.check(_lib.lib().csn_set_math_mode(mode))
     try:
         p, feats, labels = _csa_collection(world)
         graph = regular_graph(CSA_B * world, CSA_K)
