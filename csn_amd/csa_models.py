@@ -78,9 +78,18 @@ class MultiHeadAttention(nn.Module):
         self.norm = nn.LayerNorm(d_model, eps=CF.LN_EPS)
 
     # -- helpers ------------------------------------------------------------------------------------------
-    def geometry(self, block: Optional[int] = None, n_blocks: Optional[int] = None) -> CF.MHAGeometry:
-        return CF.MHAGeometry(self.n_head, self.d_k, self.block if block is None else block,
-                              self.n_blocks if n_blocks is None else n_blocks)
+    def geometry(self, block: Optional[int] = None, n_blocks: Optional[int] = None, n_points: Optional[int] = None) -> CF.MHAGeometry:
+        """The chunking of a call.  ``self.n_blocks = None`` (constructor ``n_blocks=None``) means "every point": as many
+        blocks as ``n_points`` needs, the last one short when ``n_points`` is not a multiple of ``block`` (a generalisation:
+        the reference's 20 x 500 silently drops points beyond 10000 and raises below, csa_models.py:83-90)."""
+        block = self.block if block is None else block
+        n_blocks = self.n_blocks if n_blocks is None else n_blocks
+        if n_blocks is None:
+            if n_points is None:
+                raise ValueError("n_blocks=None needs the point count of the call")
+            n_blocks = (n_points + block - 1) // block
+            return CF.MHAGeometry(self.n_head, self.d_k, block, n_blocks, 0 if n_blocks * block == n_points else n_points)
+        return CF.MHAGeometry(self.n_head, self.d_k, block, n_blocks)
 
     def dropout_rates(self):
         """(attention-probability p, post-fc p): live only in train mode (csa_models.py:133-141, 56, 115)."""
@@ -180,7 +189,7 @@ class MultiHeadAttention(nn.Module):
 
     def forward(self, Q, K, V, mode=None, return_attn: bool = False):
         """(B, C, N, 1) x3 -> ((B, n_blocks*block, C), attn-of-last-block or None)   (csa_models.py:81-125)."""
-        y = self._run(Q, K, V, self.geometry())
+        y = self._run(Q, K, V, self.geometry(n_points=Q.shape[2]))
         attn = None
         if return_attn:
             from .sdpa import last_block_probabilities
@@ -255,7 +264,7 @@ class CrossShapeAt(nn.Module):
 
     def _ssa_cm(self, x) -> torch.Tensor:
         att = self.attention
-        geo = att.geometry()
+        geo = att.geometry(n_points=x.shape[2])
         xc = _channel_major(x, geo.n_points)
         return att.affine(att.evaluate(xc, att.plan("self", xc.shape[0], 1, xc.device), geo))
 
@@ -272,7 +281,7 @@ class CrossShapeAt(nn.Module):
         In eval mode the reference's two self calls (:210 and :232) are the same numbers; they are computed once.
         """
         att = self.attention
-        geo = att.geometry()
+        geo = att.geometry(n_points=x.shape[2])
         npts = geo.n_points
         xc = _channel_major(x, npts)                                           # (B, C, NP)
         B, C, _ = xc.shape
@@ -318,7 +327,7 @@ class CrossShapeAt(nn.Module):
         query shapes — a quarter of the work at K = 3 — run first, under the exchange; everything that reads neighbour data
         follows the wait.  Same arithmetic as ``_csa_cm`` (in train mode the dropout masks are drawn in a different order)."""
         att = self.attention
-        geo = att.geometry()
+        geo = att.geometry(n_points=xc.shape[2])
         npts = geo.n_points
         B, C, _ = xc.shape
         dev = xc.device

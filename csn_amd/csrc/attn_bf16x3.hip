@@ -120,9 +120,10 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   const int e0 = p.eval_ids ? p.eval_ids[it0] : it0;
   const int hd = (u % Y) % p.H, blk = (u % Y) / p.H;
   // ragged batches: this evaluation's own query / key counts (Tq, p.T stay the maxima that lay out the buffers)
-  const int Tq_e = p.tq_arr ? p.tq_arr[e0] : Tq;
+  const bool short_blk = p.T_last > 0 && blk == p.n_blocks - 1;     // the row ends inside the last block
+  const int Tq_e = p.tq_arr ? p.tq_arr[e0] : (short_blk ? p.T_last : Tq);
   if (qt * 128 >= Tq_e) return;                                // a query tile beyond a short evaluation (whole work-group)
-  const int T = p.t_arr ? p.t_arr[e0] : p.T, Tp = p.Tp, ld = p.ld, ldk = p.ld_kv > 0 ? p.ld_kv : p.ld;
+  const int T = p.t_arr ? p.t_arr[e0] : (short_blk ? p.T_last : p.T), Tp = p.Tp, ld = p.ld, ldk = p.ld_kv > 0 ? p.ld_kv : p.ld;
   const bool ragged = (T & 3) != 0;                            // keys of the last 4-key group are masked one by one
   const int qrow = qt * 128 + wave * 16 + lq;                  // query index inside the block
   const bool q_ok = qrow < Tq_e;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   const int e = p.eval_ids ? p.eval_ids[it] : it;
   const long long qs = p.q_index ? p.q_index[e] : e;
   const long long ks = p.kv_index ? p.kv_index[e] : e;
-  const long long head_off_kv = (long long)hd * D * ldk + (long long)blk * T;
+  const long long head_off_kv = (long long)hd * D * ldk + (long long)blk * p.T;   // (p.T: the layout; T may be a short last block)
   const long long win_kv = ((long long)(D - 1) * ldk + (T + 3) / 4 * 4) * 4;
   const csn_rsrc_t Rr = csn_make_rsrc(p.q + qs * p.q_shape_stride + head_off, win);
   // tile planes: 16-bit elements, row pitch kv_ld = n_blocks * 512 NPL, this block's 16 tiles start at blk * 512 NPL

@@ -68,9 +68,10 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
   const int e = p.eval_ids ? p.eval_ids[u / Y] : u / Y;
   const int hd = (u % Y) % p.H, blk = (u % Y) / p.H;
   // ragged batches: this evaluation's own query / key counts (Tq, p.T stay the maxima that lay out the buffers)
-  const int Tq_e = p.tq_arr ? p.tq_arr[e] : Tq;
+  const bool short_blk = p.T_last > 0 && blk == p.n_blocks - 1;     // the row ends inside the last block
+  const int Tq_e = p.tq_arr ? p.tq_arr[e] : (short_blk ? p.T_last : Tq);
   if (qt * 128 >= Tq_e) return;                                // a query tile beyond a short evaluation (whole work-group)
-  const int T = p.t_arr ? p.t_arr[e] : p.T, Tp = p.Tp, ld = p.ld, ldk = p.ld_kv > 0 ? p.ld_kv : p.ld;
+  const int T = p.t_arr ? p.t_arr[e] : (short_blk ? p.T_last : p.T), Tp = p.Tp, ld = p.ld, ldk = p.ld_kv > 0 ? p.ld_kv : p.ld;
   const int qrow = qt * 128 + wave * 16 + lq;                  // query index inside the block
   const bool q_ok = qrow < Tq_e;
 
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_f32_kernel(CsnAttnArgs p) {
   const long long os = p.out_index ? p.out_index[e] : e;
   const long long head_off = (long long)hd * D * ld + (long long)blk * Tq;
   const long long win = ((long long)(D - 1) * ld + Tq) * 4;    // bytes spanned by a [D][Tq] window of pitch ld
-  const long long head_off_kv = (long long)hd * D * ldk + (long long)blk * T;
+  const long long head_off_kv = (long long)hd * D * ldk + (long long)blk * p.T;   // (p.T: the layout; T may be a short last block)
   const long long win_kv = ((long long)(D - 1) * ldk + (T + 3) / 4 * 4) * 4;
   const csn_rsrc_t Rr = csn_make_rsrc(p.q + qs * p.q_shape_stride + head_off, win);
   const csn_rsrc_t Ar = csn_make_rsrc((BWD ? p.v : p.k) + ks * p.kv_shape_stride + head_off_kv, win_kv);

@@ -30,6 +30,15 @@ int launch_gemm(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st) {
 }
 
 inline bool mis16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
+
+// Block mode, n_blocks * block > ld: the row of ld points ends inside the last block, which then holds
+// ld - (n_blocks - 1) * block points (a multiple of 4).  Returns that count, 0 for full blocks, or a negative status.
+inline int last_block_points(int block, int n_blocks, int ld, int block_q) {
+  if ((long long)n_blocks * block <= ld) return 0;
+  if (block_q != 0 || (long long)(n_blocks - 1) * block >= ld) return CSN_E_ARG;
+  const int t = ld - (n_blocks - 1) * block;
+  return (t & 3) ? CSN_E_ALIGN : t;
+}
 inline bool dim_ok(int d) { return d == 32 || d == 64 || d == 96 || d == 128 || d == 256; }
 
 CsnOperand operand(const float* p, long long s0, long long s1, long long s2, const int* idx2, int ld) {
@@ -149,7 +158,11 @@ static int attn_fwd_impl(const float* q, const float* k, const float* v, long lo
   // their own leading dimension; key counts need not be multiples of 4 then (fp32 K/V maps only).  tq_arr / t_arr: the
   // per-evaluation counts of a ragged batch (block_q / block are then the maxima)
   const int bq = block_q > 0 ? block_q : block, lk = ld_kv > 0 ? ld_kv : ld;
-  if (block_q < 0 || ld_kv < 0 || (ld_kv & 3) || (long long)n_blocks * ((block + 3) / 4 * 4) > lk) return CSN_E_ARG;
+  if (block_q < 0 || ld_kv < 0 || (ld_kv & 3)) return CSN_E_ARG;
+  if (n_blocks <= 0 || block <= 0) return CSN_E_ARG;
+  const int t_last = last_block_points(block, n_blocks, ld, block_q);
+  if (t_last < 0) return t_last;
+  if (block_q != 0 && (long long)n_blocks * ((block + 3) / 4 * 4) > lk) return CSN_E_ARG;
   if ((block & 3) && (block_q == 0 || qkv_split)) return CSN_E_ALIGN;
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
   if (qkv_split && mode() == 0) return CSN_E_ARG;
@@ -163,8 +176,9 @@ static int attn_fwd_impl(const float* q, const float* k, const float* v, long lo
   if ((ld & 3) || (score_pitch & 3) || score_pitch < (block + 3) / 4 * 4) return CSN_E_ALIGN;
   if (mis16(q) || mis16(k) || mis16(v) || mis16(ctx) || mis16(scores)) return CSN_E_PTR;
   if ((q_shape_stride & 3) || (kv_shape_stride & 3) || (ctx_eval_stride & 3)) return CSN_E_STRIDE;
-  if ((long long)n_blocks * bq > ld) return CSN_E_ARG;
+  if (block_q != 0 && (long long)n_blocks * bq > ld) return CSN_E_ARG;
   CsnAttnArgs a;
+  a.T_last = t_last;
   a.Tq = block_q; a.ld_kv = ld_kv;
   a.q = q; a.k = k; a.v = v;
   a.q_shape_stride = q_shape_stride; a.kv_shape_stride = kv_shape_stride;
@@ -214,6 +228,9 @@ static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_e
                             int n_groups, void* stream, const int* tq_arr = nullptr, const int* t_arr = nullptr) {
   if (block_q < 0 || ld_kv < 0 || (ld_kv & 3)) return CSN_E_ARG;
   if ((tq_arr || t_arr) && (group_offsets || n_blocks != 1)) return CSN_E_ARG;
+  if (n_blocks <= 0 || block <= 0) return CSN_E_ARG;
+  const int t_last = last_block_points(block, n_blocks, ld, block_q);
+  if (t_last < 0) return t_last;
   if (group_offsets && (n_groups <= 0 || !eval_ids || !(csn_attn_bwd_grouping(d_head, block) & 1))) return CSN_E_ARG;
   if ((block & 3) && (block_q == 0 || kv_split)) return CSN_E_ALIGN;
   if (probs_tiles && (mode() == 0 || score_pitch < (block + 31) / 32 * 32)) return CSN_E_ARG;
@@ -237,6 +254,7 @@ static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_e
   // the dctx columns are being loaded anyway
   CsnAttnArgs a;
   a.ctx = ctx;
+  a.T_last = t_last;
   a.Tq = block_q; a.ld_kv = ld_kv;
   a.q = dctx; a.k = k; a.v = v;
   a.q_shape_stride = dctx_split ? 2 * ctx_eval_stride : ctx_eval_stride;     // split dctx: [eval][2 planes][D][ld]
@@ -281,7 +299,10 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   if (block_q < 0 || ld_kv < 0 || (ld_kv & 3) || (block_q & 3)) return CSN_E_ARG;
   if ((block & 3) && block_q == 0) return CSN_E_ALIGN;
   const int bq = block_q > 0 ? block_q : block, lk = ld_kv > 0 ? ld_kv : ld, bk4 = (block + 3) / 4 * 4;
-  if ((long long)n_blocks * bk4 > lk) return CSN_E_ARG;
+  if (n_blocks <= 0 || block <= 0) return CSN_E_ARG;
+  const int t_last = last_block_points(block, n_blocks, ld, block_q);
+  if (t_last < 0) return t_last;
+  if (block_q != 0 && (long long)n_blocks * bk4 > lk) return CSN_E_ARG;
   if (probs_tiles && (mode() == 0 || score_pitch < (block + 31) / 32 * 32)) return CSN_E_ARG;
   if (mode() == 3 || (mode() == 2 && !probs_tiles)) return CSN_E_ARG;
   if (dctx_split || q_split) return CSN_E_ARG;                       // reserved (see header)
@@ -302,6 +323,7 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = accumulate; g.eval_ids = eval_ids;
   if (group_offsets) { g.eval_ids = nullptr; g.grp_off = group_offsets; g.grp_items = eval_ids; }
   g.n_arr = t_arr; g.k_arr = tq_arr;            // ragged batch: keys (rounded up to 4 by the kernel) / queries of every evaluation
+  g.n_last = g.k_last = t_last;                 // the row ends inside the last block
   const int n_batch = group_offsets ? n_groups : n_launch_evals;
   g.A = operand(dctx, bq, (long long)d_head * ld, dctx_split ? 2 * ctx_eval_stride : ctx_eval_stride, nullptr, ld);
   g.A.planes = dctx_split; g.A.plane_stride = dctx_plane_stride;

@@ -23,6 +23,9 @@ struct CsnGemmArgs {
   // z2 (after eval_ids); N and K above are then the maxima that size the grid.  n_arr[z] is rounded up to 4; k_arr[z] % 4 == 0.
   const int* n_arr = nullptr;
   const int* k_arr = nullptr;
+  // ragged last block (block attention backward): the LAST item of the fastest batch index z0 (= the last attention block)
+  // has n_last columns and k_last contraction steps (0 = like the others)
+  int n_last = 0, k_last = 0;
 };
 
 int csn_launch_gemm_f32(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st);
@@ -65,6 +68,7 @@ struct CsnAttnArgs {
   // Tq and T are then the maxima: they size the grid, the score pitch and the buffers; tq_arr[e] % 4 == 0.
   const int* tq_arr;
   const int* t_arr;
+  int T_last;                                            // block mode: queries = keys of the LAST block (0: = T) — a row that ends inside it
 };
 int csn_launch_attn_fwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
 int csn_launch_attn_bwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);

@@ -92,10 +92,10 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   const int z1 = z % p.n1;
   const int z2 = p.eval_ids ? p.eval_ids[z / p.n1] : z / p.n1;
   const int lda = p.A.ld, ldb = p.B.ld, ldc = p.C.ld;
-  const int M = p.M, N = p.n_arr ? ((p.n_arr[z2] + 3) & ~3) : p.N;   // ragged batches: this item's own columns (rounded up to 4) / contraction count
-  int K = p.k_arr ? p.k_arr[z2] : p.K;
+  const int M = p.M, N = (p.n_last > 0 && z0 == p.n0 - 1) ? p.n_last : (p.n_arr ? ((p.n_arr[z2] + 3) & ~3) : p.N);   // ragged batches: this item's own columns (rounded up to 4) / contraction count
+  int K = (p.k_last > 0 && z0 == p.n0 - 1) ? p.k_last : (p.k_arr ? p.k_arr[z2] : p.K);
   if (p.k_chunk > 0) { K = min(p.k_chunk, p.K - z0 * p.k_chunk); }
-  if (tile_n * BN >= N) return;                                // (a tile beyond a short item's columns; before any barrier)
+  if (tile_n * BN >= N) return;                                // (a tile beyond a short item's columns; before any barrier)                                // (a tile beyond a short item's columns; before any barrier)
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const bool c_pl = p.C.planes != 0;
@@ -367,10 +367,10 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
   auto item_id = [&](int it) { return p.grp_off ? p.grp_items[it] : (p.eval_ids ? p.eval_ids[it] : it); };
   const int z2 = item_id(it0);
   const int lda = p.A.ld, ldb = p.B.ld, ldc = p.C.ld;
-  const int M = p.M, N = p.n_arr ? ((p.n_arr[z2] + 3) & ~3) : p.N;   // ragged batches: this item's own columns (rounded up to 4) / contraction count
-  int K = p.k_arr ? p.k_arr[z2] : p.K;
+  const int M = p.M, N = (p.n_last > 0 && z0 == p.n0 - 1) ? p.n_last : (p.n_arr ? ((p.n_arr[z2] + 3) & ~3) : p.N);   // ragged batches: this item's own columns (rounded up to 4) / contraction count
+  int K = (p.k_last > 0 && z0 == p.n0 - 1) ? p.k_last : (p.k_arr ? p.k_arr[z2] : p.K);
   if (p.k_chunk > 0) { K = min(p.k_chunk, p.K - z0 * p.k_chunk); }
-  if (tile_n * BN >= N) return;                                // (a tile beyond a short item's columns; before any barrier)
+  if (tile_n * BN >= N) return;                                // (a tile beyond a short item's columns; before any barrier)                                // (a tile beyond a short item's columns; before any barrier)
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   const bool c_pl = p.C.planes != 0;

@@ -70,9 +70,16 @@ class MHAGeometry:
     d_head: int            # d_k == d_v (csa_models.py:147 fixes both to 256)
     block: int             # points per attention block (csa_models.py:84)
     n_blocks: int          # csa_models.py:83
+    n_total: int = 0       # points per shape when the row ends INSIDE the last block (a ragged last block); 0: block * n_blocks
 
     @property
     def n_points(self) -> int:
+        """points per shape that take part: n_blocks full blocks, or n_total with a short last block"""
+        return self.n_total or self.block * self.n_blocks
+
+    @property
+    def n_padded(self) -> int:
+        """n_blocks * block: the layout of the per-point statistics (lse, delta) and of the score blocks"""
         return self.block * self.n_blocks
 
     @property
@@ -301,11 +308,14 @@ class _MHAEvals(torch.autograd.Function):
         assert S == plan.S
         E = plan.E
         T, nb, Tp = geo.block, geo.n_blocks, geo.score_pitch
+        NPP = geo.n_padded                                             # (= NP unless the last block is ragged)
+        if not (0 < NP <= NPP and NPP - NP < T and NP % 4 == 0):
+            raise _lib.CsnError(f"{NP} points do not fill {nb} blocks of {T} (the last block may be short; counts are multiples of 4)")
         dev = x_all.device
         temperature = float(d) ** 0.5                                  # csa_models.py:54
         w_qkv = torch.cat((w_qs, w_ks, w_vs), dim=0).contiguous()      # (3D, C)
         att = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
-        lse = torch.empty((E, H, NP), device=dev, dtype=torch.float32)
+        lse = torch.empty((E, H, NPP), device=dev, dtype=torch.float32)
         scores = torch.empty((E, H, nb, T, Tp), device=dev, dtype=torch.float32) if keep_scores else None
         # values may come from a different slot than the keys (slot kv + v_shift): only the generic
         # MultiHeadAttention.forward(Q, K, V) with three distinct inputs uses that
@@ -317,7 +327,11 @@ class _MHAEvals(torch.autograd.Function):
             npl = planes()
             ldp = nb * 512 * npl
             qkv = torch.empty((S, D, NP), device=dev, dtype=torch.float32)                    # Qs
-            kv = torch.empty((S, 2 * D, ldp), device=dev, dtype=torch.float16 if ctx.mode == 3 else torch.bfloat16)
+            kv_dtype = torch.float16 if ctx.mode == 3 else torch.bfloat16
+            if NP < NPP:
+                kv = torch.zeros((S, 2 * D, ldp), device=dev, dtype=kv_dtype)                  # ragged last block: its tail tiles read as zeros
+            else:
+                kv = torch.empty((S, 2 * D, ldp), device=dev, dtype=kv_dtype)
             if T % 32:
                 kv.view(S, 2 * D, nb, 16, npl, 32)[:, :, :, (T - 1) // 32, :, T % 32:] = 0     # padding keys of the last tile
             for first, step, count in (plan.q_ranges or [(0, 1, S)]):
@@ -453,7 +467,7 @@ class _MHAEvals(torch.autograd.Function):
         # ---- attention backward, straight into per-slot gradient maps ---------------------------------------
         # evaluations that share a slot (Q of the query shape, K/V of each neighbour) add up: one launch per colour
         dscores = torch.empty_like(scores)
-        delta = torch.empty((E, H, NP), device=dev, dtype=torch.float32)
+        delta = torch.empty((E, H, geo.n_padded), device=dev, dtype=torch.float32)
         dqkv = torch.empty((S, 3 * D, NP), device=dev, dtype=torch.float32)
         # the weight gradients contract every slot's gradient maps — or, for a plan with slot ranges (and no input gradients
         # wanted), only the ranges: the maps of the other (slot, projection) pairs are then neither cleared nor read
@@ -472,7 +486,7 @@ class _MHAEvals(torch.autograd.Function):
             if ctx.mode == 3:
                 # fp16 forward / bf16 backward: the forward's K / V planes hold fp16 bits — project them again as bf16 planes
                 # (one GEMM over the slots; the alternative, fp16 gradient products, underflows)
-                kv = torch.empty_like(kv, dtype=torch.bfloat16)
+                kv = (torch.zeros_like if NP < geo.n_padded else torch.empty_like)(kv, dtype=torch.bfloat16)
                 if T % 32:
                     kv.view(S, 2 * D, nb, 16, 1, 32)[:, :, :, (T - 1) // 32, :, T % 32:] = 0
                 _lib.check(L.csn_project_f32(_ptr(x_all), x_all.stride(0), NP, _ptr(w_qkv[D:]), 2 * D, C, _ptr(kv), kv_stride,

@@ -118,8 +118,8 @@ def last_block_probabilities(mha, Q, K):
     """Probabilities of the last block, (B, H, T, T), as the reference returns them (csa_models.py:125): the last block is
     projected again (HIP GEMM, csn_project_f32) and scored by the stand-alone entry.  In train mode these are dropped
     probabilities under a mask of their own draw (the hot path does not keep its masks)."""
-    geo = mha.geometry()
-    lo, hi = (geo.n_blocks - 1) * geo.block, geo.n_blocks * geo.block
+    geo = mha.geometry(n_points=Q.shape[2])
+    lo, hi = (geo.n_blocks - 1) * geo.block, geo.n_points            # (a ragged last block ends with the row)
 
     def chunk(x):
         if x.dim() == 4:
@@ -128,7 +128,7 @@ def last_block_probabilities(mha, Q, K):
 
     with torch.no_grad():
         B = Q.shape[0]
-        heads = lambda m: m.view(B, geo.n_head, geo.d_head, geo.block).transpose(2, 3).contiguous()   # (B, H, T, d)
+        heads = lambda m: m.view(B, geo.n_head, geo.d_head, hi - lo).transpose(2, 3).contiguous()     # (B, H, T, d)
         q = heads(CF.project(chunk(Q), mha.w_qs.weight.contiguous()))
         k = heads(CF.project(chunk(K), mha.w_ks.weight.contiguous()))
         p_drop = mha.attention.dropout.p if mha.training else 0.0

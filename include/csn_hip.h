@@ -103,6 +103,9 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
  *   lse    [n_evals][n_heads][n_blocks*block]   log-sum-exp of every score row (for the backward)
  *   scores [n_evals][n_heads][n_blocks][block][score_pitch]  raw scores S[query][key]; may be NULL
  *          (inference).  score_pitch >= block, % 4.
+ * RAGGED LAST BLOCK: when n_blocks * block > ld the row of ld points ends inside the last block, which then holds
+ * ld - (n_blocks - 1) * block points (a multiple of 4; CSN_E_ARG if that is not positive): queries and keys of the last block
+ * are cut there in all three block-attention entry points.  lse / delta / scores keep their n_blocks * block layout.
  * rescale_threshold: the running softmax maximum is only re-based when it grows by more than this
  * (0 = re-base on every key tile); results agree to fp32 rounding for any value <= ~40.
  * dropout_p / seed: train-mode dropout on the probabilities (nn.Dropout(0.1), csa_models.py:133-141):

@@ -117,6 +117,52 @@ def test_points_beyond_block_grid_are_ignored_and_short_inputs_raise():
         m(xs, xs, xs, "test")
 
 
+@pytest.mark.parametrize("N,T", [(360, 100), (1300, 500), (96, 64)])
+def test_ragged_last_block(N, T):
+    """n_blocks=None: every point takes part, the last block is short when N is not a multiple of the block (the reference's
+    20 x 500 cannot: csa_models.py:83-90) — self and cross evaluations, gradients to weights and inputs, against the oracle's
+    ragged closed form; and through CrossShapeAt."""
+    from csn_amd.csa_models import MultiHeadAttention, get_model
+    rng = np.random.default_rng(55)
+    C, H, d = 64, 2, 32
+    p = orc.make_params(rng, H, d_model=C, d_k=d, d_v=d, csa=False)
+    m = MultiHeadAttention(H, C, d, d, block=T, n_blocks=None).cuda().eval()
+    m.load_state_dict({k[len("attention."):]: v for k, v in p.items() if k.startswith("attention.")})
+    xa, xb = (orc.synth_points(rng, (2, C, N, 1)) for _ in range(2))
+    xa_d, xb_d = xa.cuda().requires_grad_(True), xb.cuda().requires_grad_(True)
+    ys, _ = m(xa_d, xa_d, xa_d, "test")
+    yc, attn = m(xa_d, xb_d, xb_d, "test", return_attn=True)
+    assert ys.shape == (2, N, C) and attn.shape == (2, H, N - (N - 1) // T * T, N - (N - 1) // T * T)
+    gs, gc = (torch.from_numpy(rng.standard_normal((2, N, C)).astype(np.float32)) for _ in range(2))
+    ((ys * gs.cuda()).sum() + (yc * gc.cuda()).sum()).backward()
+    p64 = {k: v.double().requires_grad_(True) for k, v in p.items() if k.startswith("attention.")}
+    xa64, xb64 = xa.double().requires_grad_(True), xb.double().requires_grad_(True)
+    rs = orc.mha_blockdiag(xa64, xa64, xa64, p64, H, d_k=d, d_v=d, block=T, n_blocks=None)
+    rc, rattn = orc.mha_blockdiag(xa64, xb64, xb64, p64, H, d_k=d, d_v=d, block=T, n_blocks=None, return_attn=True)
+    ((rs * gs.double()).sum() + (rc * gc.double()).sum()).backward()
+    assert (ys.detach().cpu().double() - rs.detach()).abs().max().item() < ATOL
+    assert (yc.detach().cpu().double() - rc.detach()).abs().max().item() < ATOL
+    assert (attn.cpu().double() - rattn[-1].detach()).abs().max().item() < 1e-5
+    rel = lambda got, ref: ((got.cpu().double() - ref).abs().max() / ref.abs().max()).item()
+    assert rel(xa_d.grad, xa64.grad) < 1e-4
+    assert rel(xb_d.grad, xb64.grad) < 1e-4
+    for name, prm in m.named_parameters():
+        assert rel(prm.grad, p64["attention." + name].grad) < 1e-4, name
+    # the whole CSA module on a ragged geometry
+    n_cls, K = 5, 2
+    pc = orc.make_params(rng, 1, d_model=C, d_k=C, d_v=C, n_cls=n_cls, csa=True)
+    x = orc.synth_points(rng, (2, C, N, 1))
+    nb = orc.synth_points(rng, (2, K + 1, C, N, 1))
+    nb[:, 0] = x
+    model = get_model("csa", n_cls, 1, K, d_model=C, d_k=C, d_v=C, block=T, n_blocks=None)
+    model.load_state_dict(pc, strict=False)
+    model = model.cuda().eval()
+    with torch.no_grad():
+        logits = model(x.cuda(), "test", nb.cuda())
+    ref = orc.forward_csa(x, nb, pc, 1, d_k=C, d_v=C, block=T, n_blocks=None)
+    assert logits.shape == (2, n_cls, N, 1) and (logits.cpu() - ref).abs().max().item() < ATOL
+
+
 def test_three_distinct_inputs():
     """MultiHeadAttention.forward(Q, K, V) with three different tensors (the signature allows it, csa_models.py:81)."""
     from csn_amd.csa_models import MultiHeadAttention
