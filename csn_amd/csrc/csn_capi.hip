@@ -34,8 +34,9 @@ inline bool mis16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) 
 // Block mode, n_blocks * block > ld: the row of ld points ends inside the last block, which then holds
 // ld - (n_blocks - 1) * block points (a multiple of 4).  Returns that count, 0 for full blocks, or a negative status.
 inline int last_block_points(int block, int n_blocks, int ld, int block_q) {
+  if (block_q != 0) return 0;                                  // cross-length entries: key and query counts are explicit
   if ((long long)n_blocks * block <= ld) return 0;
-  if (block_q != 0 || (long long)(n_blocks - 1) * block >= ld) return CSN_E_ARG;
+  if ((long long)(n_blocks - 1) * block >= ld) return CSN_E_ARG;
   const int t = ld - (n_blocks - 1) * block;
   return (t & 3) ? CSN_E_ALIGN : t;
 }
