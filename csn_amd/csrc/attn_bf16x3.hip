@@ -541,6 +541,8 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     const bool dbg_on = (BWD == (CSN_STAMPS != 0)) && DT == 8 && blockIdx.x < 2048 && kt >= 4 && kt < 8;   // -DCSN_STAMPS=0: forward, =1: backward
 #endif
     STAMP(0);
+    // (requesting the NEXT tile's saved scores right after this tile's pointwise — a phase earlier — was measured in the
+    //  backward: 16 more spilled registers inside the loop, 6.8 -> 9.4 ms; the request stays at the top of its own trip)
     load_sv(kt);
     phase1(cur);
     STAMP(1);
