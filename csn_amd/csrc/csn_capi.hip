@@ -425,6 +425,7 @@ int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const fl
                            float* sum_ws, long long sum_ws_floats, void* stream) {
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
   if (!ctx || !wfc || !xres || !xhat || !rstd || n_evals <= 0 || n_points <= 0 || d_inner <= 0) return CSN_E_ARG;
+  if (dropout_p > 0.f && (long long)(d_model / 2 + 1) * ld >= (1ll << 32)) return CSN_E_ARG;   // 32-bit mask pair index
   if (xhat_sum && xhat_eval_stride != (long long)d_model * ld) return CSN_E_STRIDE;     // the row-sum pass walks dense maps
   if (!dim_ok(d_model)) return CSN_E_DIM;
   if ((ld & 3) || (d_inner & 3) || (n_points & 3)) return CSN_E_ALIGN;
@@ -449,6 +450,7 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
                            void* stream) {
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
   if (dxhat_group < 0) return CSN_E_ARG;
+  if (dropout_p > 0.f && (long long)(d_model / 2 + 1) * ld >= (1ll << 32)) return CSN_E_ARG;   // 32-bit mask pair index
   if (dctx_split && mode() == 0) return CSN_E_ARG;
   if (n_dense_evals < 0 || n_dense_evals > n_evals || (n_dense_evals > 0 && !dxhat)) return CSN_E_ARG;
   if (!xhat || !rstd || !ctx || !wfc_t || !dz || !dctx || !dwfc || !ws) return CSN_E_ARG;

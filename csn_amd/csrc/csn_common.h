@@ -111,24 +111,16 @@ CSN_DEVINL float* csn_operand_base(const CsnOperand& o, int z0, int z1, int z2) 
 }
 
 // ---- dropout masks ------------------------------------------------------------------------------------
-// Counter-based: the keep/drop decision of an element is a pure function of (seed, 64-bit element index), so the
-// backward pass regenerates the forward's mask instead of storing it.  Two rounds of the murmur3 32-bit
-// finaliser over the index words and the seed words; keep  <=>  top 24 bits >= p * 2^24.
-// (tests/dropout_ref.py restates this function in numpy; keep the two in step.)
+// Counter-based: the keep/drop decision of an element is a pure function of (seed, position), so the backward pass
+// regenerates the forward's mask instead of storing it.  The mixer is the murmur3 32-bit finaliser.
+// (tests/dropout_ref.py restates these functions in numpy; keep the two in step.)
 CSN_DEVINL unsigned csn_mix32(unsigned h) {
   h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
   return h;
 }
-CSN_DEVINL bool csn_keep(unsigned long long idx, unsigned long long seed, unsigned thr24) {
-  unsigned h = csn_mix32((unsigned)idx ^ (unsigned)seed);
-  h = csn_mix32(h + ((unsigned)(idx >> 32) ^ (unsigned)(seed >> 32)) + 0x9e3779b9u);
-  return (h >> 8) >= thr24;
-}
-CSN_DEVINL unsigned csn_drop_threshold(float p) { return (unsigned)(p * 16777216.0f); }
 
-// Attention-probability masks (the bulk of all mask decisions: T*T per block) use a cheaper form of the same idea:
-// a score block (evaluation, head, block) draws a 32-bit salt from (seed, block id) with the two-round hash above —
-// wave-uniform, scalar unit — and ONE mixer round over (pair index ^ salt) decides two elements at once: the
+// Attention-probability masks (the bulk of all mask decisions: T*T per block): a score block (evaluation, head, block)
+// draws a 32-bit salt from (seed, block id) with two mixer rounds — wave-uniform, scalar unit — and ONE mixer round over (pair index ^ salt) decides two elements at once: the
 // keys 2w and 2w+1 of query q have pair index w * max(score pitch, queries per block) + q and take the low / high 16 bits;
 // keep  <=>  16-bit field >= p * 2^16.
 CSN_DEVINL unsigned csn_block_salt(unsigned long long block_id, unsigned long long seed) {
@@ -137,6 +129,14 @@ CSN_DEVINL unsigned csn_block_salt(unsigned long long block_id, unsigned long lo
 }
 CSN_DEVINL unsigned csn_pair_hash(unsigned pair_index, unsigned salt) { return csn_mix32(pair_index ^ salt); }
 CSN_DEVINL unsigned csn_drop_threshold16(float p) { return (unsigned)(p * 65536.0f); }
+// The fc-output masks (dropout before the residual add, csa_models.py:115-116) take the same form: an evaluation draws its
+// salt from (seed, evaluation index) and one mixer round over (pair index ^ salt) decides the channels 2w (low 16 bits) and
+// 2w+1 (high 16 bits) of point n, pair index = w * row pitch + n.  (A two-round hash per element cost the 256 x 256
+// out-projection tile 36 k of its 100 k cycles: two quarter-rate multiplies per round.)
+CSN_DEVINL unsigned csn_fc_pair(int channel, unsigned ld, unsigned n, unsigned salt) {
+  return csn_pair_hash((unsigned)(channel >> 1) * ld + n, salt);
+}
+CSN_DEVINL bool csn_keep16(unsigned h, int odd, unsigned thr16) { return (odd ? (h >> 16) : (h & 0xffffu)) >= thr16; }
 
 // ---- 16-bit matrix-core arithmetic: math modes 1..3 -----------------------------------------------------------------
 // A mode is a compile-time policy of the 16-bit kernels (gemm_bf16x3.hip, attn_bf16x3.hip, outproj_ln.hip):

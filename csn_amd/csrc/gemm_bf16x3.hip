@@ -535,7 +535,8 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
     const long long rs = q.res_index ? q.res_index[z2] : z2;
     const csn_rsrc_t Rr = csn_make_rsrc(q.xres + rs * q.xres_shape_stride + n0, ((long long)(BM - 1) * ldc + (N - n0)) * 4);
     const bool drop = q.dropout_p > 0.f;
-    const unsigned thr24 = csn_drop_threshold(q.dropout_p);
+    const unsigned thr16 = csn_drop_threshold16(q.dropout_p);
+    const unsigned salt = drop ? csn_block_salt((unsigned long long)z2, q.seed) : 0u;
     const float keep_scale = drop ? 1.f / (1.f - q.dropout_p) : 1.f;
     float mean[NT], rstd[NT];
     unsigned voff[NT];
@@ -543,15 +544,18 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
     for (int j = 0; j < NT; ++j) {
       const int nl = wn0 + 32 * j + l31;
       voff[j] = (n0 + nl) < N ? (unsigned)(4 * h * ldc + nl) * 4u : CSN_OOB;
-      const long long ebase = (long long)z2 * q.xhat_eval_stride + n0 + nl;
       float s1 = 0.f;
+      unsigned hp = 0;
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = wm0 + 32 * i + csn_acc_row(r, 0);         // + 4 h lives in the lane offset
           float v = acc[i][j][r];
-          if (drop) v = csn_keep((unsigned long long)(ebase + (long long)(row + 4 * h) * ldc), q.seed, thr24) ? v * keep_scale : 0.f;
+          if (drop) {                                               // rows r, r + 1 (r even) are one channel pair: one hash
+            if (!(r & 1)) hp = csn_fc_pair(row + 4 * h, (unsigned)ldc, (unsigned)(n0 + nl), salt);
+            v = csn_keep16(hp, r & 1, thr16) ? v * keep_scale : 0.f;
+          }
           v += csn_bload(Rr, voff[j], (unsigned)row * (unsigned)ldc * 4u);
           acc[i][j][r] = v;
           s1 += v;

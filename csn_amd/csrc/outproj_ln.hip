@@ -95,15 +95,16 @@ __global__ __launch_bounds__(256, 2) void csn_outproj_ln_fwd_kernel(CsnOutProjAr
   const unsigned n_off = n_ok ? (unsigned)(4 * h * ld + nl) * 4u : CSN_OOB;
   // dropout on the fc output, before the residual add (csa_models.py:115-116); element index = position in xhat
   if (p.dropout_p > 0.f) {
-    const unsigned thr24 = csn_drop_threshold(p.dropout_p);
+    const unsigned thr16 = csn_drop_threshold16(p.dropout_p);
+    const unsigned salt = csn_block_salt((unsigned long long)e, p.seed);
     const float keep_scale = 1.f / (1.f - p.dropout_p);
-    const long long ebase = (long long)e * p.xhat_eval_stride + n0 + nl;
+    unsigned hp = 0;
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const long long idx = ebase + (long long)(c * 32 + csn_acc_row(r, h)) * ld;
-        acc[c][r] = csn_keep((unsigned long long)idx, p.seed, thr24) ? acc[c][r] * keep_scale : 0.f;
+        if (!(r & 1)) hp = csn_fc_pair(c * 32 + csn_acc_row(r, h), (unsigned)ld, (unsigned)(n0 + nl), salt);
+        acc[c][r] = csn_keep16(hp, r & 1, thr16) ? acc[c][r] * keep_scale : 0.f;
       }
   }
   float sum = 0.f;
@@ -242,15 +243,16 @@ __global__ __launch_bounds__(256, 2) void csn_outproj_ln_fwd_bf16x3_kernel(CsnOu
   const unsigned n_off = n_ok ? (unsigned)(4 * h * ld + nl) * 4u : CSN_OOB;
   // dropout on the fc output, before the residual add (csa_models.py:115-116); element index = position in xhat
   if (p.dropout_p > 0.f) {
-    const unsigned thr24 = csn_drop_threshold(p.dropout_p);
+    const unsigned thr16 = csn_drop_threshold16(p.dropout_p);
+    const unsigned salt = csn_block_salt((unsigned long long)e, p.seed);
     const float keep_scale = 1.f / (1.f - p.dropout_p);
-    const long long ebase = (long long)e * p.xhat_eval_stride + n0 + nl;
+    unsigned hp = 0;
 #pragma unroll
     for (int c = 0; c < CT; ++c)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const long long idx = ebase + (long long)(c * 32 + csn_acc_row(r, h)) * ld;
-        acc[c][r] = csn_keep((unsigned long long)idx, p.seed, thr24) ? acc[c][r] * keep_scale : 0.f;
+        if (!(r & 1)) hp = csn_fc_pair(c * 32 + csn_acc_row(r, h), (unsigned)ld, (unsigned)(n0 + nl), salt);
+        acc[c][r] = csn_keep16(hp, r & 1, thr16) ? acc[c][r] * keep_scale : 0.f;
       }
   }
   float sum = 0.f;
@@ -338,20 +340,23 @@ __global__ __launch_bounds__(256) void csn_ln_bwd_kernel(CsnLnBwdArgs p) {
   const float m2 = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / C;
   const float rstd = ok ? p.rstd[(long long)e * p.n_points + n] : 0.f;
   const bool drop = p.dropout_p > 0.f;
-  const unsigned thr24 = csn_drop_threshold(p.dropout_p);
+  const unsigned thr16 = csn_drop_threshold16(p.dropout_p);
+  const unsigned salt = drop ? csn_block_salt((unsigned long long)e, p.seed) : 0u;
   const float keep_scale = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
   const csn_rsrc_t Zr = csn_make_rsrc(p.dz + (long long)e * p.eval_stride, win);
   const csn_rsrc_t Zres = csn_make_rsrc(p.dz_res ? p.dz_res + (long long)e * p.eval_stride : nullptr, p.dz_res ? win : 0);
-  const long long base = (long long)e * p.eval_stride + n;
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
     gx[i] = rstd * (gx[i] - m1 - xx[i] * m2);
     csn_bstore(gx[i], Zres, voff, (unsigned)(g * CPT + i) * ldb);     // the residual branch sees no mask (vanishes when absent)
   }
   if (drop) {                                                         // one uniform branch, not one per element
+    unsigned hp = 0;
 #pragma unroll
-    for (int i = 0; i < CPT; ++i)
-      gx[i] = csn_keep((unsigned long long)(base + (long long)(g * CPT + i) * p.ld), p.seed, thr24) ? gx[i] * keep_scale : 0.f;
+    for (int i = 0; i < CPT; ++i) {                                   // CPT even: channels g CPT + i, + 1 (i even) are one pair
+      if ((CPT & 1) || !(i & 1)) hp = csn_fc_pair(g * CPT + i, (unsigned)p.ld, (unsigned)n, salt);
+      gx[i] = csn_keep16(hp, (g * CPT + i) & 1, thr16) ? gx[i] * keep_scale : 0.f;
+    }
   }
 #pragma unroll
   for (int i = 0; i < CPT; ++i) csn_bstore(gx[i], Zr, voff, (unsigned)(g * CPT + i) * ldb);

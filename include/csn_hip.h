@@ -213,7 +213,8 @@ int csn_varlen_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_e
  * LayerNorm's affine (gamma, beta), which the caller applies (it is needed un-applied by the backward).
  *   xhat [n_evals][d_model][ld],  rstd [n_evals][n_points].
  * dropout_p / seed: train-mode dropout on the fc output before the residual add (csa_models.py:56,115);
- * mask = function of (seed, position in xhat).  0 = eval mode.
+ * mask = function of (seed, evaluation, channel, point, ld) — the backward entry regenerates it from the same values.
+ * 0 = eval mode.
  * xhat_sum (optional) [n_evals][d_model]: sum over the points of every xhat row — n_points * the pooled descriptor
  * mean_n SSA(x) of csa_models.py:211-212, 218-219 before the affine.  With a workspace sum_ws of
  * n_evals * ceil(n_points / 256) * d_model floats (sum_ws_floats says how many there are) the 256-channel bf16x3 kernel forms

@@ -1,5 +1,5 @@
-"""numpy restatement of the counter-based dropout mask of csn_amd/csrc/csn_common.h (csn_keep) — test infrastructure.
-keep(idx) is a pure function of (seed, 64-bit element index); the kernels regenerate it in the backward pass."""
+"""numpy restatement of the counter-based dropout masks of csn_amd/csrc/csn_common.h — test infrastructure.
+A keep decision is a pure function of (seed, position); the kernels regenerate it in the backward pass."""
 import numpy as np
 
 
@@ -49,6 +49,16 @@ def attention_mask(E, H, nb, T, Tp, seed, p, Tq=None):
     return field >= thr
 
 
-def fc_mask(E, C, N, seed, p):
-    """mask[e][c][n] for the xhat buffer geometry [E][C][N]."""
-    return keep_mask(np.arange(E * C * N, dtype=np.uint64).reshape(E, C, N), seed, p)
+def fc_mask(E, C, N, seed, p, ld=None):
+    """mask[e][c][n] of the fc-output dropout (csn_fc_pair / csn_keep16): evaluation e draws a salt from (seed, e); one mixer
+    round over (pair index ^ salt) decides the channels 2w (low 16 bits) and 2w+1 (high 16 bits) of point n, pair index =
+    w * ld + n with ld the row pitch of the xhat maps (None: = N); keep <=> field >= p * 2^16."""
+    ld = N if ld is None else ld
+    salt = _hash2(np.arange(E, dtype=np.uint64), seed).reshape(E, 1, 1)
+    c = np.arange(C, dtype=np.uint64).reshape(1, C, 1)
+    n = np.arange(N, dtype=np.uint64).reshape(1, 1, N)
+    pair = ((c >> np.uint64(1)) * np.uint64(ld) + n) & np.uint64(0xffffffff)
+    h = _mix32(pair ^ salt)
+    field = np.where((c & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xffff))
+    thr = np.uint64(int(np.float32(p) * np.float32(65536.0)))
+    return field >= thr
