@@ -14,5 +14,5 @@ cp $(ls $OUT/kt/*/*kernel_stats.csv | head -1) $OUT/stats.csv
 { echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), python3 bench.py --steps 1 --warmup 1 --headline-only --no-cpu-baseline $*";
   echo "# mean per launch, KB; gfx950 HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (MI355X_MICROARCH.md)";
   python3 scripts/pmc_summary.py $OUT/f csn_; python3 scripts/pmc_summary.py $OUT/w csn_; } > $OUT/hbm.txt 2>&1
-tail -1 $OUT/kt.log > $OUT/bench.json
+grep '^{' $OUT/kt.log | tail -1 > $OUT/bench.json   # (the profiler prints after the program's line)
 rm -rf $OUT/kt $OUT/f $OUT/w          # the raw traces are large: only the summaries travel back
