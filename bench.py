@@ -40,6 +40,7 @@ if ROOT not in sys.path:
 PEAK_TFLOPS = {"fp32": 157.3,       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4, 64 FLOP/clk/SIMD
                "bf16x3": 2500.0,    # dense bf16 MFMA; the mode issues 3 bf16 matrix FLOPs per algorithmic FLOP
                "bf16": 2500.0, "fp16": 2500.0}
+PEAK_HBM_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 MATH_MODES = {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp16": 3}
 DTYPE_TEXT = {"fp32": "f32", "bf16x3": "bf16x3 (fp32 operands split into 2 bf16, 3 bf16 MFMA per product, fp32 accumulate)",
               "bf16": "bf16 (one bf16 MFMA per product, fp32 accumulate; outside the 1e-4 contract)",
@@ -324,6 +325,12 @@ def main():
                          f"{n_evals} evaluations in the launch"}
             if math == "bf16x3":
                 r["note"] += "; this mode issues 3 bf16 matrix FLOPs per algorithmic FLOP, so the matrix pipe sees 3x `achieved`"
+            if entry:
+                # the matrix roofline binds on algorithmic bytes; the bytes the kernel really moves (it keeps the
+                # score blocks in HBM between forward and backward) against the HBM roof, so that both distances are on the line
+                gbs = entry["bytes_per_launch"] / (ms * 1e-3) / 1e9
+                r["hbm"] = {"achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                            "note": "measured traffic / this run's launch time"}
             return r
 
         def roofs(math, ms):
