@@ -184,7 +184,8 @@ def g6_retrieval(out):
         out[f"g6_{i}_graph"] = g.numpy().astype(np.int64)
 
 
-G7_CASES = [(1, 2, 1, 39, 4.0, 1.0, 0.8), (2, 3, 1, 39, 4.0, 3.0, 1.0)]     # B, K, H, n_cls, fc scale, w_qs scale, offset
+G7_CASES = [(1, 2, 1, 39, 4.0, 1.0, 0.8), (2, 3, 1, 39, 4.0, 3.0, 1.0),     # B, K, H, n_cls, fc scale, w_qs scale, offset
+            (1, 4, 8, 39, 4.0, 1.0, 0.8)]                                   # the published checkpoint's geometry (get_csa_pred.py:35-36)
 
 
 def g7_csa_conditioned(out):

@@ -334,9 +334,10 @@ def test_g7_conditioned_csa_holds_all_11_gradients_to_1e4(golden_dir):
     """The compatibility head on a WELL-CONDITIONED problem (oracle.conditioned_csa_case: per-shape channel offsets, scaled
     fc / w_qs — the reference's own fp32 noise on these gradients is ~1e-6 relative, recorded in the goldens): every one of
     the 11 trained tensors, compatibility_{q,k}.{weight,bias} included, within 1e-4 relative of the reference's gradients,
-    no noise allowance, in both math modes; and within 1e-4 of the float64 oracle's as well."""
+    no noise allowance, in both math modes; and within 1e-4 of the float64 oracle's as well.  Case 2 is the geometry of the
+    published checkpoint (8 heads, K = 4: get_csa_pred.py:35-36)."""
     g = _load(golden_dir, "g7_csa_conditioned")
-    for i in range(2):
+    for i in range(3):
         B, K, H, n_cls, seed = (int(v) for v in g[f"g7_{i}_cfg"])
         fc_s, q_s, off = (float(v) for v in g[f"g7_{i}_scales"])
         p, x, nb, lab = orc.conditioned_csa_case(np.random.default_rng(seed), B, K, H, n_cls, fc_s, q_s, off)

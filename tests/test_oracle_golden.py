@@ -135,7 +135,7 @@ def test_g7_conditioned_csa_all_gradients_at_1e4(golden_dir):
     """G7: the compatibility-head gradients are well-conditioned here (oracle.conditioned_csa_case), so the oracle must
     reproduce all 11 of the reference's gradients to 1e-4 relative with NO noise allowance."""
     g = _load(golden_dir, "g7_csa_conditioned")
-    for i in range(1 if os.environ.get("CSN_SLOW", "0") != "1" else 2):       # case 1 (B = 2, K = 3): CSN_SLOW=1
+    for i in range(1 if os.environ.get("CSN_SLOW", "0") != "1" else 3):       # cases 1 (B = 2, K = 3), 2 (8 heads, K = 4): CSN_SLOW=1
         B, K, H, n_cls, seed = (int(v) for v in g[f"g7_{i}_cfg"])
         fc_s, q_s, off = (float(v) for v in g[f"g7_{i}_scales"])
         p, x, nb, lab = orc.conditioned_csa_case(np.random.default_rng(seed), B, K, H, n_cls, fc_s, q_s, off)
