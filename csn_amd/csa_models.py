@@ -65,9 +65,10 @@ class MultiHeadAttention(nn.Module):
         # arithmetic of this module's contractions: None = the library's process default (bf16x3 unless csn_set_math_mode
         # changed it), or 'fp32' | 'bf16x3' | 'bf16' | 'fp16' (include/csn_hip.h, CSN_MATH_*) for this module only
         self.math_mode = CF.mode_id(math)
-        if d_k != d_v:
-            raise ValueError("the HIP attention kernels need d_k == d_v (the reference always uses 256/256)")
         self.n_head, self.d_k, self.d_v = n_head, d_k, d_v
+        # the fused attention kernels run one head width for Q / K and V / O: d_k != d_v (csa_models.py:42 allows it; no
+        # caller uses it) or a width without a kernel instance runs at the next instance with zero-padded weights
+        self.d_head = CF.kernel_head_width(max(d_k, d_v))
         self.block, self.n_blocks = block, n_blocks
         self.w_qs = nn.Linear(d_model, n_head * d_k, bias=False)
         self.w_ks = nn.Linear(d_model, n_head * d_k, bias=False)
@@ -88,8 +89,26 @@ class MultiHeadAttention(nn.Module):
             if n_points is None:
                 raise ValueError("n_blocks=None needs the point count of the call")
             n_blocks = (n_points + block - 1) // block
-            return CF.MHAGeometry(self.n_head, self.d_k, block, n_blocks, 0 if n_blocks * block == n_points else n_points)
-        return CF.MHAGeometry(self.n_head, self.d_k, block, n_blocks)
+            return CF.MHAGeometry(self.n_head, self.d_head, block, n_blocks, 0 if n_blocks * block == n_points else n_points,
+                                  self._temperature())
+        return CF.MHAGeometry(self.n_head, self.d_head, block, n_blocks, 0, self._temperature())
+
+    def _temperature(self) -> float:
+        return 0.0 if self.d_head == self.d_k else float(self.d_k) ** 0.5       # sqrt(d_k) whatever width the kernels run at
+
+    def kernel_weights(self):
+        """(W_q, W_k, W_v, W_fc) at the kernels' head width: the modules' own weights when d_k = d_v = that width, else
+        zero rows appended per head to W_q / W_k (d_k -> d_head) and W_v (d_v -> d_head), zero columns per head to W_fc.
+        Built with differentiable pads, so the parameters receive the gradients of their real rows."""
+        H, d = self.n_head, self.d_head
+
+        def rows(w, dh):
+            return w if dh == d else F.pad(w.view(H, dh, -1), (0, 0, 0, d - dh)).reshape(H * d, -1)
+
+        wfc = self.fc.weight
+        if self.d_v != d:
+            wfc = F.pad(wfc.view(-1, H, self.d_v), (0, d - self.d_v)).reshape(-1, H * d)
+        return rows(self.w_qs.weight, self.d_k), rows(self.w_ks.weight, self.d_k), rows(self.w_vs.weight, self.d_v), wfc
 
     def dropout_rates(self):
         """(attention-probability p, post-fc p): live only in train mode (csa_models.py:133-141, 56, 115)."""
@@ -102,8 +121,7 @@ class MultiHeadAttention(nn.Module):
         CF.csa_mix takes; want_sums: also their (E, C) sums over the points, see CF.mha_evals)."""
         p_attn, p_fc = self.dropout_rates()
         with CF.math_mode(self.math_mode):
-            return CF.mha_evals(x_all, self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight,
-                                plan, geo or self.geometry(), p_attn, p_fc, n_head_evals, want_sums, link_mix)
+            return CF.mha_evals(x_all, *self.kernel_weights(), plan, geo or self.geometry(), p_attn, p_fc, n_head_evals, want_sums, link_mix)
 
     def plan(self, kind: str, B: int, K1: int, dev) -> CF.EvalPlan:
         """Cached evaluation plans (slot maps live on the device; building one costs a few small H2D copies)."""

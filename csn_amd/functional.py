@@ -64,13 +64,28 @@ def _need_cuda(*ts):
             raise _lib.CsnError(f"csn_amd ops are fp32 (got {t.dtype})")
 
 
+KERNEL_HEAD_WIDTHS = (32, 64, 96, 128, 256)        # instances of the fused attention kernels (csrc/csn_capi.hip dim_ok)
+
+
+def kernel_head_width(d: int) -> int:
+    """The narrowest head width the attention kernels are instantiated for that holds d channels.  Narrower heads run at
+    that width with zero channels appended (zero rows of W_q / W_k / W_v, zero columns of W_fc): scores, outputs and the
+    gradients of the real rows are unchanged."""
+    for w in KERNEL_HEAD_WIDTHS:
+        if d <= w:
+            return w
+    raise ValueError(f"head width {d} exceeds the widest attention kernel ({KERNEL_HEAD_WIDTHS[-1]})")
+
+
 @dataclass(frozen=True)
 class MHAGeometry:
     n_head: int
-    d_head: int            # d_k == d_v (csa_models.py:147 fixes both to 256)
+    d_head: int            # head width the kernels run at (= d_k = d_v in every call of the reference, csa_models.py:147)
     block: int             # points per attention block (csa_models.py:84)
     n_blocks: int          # csa_models.py:83
     n_total: int = 0       # points per shape when the row ends INSIDE the last block (a ragged last block); 0: block * n_blocks
+    temperature: float = 0.0   # softmax temperature; 0: sqrt(d_head) (csa_models.py:54).  Set when d_head is a kernel width that
+                               # zero-padded projection weights fill (d_k != d_v, or a d_k the kernels have no instance for)
 
     @property
     def n_points(self) -> int:
@@ -312,7 +327,7 @@ class _MHAEvals(torch.autograd.Function):
         if not (0 < NP <= NPP and NPP - NP < T and NP % 4 == 0):
             raise _lib.CsnError(f"{NP} points do not fill {nb} blocks of {T} (the last block may be short; counts are multiples of 4)")
         dev = x_all.device
-        temperature = float(d) ** 0.5                                  # csa_models.py:54
+        temperature = geo.temperature or float(d) ** 0.5               # csa_models.py:54
         w_qkv = torch.cat((w_qs, w_ks, w_vs), dim=0).contiguous()      # (3D, C)
         att = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
         lse = torch.empty((E, H, NPP), device=dev, dtype=torch.float32)
@@ -445,7 +460,7 @@ class _MHAEvals(torch.autograd.Function):
                 dense[:ctx.n_head] += link.scale[:, :, None] * link.dfeats.repeat_interleave(link.group, dim=0)[:ctx.n_head]
                 n_dense = E
             link.dfeats = link.scale = None
-        temperature = float(d) ** 0.5
+        temperature = geo.temperature or float(d) ** 0.5
         p_attn, seed_attn, p_fc, seed_fc = ctx.drop
         need_dx = ctx.needs_input_grad[0]
 

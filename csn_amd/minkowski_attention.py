@@ -38,7 +38,7 @@ class _CrossMHA(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xq, xk, xv, w_qs, w_ks, w_vs, w_fc, n_head: int, d_head: int, p_attn: float, p_fc: float,
-                want_attn: bool, keep: bool, q_lens=None, k_lens=None):
+                want_attn: bool, keep: bool, q_lens=None, k_lens=None, temperature: float = 0.0):
         """q_lens / k_lens (int32 device tensors, one entry per batch item; q_lens % 4 == 0): a RAGGED batch — item i uses
         the first q_lens[i] query points and k_lens[i] key points of its zero-padded rows, in one launch chain
         (csn_varlen_attn_fwd_f32 / _bwd_f32)."""
@@ -53,7 +53,8 @@ class _CrossMHA(torch.autograd.Function):
         lq4, lk4 = _up(lq, 4), _up(lk, 4)
         Tp = _up(lk, 32)
         dev = xq.device
-        temperature = float(d) ** 0.5
+        temperature = temperature or float(d) ** 0.5     # (given when d_head is a kernel width that padded weights fill)
+        ctx.temperature = temperature
         xq_cm, xk_cm = _to_cm(xq, lq4), _to_cm(xk, lk4)
         xv_cm = xk_cm if xv is xk else _to_cm(xv, lk4)
         q = CF.project(xq_cm, w_qs.contiguous(), div_rows=D, temperature=temperature)     # (b, D, lq4), pre-scaled
@@ -102,7 +103,7 @@ class _CrossMHA(torch.autograd.Function):
         D = H * d
         lq4, lk4 = xq_cm.shape[2], xk_cm.shape[2]
         dev = xq_cm.device
-        temperature = float(d) ** 0.5
+        temperature = ctx.temperature
         dxhat = dxhat.contiguous()
         # LayerNorm + fc backward
         dz = torch.empty((b, C, lq4), device=dev, dtype=torch.float32)
@@ -150,7 +151,7 @@ class _CrossMHA(torch.autograd.Function):
             dxk = CF.project(dk, w_ks.t().contiguous())[:, :, :lk].transpose(1, 2)
         if need[2]:
             dxv = CF.project(dv, w_vs.t().contiguous())[:, :, :lk].transpose(1, 2)
-        return dxq, dxk, dxv, dw_q, dw_k, dw_v, dw_fc, None, None, None, None, None, None, None, None
+        return dxq, dxk, dxv, dw_q, dw_k, dw_v, dw_fc, None, None, None, None, None, None, None, None, None
 
 
 class ScaledDotProductAttention(nn.Module):
@@ -194,9 +195,10 @@ class MultiHeadAttention(nn.Module):
 
     def __init__(self, n_head, d_model, d_k, d_v, dropout=0.1, return_attention: bool = True):
         super().__init__()
-        if d_k != d_v:
-            raise NotImplementedError("d_k != d_v is not supported (the reference always builds d_k == d_v, hrnet.py:343)")
         self.n_head, self.d_k, self.d_v = n_head, d_k, d_v
+        # one kernel head width for Q / K and V / O: d_k != d_v, or a width without a kernel instance (the reference builds
+        # d_k = d_v = d_model / n_head, hrnet.py:343 — whatever that is), runs at the next instance with zero-padded weights
+        self.d_head = CF.kernel_head_width(max(d_k, d_v))
         self.w_qs = nn.Linear(d_model, n_head * d_k, bias=False)
         self.w_ks = nn.Linear(d_model, n_head * d_k, bias=False)
         self.w_vs = nn.Linear(d_model, n_head * d_v, bias=False)
@@ -206,15 +208,31 @@ class MultiHeadAttention(nn.Module):
         self.norm = nn.LayerNorm(d_model, eps=1e-6)
         self.return_attention = return_attention
 
+    def kernel_weights(self):
+        """(W_q, W_k, W_v, W_fc) at the kernels' head width (see csn_amd.csa_models.MultiHeadAttention.kernel_weights)."""
+        H, d = self.n_head, self.d_head
+        F = torch.nn.functional
+
+        def rows(w, dh):
+            return w if dh == d else F.pad(w.view(H, dh, -1), (0, 0, 0, d - dh)).reshape(H * d, -1)
+
+        wfc = self.fc.weight
+        if self.d_v != d:
+            wfc = F.pad(wfc.view(-1, H, self.d_v), (0, d - self.d_v)).reshape(-1, H * d)
+        return rows(self.w_qs.weight, self.d_k), rows(self.w_ks.weight, self.d_k), rows(self.w_vs.weight, self.d_v), wfc
+
+    def _temperature(self) -> float:
+        return 0.0 if self.d_head == self.d_k else float(self.d_k) ** 0.5
+
     def forward(self, q, k, v):
         if not q.is_cuda:
             raise _lib.CsnError("csn_amd ops need tensors on the MI355X (cuda) device; there is no CPU path")
         p_attn, p_fc = (self.attention.dropout.p, self.dropout.p) if self.training else (0.0, 0.0)
         lq = q.shape[1]
-        ws = (self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight)
+        ws = self.kernel_weights()
         keep = torch.is_grad_enabled() and any(t.requires_grad for t in (q, k, v) + ws)     # (grad mode is off inside forward)
-        xhat, attn = _CrossMHA.apply(q.float(), k.float(), v.float(), *ws, self.n_head, self.d_k, float(p_attn), float(p_fc),
-                                     self.return_attention, keep)
+        xhat, attn = _CrossMHA.apply(q.float(), k.float(), v.float(), *ws, self.n_head, self.d_head, float(p_attn), float(p_fc),
+                                     self.return_attention, keep, None, None, self._temperature())
         out = xhat[:, :, :lq].transpose(1, 2) * self.norm.weight + self.norm.bias
         return out, attn
 
@@ -241,8 +259,9 @@ class MultiHeadAttention(nn.Module):
         q_lens = torch.tensor([_up(n, 4) for n in nq], dtype=torch.int32, device=dev)
         k_lens = torch.tensor(nk, dtype=torch.int32, device=dev)
         p_attn, p_fc = (self.attention.dropout.p, self.dropout.p) if self.training else (0.0, 0.0)
-        ws = (self.w_qs.weight, self.w_ks.weight, self.w_vs.weight, self.fc.weight)
+        ws = self.kernel_weights()
         keep = torch.is_grad_enabled() and any(t.requires_grad for t in tuple(qs) + tuple(ks) + tuple(vs) + ws)
-        xhat, _ = _CrossMHA.apply(q, k, v, *ws, self.n_head, self.d_k, float(p_attn), float(p_fc), False, keep, q_lens, k_lens)
+        xhat, _ = _CrossMHA.apply(q, k, v, *ws, self.n_head, self.d_head, float(p_attn), float(p_fc), False, keep, q_lens, k_lens,
+                                  self._temperature())
         out = xhat.transpose(1, 2) * self.norm.weight + self.norm.bias                     # (b, Lq4, C)
         return [out[i, :n] for i, n in enumerate(nq)]

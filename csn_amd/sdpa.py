@@ -5,6 +5,7 @@ class keeps working as a drop-in, and to materialise the probabilities when a ca
 from __future__ import annotations
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib
 from . import functional as CF
@@ -108,7 +109,16 @@ class _SDPA(torch.autograd.Function):
 
 
 def sdpa_block(q, k, v, temperature: float, p_drop: float = 0.0):
-    return _SDPA.apply(q, k, v, temperature, float(p_drop))
+    """(out, probabilities).  q / k of width d_k and v of width d_v run at one kernel head width with zero channels appended
+    (scores unchanged; the extra output channels are zero and cut off again)."""
+    dk, dv = q.shape[-1], v.shape[-1]
+    d = CF.kernel_head_width(max(dk, dv))
+    if dk != d:
+        q, k = F.pad(q, (0, d - dk)), F.pad(k, (0, d - dk))
+    if dv != d:
+        v = F.pad(v, (0, d - dv))
+    out, prob = _SDPA.apply(q, k, v, temperature, float(p_drop))
+    return (out if dv == d else out[..., :dv]), prob
 
 
 sdpa_cross = sdpa_block        # same entry: query and key counts may differ (MinkowskiNet/models/attention.py:59-73)
@@ -128,11 +138,11 @@ def last_block_probabilities(mha, Q, K):
 
     with torch.no_grad():
         B = Q.shape[0]
-        heads = lambda m: m.view(B, geo.n_head, geo.d_head, hi - lo).transpose(2, 3).contiguous()     # (B, H, T, d)
+        heads = lambda m: m.view(B, geo.n_head, mha.d_k, hi - lo).transpose(2, 3).contiguous()        # (B, H, T, d_k)
         q = heads(CF.project(chunk(Q), mha.w_qs.weight.contiguous()))
         k = heads(CF.project(chunk(K), mha.w_ks.weight.contiguous()))
         p_drop = mha.attention.dropout.p if mha.training else 0.0
-        return sdpa_block(q, k, k, float(geo.d_head) ** 0.5, p_drop)[1]
+        return sdpa_block(q, k, k, float(mha.d_k) ** 0.5, p_drop)[1]
 
 
 def CF_device():

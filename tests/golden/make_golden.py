@@ -217,12 +217,39 @@ def g7_csa_conditioned(out):
         assert worst < 5e-5, "the case is not well-conditioned"
 
 
+G8_CASES = [(2, 256, 64, 128, 10000, "forward"), (3, 96, 48, 80, 400, "self_attention"), (1, 256, 256, 96, 10000, "forward")]
+
+
+def g8_mha_unequal_head_widths(out):
+    """MultiHeadAttention with d_k != d_v and head widths the kernels have no instance for (csa_models.py:42 allows both; no
+    caller uses them): outputs of the chunked forward (cross: K / V from a second shape) or the unchunked self_attention,
+    and the gradients of the six weight tensors under loss = sum(y * g)."""
+    for i, (H, C, dk, dv, N, how) in enumerate(G8_CASES):
+        seed = 800 + i
+        rng = np.random.default_rng(seed)
+        p = orc.make_params(rng, H, d_model=C, d_k=dk, d_v=dv, csa=False)
+        xa = orc.synth_points(rng, (1, C, N, 1))
+        xb = orc.synth_points(rng, (1, C, N, 1))
+        g = orc.synth_points(rng, (1, N, C))
+        m = ref.MultiHeadAttention(H, C, dk, dv).eval()
+        m.load_state_dict({k[len("attention."):]: v for k, v in p.items() if k.startswith("attention.")})
+        y = m(xa, xb, xb, "test")[0] if how == "forward" else m.self_attention(xa)[0]
+        (y * g).sum().backward()
+        out[f"g8_{i}_cfg"] = np.array([H, C, dk, dv, N, seed, 1 if how == "forward" else 0])
+        out[f"g8_{i}_rows"] = sample_rows(y, 29)
+        out[f"g8_{i}_stats"] = stats(y)
+        for name, prm in m.named_parameters():
+            gr = prm.grad.detach()
+            out[f"g8_{i}_gstats_{name}"] = stats(gr)
+            out[f"g8_{i}_grad_{name}"] = (gr if gr.numel() <= 10000 else gr.reshape(gr.shape[0], -1)[::5, ::7].contiguous()).numpy().astype(np.float32)
+
+
 def main():
     only = set(sys.argv[1:])
     for name, fn in [("g1_sdpa", g1_sdpa), ("g2_self_attention", g2_self_attention),
                      ("g3_mha_forward", g3_mha_forward), ("g4_csa", g4_csa), ("g5_ssa", g5_ssa),
                      ("g6_retrieval", g6_retrieval),
-                     ("g7_csa_conditioned", g7_csa_conditioned)]:
+                     ("g7_csa_conditioned", g7_csa_conditioned), ("g8_mha_unequal_head_widths", g8_mha_unequal_head_widths)]:
         if only and name not in only:
             continue
         out = {}

@@ -38,8 +38,10 @@ def _module(p, H, C, d):
 
 
 @pytest.mark.parametrize("b,lq,lk,H,C", [(2, 100, 64, 4, 256), (1, 37, 53, 4, 256), (1, 1000, 1301, 4, 256), (2, 48, 48, 1, 128),
-                                         (1, 130, 7, 2, 64)])
+                                         (1, 130, 7, 2, 64), (1, 90, 61, 5, 256), (2, 75, 40, 3, 128)])
 def test_cross_length_mha_forward_backward(L, math_mode, b, lq, lk, H, C):
+    """(the last two cases: d = d_model // n_head = 51 and 42 — hrnet.py:343 builds whatever that division gives — run at the
+    64-wide kernel instance with zero-padded weights)"""
     from oracle import csa_oracle as orc
     rng = np.random.default_rng(17)
     d = C // H
@@ -175,3 +177,33 @@ def test_ragged_batch_in_one_launch_chain(L, math_mode):
     torch.manual_seed(1)
     outs = m.forward_varlen([t.cuda() for t in qs], [t.cuda() for t in ks], [t.cuda() for t in vs])
     assert all(torch.isfinite(o).all() for o in outs) and (outs[3].cpu() - o1[3]).abs().max().item() > 1e-3
+
+
+def test_unequal_head_widths(L, math_mode):
+    """d_k = 40, d_v = 72 (attention.py:12 takes both; hrnet.py always passes equal ones): outputs and every gradient against
+    the float64 oracle."""
+    from oracle import csa_oracle as orc
+    from csn_amd.minkowski_attention import MultiHeadAttention
+    rng = np.random.default_rng(31)
+    b, lq, lk, H, C, dk, dv = 2, 83, 131, 3, 96, 40, 72
+    p = orc.make_params(rng, H, d_model=C, d_k=dk, d_v=dv)
+    m = MultiHeadAttention(H, C, dk, dv)
+    m.load_state_dict({k[len("attention."):]: v for k, v in p.items() if k.startswith("attention.")}, strict=False)
+    m = m.cuda().eval()
+    q, k, v = (torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for s in ((b, lq, C), (b, lk, C), (b, lk, C)))
+    g = torch.from_numpy(rng.standard_normal((b, lq, C)).astype(np.float32))
+    qd, kd, vd = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    out, attn = m(qd, kd, vd)
+    assert attn.shape == (b, H, lq, lk)
+    out.backward(g.cuda())
+    p64 = {n: t.double().requires_grad_(True) for n, t in p.items() if n.startswith("attention.")}
+    q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref, rattn = orc.mha_pointmajor(q64, k64, v64, p64, H, dk, dv)
+    ref.backward(g.double())
+    rel = lambda got, want: ((got.detach().cpu().double() - want).abs().max() / want.abs().max()).item()
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() < 1e-4
+    assert (attn.cpu().double() - rattn.detach()).abs().max().item() < 1e-4
+    for a, r in ((qd, q64), (kd, k64), (vd, v64)):
+        assert rel(a.grad, r.grad) < 1e-4
+    for name, prm in m.named_parameters():
+        assert prm.grad.shape == prm.shape and rel(prm.grad, p64["attention." + name].grad) < 1e-4, name

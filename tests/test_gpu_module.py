@@ -98,6 +98,35 @@ def test_g3_mha_forward_self_and_cross(golden_dir):
         assert np.abs(attn.cpu()[0, :, 0].numpy() - g[f"g3_{i}_attn_last_row0"]).max() < 1e-6
 
 
+def test_g8_unequal_head_widths_against_reference_goldens(golden_dir):
+    """d_k != d_v and head widths without a kernel instance (csa_models.py:42 allows both): the module runs them at the next
+    kernel width with zero-padded weights.  Outputs and the gradients of all six weight tensors against the REFERENCE's
+    (golden set G8: (H, C, d_k, d_v) = (2, 256, 64, 128) and (1, 256, 256, 96) through the chunked cross call at N = 10000,
+    (3, 96, 48, 80) through the unchunked self_attention), 1e-4, both math modes."""
+    from csn_amd.csa_models import MultiHeadAttention
+    g = _load(golden_dir, "g8_mha_unequal_head_widths")
+    for i in range(3):
+        H, C, dk, dv, N, seed, chunked = (int(v) for v in g[f"g8_{i}_cfg"])
+        rng = np.random.default_rng(seed)
+        p = orc.make_params(rng, H, d_model=C, d_k=dk, d_v=dv, csa=False)
+        xa, xb = orc.synth_points(rng, (1, C, N, 1)), orc.synth_points(rng, (1, C, N, 1))
+        gy = orc.synth_points(rng, (1, N, C))
+        m = MultiHeadAttention(H, C, dk, dv).cuda().eval()
+        m.load_state_dict({k[len("attention."):]: v for k, v in p.items() if k.startswith("attention.")})
+        assert m.w_qs.weight.shape == (H * dk, C) and m.fc.weight.shape == (C, H * dv)      # the checkpoint layout is the reference's
+        y = m(xa.cuda(), xb.cuda(), xb.cuda(), "test")[0] if chunked else m.self_attention(xa.cuda())[0]
+        (y * gy.cuda()).sum().backward()
+        assert np.abs(y.detach().cpu()[:, ::29].numpy() - g[f"g8_{i}_rows"]).max() < ATOL
+        for name, prm in m.named_parameters():
+            ref = g[f"g8_{i}_grad_{name}"]
+            gr = prm.grad.detach().cpu()
+            got = (gr if gr.numel() <= 10000 else gr.reshape(gr.shape[0], -1)[::5, ::7]).numpy()
+            assert got.shape == ref.shape
+            assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), (i, name, np.abs(got - ref).max() / np.abs(ref).max())
+            st = g[f"g8_{i}_gstats_{name}"]
+            assert abs(gr.double().norm().item() - st[1]) <= 1e-4 * st[1], (i, name)
+
+
 def test_points_beyond_block_grid_are_ignored_and_short_inputs_raise():
     """csa_models.py:83-90: 20 blocks of 500 — N = 12000 yields 10000 rows, N = 2048 raises IndexError."""
     from csn_amd.csa_models import MultiHeadAttention

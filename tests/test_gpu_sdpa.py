@@ -68,3 +68,28 @@ def test_train_mode_returns_the_dropped_probabilities(Tq, Tk, math_mode):
         a = mask[..., :Tq - Tp, 2:]
         b = mask[..., Tp:, :Tk - 2]
         assert (a == b).double().mean().item() < 0.9            # independent masks agree on 0.82 of the positions
+
+
+def test_unequal_and_odd_head_widths(math_mode):
+    """q / k of width 48 and v of width 80 (no kernel instance for either): out, probabilities and the three input gradients
+    against float64."""
+    import math
+    from csn_amd.csa_models import ScaledDotProductAttention
+    rng = np.random.default_rng(77)
+    B, H, Tq, Tk, dk, dv = 2, 3, 70, 45, 48, 80
+    q, k, v = (torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for s in ((B, H, Tq, dk), (B, H, Tk, dk), (B, H, Tk, dv)))
+    att = ScaledDotProductAttention(temperature=math.sqrt(dk)).cuda().eval()
+    qd, kd, vd = (t.cuda().requires_grad_(True) for t in (q, k, v))
+    out, prob = att(qd, kd, vd)
+    assert out.shape == (B, H, Tq, dv) and prob.shape == (B, H, Tq, Tk)
+    g = torch.from_numpy(rng.standard_normal((B, H, Tq, dv)).astype(np.float32))
+    (out * g.cuda()).sum().backward()
+    q64, k64, v64 = (t.double().requires_grad_(True) for t in (q, k, v))
+    rp = torch.softmax((q64 / math.sqrt(dk)) @ k64.transpose(2, 3), dim=-1)
+    ro = rp @ v64
+    (ro * g.double()).sum().backward()
+    assert (out.detach().cpu().double() - ro.detach()).abs().max().item() < 1e-4
+    assert (prob.cpu().double() - rp.detach()).abs().max().item() < 2e-5
+    for got, want in ((qd.grad, q64.grad), (kd.grad, k64.grad), (vd.grad, v64.grad)):
+        assert got.shape == want.shape
+        assert ((got.cpu().double() - want).abs().max() / want.abs().max()).item() < 1e-4

@@ -216,3 +216,34 @@ def test_pointmajor_mha_equals_full_self():
     out, attn = orc.mha_pointmajor(pts, pts, pts, p, H, C // H, C // H)
     assert (out - ref).abs().max().item() < 2e-5
     assert attn.shape == (2, H, N, N) and (attn.sum(-1) - 1).abs().max().item() < 1e-5
+
+
+def _g8_case(g, i):
+    H, C, dk, dv, N, seed, chunked = (int(v) for v in g[f"g8_{i}_cfg"])
+    rng = np.random.default_rng(seed)
+    p = orc.make_params(rng, H, d_model=C, d_k=dk, d_v=dv, csa=False)
+    xa = orc.synth_points(rng, (1, C, N, 1))
+    xb = orc.synth_points(rng, (1, C, N, 1))
+    gy = orc.synth_points(rng, (1, N, C))
+    return H, C, dk, dv, N, chunked, p, xa, xb, gy
+
+
+def test_g8_unequal_head_widths(golden_dir):
+    """G8: d_k != d_v and head widths that are no multiple of 32 — the oracle against the reference's MultiHeadAttention
+    (chunked cross call / unchunked self_attention), outputs and the gradients of all six weight tensors."""
+    g = _load(golden_dir, "g8_mha_unequal_head_widths")
+    i = 0
+    while f"g8_{i}_cfg" in g:
+        H, C, dk, dv, N, chunked, p, xa, xb, gy = _g8_case(g, i)
+        q = {k: v.clone().requires_grad_(True) for k, v in p.items() if k.startswith("attention.")}
+        y = orc.mha_blockdiag(xa, xb, xb, q, H, dk, dv) if chunked else orc.mha_full_self(xa, q, H, dk, dv)
+        (y * gy).sum().backward()
+        _close(y.detach()[:, ::29].numpy(), g[f"g8_{i}_rows"])
+        _close(_stats(y), g[f"g8_{i}_stats"], 1e-5)
+        for name, t in q.items():
+            ref = g[f"g8_{i}_grad_{name[len('attention.'):]}"]
+            gr = t.grad
+            got = (gr if gr.numel() <= 10000 else gr.reshape(gr.shape[0], -1)[::5, ::7]).numpy()
+            assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), name
+        i += 1
+    assert i == 3

@@ -191,3 +191,29 @@ def test_device_feature_cache_builds_the_same_neighbour_stacks_as_csadatasetk(tm
         assert torch.equal(f, cf) and torch.equal(lab, cl) and torch.equal(nb, cnb)
     with pytest.raises(IndexError):
         D.DeviceFeatureCache(ds_train, "cpu", first=2, count=2, n_points=64).batch([0])
+
+
+def test_head_width_generalisation_host_side():
+    """d_k != d_v / odd widths: parameters keep the reference's shapes; the kernels see zero-padded weights at one width."""
+    import torch
+    from csn_amd import functional as CF
+    from csn_amd.csa_models import MultiHeadAttention
+    from csn_amd.minkowski_attention import MultiHeadAttention as MinkMHA
+    assert [CF.kernel_head_width(d) for d in (1, 32, 33, 96, 100, 129, 256)] == [32, 32, 64, 96, 128, 256, 256]
+    with pytest.raises(ValueError):
+        CF.kernel_head_width(257)
+    for cls in (MultiHeadAttention, MinkMHA):
+        m = cls(3, 96, 48, 80)
+        assert m.w_qs.weight.shape == (144, 96) and m.w_vs.weight.shape == (240, 96) and m.fc.weight.shape == (96, 240)
+        assert m.d_head == 96
+        wq, wk, wv, wfc = m.kernel_weights()
+        assert wq.shape == wk.shape == wv.shape == (288, 96) and wfc.shape == (96, 288)
+        assert torch.equal(wq.view(3, 96, 96)[:, :48], m.w_qs.weight.view(3, 48, 96)) and float(wq.detach().view(3, 96, 96)[:, 48:].abs().max()) == 0.0
+        assert torch.equal(wfc.view(96, 3, 96)[:, :, :80], m.fc.weight.view(96, 3, 80)) and float(wfc.detach().view(96, 3, 96)[:, :, 80:].abs().max()) == 0.0
+        wfc.sum().backward()
+        assert m.fc.weight.grad.shape == (96, 240)
+        same = cls(2, 128, 64, 64)
+        assert same.kernel_weights()[0] is same.w_qs.weight            # equal, instanced widths: the parameters themselves
+    geo = MultiHeadAttention(3, 96, 48, 80, block=100, n_blocks=4).geometry()
+    assert geo.d_head == 96 and abs(geo.temperature - 48 ** 0.5) < 1e-12
+    assert MultiHeadAttention(1, 256, 256, 256).geometry().temperature == 0.0
