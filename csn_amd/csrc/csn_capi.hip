@@ -135,6 +135,7 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
     if (out_shape_stride & 7) return CSN_E_STRIDE;
   }
   if (out_split == 1 && mode() != 1) return CSN_E_ARG;              // whole hi / lo planes: mode 1 only
+  if (n_points > ld_x || (out_split != 2 && n_points > ld_out)) return CSN_E_ARG;      // a row holds the points it is read for
   if ((ld_x & 3) || (ld_out & 3) || (n_points & 3) || (channels & 3)) return CSN_E_ALIGN;
   if (mis16(x) || mis16(w) || mis16(out)) return CSN_E_PTR;
   if ((x_shape_stride & 3) || (out_shape_stride & 3)) return CSN_E_STRIDE;
@@ -212,7 +213,8 @@ int csn_cross_attn_fwd_f32(const float* q, const float* k, const float* v, long 
                            long long kv_shape_stride, int ld_q, int ld_kv, float* ctx, long long ctx_eval_stride,
                            float* scores, float* lse, int n_evals, int n_heads, int d_head, int n_queries, int n_keys,
                            int score_pitch, float rescale_threshold, float dropout_p, unsigned long long seed, void* stream) {
-  if (n_queries <= 0 || n_keys <= 0 || (n_queries & 3)) return CSN_E_ARG;
+  if (n_queries <= 0 || n_keys <= 0) return CSN_E_ARG;
+  if (n_queries & 3) return CSN_E_ALIGN;
   ModeGuard guard(mode() >= 2 ? 1 : mode());
   return attn_fwd_impl(q, k, v, q_shape_stride, kv_shape_stride, nullptr, nullptr, ld_q, ctx, ctx_eval_stride, scores, lse,
                        n_evals, n_heads, d_head, n_keys, 1, score_pitch, rescale_threshold, dropout_p, seed, 0, 0, n_queries,
@@ -232,6 +234,8 @@ static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_e
   if (n_blocks <= 0 || block <= 0) return CSN_E_ARG;
   const int t_last = last_block_points(block, n_blocks, ld, block_q);
   if (t_last < 0) return t_last;
+  if (block_q != 0 && ((long long)n_blocks * block_q > ld || (long long)n_blocks * ((block + 3) / 4 * 4) > (ld_kv > 0 ? ld_kv : ld)))
+    return CSN_E_ARG;                                                 // cross-length: queries and keys fit their rows
   if (group_offsets && (n_groups <= 0 || !eval_ids || !(csn_attn_bwd_grouping(d_head, block) & 1))) return CSN_E_ARG;
   if ((block & 3) && (block_q == 0 || kv_split)) return CSN_E_ALIGN;
   if (probs_tiles && (mode() == 0 || score_pitch < (block + 31) / 32 * 32)) return CSN_E_ARG;
@@ -303,7 +307,7 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   if (n_blocks <= 0 || block <= 0) return CSN_E_ARG;
   const int t_last = last_block_points(block, n_blocks, ld, block_q);
   if (t_last < 0) return t_last;
-  if (block_q != 0 && (long long)n_blocks * bk4 > lk) return CSN_E_ARG;
+  if (block_q != 0 && ((long long)n_blocks * bk4 > lk || (long long)n_blocks * bq > ld)) return CSN_E_ARG;
   if (probs_tiles && (mode() == 0 || score_pitch < (block + 31) / 32 * 32)) return CSN_E_ARG;
   if (mode() == 3 || (mode() == 2 && !probs_tiles)) return CSN_E_ARG;
   if (dctx_split || q_split) return CSN_E_ARG;                       // reserved (see header)
@@ -375,7 +379,8 @@ int csn_cross_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_ev
                            long long dq_eval_stride, long long dkv_eval_stride, int n_evals, int n_heads, int d_head,
                            int n_queries, int n_keys, int score_pitch, float dropout_p, unsigned long long seed,
                            void* stream) {
-  if (n_queries <= 0 || n_keys <= 0 || (n_queries & 3)) return CSN_E_ARG;
+  if (n_queries <= 0 || n_keys <= 0) return CSN_E_ARG;
+  if (n_queries & 3) return CSN_E_ALIGN;
   ModeGuard guard(mode() >= 2 ? 1 : mode());
   const int pt = (mode() != 0 && score_pitch >= (n_keys + 31) / 32 * 32) ? 1 : 0;
   int rc = attn_bwd_dq_impl(dctx, ctx, ctx_eval_stride, k, v, kv_shape_stride, nullptr, ld_q, scores, dscores, lse, delta, dq,
@@ -393,7 +398,8 @@ int csn_varlen_attn_fwd_f32(const float* q, const float* k, const float* v, long
                             float* scores, float* lse, int n_evals, int n_heads, int d_head, int max_queries, int max_keys,
                             const int* n_queries, const int* n_keys, int score_pitch, float rescale_threshold,
                             float dropout_p, unsigned long long seed, void* stream) {
-  if (max_queries <= 0 || max_keys <= 0 || (max_queries & 3) || !n_queries || !n_keys) return CSN_E_ARG;
+  if (max_queries <= 0 || max_keys <= 0 || !n_queries || !n_keys) return CSN_E_ARG;
+  if (max_queries & 3) return CSN_E_ALIGN;
   ModeGuard guard(mode() >= 2 ? 1 : mode());
   return attn_fwd_impl(q, k, v, q_shape_stride, kv_shape_stride, nullptr, nullptr, ld_q, ctx, ctx_eval_stride, scores, lse,
                        n_evals, n_heads, d_head, max_keys, 1, score_pitch, rescale_threshold, dropout_p, seed, 0, 0, max_queries,
@@ -406,7 +412,8 @@ int csn_varlen_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_e
                             long long dq_eval_stride, long long dkv_eval_stride, int n_evals, int n_heads, int d_head,
                             int max_queries, int max_keys, const int* n_queries, const int* n_keys, int score_pitch,
                             float dropout_p, unsigned long long seed, void* stream) {
-  if (max_queries <= 0 || max_keys <= 0 || (max_queries & 3) || !n_queries || !n_keys) return CSN_E_ARG;
+  if (max_queries <= 0 || max_keys <= 0 || !n_queries || !n_keys) return CSN_E_ARG;
+  if (max_queries & 3) return CSN_E_ALIGN;
   ModeGuard guard(mode() >= 2 ? 1 : mode());
   const int pt = (mode() != 0 && score_pitch >= (max_keys + 31) / 32 * 32) ? 1 : 0;
   int rc = attn_bwd_dq_impl(dctx, ctx, ctx_eval_stride, k, v, kv_shape_stride, nullptr, ld_q, scores, dscores, lse, delta, dq,
@@ -424,7 +431,7 @@ int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const fl
                            int n_points, float eps, float dropout_p, unsigned long long seed, float* xhat_sum,
                            float* sum_ws, long long sum_ws_floats, void* stream) {
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
-  if (!ctx || !wfc || !xres || !xhat || !rstd || n_evals <= 0 || n_points <= 0 || d_inner <= 0) return CSN_E_ARG;
+  if (!ctx || !wfc || !xres || !xhat || !rstd || n_evals <= 0 || n_points <= 0 || d_inner <= 0 || n_points > ld) return CSN_E_ARG;
   if (dropout_p > 0.f && (long long)(d_model / 2 + 1) * ld >= (1ll << 32)) return CSN_E_ARG;   // 32-bit mask pair index
   if (xhat_sum && xhat_eval_stride != (long long)d_model * ld) return CSN_E_STRIDE;     // the row-sum pass walks dense maps
   if (!dim_ok(d_model)) return CSN_E_DIM;
@@ -454,7 +461,7 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
   if (dctx_split && mode() == 0) return CSN_E_ARG;
   if (n_dense_evals < 0 || n_dense_evals > n_evals || (n_dense_evals > 0 && !dxhat)) return CSN_E_ARG;
   if (!xhat || !rstd || !ctx || !wfc_t || !dz || !dctx || !dwfc || !ws) return CSN_E_ARG;
-  if (n_evals <= 0 || n_points <= 0 || d_inner <= 0 || d_model <= 0) return CSN_E_ARG;
+  if (n_evals <= 0 || n_points <= 0 || d_inner <= 0 || d_model <= 0 || n_points > ld) return CSN_E_ARG;
   if ((ld & 3) || (d_inner & 3) || (d_model & 3) || (n_points & 3)) return CSN_E_ALIGN;
   if (mis16(dxhat) || mis16(xhat) || mis16(ctx) || mis16(wfc_t) || mis16(dz) || mis16(dctx) || mis16(dwfc) || mis16(ws))
     return CSN_E_PTR;
@@ -489,6 +496,7 @@ int csn_project_wgrad_f32(const float* dout, long long dout_shape_stride, int ld
                           int n_points, float scale, int accumulate, float* ws, long long ws_floats,
                           void* stream) {
   if (!dout || !x || !dw || !ws || rows <= 0 || channels <= 0 || n_shapes <= 0 || n_points <= 0) return CSN_E_ARG;
+  if (n_points > ld_dout || n_points > ld_x) return CSN_E_ARG;
   if ((ld_dout & 3) || (ld_x & 3) || (n_points & 3)) return CSN_E_ALIGN;
   if (mis16(dout) || mis16(x) || mis16(dw) || mis16(ws)) return CSN_E_PTR;
   if ((dout_shape_stride & 3) || (x_shape_stride & 3)) return CSN_E_STRIDE;
@@ -507,7 +515,7 @@ int csn_retrieval_measure_f32(const float* f1, const float* f2, float* out, int 
 }
 
 int csn_rowsum_f32(const float* x, float* out, long long rows, int n_points, long long ld, void* stream) {
-  if (!x || !out || rows <= 0 || n_points <= 0) return CSN_E_ARG;
+  if (!x || !out || rows <= 0 || n_points <= 0 || n_points > ld) return CSN_E_ARG;
   if ((n_points & 3) || (ld & 3)) return CSN_E_ALIGN;
   if (mis16(x)) return CSN_E_PTR;
   return csn_launch_rowsum_f32(x, out, rows, n_points, ld, (hipStream_t)stream);
@@ -533,6 +541,7 @@ int csn_mix_bwd_f32(const float* dfeats, const float* xhat, const float* comp, c
   const bool want_maps = xhat_self ? dxhat_self != nullptr : dxhat != nullptr;
   if (want_maps && xhat_self && xhat && !dxhat) return CSN_E_ARG;
   if (!want_maps && (dxhat || dxhat_self)) return CSN_E_ARG;
+  if (dxhat_self && !xhat_self) return CSN_E_ARG;                     // a gradient map for own-shape maps that were not given
   if (n_shapes <= 0 || k1 <= 0 || k1 > 8 || channels <= 0 || n_points <= 0) return CSN_E_ARG;
   if (n_points & 3) return CSN_E_ALIGN;
   if (mis16(dfeats) || mis16(xhat) || mis16(dxhat) || mis16(xhat_self) || mis16(dxhat_self)) return CSN_E_PTR;

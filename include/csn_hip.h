@@ -100,7 +100,7 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
  * temperature by csn_project_f32).  q/k/v point at row 0 of the projected [n_heads*d_head][ld] maps of
  * slot 0; evaluation e reads slot q_index[e] (queries) and kv_index[e] (keys, values); NULL = identity.
  *   ctx    [n_evals][n_heads*d_head][ld]   (eval stride given)         — csa_models.py:114 before `fc`
- *   lse    [n_evals][n_heads][n_blocks*block]   log-sum-exp of every score row (for the backward)
+ *   lse    [n_evals][n_heads][n_blocks*block]   log-sum-exp of every score row (for the backward); may be NULL (inference)
  *   scores [n_evals][n_heads][n_blocks][block][score_pitch]  raw scores S[query][key]; may be NULL
  *          (inference).  score_pitch >= block, % 4.
  * RAGGED LAST BLOCK: when n_blocks * block > ld the row of ld points ends inside the last block, which then holds

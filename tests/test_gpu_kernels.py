@@ -486,3 +486,168 @@ def test_abi_rejects_bad_arguments(L):
     rc = lib.csn_block_attn_fwd_f32(x.data_ptr(), x.data_ptr(), x.data_ptr(), 0, 0, None, None, 36, out.data_ptr(), 0, None,
                                     None, 1, 1, 48, 36, 1, 64, 8.0, 0.0, 0, 0, 0, _stream())
     assert rc == -5
+
+
+def _mutations(lib_fn, names, valid, cases):
+    """valid: dict name -> value (a call that succeeds).  cases: [(name, bad value, expected status or None = any error)]."""
+    call = lambda kw: lib_fn(*[kw[n] for n in names])
+    assert call(valid) == 0, "the unmutated call must succeed"
+    torch.cuda.synchronize()
+    for name, bad, want in cases:
+        rc = call({**valid, name: bad})
+        assert rc < 0, f"{name}={bad!r} was accepted"
+        if want is not None:
+            assert rc == want, f"{name}={bad!r}: status {rc}, expected {want}"
+
+
+def test_abi_argument_validation_table(L):
+    """Every entry point of the hot path refuses, with the documented status and BEFORE any launch, arguments its kernels cannot
+    take: null / misaligned pointers, sizes and strides that are not multiples of 4, head / model widths without a kernel
+    instance, non-positive counts, dropout rates outside [0, 1), workspaces that are too small."""
+    lib = L.lib()
+    L.check(lib.csn_set_math_mode(0))
+    try:
+        ARG, ALIGN, PTR, STRIDE, DIM, WS = -1, -2, -3, -4, -5, -6
+        dev = "cuda"
+        S, C, N, R = 2, 64, 40, 64
+        x = torch.randn(S, C, N, device=dev); w = torch.randn(R, C, device=dev); out = torch.empty(S, R, N, device=dev)
+        names = ["x", "xs", "ldx", "w", "rows", "ch", "out", "os", "ldo", "ns", "np", "div", "temp", "split", "ps", "st"]
+        valid = dict(x=x.data_ptr(), xs=C * N, ldx=N, w=w.data_ptr(), rows=R, ch=C, out=out.data_ptr(), os=R * N, ldo=N, ns=S,
+                     np=N, div=0, temp=1.0, split=0, ps=0, st=_stream())
+        _mutations(lib.csn_project_f32, names, valid, [
+            ("x", None, ARG), ("w", None, ARG), ("out", None, ARG), ("x", x.data_ptr() + 4, PTR), ("out", out.data_ptr() + 8, PTR),
+            ("ldx", N + 1, ALIGN), ("ldo", N + 2, ALIGN), ("np", N - 2, ALIGN), ("ldx", N - 4, ARG), ("ldo", N - 4, ARG), ("xs", C * N + 1, STRIDE), ("os", R * N + 2, STRIDE),
+            ("ns", 0, ARG), ("rows", 0, ARG), ("ch", -4, ARG), ("np", 0, ARG), ("np", N + 4, ARG), ("ch", 62, ALIGN)])
+
+        # block attention forward: 1 evaluation, 2 heads of 32, 2 blocks of 20
+        H, d, T, nb, Tp = 2, 32, 20, 2, 32
+        q = torch.randn(1, H * d, N, device=dev); ctx = torch.empty(1, H * d, N, device=dev)
+        lse = torch.empty(1, H, T * nb, device=dev); sc = torch.empty(1, H, nb, T, Tp, device=dev)
+        names = ["q", "k", "v", "qs", "kvs", "qi", "kvi", "ld", "ctx", "cs", "sc", "lse", "E", "H", "d", "T", "nb", "Tp", "thr", "p",
+                 "seed", "split", "ps", "st"]
+        valid = dict(q=q.data_ptr(), k=q.data_ptr(), v=q.data_ptr(), qs=H * d * N, kvs=H * d * N, qi=None, kvi=None, ld=N,
+                     ctx=ctx.data_ptr(), cs=H * d * N, sc=sc.data_ptr(), lse=lse.data_ptr(), E=1, H=H, d=d, T=T, nb=nb, Tp=Tp,
+                     thr=8.0, p=0.0, seed=0, split=0, ps=0, st=_stream())
+        _mutations(lib.csn_block_attn_fwd_f32, names, valid, [
+            ("q", None, ARG), ("ctx", None, ARG), ("d", 48, DIM), ("d", 0, None), ("ld", N - 1, ALIGN),
+            ("Tp", 30, ALIGN), ("Tp", 16, ALIGN), ("q", q.data_ptr() + 4, PTR), ("sc", sc.data_ptr() + 4, PTR),
+            ("qs", H * d * N + 2, STRIDE), ("cs", H * d * N + 1, STRIDE), ("E", 0, ARG), ("H", 0, ARG), ("T", 0, ARG), ("nb", 0, ARG),
+            ("p", 1.0, ARG), ("p", -0.1, ARG), ("nb", 3, ARG)])          # 3 blocks of 20 > 40 points: the last block would be empty
+
+        # cross-length and ragged-batch forward
+        lq, lk = 24, 37
+        kx = torch.randn(1, H * d, 40, device=dev)
+        qx = torch.randn(1, H * d, lq, device=dev); cx = torch.empty(1, H * d, lq, device=dev)
+        lse2 = torch.empty(1, H, lq, device=dev); sc2 = torch.empty(1, H, lq, 64, device=dev)
+        names = ["q", "k", "v", "qs", "kvs", "ldq", "ldkv", "ctx", "cs", "sc", "lse", "E", "H", "d", "nq", "nk", "Tp", "thr", "p", "seed", "st"]
+        valid = dict(q=qx.data_ptr(), k=kx.data_ptr(), v=kx.data_ptr(), qs=H * d * lq, kvs=H * d * 40, ldq=lq, ldkv=40,
+                     ctx=cx.data_ptr(), cs=H * d * lq, sc=sc2.data_ptr(), lse=lse2.data_ptr(), E=1, H=H, d=d, nq=lq, nk=lk, Tp=64,
+                     thr=8.0, p=0.0, seed=0, st=_stream())
+        _mutations(lib.csn_cross_attn_fwd_f32, names, valid, [
+            ("q", None, ARG), ("k", None, ARG), ("d", 40, DIM), ("nq", 22, ALIGN), ("nq", 0, ARG), ("nk", 0, ARG),
+            ("nk", 41, ARG), ("nq", 28, ARG), ("Tp", 36, None), ("ldq", 23, ALIGN), ("p", 1.5, ARG), ("k", kx.data_ptr() + 4, PTR)])
+        nql = torch.tensor([lq], dtype=torch.int32, device=dev); nkl = torch.tensor([lk], dtype=torch.int32, device=dev)
+        names = ["q", "k", "v", "qs", "kvs", "ldq", "ldkv", "ctx", "cs", "sc", "lse", "E", "H", "d", "mq", "mk", "nq", "nk", "Tp", "thr", "p",
+                 "seed", "st"]
+        valid = dict(q=qx.data_ptr(), k=kx.data_ptr(), v=kx.data_ptr(), qs=H * d * lq, kvs=H * d * 40, ldq=lq, ldkv=40,
+                     ctx=cx.data_ptr(), cs=H * d * lq, sc=sc2.data_ptr(), lse=lse2.data_ptr(), E=1, H=H, d=d, mq=lq, mk=lk,
+                     nq=nql.data_ptr(), nk=nkl.data_ptr(), Tp=64, thr=8.0, p=0.0, seed=0, st=_stream())
+        _mutations(lib.csn_varlen_attn_fwd_f32, names, valid, [
+            ("nq", None, ARG), ("nk", None, ARG), ("mq", 22, ALIGN), ("mq", 0, ARG), ("mk", 41, ARG), ("d", 16, DIM), ("q", None, ARG)])
+
+        # cross-length backward (scores / lse / ctx of the forward above)
+        dcx = torch.randn(1, H * d, lq, device=dev); dsc = torch.empty_like(sc2); dl = torch.empty(1, H, lq, device=dev)
+        dq_ = torch.empty(1, H * d, lq, device=dev); dk_ = torch.empty(1, H * d, 40, device=dev); dv_ = torch.empty(1, H * d, 40, device=dev)
+        work = sc2.clone()
+        names = ["dctx", "ctx", "cs", "q", "k", "v", "qs", "kvs", "ldq", "ldkv", "sc", "dsc", "lse", "delta", "dq", "dk", "dv", "dqs", "dkvs",
+                 "E", "H", "d", "nq", "nk", "Tp", "p", "seed", "st"]
+        valid = dict(dctx=dcx.data_ptr(), ctx=cx.data_ptr(), cs=H * d * lq, q=qx.data_ptr(), k=kx.data_ptr(), v=kx.data_ptr(),
+                     qs=H * d * lq, kvs=H * d * 40, ldq=lq, ldkv=40, sc=work.data_ptr(), dsc=dsc.data_ptr(), lse=lse2.data_ptr(),
+                     delta=dl.data_ptr(), dq=dq_.data_ptr(), dk=dk_.data_ptr(), dv=dv_.data_ptr(), dqs=H * d * lq, dkvs=H * d * 40,
+                     E=1, H=H, d=d, nq=lq, nk=lk, Tp=64, p=0.0, seed=0, st=_stream())
+        _mutations(lib.csn_cross_attn_bwd_f32, names, valid, [
+            ("dctx", None, ARG), ("ctx", None, ARG), ("q", None, ARG), ("sc", None, ARG), ("dsc", None, ARG), ("lse", None, ARG),
+            ("delta", None, ARG), ("dq", None, ARG), ("dk", None, ARG), ("dv", None, ARG), ("d", 24, DIM), ("nq", 26, ALIGN),
+            ("nk", 0, ARG), ("nk", 44, ARG), ("nq", 28, ARG), ("p", 1.0, ARG), ("E", 0, ARG), ("H", -1, ARG),
+            ("dq", dq_.data_ptr() + 4, PTR), ("cs", H * d * lq + 2, STRIDE)])
+
+        # out-projection + LayerNorm forward
+        E, Cm, D, NP = 1, 64, 64, 40
+        att = torch.randn(E, D, NP, device=dev); wfc = torch.randn(Cm, D, device=dev); xr = torch.randn(E, Cm, NP, device=dev)
+        xh = torch.empty(E, Cm, NP, device=dev); rs = torch.empty(E, NP, device=dev)
+        names = ["ctx", "cs", "wfc", "xres", "xs", "ri", "xhat", "xhs", "rstd", "E", "C", "D", "ld", "np", "eps", "p", "seed", "sum", "ws",
+                 "wsn", "st"]
+        valid = dict(ctx=att.data_ptr(), cs=D * NP, wfc=wfc.data_ptr(), xres=xr.data_ptr(), xs=Cm * NP, ri=None, xhat=xh.data_ptr(),
+                     xhs=Cm * NP, rstd=rs.data_ptr(), E=E, C=Cm, D=D, ld=NP, np=NP, eps=1e-6, p=0.0, seed=0, sum=None, ws=None, wsn=0,
+                     st=_stream())
+        _mutations(lib.csn_outproj_ln_fwd_f32, names, valid, [
+            ("ctx", None, ARG), ("wfc", None, ARG), ("xres", None, ARG), ("xhat", None, ARG), ("rstd", None, ARG), ("C", 48, DIM),
+            ("C", 512, DIM), ("ld", 42, ALIGN), ("np", 38, ALIGN), ("ld", 36, ARG), ("D", 62, ALIGN), ("cs", D * NP + 2, STRIDE), ("xs", Cm * NP + 1, STRIDE),
+            ("E", 0, ARG), ("np", 0, ARG), ("p", 1.0, ARG), ("ctx", att.data_ptr() + 4, PTR), ("np", 44, ARG)])
+
+        # ... and backward (xhat / rstd of the valid forward call above)
+        dxh = torch.randn(E, Cm, NP, device=dev); dz = torch.empty(E, Cm, NP, device=dev); dzr = torch.empty(E, Cm, NP, device=dev)
+        dat = torch.empty(E, D, NP, device=dev); dwf = torch.empty(Cm, D, device=dev); wt = wfc.t().contiguous()
+        wsn2 = lib.csn_wgrad_workspace_floats(Cm, D, E, NP)
+        ws2 = torch.empty(max(wsn2, 4), device=dev)
+        names = ["dxhat", "xhat", "rstd", "es", "ctx", "cs", "wt", "dz", "dzr", "dctx", "dw", "ws", "wsn", "E", "C", "D", "ld", "np", "acc", "p",
+                 "seed", "split", "ps", "rows", "nd", "scale", "grp", "st"]
+        valid = dict(dxhat=dxh.data_ptr(), xhat=xh.data_ptr(), rstd=rs.data_ptr(), es=Cm * NP, ctx=att.data_ptr(), cs=D * NP,
+                     wt=wt.data_ptr(), dz=dz.data_ptr(), dzr=dzr.data_ptr(), dctx=dat.data_ptr(), dw=dwf.data_ptr(), ws=ws2.data_ptr(),
+                     wsn=wsn2, E=E, C=Cm, D=D, ld=NP, np=NP, acc=0, p=0.0, seed=0, split=0, ps=0, rows=None, nd=E, scale=None, grp=0,
+                     st=_stream())
+        cases = [("xhat", None, ARG), ("rstd", None, ARG), ("ctx", None, ARG), ("wt", None, ARG), ("dz", None, ARG), ("dctx", None, ARG),
+                 ("dw", None, ARG), ("ws", None, ARG), ("dxhat", None, ARG), ("E", 0, ARG), ("np", 0, ARG), ("np", 44, ARG), ("ld", 42, ALIGN),
+                 ("D", 62, ALIGN), ("es", Cm * NP + 2, STRIDE), ("p", 1.0, ARG), ("nd", 2, ARG), ("grp", -1, ARG), ("split", 1, ARG),
+                 ("dz", dz.data_ptr() + 4, PTR), ("C", 48, None)]
+        if wsn2 > 0:
+            cases.append(("wsn", wsn2 - 1, WS))
+        _mutations(lib.csn_outproj_ln_bwd_f32, names, valid, cases)
+
+        # projection weight gradient: workspace too small
+        dout = torch.randn(S, R, N, device=dev); dw = torch.empty(R, C, device=dev)
+        ws_n = lib.csn_wgrad_workspace_floats(R, C, S, N)
+        ws = torch.empty(max(ws_n, 4), device=dev)
+        names = ["dout", "ds", "ldd", "x", "xs", "ldx", "dw", "rows", "ch", "ns", "np", "scale", "acc", "ws", "wsn", "st"]
+        valid = dict(dout=dout.data_ptr(), ds=R * N, ldd=N, x=x.data_ptr(), xs=C * N, ldx=N, dw=dw.data_ptr(), rows=R, ch=C, ns=S,
+                     np=N, scale=1.0, acc=0, ws=ws.data_ptr(), wsn=ws_n, st=_stream())
+        cases = [("dout", None, ARG), ("x", None, ARG), ("dw", None, ARG), ("ldd", N + 1, ALIGN), ("np", N - 1, ALIGN), ("ldx", N - 4, ARG),
+                 ("ds", R * N + 1, STRIDE), ("ns", 0, ARG), ("rows", 0, ARG)]
+        if ws_n > 0:
+            cases += [("wsn", ws_n - 1, WS), ("ws", None, None)]
+        _mutations(lib.csn_project_wgrad_f32, names, valid, cases)
+
+        # retrieval measure, pooled sums, mix
+        f1 = torch.randn(2, 50, 64, device=dev); f2 = torch.randn(3, 30, 64, device=dev); r = torch.empty(2, 3, device=dev)
+        need = 2 * 50 + 3 * 30 + 2 * 3 * 50
+        wsr = torch.empty(need, device=dev)
+        names = ["f1", "f2", "out", "s1", "n1", "s2", "n2", "ch", "ws", "wsn", "st"]
+        valid = dict(f1=f1.data_ptr(), f2=f2.data_ptr(), out=r.data_ptr(), s1=2, n1=50, s2=3, n2=30, ch=64, ws=wsr.data_ptr(), wsn=need,
+                     st=_stream())
+        _mutations(lib.csn_retrieval_measure_f32, names, valid, [
+            ("f1", None, ARG), ("f2", None, ARG), ("out", None, ARG), ("ws", None, None), ("wsn", need - 1, WS), ("s1", 0, ARG),
+            ("n2", 0, ARG), ("ch", 0, None), ("ch", 66, None)])
+        xs_ = torch.randn(6, N, device=dev); so = torch.empty(6, device=dev)
+        names = ["x", "out", "rows", "np", "ld", "st"]
+        valid = dict(x=xs_.data_ptr(), out=so.data_ptr(), rows=6, np=N, ld=N, st=_stream())
+        _mutations(lib.csn_rowsum_f32, names, valid, [("x", None, ARG), ("out", None, ARG), ("rows", 0, ARG), ("np", 0, ARG),
+                                                      ("ld", N - 4, ARG), ("ld", N + 2, ALIGN)])
+        B, K1 = 2, 3
+        xh3 = torch.randn(B * K1, C, N, device=dev); comp = torch.rand(B, K1, device=dev)
+        gam = torch.randn(C, device=dev); bet = torch.randn(C, device=dev); feats = torch.empty(B, C, N, device=dev)
+        names = ["xhat", "comp", "g", "b", "feats", "B", "k1", "ch", "np", "self", "st"]
+        valid = dict(xhat=xh3.data_ptr(), comp=comp.data_ptr(), g=gam.data_ptr(), b=bet.data_ptr(), feats=feats.data_ptr(), B=B, k1=K1,
+                     ch=C, np=N, self=None, st=_stream())
+        _mutations(lib.csn_mix_fwd_f32, names, valid, [("xhat", None, ARG), ("comp", None, ARG), ("feats", None, ARG), ("k1", 9, ARG),
+                                                       ("k1", 0, ARG), ("np", 38, ALIGN), ("B", 0, ARG)])
+        dfe = torch.randn(B, C, N, device=dev); dxh3 = torch.empty_like(xh3)
+        rdot = torch.empty(B, K1, C, device=dev); rsum = torch.empty(B, C, device=dev)
+        names = ["dfeats", "xhat", "comp", "g", "dxhat", "rowdot", "rowsum", "B", "k1", "ch", "np", "self", "dself", "st"]
+        valid = dict(dfeats=dfe.data_ptr(), xhat=xh3.data_ptr(), comp=comp.data_ptr(), g=gam.data_ptr(), dxhat=dxh3.data_ptr(),
+                     rowdot=rdot.data_ptr(), rowsum=rsum.data_ptr(), B=B, k1=K1, ch=C, np=N, self=None, dself=None, st=_stream())
+        _mutations(lib.csn_mix_bwd_f32, names, valid, [("dfeats", None, ARG), ("xhat", None, ARG), ("comp", None, ARG), ("g", None, ARG),
+                                                       ("rowdot", None, ARG), ("rowsum", None, ARG), ("k1", 9, ARG), ("np", 38, ALIGN),
+                                                       ("B", 0, ARG), ("dself", dxh3.data_ptr(), ARG)])
+        torch.cuda.synchronize()
+    finally:
+        lib.csn_set_math_mode(1)
