@@ -104,7 +104,7 @@ int csn_get_math_mode(void) { return mode(); }
 const char* csn_status_string(int status) {
   switch (status) {
     case 0: return "ok";
-    case CSN_E_ARG: return "csn: null pointer or non-positive size";
+    case CSN_E_ARG: return "csn: null pointer, non-positive size, a count beyond its row, or a flag this math mode does not take";
     case CSN_E_ALIGN: return "csn: a size or leading dimension is not a multiple of 4 floats";
     case CSN_E_PTR: return "csn: device pointer not 16-byte aligned";
     case CSN_E_STRIDE: return "csn: a stride is not a multiple of 4 floats";

@@ -35,7 +35,7 @@ extern "C" {
 #define CSN_MATH_BF16 2
 #define CSN_MATH_FP16 3
 
-#define CSN_E_ARG (-1)     /* null pointer / non-positive size            */
+#define CSN_E_ARG (-1)     /* null pointer / non-positive size / a count beyond its row (leading dimension) / bad flag */
 #define CSN_E_ALIGN (-2)   /* a size or leading dimension is not % 4      */
 #define CSN_E_PTR (-3)     /* pointer not 16-byte aligned                  */
 #define CSN_E_STRIDE (-4)  /* a stride is not % 4                          */
