@@ -145,3 +145,21 @@ def test_train_mode_and_mode_nesting(L):
                                            z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 0, None, 0, None, 1, 1, 32, 36,
                                            1, 64, 0.0, 0, 0, 0, 1, 512, 1, None, 0, torch.cuda.current_stream().cuda_stream)
     assert rc == -1
+
+
+def test_bf16_feature_tensors_are_accepted(L):
+    """BASELINE configs[1] / [3] hand the layer bf16 features ("bf16 in / fp32 acc"): bf16 (and fp16) inputs, on the device or
+    on the host like the CPU neighbour stack of csa_training.py:198-202, give exactly what their fp32 copies give."""
+    from csn_amd.csa_models import get_model
+    B, K, n_cls = 1, 2, 7
+    p, x, nb, lab = orc.conditioned_csa_case(np.random.default_rng(78), B, K, 1, n_cls, 4.0, 2.0, 1.0)
+    model = get_model("csa", n_cls, 1, K, math="bf16")
+    model.load_state_dict(p, strict=False)
+    model = model.cuda().eval()
+    for dt in (torch.bfloat16, torch.float16):
+        xl, nl = x.to(dt), nb.to(dt)
+        with torch.no_grad():
+            ref = model(xl.float().cuda(), "test", nl.float().cuda())
+            got_dev = model(xl.cuda(), "test", nl.cuda())
+            got_host = model(xl.cuda(), "test", nl)                       # neighbour stack still on the CPU
+        assert got_dev.dtype == torch.float32 and torch.equal(got_dev, ref) and torch.equal(got_host, ref)
