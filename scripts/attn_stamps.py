@@ -16,9 +16,15 @@ ks = (torch.arange(E, device="cuda", dtype=torch.int32) * 7 + 3) % S
 att = torch.empty((E, D, NP), device="cuda"); lse = torch.empty((E, H, NP), device="cuda")
 scores = torch.empty((E, H, nb, T, Tp), device="cuda")
 base = qkv.data_ptr()
-kvt = to_tiles(qkv[:, D:], T, nb)
+MODE = int(os.environ.get("CSN_STAMP_MODE", "1"))      # 1: bf16x3 (two planes per tile), 2: bf16 (one plane)
+BP = 1024 if MODE == 1 else 512                        # tile-plane block pitch
+if MODE == 1:
+    kvt = to_tiles(qkv[:, D:], T, nb)
+else:
+    x = torch.zeros((S, 2 * D, nb, 512), device="cuda"); x[..., :T] = qkv[:, D:].view(S, 2 * D, nb, T)
+    kvt = x.bfloat16().reshape(S, 2 * D, nb * 512).contiguous()
 kp = kvt.data_ptr()
-L.csn_set_math_mode(1)
+L.csn_set_math_mode(MODE)
 import time
 t_end = time.time() + float(os.environ.get("CSN_STAMP_SUSTAIN", "2.0"))     # sustained load first: the clock settles
 n_launch = 0
@@ -26,15 +32,15 @@ while n_launch < 2 or time.time() < t_end:
     n_launch += 1
     if n_launch % 8 == 0:
         torch.cuda.synchronize()
-    _lib.check(L.csn_block_attn_fwd_f32(base, kp, kp + 2 * D * nb * 1024, 3 * D * NP, 2 * D * nb * 1024, CF._ptr(qs), CF._ptr(ks), NP,
-                                        CF._ptr(att), D * NP, CF._ptr(scores), CF._ptr(lse), E, H, d, T, nb, Tp, 8.0, 0.1, 1234, 1, nb * 1024,
+    _lib.check(L.csn_block_attn_fwd_f32(base, kp, kp + 2 * D * nb * BP, 3 * D * NP, 2 * D * nb * BP, CF._ptr(qs), CF._ptr(ks), NP,
+                                        CF._ptr(att), D * NP, CF._ptr(scores), CF._ptr(lse), E, H, d, T, nb, Tp, 8.0, 0.1, 1234, 1, nb * BP,
                                         CF._stream()), "fwd")
 if os.environ.get("CSN_STAMP_BWD") == "1":       # library built with -DCSN_STAMPS=1: stamps come from the backward (dq) kernel
     datt = torch.randn((E, D, NP), device="cuda")
     dscores = torch.empty_like(scores); delta = torch.empty((E, H, NP), device="cuda"); dq = torch.empty((E, D, NP), device="cuda")
-    _lib.check(L.csn_block_attn_bwd_dq_f32(CF._ptr(datt), CF._ptr(att), D * NP, kp, kp + 2 * D * nb * 1024, 2 * D * nb * 1024,
+    _lib.check(L.csn_block_attn_bwd_dq_f32(CF._ptr(datt), CF._ptr(att), D * NP, kp, kp + 2 * D * nb * BP, 2 * D * nb * BP,
                                            CF._ptr(ks), NP, CF._ptr(scores), CF._ptr(dscores), CF._ptr(lse), CF._ptr(delta),
-                                           CF._ptr(dq), D * NP, None, 0, None, E, H, d, T, nb, Tp, 0.1, 1234, 0, 0, 1, nb * 1024, 1, None, 0,
+                                           CF._ptr(dq), D * NP, None, 0, None, E, H, d, T, nb, Tp, 0.1, 1234, 0, 0, 1, nb * BP, 1, None, 0,
                                            CF._stream()), "dq")
 torch.cuda.synchronize()
 n = 2048 * 8 * 4 * 8
