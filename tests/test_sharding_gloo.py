@@ -130,6 +130,46 @@ def _a2a_worker(rank, world, port):
     dist.destroy_process_group()
 
 
+def _a2a8_worker(rank, world, port):
+    """config 4's world size: the asynchronous neighbour-only exchange, the descriptor table and the gradient bucket."""
+    from csn_amd.sharding import ShapeGraphShard, regular_graph
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    B, Kn, C = 4, 3, 6
+    S = B * world
+    feats = torch.arange(S * C * 8, dtype=torch.float32).reshape(S, C, 8)
+    graph = regular_graph(S, Kn)
+    shard = ShapeGraphShard(graph, B, rank, world, torch.device("cpu"))
+    mine = feats[shard.first:shard.first + B].clone()
+    for mode in ("alltoall", "allgather"):
+        pending = shard.exchange_async(mine, mode=mode, reuse_descriptors=True)
+        # descriptors from their owners: row b, k = the pooled map of shape graph[first + b][k]; gradients sum back to the owners
+        own = mine.mean(dim=2).clone().requires_grad_(True)
+        table = pending.gather_pooled(own)
+        want = feats.mean(dim=2)[torch.from_numpy(graph[shard.first:shard.first + B])]
+        assert torch.equal(table.detach(), want)
+        table.sum().backward()
+        uses = torch.from_numpy((graph.reshape(-1)[None, :] == torch.arange(shard.first, shard.first + B).numpy()[:, None]).sum(axis=1))
+        assert torch.equal(own.grad, uses.float()[:, None].expand(B, C))       # one unit of gradient per use, from every rank
+        stack = pending.wait()
+        assert torch.equal(stack, shard.neighbour_stack(mine, feats))
+    assert sum(shard._recv_splits) <= B * Kn
+    g = [torch.nn.Parameter(torch.zeros(3))]
+    g[0].grad = torch.full((3,), float(rank))
+    shard.allreduce_grads(g)
+    assert torch.allclose(g[0].grad, torch.full((3,), (world - 1) / 2))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_exchange_descriptor_table_and_gradient_bucket():
+    """The collectives of the N = 8 run (BASELINE configs[3]) on 8 gloo ranks with small maps: all_to_all_single with
+    uneven splits in flight, the differentiable descriptor all-gather, the one-bucket gradient all-reduce."""
+    mp.spawn(_a2a8_worker, args=(8, _free_port()), nprocs=8, join=True)
+
+
 def test_neighbour_only_exchange_four_ranks():
     """all_to_all_single with uneven splits over 4 gloo ranks: every rank receives only the shapes its graph rows name."""
     mp.spawn(_a2a_worker, args=(4, _free_port()), nprocs=4, join=True)
