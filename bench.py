@@ -312,7 +312,10 @@ def main():
             ach = launch_flops / (ms * 1e-3) / 1e12
             peak = PEAK_TFLOPS[math]
             tmpl = f"<{d // 32},{'true' if which == 'bwd' else 'false'}{',true' if fast else ''}>"
-            entry = traffic_tab.get(f"{args.config}/{math}/{which}") if (B, K) == (CONFIGS[args.config]["B"], CONFIGS[args.config]["K"]) else None
+            # the committed counter passes are of the single-call step at the configuration's own size: other launch shapes
+            # (descriptor reuse / the two-phase order of the N > 1 path, --shapes, --K) have no measured traffic
+            same_launch = (B, K) == (CONFIGS[args.config]["B"], CONFIGS[args.config]["K"]) and not reuse and not split_probe
+            entry = traffic_tab.get(f"{args.config}/{math}/{which}") if same_launch else None
             r = {"bound": "mfma",
                  "kernel": ("csn_attn_bf16x3_kernel" if fast else "csn_attn_f32_kernel") + tmpl
                            + (" (fused block attention backward: dP, dS, dQ)" if which == "bwd" else " (fused block attention forward)"),
