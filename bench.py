@@ -196,6 +196,12 @@ def main():
         from csn_amd.sharding import ShapeGraphShard, regular_graph
         shard = ShapeGraphShard(regular_graph(S, K), B, rank, world, dev)
 
+    # CSN_BENCH_HOST_NB=1 (N = 1, development aid): the neighbour stack stays in pinned HOST memory and crosses PCIe inside
+    # every step, the way csa_training.py:198-202 hands it over — the PCIe-inclusive rate DESIGN.md quotes; never `value`
+    x_nb_host = None
+    if world == 1 and os.environ.get("CSN_BENCH_HOST_NB") == "1":
+        x_nb_host = x_nb_resident.cpu().pin_memory()
+
     attn_events = {"fwd": [], "bwd": []}
     exchange_mode = os.environ.get("CSN_EXCHANGE", "alltoall")           # "allgather": the whole collection to every rank
     overlap = os.environ.get("CSN_OVERLAP", "1") != "0"                  # exchange in flight under the self-attention evaluations
@@ -239,7 +245,7 @@ def main():
             else:
                 x_nb = shard.neighbour_stack(feats, shard.exchange(feats))   # all-gather of point features over xGMI
         else:
-            x_nb = x_nb_resident                                         # (B, K+1, C, N, 1), slot 0 = self
+            x_nb = x_nb_host if x_nb_host is not None else x_nb_resident   # (B, K+1, C, N, 1), slot 0 = self
             if split_probe:
                 x_nb = _ReadyStack(x_nb)
             elif local_graph is not None:
