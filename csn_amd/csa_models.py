@@ -44,6 +44,31 @@ def _channel_major(x: torch.Tensor, n_points: int) -> torch.Tensor:
     return x[..., :n_points].to(torch.float32).contiguous()
 
 
+class _HostNeighbourStack:
+    """A (B, K+1, C, N) neighbour stack that is still in host memory, in the form CrossShapeAt._csa_cm_overlapped takes
+    (``wait()`` -> the device stack with slot 0 = the shape itself).  The transfer is ONE copy of the whole contiguous tensor
+    (the strided view without slot 0 would first be gathered by a single host thread: 170 ms instead of 25 ms for the 1.31 GB
+    of config 3), issued from ``wait()`` on a side stream — i.e. after the caller has queued the evaluations that need no
+    neighbour data, so that a pageable source, whose staging blocks the host, still overlaps with them on the GPU."""
+    reuse_descriptors = False
+    _streams = {}
+
+    def __init__(self, nb: torch.Tensor, xc: torch.Tensor, trust_slot0: bool):
+        self._nb, self._xc, self._trust = nb, xc, trust_slot0
+
+    def wait(self) -> torch.Tensor:
+        dev = self._xc.device
+        side = self._streams.setdefault(dev, torch.cuda.Stream(dev))
+        main = torch.cuda.current_stream(dev)
+        with torch.cuda.stream(side):                # (no wait on `main`: the copy runs beside the evaluations queued there)
+            stack = self._nb.to(dev, non_blocking=True).to(torch.float32)
+        main.wait_stream(side)
+        stack.record_stream(main)
+        if not self._trust:
+            stack[:, 0] = self._xc                   # the query shape itself (csa_models.py:210, 232)
+        return stack
+
+
 class ScaledDotProductAttention(nn.Module):
     """softmax((q / temperature) k^T) v on (B, H, T, d) tensors (csa_models.py:128-144)."""
 
@@ -316,14 +341,10 @@ class CrossShapeAt(nn.Module):
         if (self.trust_neighbor_slot0 and nb.is_cuda and nb.dtype == torch.float32 and nb.is_contiguous()
                 and nb.shape[-1] == npts):
             x_all = nb.view(B * K1, C, npts)                                   # slot 0 already holds the shape itself
-        elif not nb.is_cuda and nb.is_contiguous() and nb.shape[-1] == npts:
+        elif not nb.is_cuda and nb.is_contiguous() and nb.shape[-1] == npts and K > 0:
             # the stack arrives on the CPU (csa_training.py:198-202, csa_models.py:216): ONE transfer of the whole contiguous
-            # tensor (a DMA straight out of the loader's buffer, pinned or not) — the strided view without slot 0 would first
-            # be gathered by a single host thread (measured: 170 ms instead of 45 ms for the 1.31 GB of config 3)
-            x_all = nb.to(dev, non_blocking=True).to(torch.float32)
-            if not self.trust_neighbor_slot0:
-                x_all[:, 0] = xc                                               # the query shape itself (:210, :232)
-            x_all = x_all.view(B * K1, C, npts)
+            # tensor on a side stream, under the self-attention of the query shapes, which needs no neighbour data
+            return self._csa_cm_overlapped(xc, _HostNeighbourStack(nb, xc, self.trust_neighbor_slot0), return_parts)
         else:
             x_all = torch.empty((B, K1, C, npts), device=dev, dtype=torch.float32)
             x_all[:, 0] = xc                                                   # the query shape itself (:210, :232)

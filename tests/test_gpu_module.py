@@ -279,6 +279,38 @@ def test_overlapped_path_matches_single_call():
     assert torch.isfinite(lt).all() and (lt - l0).abs().mean().item() < 0.2 and (lt - l0).abs().max().item() > 1e-4
 
 
+def test_host_neighbour_stack_equals_device_stack():
+    """The reference's loader hands the neighbour stack over on the CPU (csa_training.py:198-202, csa_models.py:216): pageable
+    or pinned, it crosses PCIe in one side-stream transfer under the self-attention of the query shapes and must give the
+    logits, loss and 11 gradients of the device-resident call — with and without a trusted slot 0."""
+    from csn_amd.csa_models import get_model
+    rng = np.random.default_rng(53)
+    B, K, H, n_cls = 2, 3, 1, 7
+    p, x, nb, lab = orc.conditioned_csa_case(rng, B, K, H, n_cls, 4.0, 3.0, 1.0)
+    xd, labd = x.cuda(), lab.cuda()
+
+    def run(stack, trust):
+        m = get_model("csa", n_cls, H, K)
+        m.load_state_dict(p, strict=False)
+        m = m.cuda().eval()
+        m.trust_neighbor_slot0 = trust
+        logits = m(xd, "test", stack)
+        loss = orc.masked_ce_loss(logits, labd)
+        loss.backward()
+        torch.cuda.synchronize()
+        return logits.detach(), loss.item(), {n: q.grad.clone() for n, q in m.named_parameters() if q.grad is not None}
+
+    l0, s0, g0 = run(nb.cuda().contiguous(), False)
+    scrambled = nb.clone()
+    scrambled[:, 0] = 7.0                                     # slot 0 is NOT trusted by default: the module puts x there itself
+    for stack, trust in ((nb.clone(), False), (nb.clone().pin_memory(), True), (scrambled, False)):
+        l1, s1, g1 = run(stack, trust)
+        assert (l0 - l1).abs().max().item() < 2e-5 and abs(s0 - s1) < 1e-5
+        assert set(g0) == set(g1) and len(g0) == 11
+        for n in g0:
+            assert (g0[n] - g1[n]).abs().max().item() <= 2e-4 * g0[n].abs().max().item() + 1e-9, n
+
+
 def test_fused_data_flow_equals_the_unfused_one(monkeypatch):
     """The passes the step no longer makes (pooled sums from the out-projection epilogue, the mix gradient rebuilt inside the
     LayerNorm backward, dQ / dK / dV accumulated per slot in registers) against the plain forms of the same arithmetic
