@@ -159,7 +159,7 @@ def main():
     torch.cuda.set_device(dev)
 
     import csn_amd
-    from csn_amd import functional as CF
+    from csn_amd import functional as CF, tuning
     from csn_amd.csa_models import get_model
     csn_amd.build()
     set_math = lambda name: csn_amd._lib.check(csn_amd.lib().csn_set_math_mode(MATH_MODES[name]))
@@ -250,12 +250,10 @@ def main():
                 x_nb = _ReadyStack(x_nb)
             elif local_graph is not None:
                 x_nb = _ReadyStack(x_nb, local_graph)
-        if record:
-            CF.EVENT_SINK = attn_events
-        logits = model(feats.unsqueeze(-1), "train", x_nb)
-        loss = masked_ce(logits, label)
-        loss.backward()
-        CF.EVENT_SINK = None
+        with tuning.override(event_sink=attn_events if record else None):   # HIP events around the fused attention launches
+            logits = model(feats.unsqueeze(-1), "train", x_nb)
+            loss = masked_ce(logits, label)
+            loss.backward()
         if shard is not None:
             shard.allreduce_grads(params)                                # one 1.6 MB bucket
         return loss

@@ -106,6 +106,11 @@ _SIGNATURES = {
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_int,
                                           c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_ulonglong,
                                           c_int, c_longlong, c_int, c_longlong, c_int, c_void_p, c_int, c_void_p]),
+    "csn_block_attn_bwd_dq_recompute_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_void_p,
+                                                    c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                                    c_void_p, c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_int, c_int,
+                                                    c_int, c_int, c_int, c_int, c_float, c_ulonglong, c_longlong, c_int,
+                                                    c_void_p, c_int, c_void_p]),
     "csn_block_attn_bwd_dkv_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                            c_int, c_int, c_int, c_int, c_int, c_int, c_longlong, c_int, c_longlong,
@@ -159,7 +164,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.csn_version() != 12:
+        if handle.csn_version() != 13:
             raise CsnError("libcsn_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -73,9 +73,14 @@ CSN_DEVINL f32x4v mma16(s16x8 ah, s16x8 al, s16x8 bh, s16x8 bl, f32x4v c) {
 // PR = csn_mode::Bf16x3 (math mode 1: hi / lo planes, three products), Bf16 / F16 (modes 2 / 3: one plane, one product;
 // tile-plane K/V only, F16 forward only).  The single-product modes drop every "lo" object of this file: the LDS planes, the
 // fragment reads, the conversions, two of the three matrix instructions, and half of the bytes of every tile plane.
-template <typename PR, int DT, bool BWD, bool KVP>
+// RC (backward, tile-plane K / V only): the scores are RECOMPUTED — S = Qs K^T from a second register operand (Qs^T of the
+// query slot) and a third LDS image (the K tile in the k-major form of tileA) — instead of being read back from the forward's
+// saved copy: no score loads, and with sc_tiles == 0 no P / dS stores either (the key-stationary dK / dV kernel of
+// attn_dkv.hip recomputes them for itself).  One more matrix product per tile; LDS holds three images per stage.
+template <typename PR, int DT, bool BWD, bool KVP, bool RC = false>
 __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) {
   static_assert(PR::NT == 3 || KVP, "single-product modes take K / V as tile planes");
+  static_assert(!RC || (BWD && KVP), "score recomputation: backward kernel on tile-plane K / V");
   constexpr int NPL = PR::NPL;                          // planes: hi (+ lo)
   constexpr int D = 32 * DT;
   constexpr int UPR = KVP ? 4 * NPL : 8;                // 16-byte pieces per tile row (tile planes: 4 per plane; fp32: 8)
@@ -92,10 +97,13 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   constexpr int PLANE = D * KT + (CSN_LDS_V ? 32 : 64);
   // [A | B][stage][plane hi/lo][row][32 keys] — one array, so that the prologue / epilogue can use all of it as a
   // [D rows][128 queries] fp32 staging block for 16-byte global accesses (which sets the size in the one-plane modes)
-  constexpr int TILE_EL = 2 * 2 * NPL * PLANE, STAGE_EL = D * 128 * 2;
+  constexpr int NIMG = RC ? 3 : 2;                      // LDS images per stage: A, B (+ C: the K tile in tileA's form)
+  constexpr int TILE_EL = NIMG * 2 * NPL * PLANE, STAGE_EL = D * 128 * 2;
+  static_assert(2 * (TILE_EL > STAGE_EL ? TILE_EL : STAGE_EL) <= 160 * 1024, "LDS budget of one CU");
   __shared__ __attribute__((aligned(16))) short tiles[TILE_EL > STAGE_EL ? TILE_EL : STAGE_EL];
   auto tileA = [&](int st, int pl) -> short* { return tiles + (st * NPL + pl) * PLANE; };
   auto tileB = [&](int st, int pl) -> short* { return tiles + ((2 + st) * NPL + pl) * PLANE; };
+  auto tileC = [&](int st, int pl) -> short* { return tiles + ((4 + st) * NPL + pl) * PLANE; };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, kq = lane >> 4;
@@ -214,6 +222,23 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     delta_q += __shfl_xor(delta_q, 16, 64);
     delta_q += __shfl_xor(delta_q, 32, 64);
   }
+  // score recomputation: the pre-scaled queries Qs^T of this evaluation's query slot, a second register operand
+  s16x8 Qh[RC ? D / 32 : 1], Ql[RC ? D / 32 : 1];
+  if constexpr (RC) {
+    const long long q2s = p.q2_index ? p.q2_index[e] : e;
+    const csn_rsrc_t Qr = csn_make_rsrc(p.q2 + q2s * p.q2_shape_stride + head_off, win);
+    __syncthreads();
+    stage_in(Qr);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < D / 32; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = pick(32 * s + 8 * kq + j);
+        Qh[s][j] = to16<PR::HALF>(v);
+        Ql[s][j] = PR::NT == 3 ? to16<PR::HALF>(v - from16<PR::HALF>(Qh[s][j])) : Qh[s][j];
+      }
+  }
   __syncthreads();                                                 // the staging block becomes the tile buffers
 
   // attention-probability dropout (csa_models.py:141): P_drop = mask * P / (1 - p); element index = position in `scores`
@@ -254,7 +279,8 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   const int a_dst = KVP ? t_pl * PLANE + t_row * KT + 8 * t_u : t_row * KT + 4 * (t_c ^ t_sw);
   const int b_dst = KVP ? t_pl * PLANE + t_row * KT + 8 * (t_u ^ t_swz) : t_row * KT + 8 * ((t_c >> 1) ^ t_swz) + 4 * (t_c & 1);
   f32x4 g[NP_T];
-  auto fetch = [&](const csn_rsrc_t& rs, int kt) {
+  f32x4 g2[RC ? NP_T : 1];                              // RC: the K tile's pieces (committed to two images) beside the V tile's
+  auto fetch_to = [&](const csn_rsrc_t& rs, int kt, f32x4* g) {
     if (KVP) {
       // keys beyond the block end are zero in the planes; units that lie entirely beyond it are not fetched at all
       const unsigned off = (kt * KT + 8 * t_u) < T ? t_off : CSN_OOB;
@@ -270,24 +296,24 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
         g[i] = csn_bload4(rs, (i == NP_T - 1 && !t_last_ok) ? CSN_OOB : off, (unsigned)(k0 + 64 * i * ldk) * 4u);
     }
   };
-  auto commitA = [&](int st) {
+  auto commitA_to = [&](short* img, short* img_lo, const f32x4* g) {       // img / img_lo: hi / lo plane of a k-major image
 #pragma unroll
     for (int i = 0; i < NP_T; ++i)
       if (i < NP_T - 1 || t_last_ok) {
         if (KVP) {
-          short* base = tileA(st, 0) + a_dst + RPP * KT * i;
+          short* base = img + a_dst + RPP * KT * i;
           const s16x8 v = __builtin_bit_cast(s16x8, g[i]);
           *reinterpret_cast<s16x4*>(base + 4 * t_sw) = s16x4{v[0], v[1], v[2], v[3]};
           *reinterpret_cast<s16x4*>(base + 4 * (t_sw ^ 1)) = s16x4{v[4], v[5], v[6], v[7]};
         } else {
           s16x4 hi, lo;
           split4<PR>(g[i], hi, lo);
-          *reinterpret_cast<s16x4*>(tileA(st, 0) + a_dst + RPP * KT * i) = hi;
-          *reinterpret_cast<s16x4*>(tileA(st, NPL - 1) + a_dst + RPP * KT * i) = lo;
+          *reinterpret_cast<s16x4*>(img + a_dst + RPP * KT * i) = hi;
+          *reinterpret_cast<s16x4*>(img_lo + a_dst + RPP * KT * i) = lo;
         }
       }
   };
-  auto commitB = [&](int st) {
+  auto commitB_from = [&](int st, const f32x4* g) {
 #pragma unroll
     for (int i = 0; i < NP_T; ++i)
       if (i < NP_T - 1 || t_last_ok) {
@@ -301,6 +327,9 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
         }
       }
   };
+  auto fetch = [&](const csn_rsrc_t& rs, int kt) { fetch_to(rs, kt, g); };
+  auto commitA = [&](int st) { commitA_to(tileA(st, 0), tileA(st, NPL - 1), g); };
+  auto commitB = [&](int st) { commitB_from(st, g); };
 
   // fragment read positions (lane constants).  tileA, transposing read: inside a 16-lane group lane 4 q' + p addresses
   // row 8 kq + q' and the 4-key chunk that feeds score rows 4 p .. 4 p + 3: keys 8 p .. 8 p + 3 for S0, 8 p + 4 .. for S1
@@ -327,7 +356,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     }
   };
   auto load_sv = [&](int kt) {                          // backward: request the saved scores of tile kt early
-    if (BWD) {
+    if (BWD && !RC) {
       score_pos(kt);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -343,11 +372,11 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   // LDS fragment reads run CSN_PD steps ahead of the matrix instructions that consume them (explicit register ring):
   // with two waves per SIMD nothing else hides the ~150-cycle LDS latency, and a step is only 48 matrix-pipe cycles.
   constexpr int PD = CSN_PD;
-  auto phase1 = [&](int st) {
+  f32x4v Z0, Z1;                                        // RC: the recomputed scores of this lane's 8 keys (S0 / S1 hold dP)
+  auto phase1_on = [&](const short* __restrict__ tAh, const short* __restrict__ tAl, const s16x8* Rh, const s16x8* Rl,
+                       f32x4v& S0, f32x4v& S1) {
     S0 = f32x4v{0.f, 0.f, 0.f, 0.f};
     S1 = f32x4v{0.f, 0.f, 0.f, 0.f};
-    const short* __restrict__ tAh = tileA(st, 0);
-    const short* __restrict__ tAl = tileA(st, NPL - 1);
     constexpr int NH = 2 * (D / 32);                    // half steps: (s, 16-key tile t)
     s16x8 ah[PD], al[PD];
     auto rd = [&](int h, s16x8& fh, s16x8& fl) {
@@ -374,6 +403,10 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     }
     __builtin_amdgcn_sched_barrier(0);
   };
+  auto phase1 = [&](int st) {
+    phase1_on(tileA(st, 0), tileA(st, NPL - 1), Rh, Rl, S0, S1);
+    if constexpr (RC) phase1_on(tileC(st, 0), tileC(st, NPL - 1), Qh, Ql, Z0, Z1);   // S = Qs K^T, as the forward formed it
+  };
   // pointwise: softmax / dropout (forward), dS (backward); leaves T1 in (ph, pl)
   auto pointwise = [&](int kt) {
     score_pos(kt);
@@ -399,9 +432,11 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
         for (int r = 0; r < 8; ++r) t1[r] = r < nv ? t1[r] : -INFINITY;
       }
       float mx = fmaxf(fmaxf(fmaxf(t1[0], t1[1]), fmaxf(t1[2], t1[3])), fmaxf(fmaxf(t1[4], t1[5]), fmaxf(t1[6], t1[7])));
+      if (have_scores) {                                       // (not kept: inference, or a backward that recomputes them)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)                              // (zero-sized window when scores are not kept)
-        csn_bstore4_stream(f32x4{t1[4 * j], t1[4 * j + 1], t1[4 * j + 2], t1[4 * j + 3]}, Sr, s_voff[j]);
+        for (int j = 0; j < 2; ++j)
+          csn_bstore4_stream(f32x4{t1[4 * j], t1[4 * j + 1], t1[4 * j + 2], t1[4 * j + 3]}, Sr, s_voff[j]);
+      }
       // lazy rescale: only when some query's running maximum would grow by more than the threshold.  The four lanes
       // of a query share m_run, so the cross-lane maximum is only needed inside the (rare) branch.
       if (__any(mx > m_run + p.rescale_threshold)) {
@@ -428,6 +463,10 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
         for (int r = 0; r < 8; ++r) t1[r] = keep[r] ? t1[r] * keep_scale : 0.f;
       }
     } else {
+      if constexpr (RC) {
+        sv[0] = Z0[0]; sv[1] = Z0[1]; sv[2] = Z0[2]; sv[3] = Z0[3];
+        sv[4] = Z1[0]; sv[5] = Z1[1]; sv[6] = Z1[2]; sv[7] = Z1[3];
+      }
       float pvs[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) pvs[r] = __builtin_amdgcn_exp2f(fmaf(sv[r], LOG2E, -lse2_q));   // softmax probability (csa_models.py:141)
@@ -443,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
         sv[r] = pv * md;                                           // what the dV product needs: the dropped probabilities
         t1[r] = ds;
       }
-      if (!p.sc_tiles) {
+      if (!RC && !p.sc_tiles) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           csn_bstore4_stream(f32x4{sv[4 * j], sv[4 * j + 1], sv[4 * j + 2], sv[4 * j + 3]}, Sr, s_voff[j]);
@@ -510,9 +549,18 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  fetch(Ar, 0); commitA(0);
-  fetch(Br, 0); commitB(0);
-  if (nkt > 1) fetch(Ar, 1);
+  if constexpr (RC) {
+    // three images: V (k-major, tileA), K (k-major, tileC) and K (key-contiguous, tileB).  Both k-major images are read in
+    // segment 1, so both are committed in segment 1 of the tile before (see the hazard note below); the K pieces stay in
+    // registers (g2) until the key-contiguous image has taken them in segment 2.
+    fetch_to(Ar, 0, g); commitA_to(tileA(0, 0), tileA(0, NPL - 1), g);
+    fetch_to(Br, 0, g2); commitA_to(tileC(0, 0), tileC(0, NPL - 1), g2); commitB_from(0, g2);
+    if (nkt > 1) { fetch_to(Ar, 1, g); fetch_to(Br, 1, g2); }
+  } else {
+    fetch(Ar, 0); commitA(0);
+    fetch(Br, 0); commitB(0);
+    if (nkt > 1) fetch(Ar, 1);
+  }
   __syncthreads();
 
   // -DCSN_STAMPS: development build that records s_memtime at the phase boundaries of tiles 4..7 (scripts/attn_stamps.py)
@@ -546,7 +594,11 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     load_sv(kt);
     phase1(cur);
     STAMP(1);
-    if (more) { commitA(nxt); fetch(Br, kt + 1); }
+    if constexpr (RC) {
+      if (more) { commitA_to(tileA(nxt, 0), tileA(nxt, NPL - 1), g); commitA_to(tileC(nxt, 0), tileC(nxt, NPL - 1), g2); }
+    } else {
+      if (more) { commitA(nxt); fetch(Br, kt + 1); }
+    }
     STAMP(2);
     __syncthreads();
     STAMP(3);
@@ -554,7 +606,11 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     STAMP(4);
     phase2(cur);
     STAMP(5);
-    if (more) { commitB(nxt); if (kt + 2 < nkt) fetch(Ar, kt + 2); }
+    if constexpr (RC) {
+      if (more) { commitB_from(nxt, g2); if (kt + 2 < nkt) { fetch_to(Ar, kt + 2, g); fetch_to(Br, kt + 2, g2); } }
+    } else {
+      if (more) { commitB(nxt); if (kt + 2 < nkt) fetch(Ar, kt + 2); }
+    }
     STAMP(6);
     __syncthreads();
     STAMP(7);
@@ -614,8 +670,13 @@ int launch_dt(const CsnAttnArgs& a, bool bwd, hipStream_t st) {
   dim3 grid((unsigned)(((units + 7) / 8) * 8 * (((a.Tq > 0 ? a.Tq : a.T) + 127) / 128)));
   if (a.kv_planes) {
     if (bwd) {
-      if constexpr (!PR::HALF) hipLaunchKernelGGL((csn_attn_bf16x3_kernel<PR, DT, true, true>), grid, dim3(512), 0, st, a);
-      else return -1;                                               // fp16: forward only (gradients underflow fp16)
+      if constexpr (!PR::HALF) {
+        if (a.q2) {                                                 // score recomputation: where three LDS images per stage fit
+          if constexpr (csn_attn_recompute_fits(PR::NPL, DT))
+            hipLaunchKernelGGL((csn_attn_bf16x3_kernel<PR, DT, true, true, true>), grid, dim3(512), 0, st, a);
+          else return -1;
+        } else hipLaunchKernelGGL((csn_attn_bf16x3_kernel<PR, DT, true, true>), grid, dim3(512), 0, st, a);
+      } else return -1;                                             // fp16: forward only (gradients underflow fp16)
     } else hipLaunchKernelGGL((csn_attn_bf16x3_kernel<PR, DT, false, true>), grid, dim3(512), 0, st, a);
   } else {
     if constexpr (PR::NT == 3) {
@@ -633,6 +694,7 @@ int launch_any(const CsnAttnArgs& a, int d, bool bwd, hipStream_t st) {
   if ((a.T & 3) && a.kv_planes) return -2;                          // ragged key counts: fp32 K/V maps only
   if ((a.q_shape_stride & 3) || (a.kv_shape_stride & 3)) return -4;
   if (a.sc_tiles && a.Tp < (a.T + 31) / 32 * 32) return -2;
+  if (a.q2 && (!bwd || !a.kv_planes || (a.q2_shape_stride & 3))) return -1;
   if (a.kv_planes && (a.T > 512 || (a.kv_ld & 7) || (a.kv_shape_stride & 7))) return -2;    // 16 tiles of 32 keys per block
   switch (d) {
     case 32: return launch_dt<PR, 1>(a, bwd, st);

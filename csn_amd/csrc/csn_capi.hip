@@ -228,8 +228,12 @@ static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_e
                             int d_head, int block, int n_blocks, int score_pitch, float dropout_p,
                             unsigned long long seed, int dctx_split, long long dctx_plane_stride, int kv_split,
                             long long kv_plane_stride, int probs_tiles, int block_q, int ld_kv, const int* group_offsets,
-                            int n_groups, void* stream, const int* tq_arr = nullptr, const int* t_arr = nullptr) {
+                            int n_groups, void* stream, const int* tq_arr = nullptr, const int* t_arr = nullptr,
+                            const float* q = nullptr, long long q_shape_stride = 0, const int* q_index = nullptr) {
   if (block_q < 0 || ld_kv < 0 || (ld_kv & 3)) return CSN_E_ARG;
+  // q != NULL: the scores are recomputed from the pre-scaled queries (block mode, tile-plane K / V, where the kernel has room)
+  if (q && (block_q != 0 || !kv_split || !(csn_attn_bwd_grouping(d_head, block) & 4) || mis16(q))) return CSN_E_ARG;
+  if (q && (q_shape_stride & 3)) return CSN_E_STRIDE;
   if ((tq_arr || t_arr) && (group_offsets || n_blocks != 1)) return CSN_E_ARG;
   if (n_blocks <= 0 || block <= 0) return CSN_E_ARG;
   const int t_last = last_block_points(block, n_blocks, ld, block_q);
@@ -243,12 +247,14 @@ static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_e
   if (dctx_split) return CSN_E_ARG;                                  // reserved (see header)
   if (kv_split && mode() == 0) return CSN_E_ARG;
   if (mode() == 3) return CSN_E_ARG;                                 // fp16: forward only — run the backward in mode 2
-  if (mode() == 2 && !(kv_split && probs_tiles)) return CSN_E_ARG;   // single-product mode: tile planes in and out
+  if (mode() == 2 && !(kv_split && (probs_tiles || q))) return CSN_E_ARG;   // single-product mode: tile planes in and out
   const int bp = 512 * planes_of(mode());
   if (kv_split && (kv_plane_stride <= 0 || (kv_plane_stride % bp) || kv_plane_stride < (long long)n_blocks * bp ||
                    block > 512 || (kv_shape_stride & 7)))
     return CSN_E_ARG;
-  if (!dctx || !ctx || !k || !v || !scores || !dscores || !lse || !delta || !dq) return CSN_E_ARG;
+  // (recomputed scores with probs_tiles == 0: nothing is read from or written to scores / dscores — they may be NULL)
+  const bool sc_used = !q || probs_tiles;
+  if (!dctx || !ctx || !k || !v || !lse || !delta || !dq || (sc_used && (!scores || !dscores))) return CSN_E_ARG;
   if (n_launch_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
   if (!dim_ok(d_head)) return CSN_E_DIM;
   if ((ld & 3) || (score_pitch & 3) || score_pitch < (block + 3) / 4 * 4) return CSN_E_ALIGN;
@@ -274,6 +280,7 @@ static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_e
   a.r_planes = 0; a.kv_planes = kv_split; a.r_plane_stride = 0; a.kv_plane_stride = 0; a.kv_ld = (int)kv_plane_stride;
   a.sc_tiles = probs_tiles;
   a.tq_arr = tq_arr; a.t_arr = t_arr;
+  a.q2 = q; a.q2_shape_stride = q_shape_stride; a.q2_index = q_index;
   return mode() != 0 ? csn_launch_attn_bwd_bf16x3(a, d_head, mode(), st) : csn_launch_attn_bwd_f32(a, d_head, st);
 }
 
@@ -289,6 +296,22 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
                           dq_slot_stride, dq_index, accumulate, eval_ids, n_launch_evals, n_heads, d_head, block, n_blocks,
                           score_pitch, dropout_p, seed, dctx_split, dctx_plane_stride, kv_split, kv_plane_stride, probs_tiles,
                           0, 0, group_offsets, n_groups, stream);
+}
+
+int csn_block_attn_bwd_dq_recompute_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* q,
+                                        long long q_shape_stride, const int* q_index, const float* k, const float* v,
+                                        long long kv_shape_stride, const int* kv_index, int ld, float* probs,
+                                        float* dscores, const float* lse, float* delta, float* dq,
+                                        long long dq_slot_stride, const int* dq_index, int accumulate, const int* eval_ids,
+                                        int n_launch_evals, int n_heads, int d_head, int block, int n_blocks,
+                                        int score_pitch, float dropout_p, unsigned long long seed,
+                                        long long kv_plane_stride, int probs_tiles, const int* group_offsets, int n_groups,
+                                        void* stream) {
+  if (!q) return CSN_E_ARG;
+  return attn_bwd_dq_impl(dctx, ctx, ctx_eval_stride, k, v, kv_shape_stride, kv_index, ld, probs, dscores, lse, delta, dq,
+                          dq_slot_stride, dq_index, accumulate, eval_ids, n_launch_evals, n_heads, d_head, block, n_blocks,
+                          score_pitch, dropout_p, seed, 0, 0, 1, kv_plane_stride, probs_tiles, 0, 0, group_offsets, n_groups,
+                          stream, nullptr, nullptr, q, q_shape_stride, q_index);
 }
 
 static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
@@ -368,7 +391,8 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
 
 int csn_attn_bwd_grouping(int d_head, int block) {
   if (mode() == 0) return 0;
-  return 1 | (csn_gemm_bf16x3_big_tiles(d_head, (block + 3) / 4 * 4) ? 2 : 0);
+  const bool recompute = mode() != 3 && block <= 512 && dim_ok(d_head) && csn_attn_recompute_fits(planes_of(mode()), d_head / 32);
+  return 1 | (csn_gemm_bf16x3_big_tiles(d_head, (block + 3) / 4 * 4) ? 2 : 0) | (recompute ? 4 : 0);
 }
 
 /* cross-length attention backward (MinkowskiNet/models/attention.py: one unchunked block per evaluation, n_queries != n_keys;

@@ -69,7 +69,12 @@ struct CsnAttnArgs {
   const int* tq_arr;
   const int* t_arr;
   int T_last;                                            // block mode: queries = keys of the LAST block (0: = T) — a row that ends inside it
+  // backward with score recomputation (16-bit modes, tile-plane K / V): the pre-scaled queries Qs^T [slot][H*d][ld] of the
+  // forward; q2 == nullptr = the scores are read from `scores` (kept by the forward)
+  const float* q2 = nullptr; long long q2_shape_stride = 0; const int* q2_index = nullptr;
 };
+// score recomputation needs three LDS tile images per stage: one plane at every width, two planes up to d = 128
+constexpr bool csn_attn_recompute_fits(int planes, int dt) { return planes == 1 || dt <= 4; }
 int csn_launch_attn_fwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
 int csn_launch_attn_bwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
 int csn_launch_attn_fwd_bf16x3(const CsnAttnArgs& a, int d, int mode, hipStream_t st);     // attn_bf16x3.hip; mode 1..3 (2, 3: tile-plane K/V only)

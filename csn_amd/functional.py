@@ -19,23 +19,14 @@ import threading
 
 import torch
 
-from . import _lib
+from . import _lib, tuning
 
 _tls = threading.local()
 
 REF_BLOCK = 500       # MID-FC/csa_models.py:84
 REF_NBLOCKS = 20      # MID-FC/csa_models.py:83
 LN_EPS = 1e-6         # MID-FC/csa_models.py:57
-RESCALE_THRESHOLD = 8.0
-USE_KV_TILES = True          # fast math: K/V leave the projection as bf16 tile planes (see csn_project_f32, out_split = 2)
-# The fused data flow of the step, and the plain forms of the same arithmetic it replaced.  Only
-# tests/test_gpu_module.py::test_fused_data_flow_equals_the_unfused_one flips these (monkeypatch) to check one against the other.
-FUSED_POINT_SUMS = True      # False: pooled sums by a streaming pass over the maps
-LINK_MIX = True              # False: the mix backward writes per-evaluation gradient maps
-GROUPED_DKV = True           # False: dK / dV by one read-modify-write launch per colour
-GROUPED_DQ = True            # False: dQ likewise
-# bench.py sets this to a dict {"fwd": [], "bwd": []} to collect (start, end) HIP-event pairs around the two fused attention launches
-EVENT_SINK = None
+RESCALE_THRESHOLD = 8.0      # the running softmax maximum is re-based when it grows by more than this (csn_hip.h (2))
 
 
 def draw_seeds(n: int):
@@ -219,6 +210,21 @@ class math_mode:
         return False
 
 
+def _score_flow(mode: int, d: int, T: int) -> int:
+    """The attention backward data flow (tuning.KEEP_SCORES / RECOMPUTE_DQ / FLASH) for a forward in `mode` at head width d and
+    block T: the configured flow of the mode the BACKWARD runs in, where the library has kernels for it."""
+    want = tuning.current().score_flow.get(backward_mode(mode), tuning.KEEP_SCORES)
+    if want == tuning.KEEP_SCORES or mode == 0:
+        return tuning.KEEP_SCORES
+    with math_mode(backward_mode(mode)):
+        bits = _lib.lib().csn_attn_bwd_grouping(d, T)
+    if not (bits & 4) or not (bits & 1):
+        return tuning.KEEP_SCORES
+    if want == tuning.FLASH and not (bits & 8):
+        return tuning.RECOMPUTE_DQ
+    return want
+
+
 def fast_math() -> bool:
     """True when the contractions run on the 16-bit matrix-core kernels (math modes 1..3)."""
     return current_mode() != 0
@@ -331,10 +337,10 @@ class _MHAEvals(torch.autograd.Function):
         w_qkv = torch.cat((w_qs, w_ks, w_vs), dim=0).contiguous()      # (3D, C)
         att = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
         lse = torch.empty((E, H, NPP), device=dev, dtype=torch.float32)
-        scores = torch.empty((E, H, nb, T, Tp), device=dev, dtype=torch.float32) if keep_scores else None
+        sink = tuning.current().event_sink
         # values may come from a different slot than the keys (slot kv + v_shift): only the generic
         # MultiHeadAttention.forward(Q, K, V) with three distinct inputs uses that
-        tiles = fast_math() and USE_KV_TILES and T <= 512
+        tiles = fast_math() and tuning.current().kv_tiles and T <= 512
         if tiles:
             # 16-bit modes: K and V leave the projection as "tile planes" (per row and block 16 tiles of [hi 32 | lo 32] bf16 in
             # bf16x3, of [32] bf16 / fp16 in the single-product modes), which the attention kernels stage with plain copies; Q
@@ -377,7 +383,10 @@ class _MHAEvals(torch.autograd.Function):
             k_ptr, kv_stride = q_ptr + 4 * D * NP, 3 * D * NP
             v_ptr = q_ptr + 4 * (2 * D * NP + v_shift * kv_stride)
             kv_flag, kv_pitch = 0, 0
-        if EVENT_SINK is not None:
+        # attention backward data flow: keep the raw scores for it, or only lse (the backward then rebuilds S from Qs and K)
+        flow = _score_flow(ctx.mode, d, T) if (keep_scores and tiles) else tuning.KEEP_SCORES
+        scores = torch.empty((E, H, nb, T, Tp), device=dev, dtype=torch.float32) if (keep_scores and flow == tuning.KEEP_SCORES) else None
+        if sink is not None:
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record()
         _lib.check(L.csn_block_attn_fwd_f32(q_ptr, k_ptr, v_ptr, q_stride, kv_stride,
@@ -385,17 +394,17 @@ class _MHAEvals(torch.autograd.Function):
                                             _ptr(lse), E, H, d, T, nb, Tp, RESCALE_THRESHOLD, p_attn, seed_attn,
                                             kv_flag, kv_pitch, _stream()),
                    "csn_block_attn_fwd_f32")
-        if EVENT_SINK is not None:
+        if sink is not None:
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record()
-            EVENT_SINK["fwd"].append((ev0, ev1))
+            sink["fwd"].append((ev0, ev1))
         xhat = torch.empty((E, C, NP), device=dev, dtype=torch.float32)
         rstd = torch.empty((E, NP), device=dev, dtype=torch.float32)
         w_fc = w_fc.contiguous()
         # third output (want_sums): sums[e][c] = sum_n xhat[e][c][n], formed in the epilogue of the out-projection (per-tile
         # partials in sum_ws) instead of a separate streaming pass over the 2.6 GB of maps
         sums = torch.empty((E, C), device=dev, dtype=torch.float32) if want_sums else None
-        sum_ws_n = E * ((NP + 255) // 256) * C if (want_sums and FUSED_POINT_SUMS) else 0
+        sum_ws_n = E * ((NP + 255) // 256) * C if (want_sums and tuning.current().fused_point_sums) else 0
         sum_ws = torch.empty((sum_ws_n,), device=dev, dtype=torch.float32) if sum_ws_n else None
         _lib.check(L.csn_outproj_ln_fwd_f32(_ptr(att), D * NP, _ptr(w_fc), _ptr(x_all), C * NP, _ptr(q_slots),
                                             _ptr(xhat), C * NP, _ptr(rstd), E, C, D, NP, NP, LN_EPS, p_fc, seed_fc,
@@ -404,6 +413,7 @@ class _MHAEvals(torch.autograd.Function):
         del sum_ws
         if keep_scores:
             ctx.save_for_backward(x_all, w_qkv, w_fc, qkv, att, lse, scores, xhat, rstd, kv)
+            ctx.flow = flow
             ctx.geo = geo
             ctx.plan = plan
             ctx.drop = (p_attn, seed_attn, p_fc, seed_fc)
@@ -481,7 +491,20 @@ class _MHAEvals(torch.autograd.Function):
 
         # ---- attention backward, straight into per-slot gradient maps ---------------------------------------
         # evaluations that share a slot (Q of the query shape, K/V of each neighbour) add up: one launch per colour
-        dscores = torch.empty_like(scores)
+        flow = ctx.flow
+        pt = 1 if (fast_math() and Tp >= (T + 31) // 32 * 32) else 0    # P / dS travel to the dV / dK products as tile planes
+        # (bf16x3: P overwrites the scores in place, dS fills `dscores`; bf16: both go to `dscores` as compact rows and the
+        #  dK / dV call reads them there — csn_hip.h (3))
+        if flow == tuning.KEEP_SCORES:
+            dscores = torch.empty_like(scores)
+        else:
+            # recomputed scores: `scores` is only the scratch the P planes travel in (two-plane mode), `dscores` that of dS
+            # (+ P in the one-plane mode); the flash flow has neither
+            assert pt == 1 and scores is None
+            shape = (E, H, nb, T, Tp)
+            travel = flow == tuning.RECOMPUTE_DQ
+            scores = torch.empty(shape, device=dev, dtype=torch.float32) if (travel and planes() == 2) else None
+            dscores = torch.empty(shape, device=dev, dtype=torch.float32) if travel else None
         delta = torch.empty((E, H, geo.n_padded), device=dev, dtype=torch.float32)
         dqkv = torch.empty((S, 3 * D, NP), device=dev, dtype=torch.float32)
         # the weight gradients contract every slot's gradient maps — or, for a plan with slot ranges (and no input gradients
@@ -511,14 +534,22 @@ class _MHAEvals(torch.autograd.Function):
         else:
             k_ptr = q_ptr + 4 * D * NP
             v_ptr = q_ptr + 4 * (2 * D * NP + plan.v_shift * kv_stride)
-        pt = 1 if (fast_math() and Tp >= (T + 31) // 32 * 32) else 0    # P / dS travel to the dV / dK products as tile planes
-        # (bf16x3: P overwrites the scores in place, dS fills `dscores`; bf16: both go to `dscores` as compact rows and the
-        #  dK / dV call reads them there — csn_hip.h (3))
         grouping = L.csn_attn_bwd_grouping(d, T)
-        if EVENT_SINK is not None:
+        tune = tuning.current()
+        sink = tune.event_sink
+        if sink is not None:
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record()
-        if GROUPED_DQ and (grouping & 1):
+        if flow != tuning.KEEP_SCORES:
+            # one grouped call, scores rebuilt from the pre-scaled queries of the evaluation's query slot
+            _lib.check(L.csn_block_attn_bwd_dq_recompute_f32(_ptr(datt), _ptr(att), D * NP, q_ptr, q_stride, _ptr(plan.q_slots),
+                                                             k_ptr, v_ptr, kv_stride, _ptr(plan.kv_slots), NP, _ptr(scores),
+                                                             _ptr(dscores), _ptr(lse), _ptr(delta), gbase, slot_stride,
+                                                             _ptr(plan.q_slots), 0, _ptr(plan.q_group_items), E, H, d, T, nb, Tp,
+                                                             p_attn, seed_attn, kv_pitch, pt if flow == tuning.RECOMPUTE_DQ else 0,
+                                                             _ptr(plan.q_group_off), plan.n_q_groups, _stream()),
+                       "csn_block_attn_bwd_dq_recompute_f32")
+        elif tune.grouped_dq and (grouping & 1):
             # one call: the evaluations of a query slot run one after the other into the same dQ accumulators
             _lib.check(L.csn_block_attn_bwd_dq_f32(_ptr(datt), _ptr(att), D * NP, k_ptr, v_ptr, kv_stride,
                                                    _ptr(plan.kv_slots), NP, _ptr(scores), _ptr(dscores), _ptr(lse),
@@ -535,11 +566,11 @@ class _MHAEvals(torch.autograd.Function):
                                                        ids.numel(), H, d, T, nb, Tp, p_attn, seed_attn, 0, 0, kv_flag,
                                                        kv_pitch, pt, None, 0, _stream()),
                            "csn_block_attn_bwd_dq_f32")
-        if EVENT_SINK is not None:
+        if sink is not None:
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record()
-            EVENT_SINK["bwd"].append((ev0, ev1))
-        if GROUPED_DKV and (grouping & 2):
+            sink["bwd"].append((ev0, ev1))
+        if tune.grouped_dkv and (grouping & 2):
             # one call: the evaluations of a key/value slot are contracted one after the other into the same accumulators
             _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, q_ptr, q_stride, _ptr(plan.q_slots), NP,
                                                     _ptr(scores), _ptr(dscores), gbase + 4 * D * NP, gbase + 8 * D * NP,
@@ -610,7 +641,7 @@ def mha_evals(x_all: torch.Tensor, w_qs: torch.Tensor, w_ks: torch.Tensor, w_vs:
     link_mix: the second result is a LinkedMaps for csa_mix — the mix's backward then hands this function's backward the
     gradient of the mixed features and its factors instead of writing one gradient map per evaluation."""
     keep = torch.is_grad_enabled() and any(t.requires_grad for t in (x_all, w_qs, w_ks, w_vs, w_fc))
-    link = MixLink() if (link_mix and LINK_MIX and keep and n_head_evals > 0) else None
+    link = MixLink() if (link_mix and tuning.current().link_mix and keep and n_head_evals > 0) else None
     xhat, head, sums, handle = _MHAEvals.apply(x_all, w_qs, w_ks, w_vs, w_fc, plan, geo, keep, float(p_attn), float(p_fc),
                                                int(n_head_evals), bool(want_sums), link)
     if link is not None:

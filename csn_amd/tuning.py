@@ -1,0 +1,56 @@
+"""Data-flow switches of the step and the bench's event hook — kept out of the product modules.
+
+Every switch selects between two forms of the SAME arithmetic (a fused pass and the plain pass it replaced, or two data
+flows of the attention backward); the defaults are the measured-faster forms.  Nothing here changes results
+beyond fp32 rounding; `tests/test_gpu_module.py::test_fused_data_flow_equals_the_unfused_one` and
+`tests/test_gpu_flash.py` flip them through ``override`` to check one form against the other, `bench.py` hangs its HIP-event
+sink here.  The state is process-wide on purpose: autograd runs the backward on its own threads, and a step must see the
+same switches in both passes.
+"""
+from __future__ import annotations
+
+import contextlib
+from dataclasses import dataclass, field, fields, replace
+from typing import Dict, Optional
+
+# attention backward data flows (csn_amd.functional._MHAEvals):
+KEEP_SCORES = 0      # the forward writes the raw scores S, the dQ kernel reads them back and leaves P / dS for the dK / dV products
+RECOMPUTE_DQ = 1     # the forward keeps only lse; the dQ kernel rebuilds S = Qs K^T (one more product), P / dS still travel
+FLASH = 2            # ... and a key-stationary kernel rebuilds P / dS for dK / dV: no score-sized tensor exists at all
+
+
+@dataclass
+class Tuning:
+    kv_tiles: bool = True            # 16-bit modes: K / V leave the projection as tile planes (csn_project_f32, out_split = 2)
+    fused_point_sums: bool = True    # False: pooled sums by a streaming pass over the maps
+    link_mix: bool = True            # False: the mix backward writes per-evaluation gradient maps
+    grouped_dkv: bool = True         # False: dK / dV by one read-modify-write launch per colour
+    grouped_dq: bool = True          # False: dQ likewise
+    # math mode (1 bf16x3, 2 bf16 — fp16 forwards run their backward in 2) -> attention backward data flow, where the kernels
+    # have an instance for it (csn_attn_bwd_grouping bits 2 / 3); measured per mode, DESIGN.md §4 "data flow A/B"
+    score_flow: Dict[int, int] = field(default_factory=lambda: {1: KEEP_SCORES, 2: KEEP_SCORES})
+    # bench.py: {"fwd": [], "bwd": []} collects (start, end) HIP-event pairs around the fused attention launches
+    event_sink: Optional[dict] = None
+
+
+_current = Tuning()
+
+
+def current() -> Tuning:
+    return _current
+
+
+@contextlib.contextmanager
+def override(**changes):
+    """``with tuning.override(grouped_dq=False): ...`` — the switches inside the block, the previous ones after it."""
+    global _current
+    names = {f.name for f in fields(Tuning)}
+    unknown = set(changes) - names
+    if unknown:
+        raise TypeError(f"unknown tuning switch(es): {sorted(unknown)}")
+    saved = _current
+    _current = replace(saved, **changes)
+    try:
+        yield _current
+    finally:
+        _current = saved

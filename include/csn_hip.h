@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSN_ABI_VERSION 12
+#define CSN_ABI_VERSION 13
 
 /* math modes (csn_set_math_mode / csn_set_thread_math_mode) */
 #define CSN_MATH_FP32 0
@@ -143,8 +143,28 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
  * an output slot are adjacent, group g = entries group_offsets[g] .. group_offsets[g+1] (n_groups + 1 offsets); a group's
  * results are accumulated in registers and its slot is written once — one call for all evaluations instead of one
  * read-modify-write pass per colour.  csn_attn_bwd_grouping() says where that is available in the current math mode:
- * bit 0 = the dq call, bit 1 = the dkv call. */
+ * bit 0 = the dq call, bit 1 = the dkv call, bit 2 = csn_block_attn_bwd_dq_recompute_f32 (below).
+ *
+ * csn_block_attn_bwd_dq_recompute_f32 — the dq call WITHOUT saved scores ("flash" data flow; math modes 1 and 2, K / V as tile
+ * planes, block mode): the forward is run with scores = NULL (only lse is kept) and this call rebuilds S = Qs K^T tile by tile
+ * from the pre-scaled queries q [slot][n_heads*d_head][ld] (+ q_index, as in the forward) — one more matrix product per tile
+ * against 4 * block bytes of score traffic per query in each direction.  Everything else as csn_block_attn_bwd_dq_f32.
+ *   probs_tiles != 0: P_drop and dS still leave as tile planes for csn_block_attn_bwd_dkv_f32 — mode 1: P in `probs`, dS in
+ *                     `dscores` (two scratch buffers of the scores' geometry); mode 2: both in `dscores`, `probs` unused;
+ *   probs_tiles == 0: nothing is written besides delta and dq (`probs` / `dscores` may be NULL) — for a dK / dV pass that
+ *                     recomputes the probabilities itself.
+ * Available where three LDS tile images per stage fit: mode 2 at every head width, mode 1 up to d_head = 128 (bit 2 of
+ * csn_attn_bwd_grouping); CSN_E_ARG elsewhere. */
 int csn_attn_bwd_grouping(int d_head, int block);
+int csn_block_attn_bwd_dq_recompute_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* q,
+                                        long long q_shape_stride, const int* q_index, const float* k, const float* v,
+                                        long long kv_shape_stride, const int* kv_index, int ld, float* probs,
+                                        float* dscores, const float* lse, float* delta, float* dq,
+                                        long long dq_slot_stride, const int* dq_index, int accumulate, const int* eval_ids,
+                                        int n_launch_evals, int n_heads, int d_head, int block, int n_blocks,
+                                        int score_pitch, float dropout_p, unsigned long long seed,
+                                        long long kv_plane_stride, int probs_tiles, const int* group_offsets, int n_groups,
+                                        void* stream);
 int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* k,
                               const float* v, long long kv_shape_stride, const int* kv_index, int ld, float* scores,
                               float* dscores, const float* lse, float* delta, float* dq, long long dq_slot_stride,

@@ -18,13 +18,15 @@ def timeit(fn, n=5):
     return sorted(a.elapsed_time(b) for a, b in ev)[n // 2]
 
 
-def to_tiles(kv, T, nb):
-    """fp32 (S, R, nb*T) -> bf16 tile planes (S, R, nb*1024): per row and block 16 tiles of [hi 32 | lo 32]."""
+def to_tiles(kv, T, nb, npl=2):
+    """fp32 (S, R, nb*T) -> bf16 tile planes (S, R, nb*512*npl): per row and block 16 tiles of [hi 32 | lo 32] (npl = 2) or [32]."""
     S, R, _ = kv.shape
     x = torch.zeros((S, R, nb, 512), device=kv.device, dtype=torch.float32)
     x[..., :T] = kv.view(S, R, nb, T)
     x = x.view(S, R, nb, 16, 32)
     hi = x.bfloat16()
+    if npl == 1:
+        return hi.reshape(S, R, nb * 512).contiguous()
     lo = (x - hi.float()).bfloat16()
     return torch.stack((hi, lo), dim=4).reshape(S, R, nb * 1024).contiguous()
 
@@ -39,9 +41,12 @@ def main():
     ap.add_argument("--drop", type=float, default=0.1)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--only", default="fwd,dq,dkv")
+    ap.add_argument("--d", type=int, default=256)
+    ap.add_argument("--nb", type=int, default=20)
+    ap.add_argument("--recompute", type=int, default=0, help="1: dq rebuilds the scores, P / dS planes still written; 2: nothing written")
     a = ap.parse_args()
     L = _lib.lib()
-    H, d, T, nb = 1, 256, 500, 20
+    H, d, T, nb = 1, a.d, 500, a.nb
     D, NP, Tp = H * d, T * nb, 512
     S, E = a.slots, a.evals
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -57,23 +62,32 @@ def main():
     delta = torch.empty((E, H, NP), device="cuda")
     dqkv = torch.zeros((E, 3 * D, NP), device="cuda")
     base = qkv.data_ptr()
+    npl = 2 if a.mode == 1 else 1
     if a.tiles:
-        kvt = to_tiles(qkv[:, D:], T, nb)
-        k_ptr, v_ptr, kv_stride, kvf, kvp = kvt.data_ptr(), kvt.data_ptr() + 2 * D * nb * 1024, 2 * D * nb * 1024, 1, nb * 1024
+        kvt = to_tiles(qkv[:, D:], T, nb, npl)
+        k_ptr, v_ptr, kv_stride, kvf, kvp = kvt.data_ptr(), kvt.data_ptr() + 2 * D * nb * 512 * npl, 2 * D * nb * 512 * npl, 1, nb * 512 * npl
     else:
         k_ptr, v_ptr, kv_stride, kvf, kvp = base + 4 * D * NP, base + 8 * D * NP, 3 * D * NP, 0, 0
     st = CF._stream()
     seed = 12345678901
 
     def fwd():
-        tl = a.tiles and L.csn_get_math_mode() == 1
+        tl = a.tiles and L.csn_get_math_mode() in (1, 2)
         _lib.check(L.csn_block_attn_fwd_f32(base, k_ptr if tl else base + 4 * D * NP, v_ptr if tl else base + 8 * D * NP,
                                             3 * D * NP, kv_stride if tl else 3 * D * NP, CF._ptr(qs),
                                             CF._ptr(ks), NP, CF._ptr(att), D * NP, None if a.noscores else CF._ptr(scores), CF._ptr(lse), E, H, d, T,
                                             nb, Tp, 8.0, a.drop, seed, kvf if tl else 0, kvp if tl else 0, st), "fwd")
 
     def dq():
-        tl = a.tiles and L.csn_get_math_mode() == 1
+        tl = a.tiles and L.csn_get_math_mode() in (1, 2)
+        if a.recompute and tl:
+            pt = 1 if a.recompute == 1 else 0
+            _lib.check(L.csn_block_attn_bwd_dq_recompute_f32(CF._ptr(datt), CF._ptr(att), D * NP, base, 3 * D * NP, CF._ptr(qs),
+                                                             k_ptr, v_ptr, kv_stride, CF._ptr(ks), NP, CF._ptr(scores) if pt else None,
+                                                             CF._ptr(dscores) if pt else None, CF._ptr(lse), CF._ptr(delta),
+                                                             dqkv.data_ptr(), 3 * D * NP, None, 0, None, E, H, d, T, nb, Tp, a.drop,
+                                                             seed, kvp, pt, None, 0, st), "dq recompute")
+            return
         _lib.check(L.csn_block_attn_bwd_dq_f32(CF._ptr(datt), CF._ptr(att), D * NP, k_ptr if tl else base + 4 * D * NP,
                                                v_ptr if tl else base + 8 * D * NP,
                                                kv_stride if tl else 3 * D * NP, CF._ptr(ks), NP, CF._ptr(scores), CF._ptr(dscores), CF._ptr(lse),
@@ -84,7 +98,7 @@ def main():
         gb = dqkv.data_ptr()
         _lib.check(L.csn_block_attn_bwd_dkv_f32(CF._ptr(datt), D * NP, base, 3 * D * NP, CF._ptr(qs), NP, CF._ptr(scores),
                                                 CF._ptr(dscores), gb + 4 * D * NP, gb + 8 * D * NP, 3 * D * NP, None, None,
-                                                0, None, E, H, d, T, nb, Tp, 0, 0, 0, 0, 1 if (a.tiles and L.csn_get_math_mode() == 1) else 0, None, 0, st), "dkv")
+                                                0, None, E, H, d, T, nb, Tp, 0, 0, 0, 0, 1 if (a.tiles and L.csn_get_math_mode() in (1, 2)) else 0, None, 0, st), "dkv")
 
     flops = 4.0 * T * d * NP * E * H
     L.csn_set_math_mode(a.mode)
@@ -108,7 +122,7 @@ def main():
             scores.copy_(s0); dq()
         t_copy = timeit(lambda: scores.copy_(s0))
         t = timeit(dq_fresh) - t_copy
-        print(f"mode {a.mode} dq   E={E}: {t:7.3f} ms  {flops / t / 1e9:7.1f} TF/s algorithmic", flush=True)
+        print(f"mode {a.mode} dq   E={E} recompute={a.recompute}: {t:7.3f} ms  {flops / t / 1e9:7.1f} TF/s algorithmic", flush=True)
         if a.check:
             print("   dq err", (dqkv[:, :D] - ref["dq"]).abs().max().item(), "scale", ref["dq"].abs().max().item(),
                   "p err", (scores[0] - ref["p"]).abs().max().item())

@@ -311,7 +311,7 @@ def test_host_neighbour_stack_equals_device_stack():
             assert (g0[n] - g1[n]).abs().max().item() <= 2e-4 * g0[n].abs().max().item() + 1e-9, n
 
 
-def test_fused_data_flow_equals_the_unfused_one(monkeypatch):
+def test_fused_data_flow_equals_the_unfused_one():
     """The passes the step no longer makes (pooled sums from the out-projection epilogue, the mix gradient rebuilt inside the
     LayerNorm backward, dQ / dK / dV accumulated per slot in registers) against the plain forms of the same arithmetic
     (row-sum pass, per-evaluation gradient maps, one read-modify-write launch per colour): logits, loss and all 11 gradients."""
@@ -323,15 +323,15 @@ def test_fused_data_flow_equals_the_unfused_one(monkeypatch):
     p, x, nb, lab = orc.conditioned_csa_case(rng, B, K, H, n_cls, 4.0, 3.0, 1.0)
     x, nb, lab = x.cuda(), nb.cuda().contiguous(), lab.cuda()
     outs = []
+    from csn_amd import tuning
     for fused in (True, False):
-        for knob in ("FUSED_POINT_SUMS", "LINK_MIX", "GROUPED_DKV", "GROUPED_DQ"):
-            monkeypatch.setattr(CF, knob, fused)
         m = get_model("csa", n_cls, H, K)
         m.load_state_dict(p, strict=False)
         m = m.cuda().eval()
-        logits = m(x, "test", nb)
-        loss = orc.masked_ce_loss(logits, lab)
-        loss.backward()
+        with tuning.override(fused_point_sums=fused, link_mix=fused, grouped_dkv=fused, grouped_dq=fused):
+            logits = m(x, "test", nb)
+            loss = orc.masked_ce_loss(logits, lab)
+            loss.backward()
         outs.append((logits.detach(), loss.item(), {n: q.grad.clone() for n, q in m.named_parameters() if q.grad is not None}))
     (l0, s0, g0), (l1, s1, g1) = outs
     assert (l0 - l1).abs().max().item() < 2e-5 and abs(s0 - s1) < 1e-5
