@@ -1,0 +1,404 @@
+// Key-stationary attention backward for the score-recomputing ("flash") data flow: dK and dV of one key/value slot without any
+// score-sized tensor (autograd of ScaledDotProductAttention.forward, MID-FC/csa_models.py:138-144, w.r.t. k and v).
+//
+// attn_bf16x3.hip keeps 16 QUERIES per wave in registers and streams key tiles; this kernel is its mirror image.  A work-group
+// owns 128 keys of one (key/value slot, head, block): wave w keeps K^T and V^T of its 16 keys as register operands and the
+// dK^T / dV^T accumulators [d][16 keys] of those keys, and the work-group streams 32-query tiles of Qs^T and dO^T through LDS,
+// for every evaluation that reads this slot, one after the other (the group loop of the grouped dK / dV product it replaces).
+// Per tile and wave, with the key on the matrix instruction's lane:
+//   phase 1   S [q][key] = sum_d Qs^T[d][q] K^T[d][key]        dP[q][key] = sum_d dO^T[d][q] V^T[d][key]
+//   pointwise P = exp2(S log2e - lse2[q]),  mask regenerated from (seed, position),  dS = P (dP mask/(1-p) - delta[q])
+//   phase 2   dV^T[c][key] += sum_q dO^T[c][q] P_drop[q][key]  dK^T[c][key] += sum_q Qs^T[c][q] dS[q][key]
+// A lane ends phase 1 with 8 CONSECUTIVE queries of its key (the row permutation of attn_bf16x3.hip), which is the B fragment
+// of phase 2 as it stands: P and dS never leave the registers.  lse comes from the forward, delta = rowsum(dO * O) from the dQ
+// call that runs before this one (csn_block_attn_bwd_dq_recompute_f32 with probs_tiles = 0).
+// LDS: per stage four images — Qs and dO tiles each in the k-major form (phase 1, transposing reads) and the query-contiguous
+// form (phase 2, 16-byte reads) — of bf16 hi / lo planes (one plane in the single-product mode), two stages; the 32 lse2 /
+// delta values of a tile beside them.  fp32 sources are split while they are staged (once per tile and work-group).
+// Schedule: the two barrier segments per tile and the one-segment stagger between waves 0..3 and 4..7 of attn_bf16x3.hip.
+#include "csn_common.h"
+#include "csn_kernels.h"
+
+namespace {
+
+constexpr int QT = 32;               // queries per streamed tile
+constexpr int KW = 128;              // keys per work-group (8 waves x 16)
+constexpr float LOG2E = 1.4426950408889634f;
+
+using namespace csn_mode;
+typedef f32x4m f32x4v;
+typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+typedef short __attribute__((address_space(3))) lds_s16;
+typedef s16x8 __attribute__((address_space(3))) lds_s16x8;
+
+CSN_DEVINL const lds_s16* opaque_lds(const short* p) {
+  const lds_s16* q = (const lds_s16*)p;
+  asm volatile("" : "+v"(q));
+  return q;
+}
+
+template <typename PR>
+CSN_DEVINL f32x4v mma16(s16x8 ah, s16x8 al, s16x8 bh, s16x8 bl, f32x4v c) {
+  if constexpr (PR::NT == 3) {
+    c = mfma16<PR::HALF>(al, bh, c);
+    c = mfma16<PR::HALF>(ah, bl, c);
+  }
+  return mfma16<PR::HALF>(ah, bh, c);
+}
+
+template <typename PR, int DT>
+__global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) {
+  constexpr int NPL = PR::NPL;
+  constexpr int D = 32 * DT;
+  constexpr int PLANE = D * QT + 32;                    // hi and lo planes 64 bytes out of phase (store banks, attn_bf16x3.hip)
+  constexpr int NP_T = (D * 8 + 511) / 512;             // 16-byte pieces of a [D][32] fp32 tile per thread
+  constexpr int IMG_EL = 4 * 2 * NPL * PLANE;           // [image: QA, OA, QB, OB][stage][plane]
+  constexpr int STAGE_EL = D * KW * 2;                  // prologue / epilogue: a [D][128 keys] fp32 block
+  constexpr int BUF_EL = IMG_EL > STAGE_EL ? IMG_EL : STAGE_EL;
+  static_assert(2 * BUF_EL + 2 * 64 * 4 <= 160 * 1024, "LDS budget of one CU");
+  __shared__ __attribute__((aligned(16))) short tiles[BUF_EL + 2 * 64 * 2];
+  auto image = [&](int img, int st, int pl) -> short* { return tiles + ((img * 2 + st) * NPL + pl) * PLANE; };
+  float* rowc = reinterpret_cast<float*>(tiles + BUF_EL);          // [stage][lse2: 32 | delta: 32]
+  float* xbuf = reinterpret_cast<float*>(tiles);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 15, kq = lane >> 4;
+  // XCD-aware order (attn_bf16x3.hip): the KC key chunks of a unit stream the same Qs / dO tiles — same residue mod 8
+  const int KC = (p.T + KW - 1) / KW;
+  const int Y = p.n_blocks * p.H;
+  const int L = blockIdx.x, slot8 = L & 7, jj = L >> 3;
+  const int kc = jj % KC, u = (jj / KC) * 8 + slot8;
+  if (u >= Y * p.n_groups) return;
+  const int grp = u / Y, hd = (u % Y) % p.H, blk = (u % Y) / p.H;
+  const int it0 = p.grp_off ? p.grp_off[grp] : grp, it1 = p.grp_off ? p.grp_off[grp + 1] : grp + 1;
+  const bool short_blk = p.T_last > 0 && blk == p.n_blocks - 1;
+  const int T = short_blk ? p.T_last : p.T;                         // queries = keys of this block
+  if (kc * KW >= T) return;
+  const int ld = p.ld, Tp = p.Tp;
+  const int e_first = p.eval_ids ? p.eval_ids[it0] : it0;
+  const long long kslot = p.kv_index ? p.kv_index[e_first] : e_first;
+  const int nqt = (T + QT - 1) / QT;
+  const int n_steps = (it1 - it0) * nqt;
+  const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+  const int col = 16 * wave + lq;                                   // this lane's key inside the chunk of 128
+  const int key = kc * KW + col;                                    // ... inside the block
+
+  // ---- register operands K^T, V^T [d][16 keys] from the tile planes -----------------------------------------------
+  // The chunk's 128 keys are 4 tiles of [hi 32 | lo 32] (one plane: [32]) per row: 256 NPL bytes.  The work-group fetches the
+  // [D][4 tiles] block with 16-byte loads into LDS (the tile buffers are idle) and every lane picks its 16-bit values.
+  constexpr int RPC = 16 * NPL;                                     // 16-byte pieces per row of the block
+  constexpr int CH_K = (D * RPC + 511) / 512;
+  s16x8 Kh[DT], Kl[DT], Vh[DT], Vl[DT];
+  {
+    const int kld = p.kv_ld;
+    const int cc = tid % RPC, crow = tid / RPC;                     // piece column, first row (rows + 512 / RPC per pass)
+    constexpr int RPS = 512 / RPC;
+    short* sbuf = tiles;                                            // [row][piece ^ swizzle][8 shorts], row pitch 128 NPL shorts
+    auto stage_planes = [&](const short* base) {
+      const long long off = kslot * p.kv_shape_stride + (long long)hd * D * kld + (long long)blk * (512 * NPL) + (long long)kc * (128 * NPL);
+      const csn_rsrc_t rs = csn_make_rsrc(base + off, ((long long)(D - 1) * kld + 128 * NPL) * 2);
+      f32x4 ch[CH_K];
+#pragma unroll
+      for (int t = 0; t < CH_K; ++t) {
+        const int row = crow + RPS * t;
+        // (tiles beyond the block's 16 are not part of the row: the last chunk of a 500-key block holds 116 keys in 4 tiles)
+        const bool ok = row < D && (kc * 4 + cc / (4 * NPL)) < 16;
+        ch[t] = csn_bload4(rs, ok ? (unsigned)(row * kld * 2 + cc * 16) : CSN_OOB);
+      }
+#pragma unroll
+      for (int t = 0; t < CH_K; ++t) {
+        const int row = crow + RPS * t;
+        if (row < D) *reinterpret_cast<f32x4*>(&sbuf[row * (128 * NPL) + ((cc ^ (2 * ((row >> 3) & 3))) << 3)]) = ch[t];
+      }
+    };
+    // element (row, local key kl): tile kl >> 5, position kl & 31 -> piece (kl >> 5) * 4 NPL + plane * 4 + ((kl & 31) >> 3)
+    auto pick = [&](int row, int plane) {
+      const int piece = (col >> 5) * (4 * NPL) + plane * 4 + ((col & 31) >> 3);
+      return sbuf[row * (128 * NPL) + (((piece ^ (2 * ((row >> 3) & 3))) << 3) | (col & 7))];
+    };
+    stage_planes(reinterpret_cast<const short*>(p.k));
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < DT; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        Kh[s][j] = pick(32 * s + 8 * kq + j, 0);
+        Kl[s][j] = pick(32 * s + 8 * kq + j, NPL - 1);
+      }
+    __syncthreads();
+    stage_planes(reinterpret_cast<const short*>(p.v));
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < DT; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        Vh[s][j] = pick(32 * s + 8 * kq + j, 0);
+        Vl[s][j] = pick(32 * s + 8 * kq + j, NPL - 1);
+      }
+    __syncthreads();                                                // the staging block becomes the tile images
+  }
+
+  f32x4v dK[D / 16], dV[D / 16];
+#pragma unroll
+  for (int c = 0; c < D / 16; ++c) { dK[c] = f32x4v{0.f, 0.f, 0.f, 0.f}; dV[c] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+
+  const bool drop = p.dropout_p > 0.f;
+  const unsigned thr16 = csn_drop_threshold16(p.dropout_p);
+  const float keep_scale = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
+  const int mp = p.T > Tp ? p.T : Tp;                               // mask pitch of the forward (queries per block vs score pitch)
+  const unsigned pw_key = (unsigned)((key >> 1) * mp);              // pair index of this lane's key: (key / 2) * mp + query
+  const bool key_odd = key & 1;
+
+  // ---- streamed tiles: fp32 [d][32 queries] -> bf16 hi / lo -> LDS, in both forms (the fp32 staging of attn_bf16x3.hip) ----
+  const int t_c = tid & 7, t_row = tid >> 3;                        // 16-byte piece of the row (queries 4 c ..), first row (+ 64 i)
+  const int t_sw = ((t_row >> 3) ^ t_row) & 1, t_swz = (-((t_row >> 2) & 3)) & 3;
+  const bool t_last_ok = ((D * 8) % 512 == 0) || (tid + 512 * (NP_T - 1) < D * 8);
+  const int a_dst = t_row * QT + 4 * (t_c ^ t_sw);
+  const int b_dst = t_row * QT + 8 * ((t_c >> 1) ^ t_swz) + 4 * (t_c & 1);
+  f32x4 gQ[NP_T], gO[NP_T];
+  float gc = 0.f;                                                   // threads 0..63: lse2 / delta of one query of the tile
+  // step -> (item, query tile); everything that depends on it is wave-uniform
+  auto step_eval = [&](int step) { const int it = it0 + step / nqt; return p.eval_ids ? p.eval_ids[it] : it; };
+  auto fetch = [&](int step) {
+    const int e = step_eval(step), qt = step % nqt;
+    const long long qs = p.q_index ? p.q_index[e] : e;
+    const long long head_off = (long long)hd * D * ld + (long long)blk * p.T + qt * QT;
+    const int nq = T - qt * QT;                                     // queries left in the block from this tile on
+    const long long win = ((long long)(D - 1) * ld + (nq < QT ? nq : QT)) * 4;
+    const csn_rsrc_t Qr = csn_make_rsrc(p.q + qs * p.q_shape_stride + head_off, win);
+    const csn_rsrc_t Or = csn_make_rsrc(p.dctx + (long long)e * p.ctx_eval_stride + head_off, win);
+    const unsigned off = (4 * t_c) < nq ? (unsigned)(t_row * ld + 4 * t_c) * 4u : CSN_OOB;      // T % 4 == 0: a piece is all in or all out
+#pragma unroll
+    for (int i = 0; i < NP_T; ++i) {
+      const unsigned o = (i == NP_T - 1 && !t_last_ok) ? CSN_OOB : off;
+      gQ[i] = csn_bload4(Qr, o, (unsigned)(64 * i * ld) * 4u);
+      gO[i] = csn_bload4(Or, o, (unsigned)(64 * i * ld) * 4u);
+    }
+    if (tid < 64) {
+      const long long stat = ((long long)e * p.H + hd) * ((long long)p.n_blocks * p.T) + (long long)blk * p.T + qt * QT;
+      const int qi = tid & 31;
+      const float v = qi < nq ? (tid < 32 ? p.lse[stat + qi] * LOG2E : p.delta[stat + qi]) : 0.f;
+      gc = v;
+    }
+  };
+  auto commit_kmajor = [&](int img, int st, const f32x4* g) {
+#pragma unroll
+    for (int i = 0; i < NP_T; ++i)
+      if (i < NP_T - 1 || t_last_ok) {
+        s16x4 hi, lo;
+        split4<PR>(g[i], hi, lo);
+        *reinterpret_cast<s16x4*>(image(img, st, 0) + a_dst + 64 * QT * i) = hi;
+        if constexpr (NPL == 2) *reinterpret_cast<s16x4*>(image(img, st, 1) + a_dst + 64 * QT * i) = lo;
+      }
+  };
+  auto commit_contig = [&](int img, int st, const f32x4* g) {
+#pragma unroll
+    for (int i = 0; i < NP_T; ++i)
+      if (i < NP_T - 1 || t_last_ok) {
+        s16x4 hi, lo;
+        split4<PR>(g[i], hi, lo);
+        *reinterpret_cast<s16x4*>(image(img, st, 0) + b_dst + 64 * QT * i) = hi;
+        if constexpr (NPL == 2) *reinterpret_cast<s16x4*>(image(img, st, 1) + b_dst + 64 * QT * i) = lo;
+      }
+  };
+  auto commit_rowc = [&](int st) { if (tid < 64) rowc[st * 64 + tid] = gc; };
+
+  // fragment read positions (lane constants; attn_bf16x3.hip)
+  const int tr_row = 8 * kq + (lq >> 2);
+  const int tr_sw = (kq ^ (lq >> 2)) & 1;
+  const int a_pos0 = tr_row * QT + 8 * (lq & 3) + 4 * tr_sw, a_pos1 = tr_row * QT + 8 * (lq & 3) + 4 * (tr_sw ^ 1);
+  const int b_pos = lq * QT + 8 * (kq ^ ((-((lq >> 2) & 3)) & 3));
+
+  constexpr int PD = 4;
+  // phase 1: T[q][key] = sum_d img[d][q] R[d][key]
+  auto phase1 = [&](int img, int st, const s16x8* Rh, const s16x8* Rl, f32x4v& S0, f32x4v& S1) {
+    S0 = f32x4v{0.f, 0.f, 0.f, 0.f};
+    S1 = f32x4v{0.f, 0.f, 0.f, 0.f};
+    const short* __restrict__ tAh = image(img, st, 0);
+    const short* __restrict__ tAl = image(img, st, NPL - 1);
+    constexpr int NH = 2 * DT;
+    s16x8 ah[PD], al[PD];
+    auto rd = [&](int h, s16x8& fh, s16x8& fl) {
+      const int o = 32 * (h >> 1) * QT + ((h & 1) ? a_pos1 : a_pos0);
+      fh = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAh + o)),
+                 __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAh + o + 4 * QT)));
+      if constexpr (NPL == 2)
+        fl = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAl + o)),
+                   __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAl + o + 4 * QT)));
+      else fl = fh;
+    };
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < PD && h < NH; ++h) rd(h, ah[h], al[h]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * NPL * (PD < NH ? PD : NH), 0);
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const int r = h % PD, sidx = h >> 1;
+      if (h & 1) S1 = mma16<PR>(ah[r], al[r], Rh[sidx], Rl[sidx], S1);
+      else S0 = mma16<PR>(ah[r], al[r], Rh[sidx], Rl[sidx], S0);
+      if (h + PD < NH) rd(h + PD, ah[r], al[r]);
+      __builtin_amdgcn_sched_group_barrier(0x008, PR::NT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NPL, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // phase 2: OUT[c][key] += sum_q img[c][q] F[q][key]
+  auto phase2 = [&](int img, int st, const s16x8& fh, const s16x8& fl, f32x4v* OUT) {
+    const lds_s16* tBh = opaque_lds(image(img, st, 0) + b_pos);
+    const lds_s16* tBl = tBh + (NPL - 1) * PLANE;
+    constexpr int NC = D / 16;
+    s16x8 vh[PD], vl[PD];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < PD && c < NC; ++c) {
+      vh[c] = *reinterpret_cast<const lds_s16x8*>(tBh + c * 16 * QT);
+      vl[c] = *reinterpret_cast<const lds_s16x8*>(tBl + c * 16 * QT);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, NPL * (PD < NC ? PD : NC), 0);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const int r = c % PD;
+      OUT[c] = mma16<PR>(vh[r], vl[r], fh, fl, OUT[c]);
+      if (c + PD < NC) {
+        vh[r] = *reinterpret_cast<const lds_s16x8*>(tBh + (c + PD) * 16 * QT);
+        vl[r] = *reinterpret_cast<const lds_s16x8*>(tBl + (c + PD) * 16 * QT);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, PR::NT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // images: 0 = Qs k-major, 1 = dO k-major, 2 = Qs query-contiguous, 3 = dO query-contiguous
+  fetch(0);
+  commit_kmajor(0, 0, gQ); commit_kmajor(1, 0, gO); commit_contig(2, 0, gQ); commit_contig(3, 0, gO); commit_rowc(0);
+  if (n_steps > 1) fetch(1);
+  __syncthreads();
+  if (late) __syncthreads();
+
+  // Two barrier segments per tile; waves 4..7 run one segment behind.  The k-major images are read in segment 1 and rewritten
+  // in segment 1 of the tile before; the query-contiguous images and the row constants are read in segment 2 and rewritten in
+  // segment 2 of the tile before (the hazard analysis of attn_bf16x3.hip with its A / B stages).  The pieces of tile t + 1
+  // stay in registers from the end of tile t - 1 to the end of tile t.
+  f32x4v S0, S1, P0, P1;
+  for (int step = 0; step < n_steps; ++step) {
+    const int cur = step & 1, nxt = cur ^ 1;
+    const bool more = step + 1 < n_steps;
+    phase1(0, cur, Kh, Kl, S0, S1);                                 // S  = Qs K^T (as the forward formed it, transposed roles)
+    phase1(1, cur, Vh, Vl, P0, P1);                                 // dP = dO V^T
+    if (more) { commit_kmajor(0, nxt, gQ); commit_kmajor(1, nxt, gO); }
+    __syncthreads();
+    // ---- pointwise: this lane's key against queries qt * 32 + 8 kq .. + 7 --------------------------------------------
+    const int e = step_eval(step), qt = step % nqt;
+    const unsigned salt = csn_block_salt((unsigned long long)(((long long)e * p.H + hd) * p.n_blocks + blk), p.seed);
+    const f32x4 l0 = *reinterpret_cast<const f32x4*>(&rowc[cur * 64 + 8 * kq]), l1 = *reinterpret_cast<const f32x4*>(&rowc[cur * 64 + 8 * kq + 4]);
+    const f32x4 d0 = *reinterpret_cast<const f32x4*>(&rowc[cur * 64 + 32 + 8 * kq]), d1 = *reinterpret_cast<const f32x4*>(&rowc[cur * 64 + 32 + 8 * kq + 4]);
+    const float lse2[8] = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+    const float dlt[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+    const float sv[8] = {S0[0], S0[1], S0[2], S0[3], S1[0], S1[1], S1[2], S1[3]};
+    const float dp[8] = {P0[0], P0[1], P0[2], P0[3], P1[0], P1[1], P1[2], P1[3]};
+    const int q0 = qt * QT + 8 * kq;                                // first of this lane's 8 queries (inside the block)
+    const int nv = T - q0;                                          // valid queries among them (only the last tile has fewer than 8)
+    float pd[8], ds[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      float pv = __builtin_amdgcn_exp2f(fmaf(sv[r], LOG2E, -lse2[r]));       // softmax probability (csa_models.py:141)
+      if (qt == nqt - 1) pv = r < nv ? pv : 0.f;                             // queries beyond the block end (wave-uniform branch)
+      bool keep = true;
+      if (drop) {
+        const unsigned h = csn_pair_hash(pw_key + (unsigned)(q0 + r), salt);
+        keep = (key_odd ? (h >> 16) : (h & 0xffffu)) >= thr16;
+      }
+      const float md = keep ? keep_scale : 0.f;                              // d P_drop / d P
+      pd[r] = pv * md;                                                       // what dV contracts: the dropped probabilities
+      ds[r] = pv * (dp[r] * md - dlt[r]);                                    // d softmax
+    }
+    s16x8 ph, pl, dh, dl;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      ph[r] = to16<PR::HALF>(pd[r]);
+      pl[r] = PR::NT == 3 ? to16<PR::HALF>(pd[r] - from16<PR::HALF>(ph[r])) : ph[r];
+      dh[r] = to16<PR::HALF>(ds[r]);
+      dl[r] = PR::NT == 3 ? to16<PR::HALF>(ds[r] - from16<PR::HALF>(dh[r])) : dh[r];
+    }
+    phase2(3, cur, ph, pl, dV);                                     // dV^T += dO^T P_drop
+    phase2(2, cur, dh, dl, dK);                                     // dK^T += Qs^T dS
+    if (more) {
+      commit_contig(2, nxt, gQ); commit_contig(3, nxt, gO); commit_rowc(nxt);
+      if (step + 2 < n_steps) fetch(step + 2);
+    }
+    __syncthreads();
+  }
+  if (!late) __syncthreads();                                       // pairs with the last barrier of the late half
+
+  // ---- epilogue: dK^T, dV^T [d][128 keys] leave as 16-byte rows through an LDS transpose ---------------------------------
+  const int cc = tid & 31, crow = tid >> 5;
+  constexpr int CH_T = D / 16;
+  const long long okslot = p.dk_index ? p.dk_index[e_first] : e_first, ovslot = p.dv_index ? p.dv_index[e_first] : e_first;
+  const long long out_off = (long long)hd * D * ld + (long long)blk * p.T + kc * KW;
+  const int nk = T - kc * KW;                                       // keys of this chunk that exist
+  const long long owin = ((long long)(D - 1) * ld + (nk < KW ? nk : KW)) * 4;
+  const unsigned c_off = (4 * cc) < nk ? (unsigned)(crow * ld + 4 * cc) * 4u : CSN_OOB;
+  auto store_out = [&](const f32x4v* OUT, float* base, long long slot) {
+#pragma unroll
+    for (int c = 0; c < D / 16; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * c + 4 * kq + r;
+        xbuf[row * KW + ((((col >> 2) ^ (4 * ((row >> 2) & 1))) << 2) | (col & 3))] = OUT[c][r];
+      }
+    __syncthreads();
+    const csn_rsrc_t rs = csn_make_rsrc(base + slot * p.dkv_slot_stride + out_off, owin);
+    f32x4 ch[CH_T];
+#pragma unroll
+    for (int t = 0; t < CH_T; ++t) {
+      const int row = crow + 16 * t;
+      ch[t] = *reinterpret_cast<const f32x4*>(&xbuf[row * KW + ((cc ^ (4 * ((row >> 2) & 1))) << 2)]);
+    }
+    if (p.accumulate) {
+      f32x4 prev[CH_T];
+#pragma unroll
+      for (int t = 0; t < CH_T; ++t) prev[t] = csn_bload4(rs, c_off, (unsigned)(16 * t * ld) * 4u);
+#pragma unroll
+      for (int t = 0; t < CH_T; ++t) ch[t] += prev[t];
+    }
+#pragma unroll
+    for (int t = 0; t < CH_T; ++t) csn_bstore4(ch[t], rs, c_off, (unsigned)(16 * t * ld) * 4u);
+  };
+  store_out(dK, p.dk, okslot);
+  __syncthreads();
+  store_out(dV, p.dv, ovslot);
+}
+
+template <typename PR, int DT>
+int launch_dt(const CsnAttnDkvArgs& a, hipStream_t st) {
+  const long long units = (long long)a.n_blocks * a.H * a.n_groups;
+  const int KC = (a.T + KW - 1) / KW;
+  dim3 grid((unsigned)(((units + 7) / 8) * 8 * KC));
+  hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT>), grid, dim3(512), 0, st, a);
+  return (int)hipGetLastError();
+}
+
+template <typename PR>
+int launch_any(const CsnAttnDkvArgs& a, int d, hipStream_t st) {
+  switch (d) {
+    case 32: return launch_dt<PR, 1>(a, st);
+    case 64: return launch_dt<PR, 2>(a, st);
+    case 96: return launch_dt<PR, 3>(a, st);
+    case 128: return launch_dt<PR, 4>(a, st);
+    default: return -5;
+  }
+}
+
+}  // namespace
+
+int csn_launch_attn_dkv_flash(const CsnAttnDkvArgs& a, int d, int mode, hipStream_t st) {
+  if (a.n_groups <= 0 || a.n_blocks <= 0) return 0;
+  if ((a.ld & 3) || (a.T & 3) || (a.T_last & 3) || a.T > 512 || (a.kv_ld & 7) || (a.kv_shape_stride & 7)) return -2;
+  if ((a.q_shape_stride & 3) || (a.ctx_eval_stride & 3) || (a.dkv_slot_stride & 3)) return -4;
+  switch (mode) {
+    case 1: return launch_any<Bf16x3>(a, d, st);
+    case 2: return launch_any<Bf16>(a, d, st);
+    default: return -1;
+  }
+}

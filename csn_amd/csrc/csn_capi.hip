@@ -391,8 +391,45 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
 
 int csn_attn_bwd_grouping(int d_head, int block) {
   if (mode() == 0) return 0;
-  const bool recompute = mode() != 3 && block <= 512 && dim_ok(d_head) && csn_attn_recompute_fits(planes_of(mode()), d_head / 32);
-  return 1 | (csn_gemm_bf16x3_big_tiles(d_head, (block + 3) / 4 * 4) ? 2 : 0) | (recompute ? 4 : 0);
+  const bool tiles_ok = mode() != 3 && block <= 512 && !(block & 3) && dim_ok(d_head);
+  const bool recompute = tiles_ok && csn_attn_recompute_fits(planes_of(mode()), d_head / 32);
+  const bool flash = recompute && csn_attn_dkv_flash_fits(d_head / 32);
+  return 1 | (csn_gemm_bf16x3_big_tiles(d_head, (block + 3) / 4 * 4) ? 2 : 0) | (recompute ? 4 : 0) | (flash ? 8 : 0);
+}
+
+int csn_block_attn_bwd_dkv_flash_f32(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
+                                     const int* q_index, const float* k, const float* v, long long kv_shape_stride,
+                                     const int* kv_index, long long kv_plane_stride, int ld, const float* lse,
+                                     const float* delta, float* dk, float* dv, long long dkv_slot_stride,
+                                     const int* dk_index, const int* dv_index, int accumulate, const int* eval_ids,
+                                     int n_launch_evals, int n_heads, int d_head, int block, int n_blocks, int score_pitch,
+                                     float dropout_p, unsigned long long seed, const int* group_offsets, int n_groups,
+                                     void* stream) {
+  if (!dctx || !q || !k || !v || !lse || !delta || !dk || !dv) return CSN_E_ARG;
+  if (n_launch_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
+  if (!dim_ok(d_head)) return CSN_E_DIM;
+  if (!(csn_attn_bwd_grouping(d_head, block) & 8)) return CSN_E_ARG;
+  if (group_offsets && (n_groups <= 0 || !eval_ids)) return CSN_E_ARG;
+  if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
+  const int t_last = last_block_points(block, n_blocks, ld, 0);
+  if (t_last < 0) return t_last;
+  const int bp = 512 * planes_of(mode());
+  if (kv_plane_stride <= 0 || (kv_plane_stride % bp) || kv_plane_stride < (long long)n_blocks * bp || (kv_shape_stride & 7))
+    return CSN_E_ARG;
+  if ((ld & 3) || (score_pitch & 3) || score_pitch < block) return CSN_E_ALIGN;
+  if (mis16(dctx) || mis16(q) || mis16(k) || mis16(v) || mis16(dk) || mis16(dv)) return CSN_E_PTR;
+  if ((q_shape_stride & 3) || (ctx_eval_stride & 3) || (dkv_slot_stride & 3)) return CSN_E_STRIDE;
+  CsnAttnDkvArgs a;
+  a.q = q; a.q_shape_stride = q_shape_stride; a.q_index = q_index;
+  a.dctx = dctx; a.ctx_eval_stride = ctx_eval_stride;
+  a.k = k; a.v = v; a.kv_shape_stride = kv_shape_stride; a.kv_ld = (int)kv_plane_stride; a.kv_index = kv_index;
+  a.lse = lse; a.delta = delta;
+  a.dk = dk; a.dv = dv; a.dkv_slot_stride = dkv_slot_stride; a.dk_index = dk_index; a.dv_index = dv_index;
+  a.accumulate = accumulate;
+  a.eval_ids = eval_ids; a.grp_off = group_offsets; a.n_groups = group_offsets ? n_groups : n_launch_evals;
+  a.ld = ld; a.H = n_heads; a.T = block; a.Tp = score_pitch; a.n_blocks = n_blocks; a.T_last = t_last;
+  a.dropout_p = dropout_p; a.seed = seed;
+  return csn_launch_attn_dkv_flash(a, d_head, mode(), (hipStream_t)stream);
 }
 
 /* cross-length attention backward (MinkowskiNet/models/attention.py: one unchunked block per evaluation, n_queries != n_keys;

@@ -75,6 +75,23 @@ struct CsnAttnArgs {
 };
 // score recomputation needs three LDS tile images per stage: one plane at every width, two planes up to d = 128
 constexpr bool csn_attn_recompute_fits(int planes, int dt) { return planes == 1 || dt <= 4; }
+// ---- key-stationary dK / dV with recomputed scores (attn_dkv.hip; 16-bit modes, block mode, d <= 128) ----------------
+struct CsnAttnDkvArgs {
+  const float* q;     long long q_shape_stride;  const int* q_index;     // pre-scaled queries Qs^T [slot][H*d][ld], evaluation -> slot
+  const float* dctx;  long long ctx_eval_stride;                          // dO^T [evaluation][H*d][ld]
+  const float* k;  const float* v;                                        // tile planes (16-bit) of the slots' keys / values
+  long long kv_shape_stride;  int kv_ld;  const int* kv_index;            // in 16-bit elements; evaluation -> key/value slot
+  const float* lse;  const float* delta;                                  // [evaluation][H][n_blocks * T]
+  float* dk;  float* dv;  long long dkv_slot_stride;                      // fp32 gradient maps [slot][..][ld]
+  const int* dk_index;  const int* dv_index;                              // evaluation -> output slot (nullptr: the evaluation)
+  int accumulate;
+  const int* eval_ids;  const int* grp_off;  int n_groups;                // group g = eval_ids[grp_off[g] .. grp_off[g+1]); no offsets: one evaluation each
+  int ld, H, T, Tp, n_blocks, T_last;
+  float dropout_p;  unsigned long long seed;
+};
+int csn_launch_attn_dkv_flash(const CsnAttnDkvArgs& a, int d, int mode, hipStream_t st);
+constexpr bool csn_attn_dkv_flash_fits(int dt) { return dt <= 4; }         // K^T, V^T, dK^T, dV^T of 16 keys in one wave's registers
+
 int csn_launch_attn_fwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
 int csn_launch_attn_bwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
 int csn_launch_attn_fwd_bf16x3(const CsnAttnArgs& a, int d, int mode, hipStream_t st);     // attn_bf16x3.hip; mode 1..3 (2, 3: tile-plane K/V only)

@@ -213,7 +213,7 @@ class math_mode:
 def _score_flow(mode: int, d: int, T: int) -> int:
     """The attention backward data flow (tuning.KEEP_SCORES / RECOMPUTE_DQ / FLASH) for a forward in `mode` at head width d and
     block T: the configured flow of the mode the BACKWARD runs in, where the library has kernels for it."""
-    want = tuning.current().score_flow.get(backward_mode(mode), tuning.KEEP_SCORES)
+    want = tuning.current().flow_for(backward_mode(mode), d)
     if want == tuning.KEEP_SCORES or mode == 0:
         return tuning.KEEP_SCORES
     with math_mode(backward_mode(mode)):
@@ -570,7 +570,16 @@ class _MHAEvals(torch.autograd.Function):
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record()
             sink["bwd"].append((ev0, ev1))
-        if tune.grouped_dkv and (grouping & 2):
+        if flow == tuning.FLASH:
+            # key-stationary kernel: P and dS are rebuilt per (key/value slot, head, block, 128 keys) from lse, delta and the
+            # masks' seed; the evaluations of a key/value slot accumulate in registers (grouped) — no score-sized tensor exists
+            _lib.check(L.csn_block_attn_bwd_dkv_flash_f32(_ptr(datt), D * NP, q_ptr, q_stride, _ptr(plan.q_slots), k_ptr, v_ptr,
+                                                          kv_stride, _ptr(plan.kv_slots), kv_pitch, NP, _ptr(lse), _ptr(delta),
+                                                          gbase + 4 * D * NP, gbase + 8 * D * NP, slot_stride,
+                                                          _ptr(plan.kv_slots), _ptr(plan.v_slots), 0, _ptr(plan.kv_group_items),
+                                                          E, H, d, T, nb, Tp, p_attn, seed_attn, _ptr(plan.kv_group_off),
+                                                          plan.n_kv_groups, _stream()), "csn_block_attn_bwd_dkv_flash_f32")
+        elif tune.grouped_dkv and (grouping & 2):
             # one call: the evaluations of a key/value slot are contracted one after the other into the same accumulators
             _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, q_ptr, q_stride, _ptr(plan.q_slots), NP,
                                                     _ptr(scores), _ptr(dscores), gbase + 4 * D * NP, gbase + 8 * D * NP,

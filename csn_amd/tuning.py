@@ -26,9 +26,14 @@ class Tuning:
     link_mix: bool = True            # False: the mix backward writes per-evaluation gradient maps
     grouped_dkv: bool = True         # False: dK / dV by one read-modify-write launch per colour
     grouped_dq: bool = True          # False: dQ likewise
-    # math mode (1 bf16x3, 2 bf16 — fp16 forwards run their backward in 2) -> attention backward data flow, where the kernels
-    # have an instance for it (csn_attn_bwd_grouping bits 2 / 3); measured per mode, DESIGN.md §4 "data flow A/B"
-    score_flow: Dict[int, int] = field(default_factory=lambda: {1: KEEP_SCORES, 2: KEEP_SCORES})
+    # attention backward data flow by (math mode of the backward: 1 bf16x3, 2 bf16 — fp16 forwards run their backward in 2;
+    # head width), or by mode alone; taken where the kernels have an instance for it (csn_attn_bwd_grouping bits 2 / 3),
+    # KEEP_SCORES otherwise.  Measured per mode and width, DESIGN.md §4 "data flow A/B": at d = 256 the extra matrix products
+    # cost what the score traffic saves, at d <= 128 a score costs the same bytes for a fraction of the FLOPs
+    score_flow: Dict[object, int] = field(default_factory=lambda: {1: KEEP_SCORES, 2: KEEP_SCORES})
+
+    def flow_for(self, mode: int, d_head: int) -> int:
+        return self.score_flow.get((mode, d_head), self.score_flow.get(mode, KEEP_SCORES))
     # bench.py: {"fwd": [], "bwd": []} collects (start, end) HIP-event pairs around the fused attention launches
     event_sink: Optional[dict] = None
 

@@ -143,7 +143,8 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
  * an output slot are adjacent, group g = entries group_offsets[g] .. group_offsets[g+1] (n_groups + 1 offsets); a group's
  * results are accumulated in registers and its slot is written once — one call for all evaluations instead of one
  * read-modify-write pass per colour.  csn_attn_bwd_grouping() says where that is available in the current math mode:
- * bit 0 = the dq call, bit 1 = the dkv call, bit 2 = csn_block_attn_bwd_dq_recompute_f32 (below).
+ * bit 0 = the dq call, bit 1 = the dkv call, bit 2 = csn_block_attn_bwd_dq_recompute_f32, bit 3 =
+ * csn_block_attn_bwd_dkv_flash_f32 (both below).
  *
  * csn_block_attn_bwd_dq_recompute_f32 — the dq call WITHOUT saved scores ("flash" data flow; math modes 1 and 2, K / V as tile
  * planes, block mode): the forward is run with scores = NULL (only lse is kept) and this call rebuilds S = Qs K^T tile by tile
@@ -180,6 +181,24 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
                                int block, int n_blocks, int score_pitch, int dctx_split, long long dctx_plane_stride,
                                int q_split, long long q_plane_stride, int probs_tiles, const int* group_offsets,
                                int n_groups, void* stream);
+
+/* csn_block_attn_bwd_dkv_flash_f32 — dK and dV WITHOUT P / dS tensors (bit 3 of csn_attn_bwd_grouping: math modes 1 and 2,
+ * d_head <= 128, block mode): a work-group keeps 128 keys of one (key/value slot, head, block) in registers, streams the
+ * pre-scaled queries q and the output gradient dctx of every evaluation of its group through LDS, and rebuilds P (from lse,
+ * with the dropout mask of (dropout_p, seed)) and dS (with delta, as the dq call wrote it) tile by tile:
+ *   dv[dv_index[e]] (+)= P_drop^T dctx,   dk[dk_index[e]] (+)= dS^T Qs
+ * k / v: the tile planes of the forward (kv_plane_stride = row pitch, kv_shape_stride in 16-bit elements), kv_index as in the
+ * forward; a group's evaluations must share their key and their value slot (they do when grouped by output slot).  Run after
+ * csn_block_attn_bwd_dq_recompute_f32 (probs_tiles = 0), which computes delta.  eval_ids / group_offsets / accumulate as in
+ * the grouped csn_block_attn_bwd_dkv_f32 call; without group_offsets every listed evaluation is its own group. */
+int csn_block_attn_bwd_dkv_flash_f32(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
+                                     const int* q_index, const float* k, const float* v, long long kv_shape_stride,
+                                     const int* kv_index, long long kv_plane_stride, int ld, const float* lse,
+                                     const float* delta, float* dk, float* dv, long long dkv_slot_stride,
+                                     const int* dk_index, const int* dv_index, int accumulate, const int* eval_ids,
+                                     int n_launch_evals, int n_heads, int d_head, int block, int n_blocks, int score_pitch,
+                                     float dropout_p, unsigned long long seed, const int* group_offsets, int n_groups,
+                                     void* stream);
 
 /* ---- (3b) cross-length attention: one unchunked block per evaluation, n_queries != n_keys -------------
  * The MinkowskiNet variant of the layer (MinkowskiNet/models/attention.py:31-75, used per shape pair by

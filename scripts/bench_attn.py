@@ -96,6 +96,12 @@ def main():
 
     def dkv():
         gb = dqkv.data_ptr()
+        if a.recompute == 2 and a.tiles and (L.csn_attn_bwd_grouping(d, T) & 8):
+            _lib.check(L.csn_block_attn_bwd_dkv_flash_f32(CF._ptr(datt), D * NP, base, 3 * D * NP, CF._ptr(qs), k_ptr, v_ptr, kv_stride,
+                                                          CF._ptr(ks), kvp, NP, CF._ptr(lse), CF._ptr(delta), gb + 4 * D * NP,
+                                                          gb + 8 * D * NP, 3 * D * NP, None, None, 0, None, E, H, d, T, nb, Tp, a.drop,
+                                                          seed, None, 0, st), "dkv flash")
+            return
         _lib.check(L.csn_block_attn_bwd_dkv_f32(CF._ptr(datt), D * NP, base, 3 * D * NP, CF._ptr(qs), NP, CF._ptr(scores),
                                                 CF._ptr(dscores), gb + 4 * D * NP, gb + 8 * D * NP, 3 * D * NP, None, None,
                                                 0, None, E, H, d, T, nb, Tp, 0, 0, 0, 0, 1 if (a.tiles and L.csn_get_math_mode() in (1, 2)) else 0, None, 0, st), "dkv")
@@ -128,7 +134,7 @@ def main():
                   "p err", (scores[0] - ref["p"]).abs().max().item())
     if "dkv" in only:
         t = timeit(dkv)
-        print(f"mode {a.mode} dkv  E={E}: {t:7.3f} ms  {flops / t / 1e9:7.1f} TF/s algorithmic", flush=True)
+        print(f"mode {a.mode} dkv  E={E} recompute={a.recompute}: {t:7.3f} ms  {flops / t / 1e9:7.1f} TF/s algorithmic", flush=True)
         if a.check:
             print("   dk err", (dqkv[:, D:2 * D] - ref["dk"]).abs().max().item(), "scale", ref["dk"].abs().max().item(),
                   "dv err", (dqkv[:, 2 * D:] - ref["dv"]).abs().max().item(), "scale", ref["dv"].abs().max().item())

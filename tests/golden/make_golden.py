@@ -19,6 +19,7 @@ sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
 sys.path.insert(0, "/root/reference/MID-FC")
 
 import csa_models as ref  # noqa: E402  (the reference)
@@ -244,12 +245,44 @@ def g8_mha_unequal_head_widths(out):
             out[f"g8_{i}_grad_{name}"] = (gr if gr.numel() <= 10000 else gr.reshape(gr.shape[0], -1)[::5, ::7].contiguous()).numpy().astype(np.float32)
 
 
+# ---- G9: the feature-file data path (features_data_loader.py:79-140); inputs in g9_spec.py -----------------------------
+import g9_spec as g9  # noqa: E402
+
+
+def g9_data_path(out):
+    """Items of the REFERENCE's CSADatasetK / FeaturesDataset over seeded temp files: per item the shapes, dtypes, sha256 of the
+    raw bytes (bit-for-bit pin) and a strided sample of feats / label / neighbor_feats, for a train graph and a test graph."""
+    import tempfile
+    import features_data_loader as fdl          # the reference (MID-FC on sys.path)
+    listdir = os.listdir
+    os.listdir = lambda p: sorted(listdir(p))    # os.listdir order is filesystem-dependent: both readers see the sorted order
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            tr, te = g9.write_both(tmp)
+            for tag, root, graph in (("train", tr, g9.TRAIN_GRAPH), ("test", te, g9.TEST_GRAPH)):
+                ds = fdl.CSADatasetK(root, tr, np.array(graph), g9.K)
+                plain = fdl.FeaturesDataset(root, "backbone_fc_csa_logit")
+                out[f"g9_{tag}_len"] = np.array([len(ds), len(plain)])
+                for i in range(len(ds)):
+                    f, lab, nb = ds[i]
+                    pf, pl = plain[i]
+                    out[f"g9_{tag}_{i}_shapes"] = np.array(list(f.shape) + list(lab.shape) + list(nb.shape) + list(pf.shape))
+                    out[f"g9_{tag}_{i}_dtypes"] = np.array([str(f.dtype), str(lab.dtype), str(nb.dtype), str(pf.dtype), str(pl.dtype)])
+                    out[f"g9_{tag}_{i}_sha"] = np.array([g9.digest(f), g9.digest(lab), g9.digest(nb), g9.digest(pf), g9.digest(pl)])
+                    out[f"g9_{tag}_{i}_feats"] = f[::16, ::997, 0].numpy()
+                    out[f"g9_{tag}_{i}_label"] = lab[::97].numpy()
+                    out[f"g9_{tag}_{i}_nb"] = nb[:, ::16, ::997, 0].numpy()
+    finally:
+        os.listdir = listdir
+
+
 def main():
     only = set(sys.argv[1:])
     for name, fn in [("g1_sdpa", g1_sdpa), ("g2_self_attention", g2_self_attention),
                      ("g3_mha_forward", g3_mha_forward), ("g4_csa", g4_csa), ("g5_ssa", g5_ssa),
                      ("g6_retrieval", g6_retrieval),
-                     ("g7_csa_conditioned", g7_csa_conditioned), ("g8_mha_unequal_head_widths", g8_mha_unequal_head_widths)]:
+                     ("g7_csa_conditioned", g7_csa_conditioned), ("g8_mha_unequal_head_widths", g8_mha_unequal_head_widths),
+                     ("g9_data_path", g9_data_path)]:
         if only and name not in only:
             continue
         out = {}

@@ -140,14 +140,24 @@ def test_recomputed_scores_equal_the_kept_ones(L, mode, S, E, H, d, T, nb, p_dro
                                                     H, d, T, nb, Tp, p_drop, seed, ldp, 0, None, 0, _stream()), "dq recompute, no planes")
     torch.cuda.synchronize()
     assert torch.equal(delta0, delta1) and torch.equal(delta0, delta2)
-    # the recomputed S is the forward's product in the forward's order: the same bits, hence the same dQ, P and dS
-    assert torch.equal(dq0, dq1) and torch.equal(dq1, dq2)
+    # the recomputed S is the forward's product in the forward's order (the same bits: the P planes below are equal); the two
+    # kernel instances round the dS formula differently (fused multiply-add contraction), so dS and dQ agree to fp32 rounding
+    assert torch.equal(dq1, dq2)                                               # with and without the planes: the same kernel
+    rnd = 2e-5 if mode == 1 else 1e-2                                          # (one plane: a flipped bf16 rounding of dS is 2^-9)
+    assert _err(dq1, dq0.cpu()) < rnd
+
+    def planes_of(buf, rows):                                                  # 16-bit tile-plane rows -> values
+        if mode == 1:
+            pl = buf.view(torch.bfloat16).view(E, H, nb, rows, Tp // 32, 2, 32).float()
+            return (pl[..., 0, :] + pl[..., 1, :]).reshape(E, H, nb, rows, Tp)
+        return buf.view(torch.bfloat16).view(E, H, nb, 2 * T, Tp)[..., :rows, :].float()
+
     if mode == 1:
         assert torch.equal(scores.view(torch.int32), pr1.view(torch.int32))    # P planes (kept flow: in place over the scores)
-        assert torch.equal(ds0.view(torch.int32)[..., :T, :], ds1.view(torch.int32)[..., :T, :])
-    else:
-        a, b = ds0.view(torch.int16).view(E, H, nb, 2 * T * Tp), ds1.view(torch.int16).view(E, H, nb, 2 * T * Tp)
-        assert torch.equal(a, b)                                               # [P rows | dS rows] of 16-bit elements
+        assert _err(planes_of(ds1, T), planes_of(ds0, T).cpu()) < rnd
+    else:                                                                      # [P rows | dS rows] of 16-bit elements in `dscores`
+        a, b = planes_of(ds0, 2 * T), planes_of(ds1, 2 * T)
+        assert torch.equal(a[..., :T, :], b[..., :T, :]) and _err(b[..., T:, :], a[..., T:, :].cpu()) < rnd
     # ... and the float64 restatement, with the same masks (tests/dropout_ref.py restates the counter-based mask)
     keep = None
     if p_drop > 0:
@@ -156,9 +166,28 @@ def test_recomputed_scores_equal_the_kept_ones(L, mode, S, E, H, d, T, nb, p_dro
     kr, vr = k, v
     if mode == 2:                                                              # one plane: the operands ARE bf16-rounded
         kr, vr = k.bfloat16().float(), v.bfloat16().float()
-    _, rq, _, _ = _reference(q.cpu(), kr, vr, dctx.cpu(), q_idx, kv_idx, H, d, T, nb, keep, 1.0 / (1.0 - p_drop))
+    _, rq, rk, rv = _reference(q.cpu(), kr, vr, dctx.cpu(), q_idx, kv_idx, H, d, T, nb, keep, 1.0 / (1.0 - p_drop))
     bound = 2e-4 if mode == 1 else 3e-2
     assert _err(dq2, rq) < bound, _err(dq2, rq)
+
+    # dK / dV: the products over the kept flow's P / dS planes against the key-stationary kernel that rebuilds them
+    dk0, dv0 = (torch.full((E, D, N), float("nan"), device="cuda") for _ in range(2))
+    L.check(lib.csn_block_attn_bwd_dkv_f32(dctx.data_ptr(), D * N, q.data_ptr(), D * N, qi.data_ptr(), N, scores.data_ptr(),
+                                           ds0.data_ptr(), dk0.data_ptr(), dv0.data_ptr(), D * N, None, None, 0, None, E, H, d, T,
+                                           nb, Tp, 0, 0, 0, 0, 1, None, 0, _stream()), "dkv products")
+    torch.cuda.synchronize()
+    assert _err(dk0, rk) < bound and _err(dv0, rv) < bound
+    flash = bool(lib.csn_attn_bwd_grouping(d, T) & 8)
+    assert flash == (d <= 128)
+    if flash:
+        dk2, dv2 = (torch.full((E, D, N), float("nan"), device="cuda") for _ in range(2))
+        L.check(lib.csn_block_attn_bwd_dkv_flash_f32(dctx.data_ptr(), D * N, q.data_ptr(), D * N, qi.data_ptr(), k_ptr, v_ptr,
+                                                     kv_stride, ki.data_ptr(), ldp, N, lse.data_ptr(), delta2.data_ptr(),
+                                                     dk2.data_ptr(), dv2.data_ptr(), D * N, None, None, 0, None, E, H, d, T, nb,
+                                                     Tp, p_drop, seed, None, 0, _stream()), "dkv flash")
+        torch.cuda.synchronize()
+        assert _err(dk2, rk) < bound and _err(dv2, rv) < bound, (_err(dk2, rk), _err(dv2, rv))
+        assert _err(dk2, dk0.cpu()) < rnd * 4 and _err(dv2, dv0.cpu()) < rnd * 4
 
     # grouped form: the evaluations of a query slot into one set of accumulators
     from csn_amd.functional import EvalPlan
@@ -173,6 +202,19 @@ def test_recomputed_scores_equal_the_kept_ones(L, mode, S, E, H, d, T, nb, p_dro
     ref = torch.zeros(S, D, N, dtype=torch.float64).index_add_(0, torch.from_numpy(q_idx).long(), rq)
     used = torch.from_numpy(np.unique(q_idx)).long()
     assert _err(gq[used], ref[used]) < bound
+    if flash:       # the evaluations of a key/value slot into one set of dK / dV accumulators
+        gk, gv = (torch.full((S, D, N), float("nan"), device="cuda") for _ in range(2))
+        L.check(lib.csn_block_attn_bwd_dkv_flash_f32(dctx.data_ptr(), D * N, q.data_ptr(), D * N, qi.data_ptr(), k_ptr, v_ptr,
+                                                     kv_stride, ki.data_ptr(), ldp, N, lse.data_ptr(), delta2.data_ptr(),
+                                                     gk.data_ptr(), gv.data_ptr(), D * N, ki.data_ptr(), ki.data_ptr(), 0,
+                                                     plan.kv_group_items.data_ptr(), E, H, d, T, nb, Tp, p_drop, seed,
+                                                     plan.kv_group_off.data_ptr(), plan.n_kv_groups, _stream()), "dkv flash grouped")
+        torch.cuda.synchronize()
+        ki64 = torch.from_numpy(kv_idx).long()
+        ref_k = torch.zeros(S, D, N, dtype=torch.float64).index_add_(0, ki64, rk)
+        ref_v = torch.zeros(S, D, N, dtype=torch.float64).index_add_(0, ki64, rv)
+        used = torch.from_numpy(np.unique(kv_idx)).long()
+        assert _err(gk[used], ref_k[used]) < bound and _err(gv[used], ref_v[used]) < bound
 
 
 def test_recompute_is_refused_where_it_has_no_kernel(L):
@@ -227,9 +269,9 @@ def test_module_flows_agree(L, mode, geo, train):
     assert len(g0) == 11
     for flow in flows[1:]:
         l1, s1, g1 = outs[flow]
-        assert torch.equal(l0, l1) and s0 == s1
+        assert torch.equal(l0, l1) and s0 == s1                                # the forward is the same kernel, store or no store
         for n in g0:
             scale = g0[n].abs().max().item()
-            # dQ is bit-identical; dK / dV come from another kernel in the FLASH flow (same products, another summation order)
-            lim = 0.0 if flow == tuning.RECOMPUTE_DQ else (2e-5 if mode == 1 else 2e-2)
+            # same products from other kernel instances (another rounding of the dS formula, another summation order of dK / dV)
+            lim = 5e-5 if mode == 1 else 2e-2
             assert (g0[n] - g1[n]).abs().max().item() <= lim * scale, (flow, n)

@@ -193,6 +193,39 @@ def test_device_feature_cache_builds_the_same_neighbour_stacks_as_csadatasetk(tm
         D.DeviceFeatureCache(ds_train, "cpu", first=2, count=2, n_points=64).batch([0])
 
 
+def test_g9_data_path_against_the_reference_loader(tmp_path, monkeypatch):
+    """Golden set G9: the REFERENCE's CSADatasetK / FeaturesDataset (features_data_loader.py:9-48, 79-140) were run over
+    seeded shape files (10000, 7000 and 5100 points: two kinds get wrap-around padded) with a train graph and a test graph
+    whose ids point into the train set; tests/golden/make_golden.py stored per item the shapes, dtypes, a sha256 of the raw
+    bytes and strided samples.  The same files are rebuilt here and csn_amd.data.CSADatasetK, FeaturesDataset and
+    DeviceFeatureCache must reproduce every item bit for bit."""
+    from tests.golden import g9_spec as g9
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "g9_data_path.npz"))
+    monkeypatch.setattr(os, "listdir", lambda p, _ls=os.listdir: sorted(_ls(p)))       # the order the goldens were made with
+    tr, te = g9.write_both(str(tmp_path))
+    cache_tr = None
+    for tag, root, graph in (("train", tr, g9.TRAIN_GRAPH), ("test", te, g9.TEST_GRAPH)):
+        ds = D.CSADatasetK(root, tr, np.array(graph), g9.K)
+        plain = D.FeaturesDataset(root)
+        assert [len(ds), len(plain)] == z[f"g9_{tag}_len"].tolist()
+        cache = D.DeviceFeatureCache(ds, "cpu")
+        cache_tr = cache if tag == "train" else cache_tr
+        table = D.neighbour_table(np.array(graph), g9.K)
+        for i in range(len(ds)):
+            f, lab, nb = ds[i]
+            pf, pl = plain[i]
+            assert list(f.shape) + list(lab.shape) + list(nb.shape) + list(pf.shape) == z[f"g9_{tag}_{i}_shapes"].tolist()
+            assert [str(t.dtype) for t in (f, lab, nb, pf, pl)] == z[f"g9_{tag}_{i}_dtypes"].tolist()
+            assert np.array_equal(f[::16, ::997, 0].numpy(), z[f"g9_{tag}_{i}_feats"])
+            assert np.array_equal(lab[::97].numpy(), z[f"g9_{tag}_{i}_label"])
+            assert np.array_equal(nb[:, ::16, ::997, 0].numpy(), z[f"g9_{tag}_{i}_nb"])
+            assert [g9.digest(t) for t in (f, lab, nb, pf, pl)] == z[f"g9_{tag}_{i}_sha"].tolist()
+            # the device-resident cache hands out the same three tensors (as a batch of one) without touching the files again
+            cf, cl = cache.batch([i])
+            cnb = cache.neighbour_stack([i], table, cache_tr)
+            assert [g9.digest(t) for t in (cf[0], cl[0], cnb[0])] == z[f"g9_{tag}_{i}_sha"].tolist()[:3]
+
+
 def test_head_width_generalisation_host_side():
     """d_k != d_v / odd widths: parameters keep the reference's shapes; the kernels see zero-padded weights at one width."""
     import torch
