@@ -155,18 +155,32 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
   const bool t_last_ok = ((D * 8) % 512 == 0) || (tid + 512 * (NP_T - 1) < D * 8);
   const int a_dst = t_row * QT + 4 * (t_c ^ t_sw);
   const int b_dst = t_row * QT + 8 * ((t_c >> 1) ^ t_swz) + 4 * (t_c & 1);
+  // The pieces of a tile are split into bf16 hi / lo ONCE, when they are committed to the k-major image (segment 1), and wait
+  // in that form (as many registers as the fp32 piece in the two-plane mode, half in the one-plane mode) for the
+  // query-contiguous image (segment 2).
   f32x4 gQ[NP_T], gO[NP_T];
+  s16x4 cQh[NP_T], cQl[NP_T], cOh[NP_T], cOl[NP_T];
   float gc = 0.f;                                                   // threads 0..63: lse2 / delta of one query of the tile
-  // step -> (item, query tile); everything that depends on it is wave-uniform
-  auto step_eval = [&](int step) { const int it = it0 + step / nqt; return p.eval_ids ? p.eval_ids[it] : it; };
-  auto fetch = [&](int step) {
-    const int e = step_eval(step), qt = step % nqt;
+  // fetch stream: (item, query tile) of the next tile to request — it runs two tiles ahead of the products.  Everything that
+  // depends on the item (evaluation id, query slot, base pointers) is scalar and reloaded only when the item changes.
+  int f_it = it0, f_qt = 0;
+  const float* f_q = nullptr; const float* f_o = nullptr; const float* f_lse = nullptr; const float* f_dl = nullptr;
+  auto fetch_item = [&]() {
+    const int e = p.eval_ids ? p.eval_ids[f_it] : f_it;
     const long long qs = p.q_index ? p.q_index[e] : e;
-    const long long head_off = (long long)hd * D * ld + (long long)blk * p.T + qt * QT;
-    const int nq = T - qt * QT;                                     // queries left in the block from this tile on
+    const long long head_off = (long long)hd * D * ld + (long long)blk * p.T;
+    const long long stat = ((long long)e * p.H + hd) * ((long long)p.n_blocks * p.T) + (long long)blk * p.T;
+    f_q = p.q + qs * p.q_shape_stride + head_off;
+    f_o = p.dctx + (long long)e * p.ctx_eval_stride + head_off;
+    f_lse = p.lse + stat;
+    f_dl = p.delta + stat;
+  };
+  fetch_item();
+  auto fetch = [&]() {
+    const int nq = T - f_qt * QT;                                   // queries left in the block from this tile on
     const long long win = ((long long)(D - 1) * ld + (nq < QT ? nq : QT)) * 4;
-    const csn_rsrc_t Qr = csn_make_rsrc(p.q + qs * p.q_shape_stride + head_off, win);
-    const csn_rsrc_t Or = csn_make_rsrc(p.dctx + (long long)e * p.ctx_eval_stride + head_off, win);
+    const csn_rsrc_t Qr = csn_make_rsrc(f_q + f_qt * QT, win);
+    const csn_rsrc_t Or = csn_make_rsrc(f_o + f_qt * QT, win);
     const unsigned off = (4 * t_c) < nq ? (unsigned)(t_row * ld + 4 * t_c) * 4u : CSN_OOB;      // T % 4 == 0: a piece is all in or all out
 #pragma unroll
     for (int i = 0; i < NP_T; ++i) {
@@ -175,33 +189,42 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
       gO[i] = csn_bload4(Or, o, (unsigned)(64 * i * ld) * 4u);
     }
     if (tid < 64) {
-      const long long stat = ((long long)e * p.H + hd) * ((long long)p.n_blocks * p.T) + (long long)blk * p.T + qt * QT;
       const int qi = tid & 31;
-      const float v = qi < nq ? (tid < 32 ? p.lse[stat + qi] * LOG2E : p.delta[stat + qi]) : 0.f;
-      gc = v;
+      gc = qi < nq ? (tid < 32 ? f_lse[f_qt * QT + qi] * LOG2E : f_dl[f_qt * QT + qi]) : 0.f;
+    }
+    if (++f_qt == nqt) {                                            // next tile: the first of the next item (if any)
+      f_qt = 0;
+      if (++f_it < it1) fetch_item();
     }
   };
-  auto commit_kmajor = [&](int img, int st, const f32x4* g) {
+  auto commit_kmajor = [&](int st) {                                // Qs -> image 0, dO -> image 1
 #pragma unroll
     for (int i = 0; i < NP_T; ++i)
       if (i < NP_T - 1 || t_last_ok) {
-        s16x4 hi, lo;
-        split4<PR>(g[i], hi, lo);
-        *reinterpret_cast<s16x4*>(image(img, st, 0) + a_dst + 64 * QT * i) = hi;
-        if constexpr (NPL == 2) *reinterpret_cast<s16x4*>(image(img, st, 1) + a_dst + 64 * QT * i) = lo;
+        split4<PR>(gQ[i], cQh[i], cQl[i]);
+        split4<PR>(gO[i], cOh[i], cOl[i]);
+        *reinterpret_cast<s16x4*>(image(0, st, 0) + a_dst + 64 * QT * i) = cQh[i];
+        *reinterpret_cast<s16x4*>(image(1, st, 0) + a_dst + 64 * QT * i) = cOh[i];
+        if constexpr (NPL == 2) {
+          *reinterpret_cast<s16x4*>(image(0, st, 1) + a_dst + 64 * QT * i) = cQl[i];
+          *reinterpret_cast<s16x4*>(image(1, st, 1) + a_dst + 64 * QT * i) = cOl[i];
+        }
       }
   };
-  auto commit_contig = [&](int img, int st, const f32x4* g) {
+  auto commit_contig = [&](int st) {                                // Qs -> image 2, dO -> image 3
 #pragma unroll
     for (int i = 0; i < NP_T; ++i)
       if (i < NP_T - 1 || t_last_ok) {
-        s16x4 hi, lo;
-        split4<PR>(g[i], hi, lo);
-        *reinterpret_cast<s16x4*>(image(img, st, 0) + b_dst + 64 * QT * i) = hi;
-        if constexpr (NPL == 2) *reinterpret_cast<s16x4*>(image(img, st, 1) + b_dst + 64 * QT * i) = lo;
+        *reinterpret_cast<s16x4*>(image(2, st, 0) + b_dst + 64 * QT * i) = cQh[i];
+        *reinterpret_cast<s16x4*>(image(3, st, 0) + b_dst + 64 * QT * i) = cOh[i];
+        if constexpr (NPL == 2) {
+          *reinterpret_cast<s16x4*>(image(2, st, 1) + b_dst + 64 * QT * i) = cQl[i];
+          *reinterpret_cast<s16x4*>(image(3, st, 1) + b_dst + 64 * QT * i) = cOl[i];
+        }
       }
   };
-  auto commit_rowc = [&](int st) { if (tid < 64) rowc[st * 64 + tid] = gc; };
+  float gc_hold = 0.f;                                              // the row constant of tile t + 1 while tile t + 2 is being requested
+  auto commit_rowc = [&](int st) { if (tid < 64) rowc[st * 64 + tid] = gc_hold; };
 
   // fragment read positions (lane constants; attn_bf16x3.hip)
   const int tr_row = 8 * kq + (lq >> 2);
@@ -270,40 +293,50 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
   };
 
   // images: 0 = Qs k-major, 1 = dO k-major, 2 = Qs query-contiguous, 3 = dO query-contiguous
-  fetch(0);
-  commit_kmajor(0, 0, gQ); commit_kmajor(1, 0, gO); commit_contig(2, 0, gQ); commit_contig(3, 0, gO); commit_rowc(0);
-  if (n_steps > 1) fetch(1);
+  fetch();
+  commit_kmajor(0); commit_contig(0); gc_hold = gc; commit_rowc(0);
+  if (n_steps > 1) fetch();
   __syncthreads();
   if (late) __syncthreads();
 
   // Two barrier segments per tile; waves 4..7 run one segment behind.  The k-major images are read in segment 1 and rewritten
   // in segment 1 of the tile before; the query-contiguous images and the row constants are read in segment 2 and rewritten in
-  // segment 2 of the tile before (the hazard analysis of attn_bf16x3.hip with its A / B stages).  The pieces of tile t + 1
-  // stay in registers from the end of tile t - 1 to the end of tile t.
+  // segment 2 of the tile before (the hazard analysis of attn_bf16x3.hip with its A / B stages).  Tile t + 2 is requested in
+  // segment 1 of tile t, right after the pieces of tile t + 1 have been split and committed — a whole tile of cover for the
+  // HBM latency, which the short matrix phases of the narrow head widths cannot give.
   f32x4v S0, S1, P0, P1;
+  int c_it = it0, c_qt = 0;                                         // (item, query tile) of the products
+  unsigned salt = 0;
   for (int step = 0; step < n_steps; ++step) {
     const int cur = step & 1, nxt = cur ^ 1;
     const bool more = step + 1 < n_steps;
+    if (c_qt == 0) {                                                // a new item: its mask salt (scalar unit)
+      const int e = p.eval_ids ? p.eval_ids[c_it] : c_it;
+      salt = csn_block_salt((unsigned long long)(((long long)e * p.H + hd) * p.n_blocks + blk), p.seed);
+    }
     phase1(0, cur, Kh, Kl, S0, S1);                                 // S  = Qs K^T (as the forward formed it, transposed roles)
     phase1(1, cur, Vh, Vl, P0, P1);                                 // dP = dO V^T
-    if (more) { commit_kmajor(0, nxt, gQ); commit_kmajor(1, nxt, gO); }
+    if (more) {
+      commit_kmajor(nxt);                                           // (splits the pieces: the fp32 registers are free again)
+      gc_hold = gc;
+      if (step + 2 < n_steps) fetch();                              // a whole tile ahead of its first use
+    }
     __syncthreads();
     // ---- pointwise: this lane's key against queries qt * 32 + 8 kq .. + 7 --------------------------------------------
-    const int e = step_eval(step), qt = step % nqt;
-    const unsigned salt = csn_block_salt((unsigned long long)(((long long)e * p.H + hd) * p.n_blocks + blk), p.seed);
     const f32x4 l0 = *reinterpret_cast<const f32x4*>(&rowc[cur * 64 + 8 * kq]), l1 = *reinterpret_cast<const f32x4*>(&rowc[cur * 64 + 8 * kq + 4]);
     const f32x4 d0 = *reinterpret_cast<const f32x4*>(&rowc[cur * 64 + 32 + 8 * kq]), d1 = *reinterpret_cast<const f32x4*>(&rowc[cur * 64 + 32 + 8 * kq + 4]);
     const float lse2[8] = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
     const float dlt[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
     const float sv[8] = {S0[0], S0[1], S0[2], S0[3], S1[0], S1[1], S1[2], S1[3]};
     const float dp[8] = {P0[0], P0[1], P0[2], P0[3], P1[0], P1[1], P1[2], P1[3]};
-    const int q0 = qt * QT + 8 * kq;                                // first of this lane's 8 queries (inside the block)
+    const int q0 = c_qt * QT + 8 * kq;                              // first of this lane's 8 queries (inside the block)
     const int nv = T - q0;                                          // valid queries among them (only the last tile has fewer than 8)
+    const bool last_tile = c_qt == nqt - 1;
     float pd[8], ds[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       float pv = __builtin_amdgcn_exp2f(fmaf(sv[r], LOG2E, -lse2[r]));       // softmax probability (csa_models.py:141)
-      if (qt == nqt - 1) pv = r < nv ? pv : 0.f;                             // queries beyond the block end (wave-uniform branch)
+      if (last_tile) pv = r < nv ? pv : 0.f;                                 // queries beyond the block end (wave-uniform branch)
       bool keep = true;
       if (drop) {
         const unsigned h = csn_pair_hash(pw_key + (unsigned)(q0 + r), salt);
@@ -323,10 +356,8 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
     }
     phase2(3, cur, ph, pl, dV);                                     // dV^T += dO^T P_drop
     phase2(2, cur, dh, dl, dK);                                     // dK^T += Qs^T dS
-    if (more) {
-      commit_contig(2, nxt, gQ); commit_contig(3, nxt, gO); commit_rowc(nxt);
-      if (step + 2 < n_steps) fetch(step + 2);
-    }
+    if (more) { commit_contig(nxt); commit_rowc(nxt); }
+    if (++c_qt == nqt) { c_qt = 0; ++c_it; }
     __syncthreads();
   }
   if (!late) __syncthreads();                                       // pairs with the last barrier of the late half

@@ -253,8 +253,9 @@ static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_e
                    block > 512 || (kv_shape_stride & 7)))
     return CSN_E_ARG;
   // (recomputed scores with probs_tiles == 0: nothing is read from or written to scores / dscores — they may be NULL)
-  const bool sc_used = !q || probs_tiles;
-  if (!dctx || !ctx || !k || !v || !lse || !delta || !dq || (sc_used && (!scores || !dscores))) return CSN_E_ARG;
+  // (recomputed scores in the one-plane mode: P and dS both travel in dscores, `scores` is never touched)
+  const bool need_sc = !q || (probs_tiles && mode() == 1), need_ds = !q || probs_tiles;
+  if (!dctx || !ctx || !k || !v || !lse || !delta || !dq || (need_sc && !scores) || (need_ds && !dscores)) return CSN_E_ARG;
   if (n_launch_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
   if (!dim_ok(d_head)) return CSN_E_DIM;
   if ((ld & 3) || (score_pitch & 3) || score_pitch < (block + 3) / 4 * 4) return CSN_E_ALIGN;
@@ -335,7 +336,8 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   if (mode() == 3 || (mode() == 2 && !probs_tiles)) return CSN_E_ARG;
   if (dctx_split || q_split) return CSN_E_ARG;                       // reserved (see header)
   if (group_offsets && (n_groups <= 0 || !eval_ids || !(csn_attn_bwd_grouping(d_head, block) & 2))) return CSN_E_ARG;
-  if (!dctx || !q || !probs || !dscores || !dk || !dv) return CSN_E_ARG;
+  if (!dctx || !q || !dscores || !dk || !dv) return CSN_E_ARG;
+  if (!probs && !(probs_tiles && mode() == 2)) return CSN_E_ARG;       // (one plane: P and dS are both read from dscores)
   if (n_launch_evals <= 0 || n_heads <= 0 || block <= 0 || n_blocks <= 0) return CSN_E_ARG;
   if (!dim_ok(d_head)) return CSN_E_DIM;
   if ((ld & 3) || (score_pitch & 3) || score_pitch < bk4) return CSN_E_ALIGN;

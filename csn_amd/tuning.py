@@ -30,7 +30,9 @@ class Tuning:
     # head width), or by mode alone; taken where the kernels have an instance for it (csn_attn_bwd_grouping bits 2 / 3),
     # KEEP_SCORES otherwise.  Measured per mode and width, DESIGN.md §4 "data flow A/B": at d = 256 the extra matrix products
     # cost what the score traffic saves, at d <= 128 a score costs the same bytes for a fraction of the FLOPs
-    score_flow: Dict[object, int] = field(default_factory=lambda: {1: KEEP_SCORES, 2: KEEP_SCORES})
+    score_flow: Dict[object, int] = field(default_factory=lambda: {
+        1: KEEP_SCORES, 2: KEEP_SCORES,
+        **{(m, d): RECOMPUTE_DQ for m in (1, 2) for d in (32, 64, 96, 128)}})
 
     def flow_for(self, mode: int, d_head: int) -> int:
         return self.score_flow.get((mode, d_head), self.score_flow.get(mode, KEEP_SCORES))
