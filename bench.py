@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: CSA forward + backward query-points/sec (BASELINE.json metric) on N MI355X.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3                      # BASELINE.json configs[2] (the metric's config)
+    python bench.py --gpus 1 --steps 20 --warmup 5                      # BASELINE.json configs[2] (the metric's config)
+    python bench.py --same-work                                         # N = 1 with the per-GPU work of the N > 1 path (K+2 evaluations)
     python bench.py --config 2 | --config 5                             # configs[1] / configs[4] as workloads of their own
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
@@ -122,8 +123,8 @@ def cpu_baseline(cfg, sample_shapes, threads, dropout=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)       # median of >= 20 timed steps after >= 5 warm-ups
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, choices=sorted(CONFIGS), default=3,
                     help="workload: 3 = the metric's configuration (default), 2 / 5 = BASELINE configs[1] / configs[4]")
     ap.add_argument("--shapes", type=int, default=None, help="query shapes per GPU (default: the configuration's)")
@@ -132,6 +133,10 @@ def main():
     ap.add_argument("--math", choices=sorted(MATH_MODES), default="bf16x3",
                     help="arithmetic of the contractions: exact fp32 matrix cores; three bf16 products per fp32 product "
                          "(default: inside the 1e-4 contract); one bf16 / fp16 product (outside it, reported with its error)")
+    ap.add_argument("--same-work", action="store_true",
+                    help="N = 1 only: run the per-GPU work of the N > 1 path (K+2 evaluations per shape: every pooled descriptor "
+                         "computed once, by its owner; the 32 shapes are their own collection, no exchange) instead of the "
+                         "reference's 2K+2 — the like-for-like N = 1 point of the scaling curve")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the secondary runs (other math mode, eval-mode arithmetic): what the profiles are taken with")
     args = ap.parse_args()
@@ -183,12 +188,12 @@ def main():
     label = torch.from_numpy(np.where(rng.random(size=(B, N)) < 0.1, 0,
                                       rng.integers(0, N_CLS, size=(B, N))).astype(np.int64)).to(dev)
     shard = None
+    # K independent synthetic neighbour maps per query shape.  The neighbour stack (B, K+1, C, N, 1) is an input of the
+    # step — what CSADatasetK hands the model, slot 0 = the shape itself (features_data_loader.py:66-82) — so it is
+    # resident in HBM before the timed region.  (N > 1: only the same-work reference run below uses it.)
+    x_nb_resident = torch.empty((B, K + 1, C, N, 1), device=dev, dtype=torch.float32)
+    x_nb_resident[:, 0, :, :, 0] = feats
     if world == 1:
-        # K independent synthetic neighbour maps per query shape.  The neighbour stack (B, K+1, C, N, 1) is an input of the
-        # step — what CSADatasetK hands the model, slot 0 = the shape itself (features_data_loader.py:66-82) — so it is
-        # resident in HBM before the timed region
-        x_nb_resident = torch.empty((B, K + 1, C, N, 1), device=dev, dtype=torch.float32)
-        x_nb_resident[:, 0, :, :, 0] = feats
         for k in range(K):
             x_nb_resident[:, k + 1, :, :, 0] = torch.from_numpy(rng.standard_normal(size=(B, C, N)).astype(np.float32)).to(dev)
     else:
@@ -224,19 +229,21 @@ def main():
         def gather_pooled(self, own_pooled):
             return own_pooled[self.graph]            # every neighbour is one of this process's own shapes
 
-    # CSN_BENCH_SPLIT=2 (N = 1, development aid): the per-GPU compute of the N > 1 path without any exchange — the 32 shapes
-    # are their own collection (K-regular graph among them), neighbour descriptors are taken from their "owners" (K+2
-    # evaluations per shape)
-    local_graph = None
-    if world == 1 and os.environ.get("CSN_BENCH_SPLIT") == "2":
-        from csn_amd.sharding import regular_graph
-        local_graph = torch.from_numpy(regular_graph(B, K)).to(dev)
+    # The per-GPU work of the N > 1 path without any exchange ("same work"): the B shapes are their own collection (K-regular
+    # graph among them), neighbour descriptors are taken from their "owners" — K+2 evaluations per shape instead of the 2K+2
+    # the reference runs.  N = 1: selected by --same-work.  N > 1: every rank times it before the group step, so that the
+    # scaling line carries its own like-for-like single-GPU reference (config.n1_same_work_ms_per_step).
+    from csn_amd.sharding import regular_graph as _regular_graph
+    local_graph = torch.from_numpy(_regular_graph(B, K)).to(dev) if (args.same_work or world > 1) else None
+    if local_graph is not None:
         x_nb_resident[:, 1:, :, :, 0] = feats[local_graph]
+    same_work_n1 = world == 1 and args.same_work
 
-    def step(record=False):
+    def step(record=False, local=False):
+        """local: the same-work step on this rank's own shapes (no exchange, no gradient all-reduce)"""
         for p in params:
             p.grad = None
-        if shard is not None:
+        if shard is not None and not local:
             if overlap:
                 x_nb = shard.exchange_async(feats, mode=exchange_mode,   # the model overlaps its self-attention with it
                                             reuse_descriptors=os.environ.get("CSN_REUSE", "1") != "0")
@@ -248,58 +255,72 @@ def main():
             x_nb = x_nb_host if x_nb_host is not None else x_nb_resident   # (B, K+1, C, N, 1), slot 0 = self
             if split_probe:
                 x_nb = _ReadyStack(x_nb)
-            elif local_graph is not None:
-                x_nb = _ReadyStack(x_nb, local_graph)
+            elif local or same_work_n1:
+                x_nb = _ReadyStack(x_nb_resident, local_graph)
         with tuning.override(event_sink=attn_events if record else None):   # HIP events around the fused attention launches
             logits = model(feats.unsqueeze(-1), "train", x_nb)
             loss = masked_ce(logits, label)
             loss.backward()
-        if shard is not None:
+        if shard is not None and not local:
             shard.allreduce_grads(params)                                # one 1.6 MB bucket
         return loss
 
-    def timed(train_mode):
+    def timed(train_mode, local=False):
         """W warm-up + K timed steps, barrier + synchronize on both sides, max over ranks.  Every run starts from the same
         generator state, so the dropout masks (pure functions of seed and position) are the same in every math mode and
-        the losses of two modes can be compared."""
+        the losses of two modes can be compared.  Returns the bracketed wall time of the K steps (max over ranks) and the
+        per-step times (HIP events at the step boundaries on the launch stream, per step the max over ranks): the metric's
+        value is quoted on their MEDIAN, the mean of the bracketed time beside it."""
         model.train(train_mode)                                          # train: dropout p = 0.1 live (csa_training.py:192)
         torch.manual_seed(1)
         for v in attn_events.values():
             v.clear()
+        group = world > 1 and not local
         for _ in range(args.warmup):
-            step()
+            step(local=local)
         torch.cuda.synchronize()
-        if world > 1:
+        if group:
             dist.barrier()
         torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = step(record=True)
+        for i in range(args.steps):
+            marks[i].record()
+            loss = step(record=True, local=local)
+        marks[args.steps].record()
         torch.cuda.synchronize()
-        if world > 1:
+        if group:
             dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        if world > 1:
+        step_ms = torch.tensor([marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)], device=dev, dtype=torch.float64)
+        if group:
             tmax = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(step_ms, op=dist.ReduceOp.MAX)
             el = tmax.item()
+        step_ms = step_ms.cpu().numpy()
         # per STEP: the attention launches of one step summed (N = 1: one forward and one backward launch; the overlapped
         # multi-GPU path: two of each — own shapes first, the evaluations that need neighbour data after the exchange)
         ms = {k: (float(np.sum([a.elapsed_time(b) for a, b in v])) / args.steps if v else float("nan")) for k, v in attn_events.items()}
         gnorm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params if p.grad is not None)).item())
-        return el, float(loss.item()), ms, gnorm
+        return el, float(loss.item()), ms, gnorm, step_ms
 
     # headline first (the training step as the reference runs it), then the secondary runs: eval-mode arithmetic in the
     # headline mode, and the same train-mode step in the other arithmetic mode
     other = "fp32" if args.math != "fp32" else "bf16x3"
-    elapsed, loss_val, attn_ms, gnorm = timed(True)
+    same_work_ms = None
+    if world > 1:
+        # the like-for-like single-GPU reference of this line: the same K+2 evaluations per shape on this rank's own shapes
+        _, _, _, _, sw = timed(True, local=True)
+        same_work_ms = float(np.median(sw))
+    elapsed, loss_val, attn_ms, gnorm, step_ms = timed(True)
     if not args.headline_only:
-        elapsed_eval, loss_eval, _, _ = timed(False)      # eval-mode arithmetic (dropout off), gradients on
+        elapsed_eval, loss_eval, _, _, step_ms_eval = timed(False)      # eval-mode arithmetic (dropout off), gradients on
         set_math(other)
-        elapsed_other, loss_other, attn_ms_other, gnorm_other = timed(True)
+        elapsed_other, loss_other, attn_ms_other, gnorm_other, step_ms_other = timed(True)
         set_math(args.math)
-    reuse = (world > 1 and overlap and os.environ.get("CSN_REUSE", "1") != "0") or local_graph is not None
+    reuse = (world > 1 and overlap and os.environ.get("CSN_REUSE", "1") != "0") or same_work_n1
     # train mode: the pooled and the mixed self evaluation differ (2K+2 per shape); with descriptor reuse (N > 1) the K
     # neighbour self-attention evaluations per shape are their owners' work: K+2 per shape
     n_evals = B * ((K + 2) if reuse else (2 * K + 2))
@@ -346,12 +367,19 @@ def main():
             return roof(math, dom, ms[dom]), roof(math, oth, ms[oth])
 
         dominant, second = roofs(args.math, attn_ms)
+        med_ms = float(np.median(step_ms))
         out = {
             "metric": "CSA fwd+bwd points/sec (10k pts x 256 ch, K=3)" if args.config == 3 else
                       f"CSA fwd+bwd points/sec ({N // 1000}k pts x {C} ch, K={K})",
-            "value": S * N * args.steps / elapsed,
+            "value": S * N / (med_ms * 1e-3),
             "unit": "points/s", "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": med_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "timing": {"value_is": "shapes x points / MEDIAN step time (SURVEY.md 8(d)); step times = HIP events at the step "
+                                   "boundaries on the launch stream, per step the max over ranks",
+                       "ms_per_step_mean": elapsed / args.steps * 1e3,
+                       "value_mean": S * N * args.steps / elapsed,
+                       "mean_is": "the K timed steps bracketed by barrier + synchronize on both sides (wall clock, max over ranks) / K",
+                       "ms_per_step_min": float(step_ms.min()), "ms_per_step_max": float(step_ms.max())},
             "dtype": DTYPE_TEXT[args.math],
             "data": "synthetic",
             "config": {"workload": f"{cfg['name']}: CSA K={K}, {B} query shapes/GPU x {N} pts x {C} ch, n_heads={H}, d_k=d_v={d}, "
@@ -363,16 +391,28 @@ def main():
                        "parallelism": (f"shape-graph sharded x{world}, exchange {exchange_mode}" + (" overlapped" if overlap else "")
                                        + (", descriptor reuse" if reuse else "")) if world > 1 else "single GPU",
                        "loss": loss_val, "grad_norm": gnorm,
-                       "step_tflops_algorithmic": 3 * algorithmic_flops_fwd(S, K, N, C, D, T) / (elapsed / args.steps) / 1e12},
+                       "step_tflops_algorithmic": 3 * algorithmic_flops_fwd(S, K, N, C, D, T) / (med_ms * 1e-3) / 1e12},
             "roofline": dominant, "roofline_other": second,
         }
+        if world > 1:
+            out["config"]["n1_same_work_ms_per_step"] = same_work_ms
+            out["config"]["scaling_note"] = (
+                f"this line runs K+2 = {K + 2} evaluations per shape (descriptor reuse: a neighbour's pooled SSA descriptor is its "
+                f"owner's), the default N = 1 line runs the reference's 2K+2 = {2 * K + 2}: compare N > 1 lines with "
+                "`bench.py --same-work` at N = 1, or with n1_same_work_ms_per_step — that step (same evaluations, own shapes as "
+                "the collection, no exchange, no gradient all-reduce) timed on rank 0 of THIS run before the group steps"
+                if reuse else "same evaluations per shape as the N = 1 line (descriptor reuse off)")
+        if same_work_n1:
+            out["config"]["scaling_note"] = ("--same-work: the per-GPU work of the N > 1 path (K+2 evaluations per shape, own shapes "
+                                             "as the collection, no exchange) — the like-for-like N = 1 point of the scaling curve; "
+                                             "NOT the metric's headline (that is the default run: the reference's 2K+2)")
         if not args.headline_only:
-            out["config"]["dropout_off"] = {"points_per_s": S * N * args.steps / elapsed_eval,
-                                            "ms_per_step": elapsed_eval / args.steps * 1e3, "loss": loss_eval,
+            out["config"]["dropout_off"] = {"points_per_s": S * N / (float(np.median(step_ms_eval)) * 1e-3),
+                                            "ms_per_step": float(np.median(step_ms_eval)), "loss": loss_eval,
                                             "note": "same step with eval-mode arithmetic (2K+1 evaluations/shape), gradients on"}
             d_o, s_o = roofs(other, attn_ms_other)
-            out["config"][f"math_{other}"] = {"points_per_s": S * N * args.steps / elapsed_other,
-                                              "ms_per_step": elapsed_other / args.steps * 1e3, "loss": loss_other,
+            out["config"][f"math_{other}"] = {"points_per_s": S * N / (float(np.median(step_ms_other)) * 1e-3),
+                                              "ms_per_step": float(np.median(step_ms_other)), "loss": loss_other,
                                               "grad_norm": gnorm_other, "roofline": d_o, "roofline_other": s_o,
                                               "note": "the same train-mode step (same dropout masks) in the other arithmetic mode"}
             # the timed step is also a checked step: same masks, two arithmetic modes — loss and gradient norm must agree

@@ -55,21 +55,39 @@ def build(force: bool = False, verbose: bool = False) -> str:
     per translation unit, compiled side by side, then one link."""
     if not force and not _stale():
         return LIB_PATH
+    # several ranks may import the package at once (mp.spawn in the tests, torchrun): one of them builds, the others wait
+    # on the lock and find the library current when they get it
+    import fcntl
+    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB_PATH
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose: bool) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if not os.path.exists(hipcc):
         hipcc = "hipcc"
     obj_dir = os.path.join(_HERE, "_obj")
     os.makedirs(obj_dir, exist_ok=True)
     compile_flags = [f for f in BUILD_FLAGS if f != "-shared"]
-    jobs = []
-    for f in SOURCES:
-        obj = os.path.join(obj_dir, f.replace(".hip", ".o"))
-        cmd = [hipcc] + compile_flags + ["-c", os.path.join(_CSRC, f), "-o", obj]
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        jobs.append((f, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     objs, errors = [], []
-    for f, obj, proc in jobs:
+    max_jobs = max(1, min(len(SOURCES), os.cpu_count() or 1))     # translation units side by side, never more than the cores
+    pending = list(SOURCES)
+    running = []
+    while pending or running:
+        while pending and len(running) < max_jobs:
+            f = pending.pop(0)
+            obj = os.path.join(obj_dir, f.replace(".hip", ".o"))
+            cmd = [hipcc] + compile_flags + ["-c", os.path.join(_CSRC, f), "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            running.append((f, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        f, obj, proc = running.pop(0)
         out, _ = proc.communicate()
         if proc.returncode != 0:
             errors.append(f"{f}:\n{out}")
@@ -95,6 +113,7 @@ _SIGNATURES = {
     "csn_set_math_mode": (c_int, [c_int]),
     "csn_set_thread_math_mode": (c_int, [c_int]),
     "csn_get_math_mode": (c_int, []),
+    "csn_get_thread_math_mode": (c_int, []),
     "csn_status_string": (c_char_p, [c_int]),
     "csn_wgrad_workspace_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
     "csn_project_f32": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_int, c_int, c_void_p, c_longlong, c_int,

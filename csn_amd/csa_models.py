@@ -51,14 +51,16 @@ class _HostNeighbourStack:
     of config 3), issued from ``wait()`` on a side stream — i.e. after the caller has queued the evaluations that need no
     neighbour data, so that a pageable source, whose staging blocks the host, still overlaps with them on the GPU."""
     reuse_descriptors = False
-    _streams = {}
 
-    def __init__(self, nb: torch.Tensor, xc: torch.Tensor, trust_slot0: bool):
+    def __init__(self, nb: torch.Tensor, xc: torch.Tensor, trust_slot0: bool, streams: dict):
         self._nb, self._xc, self._trust = nb, xc, trust_slot0
+        self._streams = streams                      # the owning module's side streams, one per device, made on first use
 
     def wait(self) -> torch.Tensor:
         dev = self._xc.device
-        side = self._streams.setdefault(dev, torch.cuda.Stream(dev))
+        if dev not in self._streams:
+            self._streams[dev] = torch.cuda.Stream(dev)
+        side = self._streams[dev]
         main = torch.cuda.current_stream(dev)
         with torch.cuda.stream(side):                # (no wait on `main`: the copy runs beside the evaluations queued there)
             stack = self._nb.to(dev, non_blocking=True).to(torch.float32)
@@ -262,6 +264,7 @@ class CrossShapeAt(nn.Module):
         # guarantees it can set this to let the kernels read a device-resident, contiguous neighbour stack in place
         # (no 1.3 GB gather per step at config 3).  Default: slot 0 is taken from x, exactly like the reference (:210, :232).
         self.trust_neighbor_slot0 = False
+        self._side_streams = {}               # device -> the stream host-resident neighbour stacks are copied on (made on first use)
         if 'csa' in self.attention_type:
             self.K = K
             self.compatibility_q = nn.Linear(d_model, d_model)
@@ -344,7 +347,7 @@ class CrossShapeAt(nn.Module):
         elif not nb.is_cuda and nb.is_contiguous() and nb.shape[-1] == npts and K > 0:
             # the stack arrives on the CPU (csa_training.py:198-202, csa_models.py:216): ONE transfer of the whole contiguous
             # tensor on a side stream, under the self-attention of the query shapes, which needs no neighbour data
-            return self._csa_cm_overlapped(xc, _HostNeighbourStack(nb, xc, self.trust_neighbor_slot0), return_parts)
+            return self._csa_cm_overlapped(xc, _HostNeighbourStack(nb, xc, self.trust_neighbor_slot0, self._side_streams), return_parts)
         else:
             x_all = torch.empty((B, K1, C, npts), device=dev, dtype=torch.float32)
             x_all[:, 0] = xc                                                   # the query shape itself (:210, :232)

@@ -100,6 +100,7 @@ int csn_set_thread_math_mode(int m) {
   return 0;
 }
 int csn_get_math_mode(void) { return mode(); }
+int csn_get_thread_math_mode(void) { return t_math_mode; }
 
 const char* csn_status_string(int status) {
   switch (status) {

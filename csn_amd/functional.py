@@ -15,13 +15,9 @@ import math
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
-import threading
-
 import torch
 
 from . import _lib, tuning
-
-_tls = threading.local()
 
 REF_BLOCK = 500       # MID-FC/csa_models.py:84
 REF_NBLOCKS = 20      # MID-FC/csa_models.py:83
@@ -120,7 +116,10 @@ class EvalPlan:
         if q_ranges is not None or kv_ranges is not None:
             assert v_shift == 0 and q_ranges is not None and kv_ranges is not None
             cover = lambda rs: set(int(f + st * i) for f, st, c in rs for i in range(c))
-            assert set(q.tolist()) <= cover(q_ranges) and set(kv.tolist()) <= cover(kv_ranges), "slot ranges must cover the plan"
+            # exactly the slots the plan reads: the ranged backward neither clears nor skips gradient maps, so a covered slot
+            # that no evaluation writes would put uninitialised memory into the weight gradients
+            assert set(q.tolist()) == cover(q_ranges) and set(kv.tolist()) == cover(kv_ranges), \
+                "slot ranges must be exactly the slots the plan reads"
         as_dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
         self.q_slots, self.kv_slots, self.v_slots = as_dev(q), as_dev(kv), as_dev(kv + v_shift)
         self.dq_colors = [as_dev(c) for c in self._colors(q)]
@@ -197,16 +196,13 @@ class math_mode:
     def __enter__(self):
         if self.mode is not None:
             L = _lib.lib()
-            self.prev = L.csn_get_math_mode()
-            self.had = getattr(_tls, "depth", 0)
-            _tls.depth = self.had + 1
-            _lib.check(L.csn_set_thread_math_mode(self.mode))
+            self.prev = L.csn_get_thread_math_mode()          # the thread's own override as it stands (-1: none) — restored
+            _lib.check(L.csn_set_thread_math_mode(self.mode))   # exactly, also one set directly through the C ABI
         return self
 
     def __exit__(self, *exc):
         if self.mode is not None:
-            _tls.depth = self.had
-            _lib.lib().csn_set_thread_math_mode(self.prev if self.had else -1)
+            _lib.lib().csn_set_thread_math_mode(self.prev)
         return False
 
 

@@ -44,6 +44,7 @@ class _CrossMHA(torch.autograd.Function):
         (csn_varlen_attn_fwd_f32 / _bwd_f32)."""
         CF._need_cuda(xq, xk, xv, w_qs, w_ks, w_vs, w_fc)
         L = _lib.lib()
+        ctx.mode = CF.current_mode()                 # the backward runs on autograd's threads: it re-opens this mode there
         b, lq, C = xq.shape
         lk = xk.shape[1]
         if xv.shape[1] != lk:
@@ -96,6 +97,11 @@ class _CrossMHA(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dxhat, _dattn):
+        with CF.math_mode(CF.backward_mode(ctx.mode)):
+            return _CrossMHA._backward(ctx, dxhat, _dattn)
+
+    @staticmethod
+    def _backward(ctx, dxhat, _dattn):
         xq_cm, xk_cm, xv_cm, w_qs, w_ks, w_vs, w_fc, q, k, v, att, lse, scores, xhat, rstd = ctx.saved_tensors
         b, lq, lk, C, H, d, Tp = ctx.dims
         p_attn, seed_attn, p_fc, seed_fc = ctx.drop

@@ -51,6 +51,7 @@ class _SDPA(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, temperature: float, p_drop: float = 0.0):
         CF._need_cuda(q, k, v)
+        ctx.mode = CF.current_mode()               # the backward runs on autograd's threads: it re-opens this mode there
         B, H, Tq, d = q.shape
         Tk = k.shape[2]
         if v.shape[2] != Tk:
@@ -88,6 +89,11 @@ class _SDPA(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, _dprob):
+        with CF.math_mode(CF.backward_mode(ctx.mode)):
+            return _SDPA._backward(ctx, dout, _dprob)
+
+    @staticmethod
+    def _backward(ctx, dout, _dprob):
         qm, km, vm, att, lse, scores = ctx.saved_tensors
         B, H, Tq, Tk, d, Tp = ctx.dims
         S = B * H

@@ -82,6 +82,8 @@ int csn_version(void);
 int csn_set_math_mode(int mode);
 int csn_set_thread_math_mode(int mode);
 int csn_get_math_mode(void);
+/* The calling thread's own override as set by csn_set_thread_math_mode (-1 = none): what a scoped override saves and restores. */
+int csn_get_thread_math_mode(void);
 /* Human-readable text for a status code returned by any function below. Host pointer, static storage. */
 const char* csn_status_string(int status);
 
