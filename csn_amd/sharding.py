@@ -206,6 +206,186 @@ class PendingStack:
         return table[self._shard.local_graph]
 
 
+# -- mini-batch training over a collection that is resident across the ranks (SURVEY.md §8f row 4 + §8e) ---------------------
+class BatchExchangePlan:
+    """What one training step of one rank moves: the rank's batch (global shape ids), the owned shapes it sends to each other
+    rank, what it receives, and where every slot of its (B, K+1) neighbour stack comes from — the rank's own cache or the
+    receive pool.  A pure function of (the step's batches of ALL ranks, the neighbour table, the ownership ranges)."""
+    __slots__ = ("ids", "send_local", "send_splits", "recv_splits", "n_recv", "rows_local", "src_local", "rows_remote",
+                 "src_remote", "B", "K")
+
+
+class PendingBatchStack:
+    """The neighbour stack of a mini-batch whose exchange is in flight; CrossShapeAt takes it in place of the neighbour tensor
+    and runs the self-attention of the batch's own shapes under the exchange (``wait()`` -> (B, K+1, C, N, 1), slot 0 = the
+    shape itself).  No descriptor reuse: a neighbour is in general not part of any rank's batch in this step, so its pooled
+    descriptor is computed by the consumer, as the reference does (csa_models.py:214-220)."""
+    reuse_descriptors = False
+
+    def __init__(self, coll: "ResidentCollection", plan: BatchExchangePlan, work, pool: torch.Tensor):
+        self._coll, self._plan, self._work, self._pool = coll, plan, work, pool
+        self._stack: Optional[torch.Tensor] = None
+
+    def wait(self) -> torch.Tensor:
+        if self._stack is None:
+            if self._work is not None:
+                self._work.wait()
+            self._stack = self._coll._assemble(self._plan, self._pool)
+        return self._stack
+
+
+class ResidentCollection:
+    """A training collection of any size held in the HBM of all ranks together: rank r owns the contiguous id range
+    [bounds[r], bounds[r+1]) as a csn_amd.data.DeviceFeatureCache (every feature file read once, by its owner), and a
+    training step takes a mini-batch of B OWNED shapes per rank whose K neighbours live anywhere.
+
+    The reference iterates batches of ~4 shapes over hundreds to thousands (csa_training.py:191-222) and re-reads K neighbour
+    files per item (features_data_loader.py:107-140); here a step's neighbour features cross xGMI in ONE neighbour-only
+    all-to-all with per-step splits (``exchange_async``), overlapped by the model with the self-attention of the batch's own
+    shapes.  Batches are drawn by a sampler that is a pure function of (seed, epoch) and identical on every rank
+    (``epoch_batches``), so every rank derives all ranks' batches — and with them the step's exchange plan — without any
+    metadata traffic; plans are cached per batch composition.  ShapeGraphShard is the special case "the collection IS the
+    batch" that the weak-scaling bench times."""
+
+    def __init__(self, cache, nbr_table, rank: int, world: int, bounds=None, group=None):
+        self.cache, self.rank, self.world, self.group = cache, rank, world, group
+        self.table = np.asarray(nbr_table, dtype=np.int64)                      # (S, K) global neighbour ids (data.neighbour_table)
+        self.S, self.K = self.table.shape
+        self.bounds = np.asarray(self.split_bounds(self.S, world) if bounds is None else bounds, dtype=np.int64)
+        if self.bounds.shape != (world + 1,) or self.bounds[0] != 0 or self.bounds[-1] != self.S or (np.diff(self.bounds) < 0).any():
+            raise ValueError("bounds must be world + 1 non-decreasing shape ids from 0 to S")
+        if cache.first != self.bounds[rank] or len(cache) != self.bounds[rank + 1] - self.bounds[rank]:
+            raise ValueError(f"rank {rank} owns [{self.bounds[rank]}, {self.bounds[rank + 1]}) but its cache holds "
+                             f"[{cache.first}, {cache.first + len(cache)})")
+        self.device = cache.device
+        self._plans = {}
+        self._pool: Optional[torch.Tensor] = None
+
+    @staticmethod
+    def split_bounds(n_shapes: int, world: int) -> np.ndarray:
+        """Ownership ranges of an n_shapes collection over world ranks: contiguous, sizes differing by at most one."""
+        base, extra = divmod(n_shapes, world)
+        return np.concatenate(([0], np.cumsum([base + (r < extra) for r in range(world)]))).astype(np.int64)
+
+    @classmethod
+    def from_source(cls, source, nbr_table, device, rank: int, world: int, n_points: Optional[int] = None, group=None):
+        """Read this rank's share of a feature dataset (csn_amd.data.FeaturesDataset / CSADatasetK / any dataset with their
+        item contract) into its HBM and wrap it."""
+        from .data import DeviceFeatureCache, N_POINTS
+        b = cls.split_bounds(len(source), world)
+        cache = DeviceFeatureCache(source, device, first=int(b[rank]), count=int(b[rank + 1] - b[rank]),
+                                   n_points=N_POINTS if n_points is None else n_points)
+        return cls(cache, nbr_table, rank, world, bounds=b, group=group)
+
+    def owner(self, ids) -> np.ndarray:
+        return np.searchsorted(self.bounds, np.asarray(ids), side="right") - 1
+
+    # -- the sampler: the same on every rank ---------------------------------------------------------------------------
+    def epoch_batches(self, batch_size: int, epoch: int = 0, shuffle: bool = True, seed: int = 0):
+        """The steps of one epoch: a list of steps, each a list over ranks of B global shape ids owned by that rank.  Every rank
+        walks ITS shapes (in a permutation drawn from (seed, epoch, rank) when shuffling); the number of steps is that of the
+        rank with the most shapes, ranks with fewer wrap around — every rank runs every step (the collectives line up) with a
+        full batch."""
+        per_rank = []
+        for r in range(self.world):
+            own = np.arange(self.bounds[r], self.bounds[r + 1])
+            if own.size == 0:
+                raise ValueError(f"rank {r} owns no shape: {self.S} shapes over {self.world} ranks")
+            if shuffle:
+                own = np.random.default_rng([seed, epoch, r]).permutation(own)
+            per_rank.append(own)
+        n_steps = max((o.size + batch_size - 1) // batch_size for o in per_rank)
+        steps = []
+        for t in range(n_steps):
+            steps.append([np.take(o, np.arange(t * batch_size, (t + 1) * batch_size), mode="wrap") for o in per_rank])
+        return steps
+
+    # -- a step's exchange ---------------------------------------------------------------------------------------------
+    def plan(self, batches) -> BatchExchangePlan:
+        """The exchange plan of one step from the batches of ALL ranks (sequence over ranks of global shape ids)."""
+        key = tuple(np.asarray(b, dtype=np.int64).tobytes() for b in batches)
+        hit = self._plans.get(key)
+        if hit is not None:
+            return hit
+        if len(batches) != self.world:
+            raise ValueError(f"{len(batches)} batches for {self.world} ranks")
+        me, lo, hi = self.rank, int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
+        need = []                                            # need[r][src]: sorted ids owned by src that rank r's batch references
+        for r, ids in enumerate(batches):
+            ids = np.asarray(ids, dtype=np.int64)
+            if ids.size and ((self.owner(ids) != r).any()):
+                raise ValueError(f"rank {r}'s batch holds shapes it does not own")
+            nb = np.unique(self.table[ids].reshape(-1)) if ids.size else np.zeros(0, np.int64)
+            own_r = self.owner(nb)
+            need.append([nb[own_r == src] if src != r else np.zeros(0, np.int64) for src in range(self.world)])
+        p = BatchExchangePlan()
+        ids = np.asarray(batches[me], dtype=np.int64)
+        p.ids, p.B, p.K = ids, int(ids.size), self.K
+        p.send_local = torch.from_numpy(np.concatenate([need[r][me] - lo for r in range(self.world)])).to(self.device)
+        p.send_splits = [int(need[r][me].size) for r in range(self.world)]
+        p.recv_splits = [int(need[me][src].size) for src in range(self.world)]
+        recv_ids = np.concatenate([need[me][src] for src in range(self.world)])      # global ids in arrival order
+        p.n_recv = int(recv_ids.size)
+        pos = {int(g): i for i, g in enumerate(recv_ids)}
+        # stack rows (b, k): k = 0 the shape itself, k >= 1 its neighbours in graph order
+        slot_ids = np.concatenate((ids[:, None], self.table[ids]), axis=1).reshape(-1) if ids.size else np.zeros(0, np.int64)
+        local = (slot_ids >= lo) & (slot_ids < hi)
+        rows = np.arange(slot_ids.size)
+        p.rows_local = torch.from_numpy(rows[local]).to(self.device)
+        p.src_local = torch.from_numpy(slot_ids[local] - lo).to(self.device)
+        p.rows_remote = torch.from_numpy(rows[~local]).to(self.device)
+        p.src_remote = torch.from_numpy(np.array([pos[int(g)] for g in slot_ids[~local]], dtype=np.int64)).to(self.device)
+        if len(self._plans) >= 4096:
+            self._plans.clear()
+        self._plans[key] = p
+        return p
+
+    def batch(self, plan: BatchExchangePlan):
+        """(feats (B, C, N, 1), labels (B, N)) of the rank's batch — what the model and the loss take."""
+        return self.cache.batch(plan.ids)
+
+    def exchange_async(self, plan: BatchExchangePlan) -> PendingBatchStack:
+        """Start the step's neighbour-only all-to-all (uneven per-step splits) and return at once."""
+        feats = self.cache.feats
+        tail = tuple(feats.shape[1:])
+        send = (feats.index_select(0, plan.send_local) if plan.send_local.numel() else feats[:0]).contiguous()
+        pool = torch.empty((plan.n_recv,) + tail, device=feats.device, dtype=feats.dtype)
+        work = None
+        if self.world > 1:
+            work = dist.all_to_all_single(pool, send, plan.recv_splits, plan.send_splits, group=self.group, async_op=True)
+        pending = PendingBatchStack(self, plan, work, pool)
+        pending._send = send                                  # (kept alive until the collective has consumed it)
+        return pending
+
+    def _assemble(self, plan: BatchExchangePlan, pool: torch.Tensor) -> torch.Tensor:
+        feats = self.cache.feats
+        tail = tuple(feats.shape[1:])
+        stack = torch.empty((plan.B * (plan.K + 1),) + tail, device=feats.device, dtype=feats.dtype)
+        if plan.rows_local.numel():
+            stack.index_copy_(0, plan.rows_local, feats.index_select(0, plan.src_local))
+        if plan.rows_remote.numel():
+            stack.index_copy_(0, plan.rows_remote, pool.index_select(0, plan.src_remote))
+        return stack.view((plan.B, plan.K + 1) + tail).unsqueeze(-1)
+
+    def neighbour_stack(self, plan: BatchExchangePlan) -> torch.Tensor:
+        """Blocking form of exchange_async(plan).wait()."""
+        return self.exchange_async(plan).wait()
+
+    def allreduce_grads(self, params: Iterable[torch.nn.Parameter], average: bool = True) -> None:
+        """The weight gradients summed (or averaged) over the ranks in one bucket, as ShapeGraphShard.allreduce_grads."""
+        if self.world == 1:
+            return
+        plist = [p for p in params if p.grad is not None]
+        flat = torch.cat([p.grad.reshape(-1) for p in plist])
+        dist.all_reduce(flat, group=self.group)
+        if average:
+            flat /= self.world
+        off = 0
+        for p in plist:
+            p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
+            off += p.numel()
+
+
 # -- kNN shape graph, rows of the retrieval matrix sharded by query shape (collective 4) --------------------
 def _gather_shards(local: torch.Tensor, group=None) -> torch.Tensor:
     """Concatenation over ranks (in rank order) of per-rank tensors (n_r, ...) whose leading sizes may differ."""

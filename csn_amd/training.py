@@ -125,6 +125,35 @@ def train_layers(model, dataloader: Iterable, optimizer, num_class: int, device,
     return float(total.item()) / max(n_batches, 1)
 
 
+def train_layers_sharded(model, collection, optimizer, num_class: int, batch_size: int, epoch: int = 0, shuffle: bool = True,
+                         seed: int = 0, max_steps: Optional[int] = None, steps=None) -> float:
+    """One epoch of ``train_layers`` (csa_training.py:191-222, one optimizer step per batch) over a collection that is resident
+    across the ranks of a torch.distributed job (csn_amd.sharding.ResidentCollection): every rank trains on mini-batches of
+    ``batch_size`` shapes it owns, the batch's neighbour features arrive through the step's neighbour-only exchange — in
+    flight under the self-attention of the batch's own shapes — and the weight gradients are averaged over the ranks before
+    the optimizer step, so all replicas stay identical.  With world = 1 this is the single-process loop over the same
+    batches.  ``steps``: an explicit list of steps (each a list over ranks of shape ids) instead of the epoch's sampler.
+    Returns the mean loss of this rank's batches (accumulated on the device, read back once)."""
+    model.train()
+    steps = collection.epoch_batches(batch_size, epoch, shuffle, seed) if steps is None else steps
+    if max_steps is not None:
+        steps = steps[:max_steps]
+    params = [p for p in model.parameters() if p.requires_grad]
+    total = torch.zeros((), device=collection.device, dtype=torch.float64)
+    for batches in steps:
+        plan = collection.plan(batches)
+        pending = collection.exchange_async(plan)              # neighbour features on their way
+        feats, label = collection.batch(plan)
+        optimizer.zero_grad()
+        out = model(feats, "train", pending)                   # own-shape self-attention first, then pending.wait()
+        loss, _ = loss_functions_seg(out, label, num_class)
+        loss.backward()
+        collection.allreduce_grads(params, average=True)
+        optimizer.step()
+        total += loss.detach().double()
+    return float(total.item()) / max(len(steps), 1)
+
+
 @torch.no_grad()
 def validate_layers(model, dataloader: Iterable, class_num: int, device, max_batches: Optional[int] = None):
     """Part IoU and mean loss in eval mode (csa_training.py:224-259); no autograd graph is built."""
