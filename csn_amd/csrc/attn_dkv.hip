@@ -55,10 +55,10 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
   constexpr int IMG_EL = 4 * 2 * NPL * PLANE;           // [image: QA, OA, QB, OB][stage][plane]
   constexpr int STAGE_EL = D * KW * 2;                  // prologue / epilogue: a [D][128 keys] fp32 block
   constexpr int BUF_EL = IMG_EL > STAGE_EL ? IMG_EL : STAGE_EL;
-  static_assert(2 * BUF_EL + 2 * 64 * 4 <= 160 * 1024, "LDS budget of one CU");
-  __shared__ __attribute__((aligned(16))) short tiles[BUF_EL + 2 * 64 * 2];
+  static_assert(2 * BUF_EL + 3 * 64 * 4 <= 160 * 1024, "LDS budget of one CU");
+  __shared__ __attribute__((aligned(16))) short tiles[BUF_EL + 3 * 64 * 2];
   auto image = [&](int img, int st, int pl) -> short* { return tiles + ((img * 2 + st) * NPL + pl) * PLANE; };
-  float* rowc = reinterpret_cast<float*>(tiles + BUF_EL);          // [stage][lse2: 32 | delta: 32]
+  float* rowc = reinterpret_cast<float*>(tiles + BUF_EL);          // [stage of 3][lse2: 32 | delta: 32]
   float* xbuf = reinterpret_cast<float*>(tiles);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -160,7 +160,10 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
   // query-contiguous image (segment 2).
   f32x4 gQ[NP_T], gO[NP_T];
   s16x4 cQh[NP_T], cQl[NP_T], cOh[NP_T], cOl[NP_T];
-  float gc = 0.f;                                                   // threads 0..63: lse2 / delta of one query of the tile
+  // wave 0 also carries the tile's 32 lse / 32 delta values (lanes 0..31 / 32..63), as buffer loads like everything else in
+  // the loop: nothing may force a wait on memory between a request and the barrier that follows it
+  float gca = 0.f, gcb = 0.f;
+  const bool wave0 = __builtin_amdgcn_readfirstlane(wave) == 0;
   // fetch stream: (item, query tile) of the next tile to request — it runs two tiles ahead of the products.  Everything that
   // depends on the item (evaluation id, query slot, base pointers) is scalar and reloaded only when the item changes.
   int f_it = it0, f_qt = 0;
@@ -188,9 +191,11 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
       gQ[i] = csn_bload4(Qr, o, (unsigned)(64 * i * ld) * 4u);
       gO[i] = csn_bload4(Or, o, (unsigned)(64 * i * ld) * 4u);
     }
-    if (tid < 64) {
-      const int qi = tid & 31;
-      gc = qi < nq ? (tid < 32 ? f_lse[f_qt * QT + qi] * LOG2E : f_dl[f_qt * QT + qi]) : 0.f;
+    if (wave0) {
+      const long long rwin = (nq < QT ? nq : QT) * 4;
+      const csn_rsrc_t Lr = csn_make_rsrc(f_lse + f_qt * QT, rwin), Dr = csn_make_rsrc(f_dl + f_qt * QT, rwin);
+      gca = csn_bload(Lr, lane < 32 ? (unsigned)lane * 4u : CSN_OOB);                  // (queries beyond the block: 0)
+      gcb = csn_bload(Dr, lane >= 32 ? (unsigned)(lane - 32) * 4u : CSN_OOB);
     }
     if (++f_qt == nqt) {                                            // next tile: the first of the next item (if any)
       f_qt = 0;
@@ -223,8 +228,10 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
         }
       }
   };
-  float gc_hold = 0.f;                                              // the row constant of tile t + 1 while tile t + 2 is being requested
-  auto commit_rowc = [&](int st) { if (tid < 64) rowc[st * 64 + tid] = gc_hold; };
+  // The row constants sit in a ring of THREE stages and are committed in segment 1 with the k-major images, straight from
+  // the load's registers (a two-stage buffer would have to wait for segment 2, behind a register copy of values that have
+  // just been requested again — and such a copy makes the compiler wait for the whole request before the barrier).
+  auto commit_rowc = [&](int st3) { if (wave0) rowc[st3 * 64 + lane] = lane < 32 ? gca * LOG2E : gcb; };
 
   // fragment read positions (lane constants; attn_bf16x3.hip)
   const int tr_row = 8 * kq + (lq >> 2);
@@ -232,99 +239,114 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
   const int a_pos0 = tr_row * QT + 8 * (lq & 3) + 4 * tr_sw, a_pos1 = tr_row * QT + 8 * (lq & 3) + 4 * (tr_sw ^ 1);
   const int b_pos = lq * QT + 8 * (kq ^ ((-((lq >> 2) & 3)) & 3));
 
-  constexpr int PD = 4;
-  // phase 1: T[q][key] = sum_d img[d][q] R[d][key]
-  auto phase1 = [&](int img, int st, const s16x8* Rh, const s16x8* Rl, f32x4v& S0, f32x4v& S1) {
-    S0 = f32x4v{0.f, 0.f, 0.f, 0.f};
-    S1 = f32x4v{0.f, 0.f, 0.f, 0.f};
-    const short* __restrict__ tAh = image(img, st, 0);
-    const short* __restrict__ tAl = image(img, st, NPL - 1);
+  // Both products of a phase run in ONE loop (the S and dP accumulators, the dV and dK accumulators are independent): the LDS
+  // fragment reads of the two images run PD steps ahead of the matrix instructions in one register ring each, and a phase
+  // pays the LDS latency once.  At the narrow head widths a phase is only 2 x D/16 matrix instructions, so what a tile costs
+  // is the number of such exposed latencies, not the matrix work.
+  constexpr int PD = 2;
+  // phase 1: S[q][key] = sum_d Qs^T[d][q] K^T[d][key]  and  dP[q][key] = sum_d dO^T[d][q] V^T[d][key]   (images 0 and 1)
+  auto phase1 = [&](int st, f32x4v& S0, f32x4v& S1, f32x4v& P0, f32x4v& P1) {
+    S0 = f32x4v{0.f, 0.f, 0.f, 0.f}; S1 = S0; P0 = S0; P1 = S0;
+    const short* __restrict__ qh_ = image(0, st, 0);
+    const short* __restrict__ ql_ = image(0, st, NPL - 1);
+    const short* __restrict__ oh_ = image(1, st, 0);
+    const short* __restrict__ ol_ = image(1, st, NPL - 1);
     constexpr int NH = 2 * DT;
-    s16x8 ah[PD], al[PD];
-    auto rd = [&](int h, s16x8& fh, s16x8& fl) {
+    s16x8 aqh[PD], aql[PD], aoh[PD], aol[PD];
+    auto rd = [&](const short* th, const short* tl, int h, s16x8& fh, s16x8& fl) {
       const int o = 32 * (h >> 1) * QT + ((h & 1) ? a_pos1 : a_pos0);
-      fh = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAh + o)),
-                 __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAh + o + 4 * QT)));
+      fh = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(th + o)),
+                 __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(th + o + 4 * QT)));
       if constexpr (NPL == 2)
-        fl = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAl + o)),
-                   __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tAl + o + 4 * QT)));
+        fl = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tl + o)),
+                   __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tl + o + 4 * QT)));
       else fl = fh;
     };
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int h = 0; h < PD && h < NH; ++h) rd(h, ah[h], al[h]);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 * NPL * (PD < NH ? PD : NH), 0);
+    for (int h = 0; h < PD && h < NH; ++h) { rd(qh_, ql_, h, aqh[h], aql[h]); rd(oh_, ol_, h, aoh[h], aol[h]); }
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 * NPL * (PD < NH ? PD : NH), 0);
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int r = h % PD, sidx = h >> 1;
-      if (h & 1) S1 = mma16<PR>(ah[r], al[r], Rh[sidx], Rl[sidx], S1);
-      else S0 = mma16<PR>(ah[r], al[r], Rh[sidx], Rl[sidx], S0);
-      if (h + PD < NH) rd(h + PD, ah[r], al[r]);
-      __builtin_amdgcn_sched_group_barrier(0x008, PR::NT, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NPL, 0);
+      if (h & 1) { S1 = mma16<PR>(aqh[r], aql[r], Kh[sidx], Kl[sidx], S1); P1 = mma16<PR>(aoh[r], aol[r], Vh[sidx], Vl[sidx], P1); }
+      else { S0 = mma16<PR>(aqh[r], aql[r], Kh[sidx], Kl[sidx], S0); P0 = mma16<PR>(aoh[r], aol[r], Vh[sidx], Vl[sidx], P0); }
+      if (h + PD < NH) { rd(qh_, ql_, h + PD, aqh[r], aql[r]); rd(oh_, ol_, h + PD, aoh[r], aol[r]); }
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * PR::NT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 4 * NPL, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  // phase 2: OUT[c][key] += sum_q img[c][q] F[q][key]
-  auto phase2 = [&](int img, int st, const s16x8& fh, const s16x8& fl, f32x4v* OUT) {
-    const lds_s16* tBh = opaque_lds(image(img, st, 0) + b_pos);
-    const lds_s16* tBl = tBh + (NPL - 1) * PLANE;
-    constexpr int NC = D / 16;
-    s16x8 vh[PD], vl[PD];
-    __builtin_amdgcn_sched_barrier(0);
+  // phase 2: dV^T[c][key] += sum_q dO^T[c][q] P_drop[q][key]  and  dK^T[c][key] += sum_q Qs^T[c][q] dS[q][key]   (images 3 and 2).
+  // Its first fragment reads do not depend on the pointwise segment: they are issued before it (phase2_ahead) and land under it.
+  constexpr int NC = D / 16;
+  s16x8 voh[PD], vol[PD], vqh[PD], vql[PD];
+  const lds_s16* tOh = nullptr; const lds_s16* tQh = nullptr;
+  auto phase2_ahead = [&](int st) {
+    tOh = opaque_lds(image(3, st, 0) + b_pos);
+    tQh = opaque_lds(image(2, st, 0) + b_pos);
 #pragma unroll
     for (int c = 0; c < PD && c < NC; ++c) {
-      vh[c] = *reinterpret_cast<const lds_s16x8*>(tBh + c * 16 * QT);
-      vl[c] = *reinterpret_cast<const lds_s16x8*>(tBl + c * 16 * QT);
+      voh[c] = *reinterpret_cast<const lds_s16x8*>(tOh + c * 16 * QT);
+      vol[c] = *reinterpret_cast<const lds_s16x8*>(tOh + (NPL - 1) * PLANE + c * 16 * QT);
+      vqh[c] = *reinterpret_cast<const lds_s16x8*>(tQh + c * 16 * QT);
+      vql[c] = *reinterpret_cast<const lds_s16x8*>(tQh + (NPL - 1) * PLANE + c * 16 * QT);
     }
-    __builtin_amdgcn_sched_group_barrier(0x100, NPL * (PD < NC ? PD : NC), 0);
+  };
+  auto phase2 = [&](const s16x8& ph, const s16x8& pl, const s16x8& dh, const s16x8& dl) {
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int r = c % PD;
-      OUT[c] = mma16<PR>(vh[r], vl[r], fh, fl, OUT[c]);
+      dV[c] = mma16<PR>(voh[r], vol[r], ph, pl, dV[c]);
+      dK[c] = mma16<PR>(vqh[r], vql[r], dh, dl, dK[c]);
       if (c + PD < NC) {
-        vh[r] = *reinterpret_cast<const lds_s16x8*>(tBh + (c + PD) * 16 * QT);
-        vl[r] = *reinterpret_cast<const lds_s16x8*>(tBl + (c + PD) * 16 * QT);
+        voh[r] = *reinterpret_cast<const lds_s16x8*>(tOh + (c + PD) * 16 * QT);
+        vol[r] = *reinterpret_cast<const lds_s16x8*>(tOh + (NPL - 1) * PLANE + (c + PD) * 16 * QT);
+        vqh[r] = *reinterpret_cast<const lds_s16x8*>(tQh + (c + PD) * 16 * QT);
+        vql[r] = *reinterpret_cast<const lds_s16x8*>(tQh + (NPL - 1) * PLANE + (c + PD) * 16 * QT);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, PR::NT, 0);
-      __builtin_amdgcn_sched_group_barrier(0x100, NPL, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * PR::NT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NPL, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
 
   // images: 0 = Qs k-major, 1 = dO k-major, 2 = Qs query-contiguous, 3 = dO query-contiguous
   fetch();
-  commit_kmajor(0); commit_contig(0); gc_hold = gc; commit_rowc(0);
+  commit_kmajor(0); commit_contig(0); commit_rowc(0);
   if (n_steps > 1) fetch();
   __syncthreads();
   if (late) __syncthreads();
 
   // Two barrier segments per tile; waves 4..7 run one segment behind.  The k-major images are read in segment 1 and rewritten
-  // in segment 1 of the tile before; the query-contiguous images and the row constants are read in segment 2 and rewritten in
+  // in segment 1 of the tile before; the query-contiguous images are read in segment 2 and rewritten in
   // segment 2 of the tile before (the hazard analysis of attn_bf16x3.hip with its A / B stages).  Tile t + 2 is requested in
   // segment 1 of tile t, right after the pieces of tile t + 1 have been split and committed — a whole tile of cover for the
   // HBM latency, which the short matrix phases of the narrow head widths cannot give.
   f32x4v S0, S1, P0, P1;
   int c_it = it0, c_qt = 0;                                         // (item, query tile) of the products
+  int rc_cur = 0;
   unsigned salt = 0;
   for (int step = 0; step < n_steps; ++step) {
     const int cur = step & 1, nxt = cur ^ 1;
+    const int rc_nxt = rc_cur == 2 ? 0 : rc_cur + 1;                // stage of the row constants of this tile / the next
     const bool more = step + 1 < n_steps;
     if (c_qt == 0) {                                                // a new item: its mask salt (scalar unit)
       const int e = p.eval_ids ? p.eval_ids[c_it] : c_it;
       salt = csn_block_salt((unsigned long long)(((long long)e * p.H + hd) * p.n_blocks + blk), p.seed);
     }
-    phase1(0, cur, Kh, Kl, S0, S1);                                 // S  = Qs K^T (as the forward formed it, transposed roles)
-    phase1(1, cur, Vh, Vl, P0, P1);                                 // dP = dO V^T
+    phase1(cur, S0, S1, P0, P1);                                    // S = Qs K^T (the forward's product, roles transposed), dP = dO V^T
     if (more) {
       commit_kmajor(nxt);                                           // (splits the pieces: the fp32 registers are free again)
-      gc_hold = gc;
+      commit_rowc(rc_nxt);
       if (step + 2 < n_steps) fetch();                              // a whole tile ahead of its first use
     }
     __syncthreads();
+    phase2_ahead(cur);
     // ---- pointwise: this lane's key against queries qt * 32 + 8 kq .. + 7 --------------------------------------------
-    const f32x4 l0 = *reinterpret_cast<const f32x4*>(&rowc[cur * 64 + 8 * kq]), l1 = *reinterpret_cast<const f32x4*>(&rowc[cur * 64 + 8 * kq + 4]);
-    const f32x4 d0 = *reinterpret_cast<const f32x4*>(&rowc[cur * 64 + 32 + 8 * kq]), d1 = *reinterpret_cast<const f32x4*>(&rowc[cur * 64 + 32 + 8 * kq + 4]);
+    const f32x4 l0 = *reinterpret_cast<const f32x4*>(&rowc[rc_cur * 64 + 8 * kq]), l1 = *reinterpret_cast<const f32x4*>(&rowc[rc_cur * 64 + 8 * kq + 4]);
+    const f32x4 d0 = *reinterpret_cast<const f32x4*>(&rowc[rc_cur * 64 + 32 + 8 * kq]), d1 = *reinterpret_cast<const f32x4*>(&rowc[rc_cur * 64 + 32 + 8 * kq + 4]);
     const float lse2[8] = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
     const float dlt[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
     const float sv[8] = {S0[0], S0[1], S0[2], S0[3], S1[0], S1[1], S1[2], S1[3]};
@@ -354,10 +376,10 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
       dh[r] = to16<PR::HALF>(ds[r]);
       dl[r] = PR::NT == 3 ? to16<PR::HALF>(ds[r] - from16<PR::HALF>(dh[r])) : dh[r];
     }
-    phase2(3, cur, ph, pl, dV);                                     // dV^T += dO^T P_drop
-    phase2(2, cur, dh, dl, dK);                                     // dK^T += Qs^T dS
-    if (more) { commit_contig(nxt); commit_rowc(nxt); }
+    phase2(ph, pl, dh, dl);                                         // dV^T += dO^T P_drop,  dK^T += Qs^T dS
+    if (more) commit_contig(nxt);
     if (++c_qt == nqt) { c_qt = 0; ++c_it; }
+    rc_cur = rc_nxt;
     __syncthreads();
   }
   if (!late) __syncthreads();                                       // pairs with the last barrier of the late half

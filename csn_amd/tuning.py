@@ -32,7 +32,8 @@ class Tuning:
     # cost what the score traffic saves, at d <= 128 a score costs the same bytes for a fraction of the FLOPs
     score_flow: Dict[object, int] = field(default_factory=lambda: {
         1: KEEP_SCORES, 2: KEEP_SCORES,
-        **{(m, d): RECOMPUTE_DQ for m in (1, 2) for d in (32, 64, 96, 128)}})
+        **{(2, d): FLASH for d in (32, 64, 96, 128)},
+        **{(1, d): FLASH for d in (32, 64, 96)}, (1, 128): RECOMPUTE_DQ})
 
     def flow_for(self, mode: int, d_head: int) -> int:
         return self.score_flow.get((mode, d_head), self.score_flow.get(mode, KEEP_SCORES))
