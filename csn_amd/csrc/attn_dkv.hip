@@ -101,8 +101,8 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
 #pragma unroll
       for (int t = 0; t < CH_K; ++t) {
         const int row = crow + RPS * t;
-        // (tiles beyond the block's 16 are not part of the row: the last chunk of a 500-key block holds 116 keys in 4 tiles)
-        const bool ok = row < D && (kc * 4 + cc / (4 * NPL)) < 16;
+        // (only the tiles that hold keys of this block: the projection writes nothing beyond the block's last 32-key tile)
+        const bool ok = row < D && (kc * 4 + cc / (4 * NPL)) < (T + 31) / 32;
         ch[t] = csn_bload4(rs, ok ? (unsigned)(row * kld * 2 + cc * 16) : CSN_OOB);
       }
 #pragma unroll

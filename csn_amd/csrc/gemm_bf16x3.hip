@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
     }
   if (c_tiles) {
     // column n of the map -> block n / Tb, key k = n % Tb -> tile k / 32, position k % 32; a row holds, per block, 16 tiles
-    // of [hi: 32 | lo: 32] bf16 (block pitch 1024; the padding of the last tile is never written: the caller keeps it zero)
+    // of [hi: 32 | lo: 32] bf16 (block pitch 1024; the padding keys of a block's last tile are written as zeros)
     const int Tb = (int)p.C.plane_stride;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -281,6 +281,12 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
           const short hi = to16<PR::HALF>(acc[i][j][r]);
           csn_bstore16(hi, Cr, off);
           if constexpr (NPL == 2) csn_bstore16(to16<PR::HALF>(acc[i][j][r] - from16<PR::HALF>(hi)), Cr, off, 64u);
+          if (off != CSN_OOB && (kib + 1 == Tb || n + 1 == N)) {       // last key of its block: zero padding up to the tile's end
+            for (int g = 1; g <= ((31 - (kib & 31)) & 31); ++g) {
+              csn_bstore16((short)0, Cr, off + 2u * (unsigned)g);
+              if constexpr (NPL == 2) csn_bstore16((short)0, Cr, off + 2u * (unsigned)g, 64u);
+            }
+          }
         }
     }
     return;
@@ -628,10 +634,12 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
   // writes 16 contiguous bytes per lane: 32 stores (and 32 loads when accumulating) instead of 128.
   const float alpha = p.alpha;
   unsigned tcol = 0;
+  int tpad = 0;                                                        // 4-key groups of zero padding behind this lane's points
   if (c_tiles) {
     const int Tb = (int)p.C.plane_stride;
     const int blk = n / Tb, kib = n - blk * Tb;                        // Tb % 4 == 0: the 4 points share block and tile
     tcol = (unsigned)(blk * (512 * NPL) + (kib >> 5) * (32 * NPL) + (kib & 31));
+    if (n_ok && (kib + 4 == Tb || n + 4 == N)) tpad = ((32 - ((kib + 4) & 31)) & 31) >> 2;
   }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
@@ -664,6 +672,18 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
           if (c_tiles) __builtin_amdgcn_raw_buffer_store_b64(l2, Cr, off[t], 64, 0);
           else __builtin_amdgcn_raw_buffer_store_b64(l2, Crl, off[t], 0, 0);
         }
+      }
+      if (c_tiles && tpad > 0) {
+        // this lane's 4 points end their block (or the map): the keys up to the end of that 32-key tile are padding the
+        // attention kernels read as zeros — written here, so that no caller has to clear them
+        const u32x2 z2 = {0u, 0u};
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+          for (int g = 1; g <= tpad; ++g) {
+            const unsigned po = off[t] == CSN_OOB ? CSN_OOB : off[t] + 8u * (unsigned)g;
+            __builtin_amdgcn_raw_buffer_store_b64(z2, Cr, po, 0, 0);
+            if constexpr (NPL == 2) __builtin_amdgcn_raw_buffer_store_b64(z2, Cr, po, 64, 0);
+          }
       }
     } else {
       if (p.accumulate) {

@@ -345,12 +345,8 @@ class _MHAEvals(torch.autograd.Function):
             ldp = nb * 512 * npl
             qkv = torch.empty((S, D, NP), device=dev, dtype=torch.float32)                    # Qs
             kv_dtype = torch.float16 if ctx.mode == 3 else torch.bfloat16
-            if NP < NPP:
-                kv = torch.zeros((S, 2 * D, ldp), device=dev, dtype=kv_dtype)                  # ragged last block: its tail tiles read as zeros
-            else:
-                kv = torch.empty((S, 2 * D, ldp), device=dev, dtype=kv_dtype)
-            if T % 32:
-                kv.view(S, 2 * D, nb, 16, npl, 32)[:, :, :, (T - 1) // 32, :, T % 32:] = 0     # padding keys of the last tile
+            # (the projection writes the zero padding of every block's last 32-key tile itself)
+            kv = torch.empty((S, 2 * D, ldp), device=dev, dtype=kv_dtype)
             for first, step, count in (plan.q_ranges or [(0, 1, S)]):
                 _lib.check(L.csn_project_f32(x_all.data_ptr() + 4 * first * C * NP, step * C * NP, NP, _ptr(w_qkv), D, C,
                                              qkv.data_ptr() + 4 * first * D * NP, step * D * NP, NP, count, NP, D, temperature,
@@ -520,9 +516,7 @@ class _MHAEvals(torch.autograd.Function):
             if ctx.mode == 3:
                 # fp16 forward / bf16 backward: the forward's K / V planes hold fp16 bits — project them again as bf16 planes
                 # (one GEMM over the slots; the alternative, fp16 gradient products, underflows)
-                kv = (torch.zeros_like if NP < geo.n_padded else torch.empty_like)(kv, dtype=torch.bfloat16)
-                if T % 32:
-                    kv.view(S, 2 * D, nb, 16, 1, 32)[:, :, :, (T - 1) // 32, :, T % 32:] = 0
+                kv = torch.empty_like(kv, dtype=torch.bfloat16)
                 _lib.check(L.csn_project_f32(_ptr(x_all), x_all.stride(0), NP, _ptr(w_qkv[D:]), 2 * D, C, _ptr(kv), kv_stride,
                                              kv_pitch, S, NP, 0, 1.0, 2, T, _stream()), "csn_project_f32")
             k_ptr = kv.data_ptr()

@@ -72,7 +72,7 @@ int csn_version(void);
  * pitch 512, ld_out = n_blocks * 512, and a probs_tiles backward leaves P and dS as compact rows — see (3)).
  * csn_project_f32 with out_split = 2 writes, per output row and per attention block of `out_plane_stride` (<= 512) points,
  * 16 tiles of [hi: 32 keys | lo: 32 keys] bf16 — block pitch 1024, row pitch ld_out = n_blocks * 1024, out_shape_stride in
- * bf16 elements; the padding keys of a block's last tile are not written and must be zero.  Every 32-key tile row is then
+ * bf16 elements; the padding keys of a block's last 32-key tile are written as zeros (tiles beyond it are not touched and never read).  Every 32-key tile row is then
  * 128 contiguous, 128-byte aligned bytes that the attention kernels stage into LDS with plain copies.  The attention
  * entry points take such a tensor for k and v when qkv_split / kv_split != 0 (then *_plane_stride = that row pitch and
  * kv_shape_stride counts bf16 elements); q stays fp32.
