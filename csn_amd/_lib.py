@@ -128,10 +128,10 @@ _SIGNATURES = {
     "csn_block_attn_bwd_dq_recompute_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_void_p,
                                                     c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                                     c_void_p, c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_int, c_int,
-                                                    c_int, c_int, c_int, c_int, c_float, c_ulonglong, c_longlong, c_int,
+                                                    c_int, c_int, c_int, c_int, c_float, c_ulonglong, c_longlong, c_int, c_int,
                                                     c_void_p, c_int, c_void_p]),
     "csn_block_attn_bwd_dkv_flash_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p,
-                                                 c_longlong, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_void_p,
+                                                 c_longlong, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                                  c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                                                  c_int, c_int, c_int, c_float, c_ulonglong, c_void_p, c_int, c_void_p]),
     "csn_block_attn_bwd_dkv_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_void_p, c_void_p,

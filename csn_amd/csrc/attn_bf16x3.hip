@@ -296,7 +296,25 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
         g[i] = csn_bload4(rs, (i == NP_T - 1 && !t_last_ok) ? CSN_OOB : off, (unsigned)(k0 + 64 * i * ldk) * 4u);
     }
   };
-  auto commitA_to = [&](short* img, short* img_lo, const f32x4* g) {       // img / img_lo: hi / lo plane of a k-major image
+  // backward of an fp16 forward (math mode 3): the K / V tile planes hold fp16 bits and the backward's products are bf16 —
+  // every piece is converted once, in registers, on its way into LDS (instead of projecting K and V a second time)
+  constexpr bool CAN_CVT = BWD && KVP && PR::NPL == 1 && !PR::HALF;
+  const bool kv_f16 = CAN_CVT && p.kv_f16;
+  auto cvt_pieces = [&](f32x4* g) {
+    if constexpr (CAN_CVT) {
+      if (kv_f16) {
+#pragma unroll
+        for (int i = 0; i < NP_T; ++i) {
+          s16x8 v = __builtin_bit_cast(s16x8, g[i]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = to16<false>(from16<true>(v[j]));
+          g[i] = __builtin_bit_cast(f32x4, v);
+        }
+      }
+    }
+  };
+  auto commitA_to = [&](short* img, short* img_lo, f32x4* g, bool cvt = true) {       // img / img_lo: hi / lo plane of a k-major image
+    if (cvt) cvt_pieces(g);
 #pragma unroll
     for (int i = 0; i < NP_T; ++i)
       if (i < NP_T - 1 || t_last_ok) {
@@ -313,7 +331,8 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
         }
       }
   };
-  auto commitB_from = [&](int st, const f32x4* g) {
+  auto commitB_from = [&](int st, f32x4* g, bool cvt = true) {
+    if (cvt) cvt_pieces(g);
 #pragma unroll
     for (int i = 0; i < NP_T; ++i)
       if (i < NP_T - 1 || t_last_ok) {
@@ -554,7 +573,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     // segment 1, so both are committed in segment 1 of the tile before (see the hazard note below); the K pieces stay in
     // registers (g2) until the key-contiguous image has taken them in segment 2.
     fetch_to(Ar, 0, g); commitA_to(tileA(0, 0), tileA(0, NPL - 1), g);
-    fetch_to(Br, 0, g2); commitA_to(tileC(0, 0), tileC(0, NPL - 1), g2); commitB_from(0, g2);
+    fetch_to(Br, 0, g2); commitA_to(tileC(0, 0), tileC(0, NPL - 1), g2); commitB_from(0, g2, false);
     if (nkt > 1) { fetch_to(Ar, 1, g); fetch_to(Br, 1, g2); }
   } else {
     fetch(Ar, 0); commitA(0);
@@ -607,7 +626,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     phase2(cur);
     STAMP(5);
     if constexpr (RC) {
-      if (more) { commitB_from(nxt, g2); if (kt + 2 < nkt) { fetch_to(Ar, kt + 2, g); fetch_to(Br, kt + 2, g2); } }
+      if (more) { commitB_from(nxt, g2, false); if (kt + 2 < nkt) { fetch_to(Ar, kt + 2, g); fetch_to(Br, kt + 2, g2); } }
     } else {
       if (more) { commitB(nxt); if (kt + 2 < nkt) fetch(Ar, kt + 2); }
     }

@@ -136,6 +136,17 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
         Vl[s][j] = pick(32 * s + 8 * kq + j, NPL - 1);
       }
     __syncthreads();                                                // the staging block becomes the tile images
+    if constexpr (NPL == 1 && !PR::HALF) {
+      if (p.kv_f16) {                                               // planes of an fp16 forward: this kernel's products are bf16
+#pragma unroll
+        for (int s = 0; s < DT; ++s)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            Kh[s][j] = Kl[s][j] = to16<false>(from16<true>(Kh[s][j]));
+            Vh[s][j] = Vl[s][j] = to16<false>(from16<true>(Vh[s][j]));
+          }
+      }
+    }
   }
 
   f32x4v dK[D / 16], dV[D / 16];

@@ -247,6 +247,7 @@ static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_e
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
   if (dctx_split) return CSN_E_ARG;                                  // reserved (see header)
   if (kv_split && mode() == 0) return CSN_E_ARG;
+  if (kv_split < 0 || kv_split > 2 || (kv_split == 2 && mode() != 2)) return CSN_E_ARG;   // 2: fp16 planes of a mode-3 forward
   if (mode() == 3) return CSN_E_ARG;                                 // fp16: forward only — run the backward in mode 2
   if (mode() == 2 && !(kv_split && (probs_tiles || q))) return CSN_E_ARG;   // single-product mode: tile planes in and out
   const int bp = 512 * planes_of(mode());
@@ -279,7 +280,8 @@ static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_e
   a.rescale_threshold = 0.f;
   a.eval_ids = eval_ids; a.grp_off = group_offsets; a.out_index = dq_index; a.accumulate = accumulate;
   a.dropout_p = dropout_p; a.seed = seed;
-  a.r_planes = 0; a.kv_planes = kv_split; a.r_plane_stride = 0; a.kv_plane_stride = 0; a.kv_ld = (int)kv_plane_stride;
+  a.r_planes = 0; a.kv_planes = kv_split != 0; a.r_plane_stride = 0; a.kv_plane_stride = 0; a.kv_ld = (int)kv_plane_stride;
+  a.kv_f16 = kv_split == 2;
   a.sc_tiles = probs_tiles;
   a.tq_arr = tq_arr; a.t_arr = t_arr;
   a.q2 = q; a.q2_shape_stride = q_shape_stride; a.q2_index = q_index;
@@ -307,13 +309,13 @@ int csn_block_attn_bwd_dq_recompute_f32(const float* dctx, const float* ctx, lon
                                         long long dq_slot_stride, const int* dq_index, int accumulate, const int* eval_ids,
                                         int n_launch_evals, int n_heads, int d_head, int block, int n_blocks,
                                         int score_pitch, float dropout_p, unsigned long long seed,
-                                        long long kv_plane_stride, int probs_tiles, const int* group_offsets, int n_groups,
-                                        void* stream) {
+                                        long long kv_plane_stride, int kv_f16, int probs_tiles, const int* group_offsets,
+                                        int n_groups, void* stream) {
   if (!q) return CSN_E_ARG;
   return attn_bwd_dq_impl(dctx, ctx, ctx_eval_stride, k, v, kv_shape_stride, kv_index, ld, probs, dscores, lse, delta, dq,
                           dq_slot_stride, dq_index, accumulate, eval_ids, n_launch_evals, n_heads, d_head, block, n_blocks,
-                          score_pitch, dropout_p, seed, 0, 0, 1, kv_plane_stride, probs_tiles, 0, 0, group_offsets, n_groups,
-                          stream, nullptr, nullptr, q, q_shape_stride, q_index);
+                          score_pitch, dropout_p, seed, 0, 0, kv_f16 ? 2 : 1, kv_plane_stride, probs_tiles, 0, 0, group_offsets,
+                          n_groups, stream, nullptr, nullptr, q, q_shape_stride, q_index);
 }
 
 static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
@@ -402,7 +404,7 @@ int csn_attn_bwd_grouping(int d_head, int block) {
 
 int csn_block_attn_bwd_dkv_flash_f32(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
                                      const int* q_index, const float* k, const float* v, long long kv_shape_stride,
-                                     const int* kv_index, long long kv_plane_stride, int ld, const float* lse,
+                                     const int* kv_index, long long kv_plane_stride, int kv_f16, int ld, const float* lse,
                                      const float* delta, float* dk, float* dv, long long dkv_slot_stride,
                                      const int* dk_index, const int* dv_index, int accumulate, const int* eval_ids,
                                      int n_launch_evals, int n_heads, int d_head, int block, int n_blocks, int score_pitch,
@@ -414,6 +416,7 @@ int csn_block_attn_bwd_dkv_flash_f32(const float* dctx, long long ctx_eval_strid
   if (!(csn_attn_bwd_grouping(d_head, block) & 8)) return CSN_E_ARG;
   if (group_offsets && (n_groups <= 0 || !eval_ids)) return CSN_E_ARG;
   if (dropout_p < 0.f || dropout_p >= 1.f) return CSN_E_ARG;
+  if (kv_f16 && mode() != 2) return CSN_E_ARG;
   const int t_last = last_block_points(block, n_blocks, ld, 0);
   if (t_last < 0) return t_last;
   const int bp = 512 * planes_of(mode());
@@ -431,7 +434,7 @@ int csn_block_attn_bwd_dkv_flash_f32(const float* dctx, long long ctx_eval_strid
   a.accumulate = accumulate;
   a.eval_ids = eval_ids; a.grp_off = group_offsets; a.n_groups = group_offsets ? n_groups : n_launch_evals;
   a.ld = ld; a.H = n_heads; a.T = block; a.Tp = score_pitch; a.n_blocks = n_blocks; a.T_last = t_last;
-  a.dropout_p = dropout_p; a.seed = seed;
+  a.dropout_p = dropout_p; a.seed = seed; a.kv_f16 = kv_f16 != 0;
   return csn_launch_attn_dkv_flash(a, d_head, mode(), (hipStream_t)stream);
 }
 

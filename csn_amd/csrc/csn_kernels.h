@@ -72,6 +72,7 @@ struct CsnAttnArgs {
   // backward with score recomputation (16-bit modes, tile-plane K / V): the pre-scaled queries Qs^T [slot][H*d][ld] of the
   // forward; q2 == nullptr = the scores are read from `scores` (kept by the forward)
   const float* q2 = nullptr; long long q2_shape_stride = 0; const int* q2_index = nullptr;
+  int kv_f16 = 0;                                        // backward, one-plane mode: the K / V tile planes hold fp16 (the forward ran in math mode 3)
 };
 // score recomputation needs three LDS tile images per stage: one plane at every width, two planes up to d = 128
 constexpr bool csn_attn_recompute_fits(int planes, int dt) { return planes == 1 || dt <= 4; }
@@ -88,6 +89,7 @@ struct CsnAttnDkvArgs {
   const int* eval_ids;  const int* grp_off;  int n_groups;                // group g = eval_ids[grp_off[g] .. grp_off[g+1]); no offsets: one evaluation each
   int ld, H, T, Tp, n_blocks, T_last;
   float dropout_p;  unsigned long long seed;
+  int kv_f16 = 0;                                                         // one-plane mode: k / v hold fp16 (forward of math mode 3)
 };
 int csn_launch_attn_dkv_flash(const CsnAttnDkvArgs& a, int d, int mode, hipStream_t st);
 constexpr bool csn_attn_dkv_flash_fits(int dt) { return dt <= 4; }         // K^T, V^T, dK^T, dV^T of 16 keys in one wave's registers

@@ -512,13 +512,10 @@ class _MHAEvals(torch.autograd.Function):
         slot_stride = 3 * D * NP                                   # of the fp32 gradient maps
         q_stride, kv_stride, kv_flag, kv_pitch = ctx.ptrs
         gbase, q_ptr = dqkv.data_ptr(), qkv.data_ptr()
+        # fp16 forward / bf16 backward: the forward's K / V planes hold fp16 bits; the attention backward kernels convert every
+        # piece to bf16 in registers while they stage it (no second projection of K and V)
+        kv_f16 = 1 if (kv_flag and ctx.mode == 3) else 0
         if kv_flag:
-            if ctx.mode == 3:
-                # fp16 forward / bf16 backward: the forward's K / V planes hold fp16 bits — project them again as bf16 planes
-                # (one GEMM over the slots; the alternative, fp16 gradient products, underflows)
-                kv = torch.empty_like(kv, dtype=torch.bfloat16)
-                _lib.check(L.csn_project_f32(_ptr(x_all), x_all.stride(0), NP, _ptr(w_qkv[D:]), 2 * D, C, _ptr(kv), kv_stride,
-                                             kv_pitch, S, NP, 0, 1.0, 2, T, _stream()), "csn_project_f32")
             k_ptr = kv.data_ptr()
             v_ptr = k_ptr + 2 * (D * kv_pitch + plan.v_shift * kv_stride)
         else:
@@ -536,7 +533,7 @@ class _MHAEvals(torch.autograd.Function):
                                                              k_ptr, v_ptr, kv_stride, _ptr(plan.kv_slots), NP, _ptr(scores),
                                                              _ptr(dscores), _ptr(lse), _ptr(delta), gbase, slot_stride,
                                                              _ptr(plan.q_slots), 0, _ptr(plan.q_group_items), E, H, d, T, nb, Tp,
-                                                             p_attn, seed_attn, kv_pitch, pt if flow == tuning.RECOMPUTE_DQ else 0,
+                                                             p_attn, seed_attn, kv_pitch, kv_f16, pt if flow == tuning.RECOMPUTE_DQ else 0,
                                                              _ptr(plan.q_group_off), plan.n_q_groups, _stream()),
                        "csn_block_attn_bwd_dq_recompute_f32")
         elif tune.grouped_dq and (grouping & 1):
@@ -545,7 +542,7 @@ class _MHAEvals(torch.autograd.Function):
                                                    _ptr(plan.kv_slots), NP, _ptr(scores), _ptr(dscores), _ptr(lse),
                                                    _ptr(delta), gbase, slot_stride, _ptr(plan.q_slots), 0,
                                                    _ptr(plan.q_group_items), E, H, d, T, nb, Tp, p_attn, seed_attn, 0, 0,
-                                                   kv_flag, kv_pitch, pt, _ptr(plan.q_group_off), plan.n_q_groups, _stream()),
+                                                   kv_flag + kv_f16, kv_pitch, pt, _ptr(plan.q_group_off), plan.n_q_groups, _stream()),
                        "csn_block_attn_bwd_dq_f32")
         else:
             for ci, ids in enumerate(plan.dq_colors):
@@ -553,7 +550,7 @@ class _MHAEvals(torch.autograd.Function):
                                                        _ptr(plan.kv_slots), NP, _ptr(scores), _ptr(dscores), _ptr(lse),
                                                        _ptr(delta), gbase, slot_stride, _ptr(plan.q_slots),
                                                        0 if ci == 0 else 1, _ptr(ids),
-                                                       ids.numel(), H, d, T, nb, Tp, p_attn, seed_attn, 0, 0, kv_flag,
+                                                       ids.numel(), H, d, T, nb, Tp, p_attn, seed_attn, 0, 0, kv_flag + kv_f16,
                                                        kv_pitch, pt, None, 0, _stream()),
                            "csn_block_attn_bwd_dq_f32")
         if sink is not None:
@@ -564,7 +561,7 @@ class _MHAEvals(torch.autograd.Function):
             # key-stationary kernel: P and dS are rebuilt per (key/value slot, head, block, 128 keys) from lse, delta and the
             # masks' seed; the evaluations of a key/value slot accumulate in registers (grouped) — no score-sized tensor exists
             _lib.check(L.csn_block_attn_bwd_dkv_flash_f32(_ptr(datt), D * NP, q_ptr, q_stride, _ptr(plan.q_slots), k_ptr, v_ptr,
-                                                          kv_stride, _ptr(plan.kv_slots), kv_pitch, NP, _ptr(lse), _ptr(delta),
+                                                          kv_stride, _ptr(plan.kv_slots), kv_pitch, kv_f16, NP, _ptr(lse), _ptr(delta),
                                                           gbase + 4 * D * NP, gbase + 8 * D * NP, slot_stride,
                                                           _ptr(plan.kv_slots), _ptr(plan.v_slots), 0, _ptr(plan.kv_group_items),
                                                           E, H, d, T, nb, Tp, p_attn, seed_attn, _ptr(plan.kv_group_off),

@@ -157,7 +157,10 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
  *   probs_tiles == 0: nothing is written besides delta and dq (`probs` / `dscores` may be NULL) — for a dK / dV pass that
  *                     recomputes the probabilities itself.
  * Available where three LDS tile images per stage fit: mode 2 at every head width, mode 1 up to d_head = 128 (bit 2 of
- * csn_attn_bwd_grouping); CSN_E_ARG elsewhere. */
+ * csn_attn_bwd_grouping); CSN_E_ARG elsewhere.
+ * kv_f16 != 0 (math mode 2 only; also csn_block_attn_bwd_dkv_flash_f32, and kv_split = 2 of csn_block_attn_bwd_dq_f32): k and
+ * v are the tile planes of a forward that ran in math mode 3 — fp16 bits.  The kernels convert every piece to bf16 in
+ * registers on its way into LDS, so the "fp16 forward / bf16 backward" pairing needs no second projection of K and V. */
 int csn_attn_bwd_grouping(int d_head, int block);
 int csn_block_attn_bwd_dq_recompute_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* q,
                                         long long q_shape_stride, const int* q_index, const float* k, const float* v,
@@ -166,8 +169,8 @@ int csn_block_attn_bwd_dq_recompute_f32(const float* dctx, const float* ctx, lon
                                         long long dq_slot_stride, const int* dq_index, int accumulate, const int* eval_ids,
                                         int n_launch_evals, int n_heads, int d_head, int block, int n_blocks,
                                         int score_pitch, float dropout_p, unsigned long long seed,
-                                        long long kv_plane_stride, int probs_tiles, const int* group_offsets, int n_groups,
-                                        void* stream);
+                                        long long kv_plane_stride, int kv_f16, int probs_tiles, const int* group_offsets,
+                                        int n_groups, void* stream);
 int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* k,
                               const float* v, long long kv_shape_stride, const int* kv_index, int ld, float* scores,
                               float* dscores, const float* lse, float* delta, float* dq, long long dq_slot_stride,
@@ -195,7 +198,7 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
  * the grouped csn_block_attn_bwd_dkv_f32 call; without group_offsets every listed evaluation is its own group. */
 int csn_block_attn_bwd_dkv_flash_f32(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
                                      const int* q_index, const float* k, const float* v, long long kv_shape_stride,
-                                     const int* kv_index, long long kv_plane_stride, int ld, const float* lse,
+                                     const int* kv_index, long long kv_plane_stride, int kv_f16, int ld, const float* lse,
                                      const float* delta, float* dk, float* dv, long long dkv_slot_stride,
                                      const int* dk_index, const int* dv_index, int accumulate, const int* eval_ids,
                                      int n_launch_evals, int n_heads, int d_head, int block, int n_blocks, int score_pitch,

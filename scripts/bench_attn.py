@@ -86,7 +86,7 @@ def main():
                                                              k_ptr, v_ptr, kv_stride, CF._ptr(ks), NP, CF._ptr(scores) if pt else None,
                                                              CF._ptr(dscores) if pt else None, CF._ptr(lse), CF._ptr(delta),
                                                              dqkv.data_ptr(), 3 * D * NP, None, 0, None, E, H, d, T, nb, Tp, a.drop,
-                                                             seed, kvp, pt, None, 0, st), "dq recompute")
+                                                             seed, kvp, 0, pt, None, 0, st), "dq recompute")
             return
         _lib.check(L.csn_block_attn_bwd_dq_f32(CF._ptr(datt), CF._ptr(att), D * NP, k_ptr if tl else base + 4 * D * NP,
                                                v_ptr if tl else base + 8 * D * NP,
@@ -98,7 +98,7 @@ def main():
         gb = dqkv.data_ptr()
         if a.recompute == 2 and a.tiles and (L.csn_attn_bwd_grouping(d, T) & 8):
             _lib.check(L.csn_block_attn_bwd_dkv_flash_f32(CF._ptr(datt), D * NP, base, 3 * D * NP, CF._ptr(qs), k_ptr, v_ptr, kv_stride,
-                                                          CF._ptr(ks), kvp, NP, CF._ptr(lse), CF._ptr(delta), gb + 4 * D * NP,
+                                                          CF._ptr(ks), kvp, 0, NP, CF._ptr(lse), CF._ptr(delta), gb + 4 * D * NP,
                                                           gb + 8 * D * NP, 3 * D * NP, None, None, 0, None, E, H, d, T, nb, Tp, a.drop,
                                                           seed, None, 0, st), "dkv flash")
             return

@@ -33,7 +33,7 @@ def run(mode, S, E, H, d, T, nb, p_drop):
         ds1, de1, dq1 = bufs(); pr1 = torch.zeros((E, H, nb, T, Tp), device="cuda")
         L.check(lib.csn_block_attn_bwd_dq_recompute_f32(dctx.data_ptr(), ctx.data_ptr(), D * N, q.data_ptr(), D * N, qi.data_ptr(), k_ptr, v_ptr, kv_stride,
                                                         ki.data_ptr(), N, pr1.data_ptr(), ds1.data_ptr(), lse.data_ptr(), de1.data_ptr(), dq1.data_ptr(), D * N,
-                                                        None, 0, None, E, H, d, T, nb, Tp, p_drop, seed, ldp, 1, None, 0, _stream()))
+                                                        None, 0, None, E, H, d, T, nb, Tp, p_drop, seed, ldp, 0, 1, None, 0, _stream()))
         outs.append((ds1, de1, dq1, pr1))
     torch.cuda.synchronize()
     ds1, de1, dq1, pr1 = outs[0]

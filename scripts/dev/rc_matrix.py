@@ -27,7 +27,7 @@ for (mode, S, E, H, d, T, nb) in [(1, 1, 1, 1, 64, 64, 1), (1, 2, 3, 1, 128, 500
         if rc:
             L.check(lib.csn_block_attn_bwd_dq_recompute_f32(dctx.data_ptr(), ctx.data_ptr(), D * N, q.data_ptr(), D * N, qi.data_ptr(), k_ptr, v_ptr, kv_stride,
                                                             ki.data_ptr(), N, sc.data_ptr(), ds.data_ptr(), lse.data_ptr(), de.data_ptr(), dq.data_ptr(), D * N,
-                                                            None, 0, None, E, H, d, T, nb, Tp, 0.0, 0, ldp, pt, None, 0, _stream()))
+                                                            None, 0, None, E, H, d, T, nb, Tp, 0.0, 0, ldp, 0, pt, None, 0, _stream()))
         else:
             L.check(lib.csn_block_attn_bwd_dq_f32(dctx.data_ptr(), ctx.data_ptr(), D * N, k_ptr, v_ptr, kv_stride, ki.data_ptr(), N, sc.data_ptr(), ds.data_ptr(),
                                                   lse.data_ptr(), de.data_ptr(), dq.data_ptr(), D * N, None, 0, None, E, H, d, T, nb, Tp, 0.0, 0, 0, 0, 1, ldp, pt, None, 0, _stream()))

@@ -131,13 +131,13 @@ def test_recomputed_scores_equal_the_kept_ones(L, mode, S, E, H, d, T, nb, p_dro
     L.check(lib.csn_block_attn_bwd_dq_recompute_f32(dctx.data_ptr(), ctx.data_ptr(), D * N, q.data_ptr(), D * N, qi.data_ptr(),
                                                     k_ptr, v_ptr, kv_stride, ki.data_ptr(), N, pr1.data_ptr(), ds1.data_ptr(),
                                                     lse.data_ptr(), delta1.data_ptr(), dq1.data_ptr(), D * N, None, 0, None, E,
-                                                    H, d, T, nb, Tp, p_drop, seed, ldp, 1, None, 0, _stream()), "dq recompute")
+                                                    H, d, T, nb, Tp, p_drop, seed, ldp, 0, 1, None, 0, _stream()), "dq recompute")
     # recomputed, nothing written besides delta and dq
     _, delta2, dq2 = buffers()
     L.check(lib.csn_block_attn_bwd_dq_recompute_f32(dctx.data_ptr(), ctx.data_ptr(), D * N, q.data_ptr(), D * N, qi.data_ptr(),
                                                     k_ptr, v_ptr, kv_stride, ki.data_ptr(), N, None, None,
                                                     lse.data_ptr(), delta2.data_ptr(), dq2.data_ptr(), D * N, None, 0, None, E,
-                                                    H, d, T, nb, Tp, p_drop, seed, ldp, 0, None, 0, _stream()), "dq recompute, no planes")
+                                                    H, d, T, nb, Tp, p_drop, seed, ldp, 0, 0, None, 0, _stream()), "dq recompute, no planes")
     torch.cuda.synchronize()
     assert torch.equal(delta0, delta1) and torch.equal(delta0, delta2)
     # the recomputed S is the forward's product in the forward's order (the same bits: the P planes below are equal); the two
@@ -182,7 +182,7 @@ def test_recomputed_scores_equal_the_kept_ones(L, mode, S, E, H, d, T, nb, p_dro
     if flash:
         dk2, dv2 = (torch.full((E, D, N), float("nan"), device="cuda") for _ in range(2))
         L.check(lib.csn_block_attn_bwd_dkv_flash_f32(dctx.data_ptr(), D * N, q.data_ptr(), D * N, qi.data_ptr(), k_ptr, v_ptr,
-                                                     kv_stride, ki.data_ptr(), ldp, N, lse.data_ptr(), delta2.data_ptr(),
+                                                     kv_stride, ki.data_ptr(), ldp, 0, N, lse.data_ptr(), delta2.data_ptr(),
                                                      dk2.data_ptr(), dv2.data_ptr(), D * N, None, None, 0, None, E, H, d, T, nb,
                                                      Tp, p_drop, seed, None, 0, _stream()), "dkv flash")
         torch.cuda.synchronize()
@@ -196,7 +196,7 @@ def test_recomputed_scores_equal_the_kept_ones(L, mode, S, E, H, d, T, nb, p_dro
     L.check(lib.csn_block_attn_bwd_dq_recompute_f32(dctx.data_ptr(), ctx.data_ptr(), D * N, q.data_ptr(), D * N, qi.data_ptr(),
                                                     k_ptr, v_ptr, kv_stride, ki.data_ptr(), N, None, None,
                                                     lse.data_ptr(), delta2.data_ptr(), gq.data_ptr(), D * N, qi.data_ptr(), 0,
-                                                    plan.q_group_items.data_ptr(), E, H, d, T, nb, Tp, p_drop, seed, ldp, 0,
+                                                    plan.q_group_items.data_ptr(), E, H, d, T, nb, Tp, p_drop, seed, ldp, 0, 0,
                                                     plan.q_group_off.data_ptr(), plan.n_q_groups, _stream()), "dq grouped")
     torch.cuda.synchronize()
     ref = torch.zeros(S, D, N, dtype=torch.float64).index_add_(0, torch.from_numpy(q_idx).long(), rq)
@@ -205,7 +205,7 @@ def test_recomputed_scores_equal_the_kept_ones(L, mode, S, E, H, d, T, nb, p_dro
     if flash:       # the evaluations of a key/value slot into one set of dK / dV accumulators
         gk, gv = (torch.full((S, D, N), float("nan"), device="cuda") for _ in range(2))
         L.check(lib.csn_block_attn_bwd_dkv_flash_f32(dctx.data_ptr(), D * N, q.data_ptr(), D * N, qi.data_ptr(), k_ptr, v_ptr,
-                                                     kv_stride, ki.data_ptr(), ldp, N, lse.data_ptr(), delta2.data_ptr(),
+                                                     kv_stride, ki.data_ptr(), ldp, 0, N, lse.data_ptr(), delta2.data_ptr(),
                                                      gk.data_ptr(), gv.data_ptr(), D * N, ki.data_ptr(), ki.data_ptr(), 0,
                                                      plan.kv_group_items.data_ptr(), E, H, d, T, nb, Tp, p_drop, seed,
                                                      plan.kv_group_off.data_ptr(), plan.n_kv_groups, _stream()), "dkv flash grouped")
@@ -217,6 +217,67 @@ def test_recomputed_scores_equal_the_kept_ones(L, mode, S, E, H, d, T, nb, p_dro
         assert _err(gk[used], ref_k[used]) < bound and _err(gv[used], ref_v[used]) < bound
 
 
+@pytest.mark.parametrize("d,T,nb", [(96, 500, 2), (256, 100, 3)])
+def test_fp16_planes_are_converted_while_staged(L, d, T, nb):
+    """The backward of an fp16 forward (math mode 3 -> backward in mode 2): K / V planes that hold fp16 bits, flagged kv_f16,
+    give exactly the gradients of the same values handed over as bf16 planes — no second projection is needed."""
+    lib = L.lib()
+    L.check(lib.csn_set_math_mode(2))
+    rng = np.random.default_rng(9)
+    S = E = 2
+    H, D, N = 1, d, T * nb
+    Tp = (T + 31) // 32 * 32
+    q = (_rand(rng, S, D, N) / math.sqrt(math.sqrt(d))).cuda()
+    kvf = torch.cat((_rand(rng, S, D, N) / math.sqrt(math.sqrt(d)), _rand(rng, S, D, N)), dim=1).cuda().half()
+    dctx = _rand(rng, E, D, N).cuda()
+    idx = torch.arange(E, dtype=torch.int32, device="cuda")
+    ldp = nb * 512
+    planes16 = tile_planes(kvf.float(), T, nb, 1).view(torch.int16)        # placeholder shape; filled with fp16 bits below
+    p = torch.zeros((S, 2 * D, nb, 512), device="cuda", dtype=torch.float16)
+    p[..., :T] = kvf.view(S, 2 * D, nb, T)
+    planes_f16 = p.reshape(S, 2 * D, ldp).contiguous()
+    planes_bf16 = tile_planes(kvf.float(), T, nb, 1)                       # bf16(fp16(x)): what the kernels' conversion yields
+    assert planes16.shape == planes_f16.view(torch.int16).shape
+    ctx, lse = torch.zeros((E, D, N), device="cuda"), torch.zeros((E, H, N), device="cuda")
+    sc = torch.zeros((E, H, nb, T, Tp), device="cuda")
+    kp = planes_bf16.data_ptr()
+    L.check(lib.csn_block_attn_fwd_f32(q.data_ptr(), kp, kp + 2 * D * ldp, D * N, 2 * D * ldp, idx.data_ptr(), idx.data_ptr(), N,
+                                       ctx.data_ptr(), D * N, sc.data_ptr(), lse.data_ptr(), E, H, d, T, nb, Tp, 8.0, 0.1, 77, 1, ldp,
+                                       _stream()))
+    outs = []
+    for planes, f16 in ((planes_bf16, 0), (planes_f16, 1)):
+        kp = planes.data_ptr()
+        vp = kp + 2 * D * ldp
+        res = []
+        ds, de, dq = torch.zeros_like(sc), torch.zeros((E, H, N), device="cuda"), torch.zeros((E, D, N), device="cuda")
+        s2 = sc.clone()
+        L.check(lib.csn_block_attn_bwd_dq_f32(dctx.data_ptr(), ctx.data_ptr(), D * N, kp, vp, 2 * D * ldp, idx.data_ptr(), N,
+                                              s2.data_ptr(), ds.data_ptr(), lse.data_ptr(), de.data_ptr(), dq.data_ptr(), D * N, None,
+                                              0, None, E, H, d, T, nb, Tp, 0.1, 77, 0, 0, 1 + f16, ldp, 1, None, 0, _stream()), "kept")
+        res.append(dq)
+        dq2, de2 = torch.zeros((E, D, N), device="cuda"), torch.zeros((E, H, N), device="cuda")
+        L.check(lib.csn_block_attn_bwd_dq_recompute_f32(dctx.data_ptr(), ctx.data_ptr(), D * N, q.data_ptr(), D * N, idx.data_ptr(),
+                                                        kp, vp, 2 * D * ldp, idx.data_ptr(), N, None, None, lse.data_ptr(),
+                                                        de2.data_ptr(), dq2.data_ptr(), D * N, None, 0, None, E, H, d, T, nb, Tp, 0.1,
+                                                        77, ldp, f16, 0, None, 0, _stream()), "recompute")
+        res.append(dq2)
+        if lib.csn_attn_bwd_grouping(d, T) & 8:
+            dk, dv = torch.zeros((E, D, N), device="cuda"), torch.zeros((E, D, N), device="cuda")
+            L.check(lib.csn_block_attn_bwd_dkv_flash_f32(dctx.data_ptr(), D * N, q.data_ptr(), D * N, idx.data_ptr(), kp, vp,
+                                                         2 * D * ldp, idx.data_ptr(), ldp, f16, N, lse.data_ptr(), de2.data_ptr(),
+                                                         dk.data_ptr(), dv.data_ptr(), D * N, None, None, 0, None, E, H, d, T, nb, Tp,
+                                                         0.1, 77, None, 0, _stream()), "flash")
+            res += [dk, dv]
+        torch.cuda.synchronize()
+        outs.append(res)
+    for a, b in zip(*outs):
+        assert a.abs().max().item() > 0 and torch.equal(a, b)
+    L.check(lib.csn_set_math_mode(1))                                      # two planes: no fp16 forward to pair with
+    assert lib.csn_block_attn_bwd_dq_f32(dctx.data_ptr(), ctx.data_ptr(), D * N, kp, vp, 2 * D * ldp, idx.data_ptr(), N, sc.data_ptr(),
+                                         ds.data_ptr(), lse.data_ptr(), de.data_ptr(), dq.data_ptr(), D * N, None, 0, None, E, H, d, T,
+                                         nb, Tp, 0.1, 77, 0, 0, 2, 2 * ldp, 1, None, 0, _stream()) == -1
+
+
 def test_recompute_is_refused_where_it_has_no_kernel(L):
     lib = L.lib()
     L.check(lib.csn_set_math_mode(1))
@@ -224,7 +285,7 @@ def test_recompute_is_refused_where_it_has_no_kernel(L):
     z = torch.zeros(64, device="cuda")
     rc = lib.csn_block_attn_bwd_dq_recompute_f32(z.data_ptr(), z.data_ptr(), 0, z.data_ptr(), 0, None, z.data_ptr(),
                                                  z.data_ptr(), 0, None, 36, None, None, z.data_ptr(), z.data_ptr(),
-                                                 z.data_ptr(), 0, None, 0, None, 1, 1, 256, 36, 1, 64, 0.0, 0, 1024, 0, None, 0,
+                                                 z.data_ptr(), 0, None, 0, None, 1, 1, 256, 36, 1, 64, 0.0, 0, 1024, 0, 0, None, 0,
                                                  _stream())
     assert rc == -1
     L.check(lib.csn_set_math_mode(0))
