@@ -141,3 +141,49 @@ def test_config3_full_size_benched_step_is_checked():
     """The step bench.py times (BASELINE configs[2]: 32 x 10000 x 256, K = 3, train mode) — loss and every gradient of the
     bf16x3 mode against the exact-fp32 mode at full size, same dropout masks."""
     _full_size_properties(B=32, K=3, N=10000, C=256, T=500, seed=3030)
+
+
+def _named_mode_report(B, K, N, C, T, seed, mode, name):
+    """A BASELINE configuration in the reduced-precision arithmetic it NAMES (configs[1]: bf16, configs[4]: "fp16 MFMA"), at full
+    size, against the same step in exact fp32 with the same dropout masks: finite everywhere, the error printed, and held to
+    loose bounds (these modes are outside the 1e-4 contract; tests/test_gpu_lowprec.py reports them per operation).  The
+    single-product modes run the score-recomputing data flows where they are the default (d <= 128), so this is also their
+    full-size check."""
+    n_cls = 39
+    geo = dict(d_model=C, d_k=C, d_v=C, block=T, n_blocks=N // T)
+    rng = np.random.default_rng(seed)
+    p = orc.make_params(rng, 1, d_model=C, d_k=C, d_v=C, n_cls=n_cls, csa=True)
+    p["attention.fc.weight"] = p["attention.fc.weight"] * 4.0
+    x = torch.from_numpy(rng.standard_normal((B, C, N, 1)).astype(np.float32)).cuda()
+    x += torch.from_numpy(rng.standard_normal((B, C, 1, 1)).astype(np.float32)).cuda()
+    nb = torch.empty((B, K + 1, C, N, 1), device="cuda")
+    nb[:, 0] = x
+    for k in range(K):
+        nb[:, k + 1] = torch.from_numpy(rng.standard_normal((B, C, N, 1)).astype(np.float32)).cuda()
+        nb[:, k + 1] += torch.from_numpy(rng.standard_normal((B, C, 1, 1)).astype(np.float32)).cuda()
+    lab = orc.synth_labels(rng, B, N, n_cls).cuda()
+    model = _module(p, n_cls, K, **geo).train()
+    res = {}
+    for m in (0, mode):
+        _set_mode(m)
+        torch.manual_seed(123)                                  # the masks are functions of (seed, position), not of the mode
+        res[m] = _step(model, x, nb, lab)
+    (l0, s0, g0), (l1, s1, g1) = res[0], res[mode]
+    assert torch.isfinite(l1).all() and np.isfinite(s1) and len(g1) == 11
+    e_logit = (l0 - l1).abs().max().item()
+    e_grad = {n: ((g0[n] - g1[n]).abs().max() / g0[n].abs().max()).item() for n in g0}
+    worst = max(e_grad, key=e_grad.get)
+    print(f"[named mode] {name}: max |dlogit| {e_logit:.2e}, |dloss| {abs(s0 - s1):.2e}, worst gradient {worst} {e_grad[worst]:.2e} (relative to its max)")
+    assert e_logit < 5e-2 and abs(s0 - s1) < 2e-3
+    for n, g in g1.items():
+        assert torch.isfinite(g).all() and e_grad[n] < 3e-2, (n, e_grad[n])
+
+
+def test_config2_full_size_in_bf16():
+    """BASELINE configs[1] as named: CSA K = 2, 4 shapes x 10000 points x 256 channels, bf16."""
+    _named_mode_report(B=4, K=2, N=10000, C=256, T=500, seed=2020, mode=2, name="config 2, bf16")
+
+
+def test_config5_full_size_in_fp16():
+    """BASELINE configs[4] as named: 8 shapes x 50000 points x 96 channels, K = 4, fp16 MFMA (forward; backward in bf16)."""
+    _named_mode_report(B=8, K=4, N=50000, C=96, T=500, seed=5151, mode=3, name="config 5, fp16")
