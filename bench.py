@@ -207,7 +207,7 @@ def main():
     if world == 1 and os.environ.get("CSN_BENCH_HOST_NB") == "1":
         x_nb_host = x_nb_resident.cpu().pin_memory()
 
-    attn_events = {"fwd": [], "bwd": []}
+    attn_events = {"fwd": [], "bwd": [], "dkv": []}      # dkv: the key-stationary dK / dV launch of the score-recomputing flow
     exchange_mode = os.environ.get("CSN_EXCHANGE", "alltoall")           # "allgather": the whole collection to every rank
     overlap = os.environ.get("CSN_OVERLAP", "1") != "0"                  # exchange in flight under the self-attention evaluations
 
@@ -332,25 +332,31 @@ def main():
             with open(TRAFFIC_FILE) as fh:
                 traffic_tab = json.load(fh)
 
-        def roof(math, which, ms):
+        def roof(math, which, ms_all):
+            ms = ms_all[which]
+            flash = not np.isnan(ms_all.get("dkv", float("nan")))       # the step ran the score-recomputing flow
             fast = math != "fp32"
             ach = launch_flops / (ms * 1e-3) / 1e12
             peak = PEAK_TFLOPS[math]
-            tmpl = f"<{d // 32},{'true' if which == 'bwd' else 'false'}{',true' if fast else ''}>"
+            tmpl = f"<{d // 32}>" if which == "dkv" else f"<{d // 32},{'true' if which == 'bwd' else 'false'}{',true' if fast else ''}>"
             # the committed counter passes are of the single-call step at the configuration's own size: other launch shapes
             # (descriptor reuse / the two-phase order of the N > 1 path, --shapes, --K) have no measured traffic
             same_launch = (B, K) == (CONFIGS[args.config]["B"], CONFIGS[args.config]["K"]) and not reuse and not split_probe
             entry = traffic_tab.get(f"{args.config}/{math}/{which}") if same_launch else None
             r = {"bound": "mfma",
-                 "kernel": ("csn_attn_bf16x3_kernel" if fast else "csn_attn_f32_kernel") + tmpl
-                           + (" (fused block attention backward: dP, dS, dQ)" if which == "bwd" else " (fused block attention forward)"),
+                 "kernel": ("csn_attn_dkv_kernel" if which == "dkv" else "csn_attn_bf16x3_kernel" if fast else "csn_attn_f32_kernel") + tmpl
+                           + {"bwd": " (fused block attention backward: dP, dS, dQ" + ("; scores recomputed)" if flash else ")"),
+                              "fwd": " (fused block attention forward)",
+                              "dkv": " (key-stationary attention backward: dV, dK from recomputed P, dS)"}[which],
                  "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                  "traffic": entry["bytes_per_launch"] if entry else None,
                  "traffic_source": (entry["source"] + " (rocprofv3 --pmc passes of this command, not measured in this run)") if entry else None,
                  "launch_ms": ms, "launch_ms_is": f"mean over {args.steps} timed steps of the step's launches of this kernel (HIP events on the launch stream)",
                  "flops_per_launch": launch_flops,
                  "note": f"algorithmic FLOPs: 4*T*d = {4 * T * d // 1000} kFLOP per query point per evaluation x {N} points x "
-                         f"{n_evals} evaluations in the launch"}
+                         f"{n_evals} evaluations in the launch"
+                         + (" (dV = P^T dO and dK = dS^T Qs; the S and dP products this kernel recomputes are not credited)" if which == "dkv" else "")
+                         + (" (dP and dQ; the recomputed S product is not credited)" if which == "bwd" and flash else "")}
             if math == "bf16x3":
                 r["note"] += "; this mode issues 3 bf16 matrix FLOPs per algorithmic FLOP, so the matrix pipe sees 3x `achieved`"
             if entry:
@@ -362,9 +368,10 @@ def main():
             return r
 
         def roofs(math, ms):
-            dom = "bwd" if not (ms["bwd"] < ms["fwd"]) else "fwd"     # NaN-safe: backward unless the forward is longer
-            oth = "fwd" if dom == "bwd" else "bwd"
-            return roof(math, dom, ms[dom]), roof(math, oth, ms[oth])
+            # the dominant of the step's fused attention launches (NaN = did not run), then the next one
+            ran = sorted((k for k in ms if not np.isnan(ms[k])), key=lambda k: -ms[k]) or ["bwd", "fwd"]
+            dom, oth = ran[0], (ran[1] if len(ran) > 1 else ran[0])
+            return roof(math, dom, ms), roof(math, oth, ms)
 
         dominant, second = roofs(args.math, attn_ms)
         med_ms = float(np.median(step_ms))

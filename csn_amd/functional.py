@@ -560,12 +560,19 @@ class _MHAEvals(torch.autograd.Function):
         if flow == tuning.FLASH:
             # key-stationary kernel: P and dS are rebuilt per (key/value slot, head, block, 128 keys) from lse, delta and the
             # masks' seed; the evaluations of a key/value slot accumulate in registers (grouped) — no score-sized tensor exists
+            if sink is not None:
+                ev0 = torch.cuda.Event(enable_timing=True)
+                ev0.record()
             _lib.check(L.csn_block_attn_bwd_dkv_flash_f32(_ptr(datt), D * NP, q_ptr, q_stride, _ptr(plan.q_slots), k_ptr, v_ptr,
                                                           kv_stride, _ptr(plan.kv_slots), kv_pitch, kv_f16, NP, _ptr(lse), _ptr(delta),
                                                           gbase + 4 * D * NP, gbase + 8 * D * NP, slot_stride,
                                                           _ptr(plan.kv_slots), _ptr(plan.v_slots), 0, _ptr(plan.kv_group_items),
                                                           E, H, d, T, nb, Tp, p_attn, seed_attn, _ptr(plan.kv_group_off),
                                                           plan.n_kv_groups, _stream()), "csn_block_attn_bwd_dkv_flash_f32")
+            if sink is not None:
+                ev1 = torch.cuda.Event(enable_timing=True)
+                ev1.record()
+                sink.setdefault("dkv", []).append((ev0, ev1))
         elif tune.grouped_dkv and (grouping & 2):
             # one call: the evaluations of a key/value slot are contracted one after the other into the same accumulators
             _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, q_ptr, q_stride, _ptr(plan.q_slots), NP,

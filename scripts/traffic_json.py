@@ -14,11 +14,11 @@ def main():
     label = sys.argv[4] if len(sys.argv) > 4 else os.path.relpath(path, ROOT)
     vals = {}
     for line in open(path):
-        m = re.match(r"csn_attn_\w+<(.*?)>.*?(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+\s+mean=\s*([0-9.]+)", line)
+        m = re.match(r"(csn_attn_\w+)<([^>]*?)(?:>\S*)?\s+(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+\s+mean=\s*([0-9.]+)", line)
         if m:
-            args = [a.strip() for a in m.group(1).split(",")]          # <mode, DT, BWD, KVP>
-            which = "bwd" if args[-2] == "true" else "fwd"
-            vals.setdefault(which, {})[m.group(2)] = float(m.group(3))
+            args = [a.strip() for a in m.group(2).split(",")]          # attention: <mode, DT, BWD, KVP[, RC]> (names may be cut short)
+            which = "dkv" if m.group(1) == "csn_attn_dkv_kernel" else ("bwd" if len(args) > 2 and args[2] == "true" else "fwd")
+            vals.setdefault(which, {})[m.group(3)] = float(m.group(4))
     out_path = os.path.join(ROOT, "profiles", "attn_hbm_traffic.json")
     tab = json.load(open(out_path)) if os.path.exists(out_path) else {}
     for which, v in vals.items():
