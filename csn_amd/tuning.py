@@ -31,8 +31,9 @@ class Tuning:
     # KEEP_SCORES otherwise.  Measured per mode and width, DESIGN.md §4 "data flow A/B": at d = 256 the extra matrix products
     # cost what the score traffic saves, at d <= 128 a score costs the same bytes for a fraction of the FLOPs
     score_flow: Dict[object, int] = field(default_factory=lambda: {
-        1: KEEP_SCORES, 2: KEEP_SCORES,
-        **{(2, d): FLASH for d in (32, 64, 96, 128)},
+        1: KEEP_SCORES,                                   # bf16x3 at d = 256: three LDS images of two planes do not fit one CU
+        2: RECOMPUTE_DQ,                                  # one plane, d = 256: -4.7 % of the config-3 step (profiles/r3l_flow_ab_step.txt)
+        **{(2, d): FLASH for d in (32, 64, 96, 128)},     # config 5: 18.5 -> 17.1 (recompute) -> 15.4 ms (flash)
         **{(1, d): FLASH for d in (32, 64, 96)}, (1, 128): RECOMPUTE_DQ})
 
     def flow_for(self, mode: int, d_head: int) -> int:
