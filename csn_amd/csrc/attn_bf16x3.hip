@@ -97,13 +97,24 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   constexpr int PLANE = D * KT + (CSN_LDS_V ? 32 : 64);
   // [A | B][stage][plane hi/lo][row][32 keys] — one array, so that the prologue / epilogue can use all of it as a
   // [D rows][128 queries] fp32 staging block for 16-byte global accesses (which sets the size in the one-plane modes)
-  constexpr int NIMG = RC ? 3 : 2;                      // LDS images per stage: A, B (+ C: the K tile in tileA's form)
-  constexpr int TILE_EL = NIMG * 2 * NPL * PLANE, STAGE_EL = D * 128 * 2;
+  // EARLY: the narrow instances (and every one-plane instance) request the tiles a whole segment earlier, into a second
+  // register set — their matrix phases are too short to cover the HBM latency of a request made one phase before its use
+#ifndef CSN_EARLY
+#define CSN_EARLY 1
+#endif
+#ifndef CSN_EARLY_ALL
+#define CSN_EARLY_ALL 0
+#endif
+  constexpr bool EARLY = CSN_EARLY && (NPL == 1 || DT <= 4 || CSN_EARLY_ALL);
+  // LDS images: A x 2 stages, B x 2 (RC && EARLY: x 3 — the key-contiguous K image is then committed in segment 1 too, which
+  // needs a third stage), RC: + C x 2 (the K tile in tileA's form)
+  constexpr int NB_ST = (RC && EARLY) ? 3 : 2;
+  constexpr int TILE_EL = (2 + NB_ST + (RC ? 2 : 0)) * NPL * PLANE, STAGE_EL = D * 128 * 2;
   static_assert(2 * (TILE_EL > STAGE_EL ? TILE_EL : STAGE_EL) <= 160 * 1024, "LDS budget of one CU");
   __shared__ __attribute__((aligned(16))) short tiles[TILE_EL > STAGE_EL ? TILE_EL : STAGE_EL];
   auto tileA = [&](int st, int pl) -> short* { return tiles + (st * NPL + pl) * PLANE; };
   auto tileB = [&](int st, int pl) -> short* { return tiles + ((2 + st) * NPL + pl) * PLANE; };
-  auto tileC = [&](int st, int pl) -> short* { return tiles + ((4 + st) * NPL + pl) * PLANE; };
+  auto tileC = [&](int st, int pl) -> short* { return tiles + ((2 + NB_ST + st) * NPL + pl) * PLANE; };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, kq = lane >> 4;
@@ -279,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   const int a_dst = KVP ? t_pl * PLANE + t_row * KT + 8 * t_u : t_row * KT + 4 * (t_c ^ t_sw);
   const int b_dst = KVP ? t_pl * PLANE + t_row * KT + 8 * (t_u ^ t_swz) : t_row * KT + 8 * ((t_c >> 1) ^ t_swz) + 4 * (t_c & 1);
   f32x4 g[NP_T];
-  f32x4 g2[RC ? NP_T : 1];                              // RC: the K tile's pieces (committed to two images) beside the V tile's
+  f32x4 g2[(RC || EARLY) ? NP_T : 1];                   // RC: the K tile's pieces (committed to two images) beside the V tile's; EARLY: tileB's
   auto fetch_to = [&](const csn_rsrc_t& rs, int kt, f32x4* g) {
     if (KVP) {
       // keys beyond the block end are zero in the planes; units that lie entirely beyond it are not fetched at all
@@ -571,10 +582,16 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   if constexpr (RC) {
     // three images: V (k-major, tileA), K (k-major, tileC) and K (key-contiguous, tileB).  Both k-major images are read in
     // segment 1, so both are committed in segment 1 of the tile before (see the hazard note below); the K pieces stay in
-    // registers (g2) until the key-contiguous image has taken them in segment 2.
+    // registers (g2) until the key-contiguous image has taken them in segment 2 — or, EARLY, go into the third stage of that
+    // image in segment 1 as well (stage (kt + 1) % 3 was last read two tiles ago), which frees both register sets for the
+    // request of tile kt + 2 a whole segment earlier.
     fetch_to(Ar, 0, g); commitA_to(tileA(0, 0), tileA(0, NPL - 1), g);
     fetch_to(Br, 0, g2); commitA_to(tileC(0, 0), tileC(0, NPL - 1), g2); commitB_from(0, g2, false);
     if (nkt > 1) { fetch_to(Ar, 1, g); fetch_to(Br, 1, g2); }
+  } else if constexpr (EARLY) {
+    fetch_to(Ar, 0, g); commitA_to(tileA(0, 0), tileA(0, NPL - 1), g);
+    fetch_to(Br, 0, g2); commitB_from(0, g2);
+    if (nkt > 1) fetch_to(Ar, 1, g);
   } else {
     fetch(Ar, 0); commitA(0);
     fetch(Br, 0); commitB(0);
@@ -603,6 +620,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   //  spilled 28 registers in the forward and 82 in the backward kernel)
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1, nxt = cur ^ 1;
+    const int b_cur = (RC && EARLY) ? kt % 3 : cur, b_nxt = (RC && EARLY) ? (kt + 1) % 3 : nxt;     // stage of the key-contiguous image
     const bool more = kt + 1 < nkt;
 #ifdef CSN_STAMPS
     const bool dbg_on = (BWD == (CSN_STAMPS != 0)) && DT == 8 && blockIdx.x < 2048 && kt >= 4 && kt < 8;   // -DCSN_STAMPS=0: forward, =1: backward
@@ -614,7 +632,19 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     phase1(cur);
     STAMP(1);
     if constexpr (RC) {
-      if (more) { commitA_to(tileA(nxt, 0), tileA(nxt, NPL - 1), g); commitA_to(tileC(nxt, 0), tileC(nxt, NPL - 1), g2); }
+      if (more) {
+        commitA_to(tileA(nxt, 0), tileA(nxt, NPL - 1), g); commitA_to(tileC(nxt, 0), tileC(nxt, NPL - 1), g2);
+        if constexpr (EARLY) {
+          commitB_from(b_nxt, g2, false);
+          if (kt + 2 < nkt) { fetch_to(Ar, kt + 2, g); fetch_to(Br, kt + 2, g2); }
+        }
+      }
+    } else if constexpr (EARLY) {
+      if (more) {
+        commitA_to(tileA(nxt, 0), tileA(nxt, NPL - 1), g);
+        fetch_to(Br, kt + 1, g2);
+        if (kt + 2 < nkt) fetch_to(Ar, kt + 2, g);            // a whole tile before its commit
+      }
     } else {
       if (more) { commitA(nxt); fetch(Br, kt + 1); }
     }
@@ -623,10 +653,14 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     STAMP(3);
     pointwise(kt);
     STAMP(4);
-    phase2(cur);
+    phase2(b_cur);
     STAMP(5);
     if constexpr (RC) {
-      if (more) { commitB_from(nxt, g2, false); if (kt + 2 < nkt) { fetch_to(Ar, kt + 2, g); fetch_to(Br, kt + 2, g2); } }
+      if constexpr (!EARLY) {
+        if (more) { commitB_from(nxt, g2, false); if (kt + 2 < nkt) { fetch_to(Ar, kt + 2, g); fetch_to(Br, kt + 2, g2); } }
+      }
+    } else if constexpr (EARLY) {
+      if (more) commitB_from(nxt, g2);
     } else {
       if (more) { commitB(nxt); if (kt + 2 < nkt) fetch(Ar, kt + 2); }
     }
