@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import functional as CF
+from . import functional as CF, tuning
 from ._lib import CsnError
 
 __all__ = ["ScaledDotProductAttention", "MultiHeadAttention", "CrossShapeAt", "get_model",
@@ -420,6 +420,10 @@ class CrossShapeAt(nn.Module):
         descriptors are concatenated neighbour-major (rows k*B + b, :213,:220) and then re-viewed as
         (B, K+1, C) (:227).  ``"per_shape"`` scores every shape against its own neighbours."""
         B, K1, C = pooled.shape
+        if pooled.is_cuda and tuning.current().fused_compat_head and C <= 256 and K1 <= 8:
+            # one launch forward, two backward (csn_compat_fwd_f32 / _bwd_f32) instead of ~45 small library launches per step
+            return CF.compat_head(pooled, self.compatibility_q.weight, self.compatibility_q.bias, self.compatibility_k.weight,
+                                  self.compatibility_k.bias, self.compat_layout == "reference")
         u_q = F.normalize(self.compatibility_q(pooled[:, 0]), dim=-1)
         keys = pooled.transpose(0, 1).reshape(K1 * B, C).view(B, K1, C) if self.compat_layout == "reference" else pooled
         u_k = F.normalize(self.compatibility_k(keys), dim=-1)

@@ -616,4 +616,24 @@ int csn_mix_bwd_f32(const float* dfeats, const float* xhat, const float* comp, c
                                 dxhat_self, (hipStream_t)stream);
 }
 
+int csn_compat_fwd_f32(const float* pooled, const float* wq_t, const float* bq, const float* wk_t, const float* bk, float* comp,
+                       double* save_u, double* save_norm, int n_shapes, int k1, int channels, int reference_layout, void* stream) {
+  if (!pooled || !wq_t || !bq || !wk_t || !bk || !comp || !save_u || !save_norm) return CSN_E_ARG;
+  if (n_shapes <= 0 || k1 <= 0 || k1 > 8 || channels <= 0 || channels > 256) return CSN_E_ARG;
+  return csn_launch_compat_fwd(pooled, wq_t, bq, wk_t, bk, comp, save_u, save_norm, n_shapes, k1, channels, reference_layout,
+                               (hipStream_t)stream);
+}
+
+int csn_compat_bwd_f32(const float* dcomp, const float* comp, const double* save_u, const double* save_norm, const float* pooled,
+                       const float* wq, const float* wk, double* ws, long long ws_doubles, float* dpooled, float* dwq, float* dbq,
+                       float* dwk, float* dbk, int n_shapes, int k1, int channels, int reference_layout, void* stream) {
+  if (!dcomp || !comp || !save_u || !save_norm || !pooled || !wq || !wk || !ws || !dpooled || !dwq || !dbq || !dwk || !dbk)
+    return CSN_E_ARG;
+  if (n_shapes <= 0 || k1 <= 0 || k1 > 8 || channels <= 0 || channels > 256) return CSN_E_ARG;
+  const long long rows = (long long)n_shapes * (k1 + 1) * channels;
+  if (ws_doubles < 2 * rows) return CSN_E_WORKSPACE;
+  return csn_launch_compat_bwd(dcomp, comp, save_u, save_norm, pooled, wq, wk, ws, ws + rows, dpooled, dwq, dbq, dwk, dbk, n_shapes,
+                               k1, channels, reference_layout, (hipStream_t)stream);
+}
+
 }  // extern "C"

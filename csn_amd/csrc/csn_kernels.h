@@ -149,3 +149,10 @@ int csn_launch_mix_bwd_f32(const float* dfeats, const float* xhat, const float* 
                            hipStream_t st);
 int csn_launch_retrieval_f32(const float* f1, const float* f2, float* out, int s1, int n1, int s2, int n2, int C,
                              float* ws, hipStream_t st);
+
+// ---- compatibility head (compat.hip): normalize(W_q y_0 + b), normalize(W_k y_k + b), dot, softmax over the K+1 keys ----
+int csn_launch_compat_fwd(const float* pooled, const float* wq_t, const float* bq, const float* wk_t, const float* bk, float* comp,
+                          double* save_u, double* save_n, int B, int K1, int C, int reference_layout, hipStream_t st);
+int csn_launch_compat_bwd(const float* dcomp, const float* comp, const double* save_u, const double* save_n, const float* pooled,
+                          const float* wq, const float* wk, double* d_raw, double* dx, float* dpooled, float* dwq, float* dbq,
+                          float* dwk, float* dbk, int B, int K1, int C, int reference_layout, hipStream_t st);

@@ -47,7 +47,7 @@ def _need_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
             raise _lib.CsnError("csn_amd ops need tensors on the MI355X (cuda) device; there is no CPU path")
-        if t is not None and t.dtype not in (torch.float32, torch.int32, torch.bfloat16):
+        if t is not None and t.dtype not in (torch.float32, torch.int32, torch.bfloat16, torch.float64):
             raise _lib.CsnError(f"csn_amd ops are fp32 (got {t.dtype})")
 
 
@@ -804,3 +804,49 @@ def csa_mix(xhat, comp: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, B
             raise TypeError("csa_mix: xhat and xself must both be LinkedMaps or both tensors")
         return _CSAMixLinked.apply(xhat.handle, None if xself is None else xself.handle, comp, gamma, beta, B, K1, xhat, xself)
     return _CSAMix.apply(xhat, comp, gamma, beta, B, K1, xself)
+
+
+# ------------------------------------------------------------------------------------------------------
+# the compatibility head (csa_models.py:222-230), one launch forward and two backward instead of ~45 library launches
+# ------------------------------------------------------------------------------------------------------
+class _CompatHead(torch.autograd.Function):
+    """comp (B, K+1) = softmax_k <normalize(Wq y_0 + bq), normalize(Wk key_k + bk)> over the pooled descriptors y (B, K+1, C)."""
+
+    @staticmethod
+    def forward(ctx, pooled, wq, bq, wk, bk, reference_layout: bool):
+        _need_cuda(pooled, wq, bq, wk, bk)
+        B, K1, C = pooled.shape
+        pooled = pooled.contiguous()
+        dev = pooled.device
+        comp = torch.empty((B, K1), device=dev, dtype=torch.float32)
+        save_u = torch.empty((B, K1 + 1, C), device=dev, dtype=torch.float64)
+        save_n = torch.empty((B, K1 + 1), device=dev, dtype=torch.float64)
+        wq_t, wk_t = wq.t().contiguous(), wk.t().contiguous()
+        _lib.check(_lib.lib().csn_compat_fwd_f32(_ptr(pooled), _ptr(wq_t), _ptr(bq.contiguous()), _ptr(wk_t), _ptr(bk.contiguous()),
+                                                 _ptr(comp), _ptr(save_u), _ptr(save_n), B, K1, C, 1 if reference_layout else 0,
+                                                 _stream()), "csn_compat_fwd_f32")
+        ctx.save_for_backward(pooled, wq, wk, comp, save_u, save_n)
+        ctx.ref = reference_layout
+        return comp
+
+    @staticmethod
+    def backward(ctx, dcomp):
+        pooled, wq, wk, comp, save_u, save_n = ctx.saved_tensors
+        B, K1, C = pooled.shape
+        dev = pooled.device
+        ws = torch.empty((2 * B * (K1 + 1) * C,), device=dev, dtype=torch.float64)
+        dpooled = torch.empty_like(pooled)
+        dwq, dwk = torch.empty_like(wq), torch.empty_like(wk)
+        dbq, dbk = torch.empty((C,), device=dev, dtype=torch.float32), torch.empty((C,), device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib().csn_compat_bwd_f32(_ptr(dcomp.contiguous()), _ptr(comp), _ptr(save_u), _ptr(save_n), _ptr(pooled),
+                                                 _ptr(wq.contiguous()), _ptr(wk.contiguous()), _ptr(ws), ws.numel(), _ptr(dpooled),
+                                                 _ptr(dwq), _ptr(dbq), _ptr(dwk), _ptr(dbk), B, K1, C, 1 if ctx.ref else 0,
+                                                 _stream()), "csn_compat_bwd_f32")
+        return dpooled, dwq, dbq, dwk, dbk, None
+
+
+def compat_head(pooled: torch.Tensor, wq: torch.Tensor, bq: torch.Tensor, wk: torch.Tensor, bk: torch.Tensor,
+                reference_layout: bool = True) -> torch.Tensor:
+    """The compatibility weights comp (B, K+1) of csa_models.py:222-230 from the pooled descriptors (B, K+1, C) and the two
+    nn.Linear heads, with the reference's key-row bookkeeping for B > 1 (``reference_layout``) or per shape."""
+    return _CompatHead.apply(pooled, wq, bq, wk, bk, bool(reference_layout))

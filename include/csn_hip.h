@@ -333,6 +333,24 @@ int csn_mix_bwd_f32(const float* dfeats, const float* xhat, const float* comp, c
                     float* rowdot, float* rowsum, int n_shapes, int k1, int channels, int n_points, const float* xhat_self,
                     float* dxhat_self, void* stream);
 
+/* ---- (9) the compatibility head (csa_models.py:222-230) -----------------------------------------------------
+ * comp[b][k] = softmax_k < normalize(wq y[b][0] + bq), normalize(wk key(b, k) + bk) >  over the k1 = K+1 pooled descriptors
+ * y (n_shapes, k1, channels) of every query shape (the shape itself in slot 0), F.normalize's eps = 1e-12, channels <= 256,
+ * k1 <= 8.  reference_layout != 0: the key rows are taken the way the reference's bookkeeping takes them for B > 1 — the key
+ * descriptors stacked neighbour-major and re-viewed as (B, k1, C) (csa_models.py:213,220,227): key(b, k) = y[(b k1 + k) % B]
+ * [(b k1 + k) / B]; 0: key(b, k) = y[b][k].
+ * Every sum accumulates in fp64 (the head's gradients are differences of nearly equal descriptors; 63 MFLOP).
+ * Forward: wq_t / wk_t are the nn.Linear weights TRANSPOSED ([in][out]); save_u (n_shapes, k1 + 1, channels) and save_norm
+ * (n_shapes, k1 + 1) keep the normalised vectors and the norms for the backward, as DOUBLES.
+ * Backward: wq / wk as stored ([out][in]); ws >= 2 n_shapes (k1 + 1) channels DOUBLES of scratch; writes the gradients
+ * dpooled (n_shapes, k1, channels), dwq / dwk (channels, channels) and dbq / dbk (channels) — overwritten, not accumulated;
+ * sums over the shapes run in a fixed order (bitwise reproducible). */
+int csn_compat_fwd_f32(const float* pooled, const float* wq_t, const float* bq, const float* wk_t, const float* bk, float* comp,
+                       double* save_u, double* save_norm, int n_shapes, int k1, int channels, int reference_layout, void* stream);
+int csn_compat_bwd_f32(const float* dcomp, const float* comp, const double* save_u, const double* save_norm, const float* pooled,
+                       const float* wq, const float* wk, double* ws, long long ws_doubles, float* dpooled, float* dwq, float* dbq,
+                       float* dwk, float* dbk, int n_shapes, int k1, int channels, int reference_layout, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -651,3 +651,39 @@ def test_abi_argument_validation_table(L):
         torch.cuda.synchronize()
     finally:
         lib.csn_set_math_mode(1)
+
+
+@pytest.mark.parametrize("B,K1,C,ref_layout", [(1, 3, 256, True), (2, 4, 256, True), (32, 4, 256, True), (5, 5, 96, True),
+                                               (3, 3, 128, False), (4, 8, 64, True)])
+def test_compat_head(L, math_mode, B, K1, C, ref_layout):
+    """csn_compat_fwd_f32 / _bwd_f32 against the torch restatement of csa_models.py:222-230 (two nn.Linear, F.normalize, dot,
+    softmax; the reference's neighbour-major key bookkeeping for B > 1) in float64: comp and all five gradients.  The head is
+    plain fp32 arithmetic in every math mode."""
+    import torch.nn.functional as F
+    from csn_amd import functional as CF
+    rng = np.random.default_rng(77 + B + K1)
+    pooled = _rand(rng, B, K1, C)
+    wq, wk = _rand(rng, C, C) / math.sqrt(C), _rand(rng, C, C) / math.sqrt(C)
+    bq, bk = _rand(rng, C) * 0.1, _rand(rng, C) * 0.1
+    dcomp = _rand(rng, B, K1)
+
+    def ref(pooled, wq, bq, wk, bk):
+        u_q = F.normalize(F.linear(pooled[:, 0], wq, bq), dim=-1)
+        keys = pooled.transpose(0, 1).reshape(K1 * B, C).view(B, K1, C) if ref_layout else pooled
+        u_k = F.normalize(F.linear(keys, wk, bk), dim=-1)
+        return F.softmax(torch.einsum("bc,bkc->bk", u_q, u_k), dim=-1)
+
+    a64 = [t.double().clone().requires_grad_(True) for t in (pooled, wq, bq, wk, bk)]
+    c64 = ref(*a64)
+    c64.backward(dcomp.double())
+    a32 = [t.cuda().clone().requires_grad_(True) for t in (pooled, wq, bq, wk, bk)]
+    comp = CF.compat_head(*a32, reference_layout=ref_layout)
+    comp.backward(dcomp.cuda())
+    torch.cuda.synchronize()
+    assert (comp.detach().cpu().double() - c64.detach()).abs().max().item() < 2e-6
+    assert abs(comp.sum(dim=1).detach().cpu() - 1).max().item() < 1e-6
+    for got, want, name in zip(a32, a64, ("pooled", "wq", "bq", "wk", "bk")):
+        assert _maxerr(got.grad, want.grad) < 2e-5, name
+    again = [t.detach().clone().requires_grad_(True) for t in a32]                 # sums over shapes in a fixed order: bitwise repeatable
+    CF.compat_head(*again, reference_layout=ref_layout).backward(dcomp.cuda())
+    assert all(torch.equal(x.grad, y.grad) for x, y in zip(a32, again))
