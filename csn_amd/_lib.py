@@ -114,6 +114,8 @@ _SIGNATURES = {
     "csn_set_thread_math_mode": (c_int, [c_int]),
     "csn_get_math_mode": (c_int, []),
     "csn_get_thread_math_mode": (c_int, []),
+    "csn_set_thread_act16": (c_int, [c_int]),
+    "csn_get_thread_act16": (c_int, []),
     "csn_status_string": (c_char_p, [c_int]),
     "csn_wgrad_workspace_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
     "csn_project_f32": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_int, c_int, c_void_p, c_longlong, c_int,
@@ -191,7 +193,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.csn_version() != 13:
+        if handle.csn_version() != 14:
             raise CsnError("libcsn_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -147,9 +147,13 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   const int qrow = qt * 128 + wave * 16 + lq;                  // query index inside the block
   const bool q_ok = qrow < Tq_e;
   const long long head_off = (long long)hd * D * ld + (long long)blk * Tq;
-  const long long win = ((long long)(D - 1) * ld + Tq) * 4;    // bytes spanned by a [D][Tq] window of pitch ld
+  const long long win = ((long long)(D - 1) * ld + Tq) * 4;    // bytes spanned by a [D][Tq] fp32 window of pitch ld
   const long long os = p.out_index ? p.out_index[e0] : e0;
-  const csn_rsrc_t Or = csn_make_rsrc(p.out + os * p.out_eval_stride + head_off, win);
+  // 16-bit activation maps (single-product modes; r_fmt / ctx_fmt / q2_fmt / out_fmt: 0 fp32, 1 bf16, 2 fp16): a [D][Tq] window
+  // of a map in format f starts `el` elements into it
+  auto map_rsrc = [&](const void* base, long long el, int f) {
+    return f ? csn_make_rsrc(reinterpret_cast<const short*>(base) + el, win / 2) : csn_make_rsrc(reinterpret_cast<const float*>(base) + el, win);
+  };
   const long long stat_off0 = ((long long)e0 * p.H + hd) * ((long long)p.n_blocks * Tq) + (long long)blk * Tq;
   float* xbuf = reinterpret_cast<float*>(tiles);
   constexpr int CH_T = D / 16;                                     // 16-byte chunks per thread: D rows x 32 chunks / 512
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   const long long ks = p.kv_index ? p.kv_index[e] : e;
   const long long head_off_kv = (long long)hd * D * ldk + (long long)blk * p.T;   // (p.T: the layout; T may be a short last block)
   const long long win_kv = ((long long)(D - 1) * ldk + (T + 3) / 4 * 4) * 4;
-  const csn_rsrc_t Rr = csn_make_rsrc(p.q + qs * p.q_shape_stride + head_off, win);
+  const csn_rsrc_t Rr = map_rsrc(p.q, qs * p.q_shape_stride + head_off, p.r_fmt);
   // tile planes: 16-bit elements, row pitch kv_ld = n_blocks * 512 NPL, this block's 16 tiles start at blk * 512 NPL
   const int kld = p.kv_ld;
   const long long kv_off = KVP ? ks * p.kv_shape_stride + (long long)hd * D * kld + (long long)blk * (512 * NPL) : 0;
@@ -179,7 +183,6 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
                             : csn_make_rsrc((BWD ? p.v : p.k) + ks * p.kv_shape_stride + head_off_kv, win_kv);
   const csn_rsrc_t Br = KVP ? csn_make_rsrc(vpl + kv_off, kv_win)
                             : csn_make_rsrc((BWD ? p.k : p.v) + ks * p.kv_shape_stride + head_off_kv, win_kv);
-  const csn_rsrc_t Or = csn_make_rsrc(p.out + os * p.out_eval_stride + head_off, win);
   const long long stat_off = ((long long)e * p.H + hd) * ((long long)p.n_blocks * Tq) + (long long)blk * Tq;
   const long long sc_off = (((long long)e * p.H + hd) * p.n_blocks + blk) * ((long long)Tq * Tp);
   const bool have_scores = p.scores != nullptr;
@@ -197,10 +200,18 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   // use different banks.  Backward: delta_q = sum_d dO[d][q] O[d][q] (the softmax-backward row constant) from a second
   // round with O.
   s16x8 Rh[D / 32], Rl[D / 32];
-  auto stage_in = [&](const csn_rsrc_t& rs) {
+  auto stage_in = [&](const csn_rsrc_t& rs, int fmt) {
     f32x4 ch[CH_T];
+    if (NPL == 1 && fmt) {                                         // a 16-bit map: half the bytes, widened on the way into LDS
+      u32x2 c2[CH_T];
 #pragma unroll
-    for (int t = 0; t < CH_T; ++t) ch[t] = csn_bload4(rs, c_off, (unsigned)(16 * t * ld) * 4u);
+      for (int t = 0; t < CH_T; ++t) c2[t] = csn_bload2(rs, c_off == CSN_OOB ? CSN_OOB : c_off >> 1, (unsigned)(16 * t * ld) * 2u);
+#pragma unroll
+      for (int t = 0; t < CH_T; ++t) ch[t] = act16_to_f32(__builtin_bit_cast(s16x4, c2[t]), fmt);
+    } else {
+#pragma unroll
+      for (int t = 0; t < CH_T; ++t) ch[t] = csn_bload4(rs, c_off, (unsigned)(16 * t * ld) * 4u);
+    }
 #pragma unroll
     for (int t = 0; t < CH_T; ++t) {
       const int row = crow + 16 * t;
@@ -208,7 +219,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     }
   };
   auto pick = [&](int row) { return xbuf[row * 128 + ((((col >> 2) ^ (4 * ((row >> 3) & 1))) << 2) | (col & 3))]; };
-  stage_in(Rr);
+  stage_in(Rr, p.r_fmt);
   __syncthreads();
   float rv[D / 4];
 #pragma unroll
@@ -222,9 +233,9 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
     }
   float delta_q = 0.f;
   if (BWD) {
-    const csn_rsrc_t Xr = csn_make_rsrc(p.ctx + qs * p.q_shape_stride + head_off, win);
+    const csn_rsrc_t Xr = map_rsrc(p.ctx, qs * p.q_shape_stride + head_off, p.ctx_fmt);
     __syncthreads();
-    stage_in(Xr);
+    stage_in(Xr, p.ctx_fmt);
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < D / 32; ++s)
@@ -237,9 +248,9 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
   s16x8 Qh[RC ? D / 32 : 1], Ql[RC ? D / 32 : 1];
   if constexpr (RC) {
     const long long q2s = p.q2_index ? p.q2_index[e] : e;
-    const csn_rsrc_t Qr = csn_make_rsrc(p.q2 + q2s * p.q2_shape_stride + head_off, win);
+    const csn_rsrc_t Qr = map_rsrc(p.q2, q2s * p.q2_shape_stride + head_off, p.q2_fmt);
     __syncthreads();
-    stage_in(Qr);
+    stage_in(Qr, p.q2_fmt);
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < D / 32; ++s)
@@ -704,15 +715,24 @@ __global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) 
       const int row = crow + 16 * t;
       ch[t] = *reinterpret_cast<const f32x4*>(&xbuf[row * 128 + ((cc ^ (4 * ((row >> 2) & 1))) << 2)]);
     }
-    if (p.accumulate) {
-      f32x4 prev[CH_T];
+    const csn_rsrc_t Or = map_rsrc(p.out, os * p.out_eval_stride + head_off, p.out_fmt);
+    if (NPL == 1 && p.out_fmt) {                                   // a 16-bit map (written once: the launcher refuses accumulate)
 #pragma unroll
-      for (int t = 0; t < CH_T; ++t) prev[t] = csn_bload4(Or, c_off, (unsigned)(16 * t * ld) * 4u);
+      for (int t = 0; t < CH_T; ++t) {
+        const s16x4 v = p.out_fmt == 2 ? to16x4<true>(ch[t]) : to16x4<false>(ch[t]);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), Or, c_off == CSN_OOB ? CSN_OOB : c_off >> 1, (unsigned)(16 * t * ld) * 2u, 0);
+      }
+    } else {
+      if (p.accumulate) {
+        f32x4 prev[CH_T];
 #pragma unroll
-      for (int t = 0; t < CH_T; ++t) ch[t] += prev[t];
+        for (int t = 0; t < CH_T; ++t) prev[t] = csn_bload4(Or, c_off, (unsigned)(16 * t * ld) * 4u);
+#pragma unroll
+        for (int t = 0; t < CH_T; ++t) ch[t] += prev[t];
+      }
+#pragma unroll
+      for (int t = 0; t < CH_T; ++t) csn_bstore4(ch[t], Or, c_off, (unsigned)(16 * t * ld) * 4u);
     }
-#pragma unroll
-    for (int t = 0; t < CH_T; ++t) csn_bstore4(ch[t], Or, c_off, (unsigned)(16 * t * ld) * 4u);
   }
   WGSTAMP(3);
 }
@@ -748,6 +768,8 @@ int launch_any(const CsnAttnArgs& a, int d, bool bwd, hipStream_t st) {
   if ((a.q_shape_stride & 3) || (a.kv_shape_stride & 3)) return -4;
   if (a.sc_tiles && a.Tp < (a.T + 31) / 32 * 32) return -2;
   if (a.q2 && (!bwd || !a.kv_planes || (a.q2_shape_stride & 3))) return -1;
+  if ((a.r_fmt || a.ctx_fmt || a.q2_fmt || a.out_fmt) && (PR::NPL != 1 || !a.kv_planes)) return -1;   // 16-bit maps: single-product modes
+  if (a.out_fmt && a.accumulate) return -1;
   if (a.kv_planes && (a.T > 512 || (a.kv_ld & 7) || (a.kv_shape_stride & 7))) return -2;    // 16 tiles of 32 keys per block
   switch (d) {
     case 32: return launch_dt<PR, 1>(a, bwd, st);

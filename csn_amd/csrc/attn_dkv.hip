@@ -37,6 +37,17 @@ CSN_DEVINL const lds_s16* opaque_lds(const short* p) {
   return q;
 }
 
+// A copy the compiler cannot see through.  The pieces of a 16-bit map are committed as they are; as a plain copy the compiler
+// merges the piece with the load's destination register and carries it around the loop — and a loop-carried copy of a
+// register with a load in flight makes it wait for ALL outstanding loads before the barrier (the lesson of the row constants
+// below).  Two moves here, after the data has arrived, keep the request of the next tile independent.
+CSN_DEVINL u32x2 moved(u32x2 v) {
+  u32x2 r;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(r[0]) : "v"(v[0]));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(r[1]) : "v"(v[1]));
+  return r;
+}
+
 template <typename PR>
 CSN_DEVINL f32x4v mma16(s16x8 ah, s16x8 al, s16x8 bh, s16x8 bl, f32x4v c) {
   if constexpr (PR::NT == 3) {
@@ -46,8 +57,12 @@ CSN_DEVINL f32x4v mma16(s16x8 ah, s16x8 al, s16x8 bh, s16x8 bl, f32x4v c) {
   return mfma16<PR::HALF>(ah, bh, c);
 }
 
-template <typename PR, int DT>
+// QF (one-plane mode): 0 = Qs and dO are fp32 maps; 1 / 2 = 16-bit activation maps, Qs in bf16 / fp16 (a math-mode-3 forward:
+// converted to bf16 at the commit) and dO in bf16 — a compile-time property: a format branch inside the tile loop costs the
+// kernel its schedule (measured: 3.7 -> 5.2 ms at config-5 geometry)
+template <typename PR, int DT, int QF = 0>
 __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) {
+  static_assert(QF == 0 || PR::NPL == 1, "16-bit activation maps: the one-plane mode");
   constexpr int NPL = PR::NPL;
   constexpr int D = 32 * DT;
   constexpr int PLANE = D * QT + 32;                    // hi and lo planes 64 bytes out of phase (store banks, attn_bf16x3.hip)
@@ -170,6 +185,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
   // in that form (as many registers as the fp32 piece in the two-plane mode, half in the one-plane mode) for the
   // query-contiguous image (segment 2).
   f32x4 gQ[NP_T], gO[NP_T];
+  u32x2 hQ[NP_T], hO[NP_T];                                         // the same pieces of 16-bit maps (loaded straight into these: no copies of in-flight registers)
   s16x4 cQh[NP_T], cQl[NP_T], cOh[NP_T], cOl[NP_T];
   // wave 0 also carries the tile's 32 lse / 32 delta values (lanes 0..31 / 32..63), as buffer loads like everything else in
   // the loop: nothing may force a wait on memory between a request and the barrier that follows it
@@ -178,29 +194,35 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
   // fetch stream: (item, query tile) of the next tile to request — it runs two tiles ahead of the products.  Everything that
   // depends on the item (evaluation id, query slot, base pointers) is scalar and reloaded only when the item changes.
   int f_it = it0, f_qt = 0;
-  const float* f_q = nullptr; const float* f_o = nullptr; const float* f_lse = nullptr; const float* f_dl = nullptr;
+  // 16-bit activation maps (one-plane mode): Qs / dO arrive as 16-bit maps — a piece is 8 bytes and is committed as it is
+  // (q_fmt == 2: fp16 bits of a math-mode-3 forward, converted to bf16 at the commit)
+  constexpr int q_fmt = QF, o_fmt = QF ? 1 : 0;
+  constexpr int q_es = q_fmt ? 2 : 4, o_es = o_fmt ? 2 : 4;
+  const char* f_q = nullptr; const char* f_o = nullptr; const float* f_lse = nullptr; const float* f_dl = nullptr;
   auto fetch_item = [&]() {
     const int e = p.eval_ids ? p.eval_ids[f_it] : f_it;
     const long long qs = p.q_index ? p.q_index[e] : e;
     const long long head_off = (long long)hd * D * ld + (long long)blk * p.T;
     const long long stat = ((long long)e * p.H + hd) * ((long long)p.n_blocks * p.T) + (long long)blk * p.T;
-    f_q = p.q + qs * p.q_shape_stride + head_off;
-    f_o = p.dctx + (long long)e * p.ctx_eval_stride + head_off;
+    f_q = reinterpret_cast<const char*>(p.q) + (qs * p.q_shape_stride + head_off) * q_es;
+    f_o = reinterpret_cast<const char*>(p.dctx) + ((long long)e * p.ctx_eval_stride + head_off) * o_es;
     f_lse = p.lse + stat;
     f_dl = p.delta + stat;
   };
   fetch_item();
   auto fetch = [&]() {
     const int nq = T - f_qt * QT;                                   // queries left in the block from this tile on
-    const long long win = ((long long)(D - 1) * ld + (nq < QT ? nq : QT)) * 4;
-    const csn_rsrc_t Qr = csn_make_rsrc(f_q + f_qt * QT, win);
-    const csn_rsrc_t Or = csn_make_rsrc(f_o + f_qt * QT, win);
-    const unsigned off = (4 * t_c) < nq ? (unsigned)(t_row * ld + 4 * t_c) * 4u : CSN_OOB;      // T % 4 == 0: a piece is all in or all out
+    const long long win = (long long)(D - 1) * ld + (nq < QT ? nq : QT);          // elements
+    const csn_rsrc_t Qr = csn_make_rsrc(f_q + (long long)f_qt * QT * q_es, win * q_es);
+    const csn_rsrc_t Or = csn_make_rsrc(f_o + (long long)f_qt * QT * o_es, win * o_es);
+    const unsigned off = (4 * t_c) < nq ? (unsigned)(t_row * ld + 4 * t_c) : CSN_OOB;      // (elements) T % 4 == 0: a piece is all in or all out
 #pragma unroll
     for (int i = 0; i < NP_T; ++i) {
       const unsigned o = (i == NP_T - 1 && !t_last_ok) ? CSN_OOB : off;
-      gQ[i] = csn_bload4(Qr, o, (unsigned)(64 * i * ld) * 4u);
-      gO[i] = csn_bload4(Or, o, (unsigned)(64 * i * ld) * 4u);
+      if constexpr (q_fmt != 0) hQ[i] = csn_bload2(Qr, o == CSN_OOB ? o : o * 2u, (unsigned)(64 * i * ld) * 2u);
+      else gQ[i] = csn_bload4(Qr, o == CSN_OOB ? o : o * 4u, (unsigned)(64 * i * ld) * 4u);
+      if constexpr (o_fmt != 0) hO[i] = csn_bload2(Or, o == CSN_OOB ? o : o * 2u, (unsigned)(64 * i * ld) * 2u);
+      else gO[i] = csn_bload4(Or, o == CSN_OOB ? o : o * 4u, (unsigned)(64 * i * ld) * 4u);
     }
     if (wave0) {
       const long long rwin = (nq < QT ? nq : QT) * 4;
@@ -217,8 +239,15 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
 #pragma unroll
     for (int i = 0; i < NP_T; ++i)
       if (i < NP_T - 1 || t_last_ok) {
-        split4<PR>(gQ[i], cQh[i], cQl[i]);
-        split4<PR>(gO[i], cOh[i], cOl[i]);
+        if constexpr (q_fmt != 0) {
+          if constexpr (q_fmt == 2) cQh[i] = f16x4_to_bf16x4(__builtin_bit_cast(s16x4, hQ[i]));
+          else cQh[i] = __builtin_bit_cast(s16x4, moved(hQ[i]));
+          cQl[i] = cQh[i];
+        } else split4<PR>(gQ[i], cQh[i], cQl[i]);
+        if constexpr (o_fmt != 0) {
+          cOh[i] = __builtin_bit_cast(s16x4, moved(hO[i]));
+          cOl[i] = cOh[i];
+        } else split4<PR>(gO[i], cOh[i], cOl[i]);
         *reinterpret_cast<s16x4*>(image(0, st, 0) + a_dst + 64 * QT * i) = cQh[i];
         *reinterpret_cast<s16x4*>(image(1, st, 0) + a_dst + 64 * QT * i) = cOh[i];
         if constexpr (NPL == 2) {
@@ -439,7 +468,14 @@ int launch_dt(const CsnAttnDkvArgs& a, hipStream_t st) {
   const long long units = (long long)a.n_blocks * a.H * a.n_groups;
   const int KC = (a.T + KW - 1) / KW;
   dim3 grid((unsigned)(((units + 7) / 8) * 8 * KC));
-  hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT>), grid, dim3(512), 0, st, a);
+  if (a.q_fmt || a.dctx_fmt) {
+    if constexpr (PR::NPL == 1) {
+      if (a.dctx_fmt != 1) return -1;
+      if (a.q_fmt == 1) hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 1>), grid, dim3(512), 0, st, a);
+      else if (a.q_fmt == 2) hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 2>), grid, dim3(512), 0, st, a);
+      else return -1;
+    } else return -1;
+  } else hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT>), grid, dim3(512), 0, st, a);
   return (int)hipGetLastError();
 }
 
@@ -460,6 +496,8 @@ int csn_launch_attn_dkv_flash(const CsnAttnDkvArgs& a, int d, int mode, hipStrea
   if (a.n_groups <= 0 || a.n_blocks <= 0) return 0;
   if ((a.ld & 3) || (a.T & 3) || (a.T_last & 3) || a.T > 512 || (a.kv_ld & 7) || (a.kv_shape_stride & 7)) return -2;
   if ((a.q_shape_stride & 3) || (a.ctx_eval_stride & 3) || (a.dkv_slot_stride & 3)) return -4;
+  if ((a.q_fmt || a.dctx_fmt) && mode != 2) return -1;              // 16-bit activation maps: the one-plane mode
+  if (a.dctx_fmt == 2) return -1;                                   // dO is a backward tensor: bf16
   switch (mode) {
     case 1: return launch_any<Bf16x3>(a, d, st);
     case 2: return launch_any<Bf16>(a, d, st);

@@ -19,14 +19,28 @@ __device__ __forceinline__ double block_sum(double v, double* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+using namespace csn_mode;
+
+// 4 consecutive values of a normalised map: fp32, or (X16: 16-bit activation maps) fp16
+template <bool X16> CSN_DEVINL f32x4 load_x4(const float* __restrict__ row, int i) {
+  if constexpr (X16) return from16x4<true>(*reinterpret_cast<const s16x4*>(reinterpret_cast<const short*>(row) + i));
+  else return *reinterpret_cast<const f32x4*>(row + i);
+}
+// the row that starts `el` elements into a map tensor
+template <bool X16> CSN_DEVINL const float* row_at(const float* base, long long el) {
+  if constexpr (X16) return reinterpret_cast<const float*>(reinterpret_cast<const short*>(base) + el);
+  else return base + el;
+}
+
 // out[r] = sum_n x[r*ld + n], n < n  (one work-group per row)
+template <bool X16>
 __global__ __launch_bounds__(256) void csn_rowsum_kernel(const float* __restrict__ x, float* __restrict__ out, int n,
                                                          long long ld) {
   __shared__ double red[4];
-  const float* __restrict__ p = x + (long long)blockIdx.x * ld;
+  const float* __restrict__ p = row_at<X16>(x, (long long)blockIdx.x * ld);
   double s = 0.0;
   for (int i = threadIdx.x * 4; i < n; i += 1024) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(p + i);
+    const f32x4 v = load_x4<X16>(p, i);
     s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
   }
   s = block_sum(s, red);
@@ -46,6 +60,7 @@ __global__ __launch_bounds__(256) void csn_partial_sums_kernel(const float* __re
 
 // feats[b][c][n] = gamma[c] * sum_k comp[b][k] xhat[(b*K1+k)][c][n] + beta[c] * sum_k comp[b][k]
 // xhat0 != null: the k = 0 maps live in their own tensor xhat0[b][c][n] and xhat holds the K1 - 1 others, [b*(K1-1) + k-1]
+template <bool X16>
 __global__ __launch_bounds__(256) void csn_mix_fwd_kernel(const float* __restrict__ xhat, const float* __restrict__ comp,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ feats, int K1, int C, int NP,
@@ -57,13 +72,14 @@ __global__ __launch_bounds__(256) void csn_mix_fwd_kernel(const float* __restric
   const float g = gamma[c], bb = beta[c] * csum;
   const float* xk[8];
   for (int k = 0; k < K1; ++k)
-    xk[k] = !xhat0 ? xhat + ((long long)(b * K1 + k) * C + c) * NP
-                   : (k == 0 ? xhat0 + ((long long)b * C + c) * NP : xhat + ((long long)(b * (K1 - 1) + k - 1) * C + c) * NP);
+    xk[k] = !xhat0 ? row_at<X16>(xhat, ((long long)(b * K1 + k) * C + c) * NP)
+                   : (k == 0 ? row_at<X16>(xhat0, ((long long)b * C + c) * NP)
+                             : row_at<X16>(xhat, ((long long)(b * (K1 - 1) + k - 1) * C + c) * NP));
   float* __restrict__ o = feats + ((long long)b * C + c) * NP;
   for (int i = threadIdx.x * 4; i < NP; i += 1024) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < K1; ++k) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(xk[k] + i);
+      const f32x4 v = load_x4<X16>(xk[k], i);
       acc += v * w[k];
     }
     *reinterpret_cast<f32x4*>(o + i) = acc * g + bb;
@@ -72,6 +88,8 @@ __global__ __launch_bounds__(256) void csn_mix_fwd_kernel(const float* __restric
 
 // dxhat[(b*K1+k)][c][n] = comp[b][k] gamma[c] dfeats[b][c][n]  (+ pool_grad[(b*K1+k)][c] if given, k = 0 only)
 // rowdot[b][k][c] = sum_n dfeats[b][c][n] xhat[(b*K1+k)][c][n],   rowsum[b][c] = sum_n dfeats[b][c][n]
+// X16: xhat / xhat0 are fp16 maps (16-bit activation maps; reductions only — no gradient maps are written in that form)
+template <bool X16>
 __global__ __launch_bounds__(256) void csn_mix_bwd_kernel(const float* __restrict__ dfeats, const float* __restrict__ xhat,
                                                           const float* __restrict__ comp, const float* __restrict__ gamma,
                                                           float* __restrict__ dxhat, float* __restrict__ rowdot,
@@ -87,11 +105,11 @@ __global__ __launch_bounds__(256) void csn_mix_bwd_kernel(const float* __restric
   for (int k = 0; k < K1; ++k) {
     const long long off = !xhat0 ? ((long long)(b * K1 + k) * C + c) * NP
                                  : (k == 0 ? ((long long)b * C + c) * NP : ((long long)(b * (K1 - 1) + k - 1) * C + c) * NP);
-    xk[k] = ((xhat0 && k == 0) ? xhat0 : xhat) + off;
+    xk[k] = row_at<X16>((xhat0 && k == 0) ? xhat0 : xhat, off);
     float* const o = (xhat0 && k == 0) ? dxhat0 : dxhat;
     ok[k] = o ? o + off : nullptr;
   }
-  const bool store = xhat0 ? dxhat0 != nullptr : dxhat != nullptr;    // no gradient maps wanted: only the reductions
+  const bool store = !X16 && (xhat0 ? dxhat0 != nullptr : dxhat != nullptr);    // no gradient maps wanted: only the reductions
   double dot[8];
   for (int k = 0; k < 8; ++k) dot[k] = 0.0;
   double sum = 0.0;
@@ -99,7 +117,7 @@ __global__ __launch_bounds__(256) void csn_mix_bwd_kernel(const float* __restric
     const f32x4 g = *reinterpret_cast<const f32x4*>(d + i);
     sum += ((double)g.x + (double)g.y) + ((double)g.z + (double)g.w);
     for (int k = 0; k < K1; ++k) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(xk[k] + i);
+      const f32x4 v = load_x4<X16>(xk[k], i);
       dot[k] += ((double)g.x * v.x + (double)g.y * v.y) + ((double)g.z * v.z + (double)g.w * v.w);
       if (store) *reinterpret_cast<f32x4*>(ok[k] + i) = g * w[k];
     }
@@ -114,9 +132,10 @@ __global__ __launch_bounds__(256) void csn_mix_bwd_kernel(const float* __restric
 
 }  // namespace
 
-int csn_launch_rowsum_f32(const float* x, float* out, long long rows, int n, long long ld, hipStream_t st) {
+int csn_launch_rowsum_f32(const float* x, float* out, long long rows, int n, long long ld, hipStream_t st, int x16) {
   if (rows <= 0) return 0;
-  hipLaunchKernelGGL(csn_rowsum_kernel, dim3((unsigned)rows), dim3(256), 0, st, x, out, n, ld);
+  if (x16) hipLaunchKernelGGL(csn_rowsum_kernel<true>, dim3((unsigned)rows), dim3(256), 0, st, x, out, n, ld);
+  else hipLaunchKernelGGL(csn_rowsum_kernel<false>, dim3((unsigned)rows), dim3(256), 0, st, x, out, n, ld);
   return (int)hipGetLastError();
 }
 
@@ -128,16 +147,23 @@ int csn_launch_partial_sums_f32(const float* ws, float* out, long long rows_oute
 }
 
 int csn_launch_mix_fwd_f32(const float* xhat, const float* comp, const float* gamma, const float* beta, float* feats, int B,
-                           int K1, int C, int NP, const float* xhat0, hipStream_t st) {
-  hipLaunchKernelGGL(csn_mix_fwd_kernel, dim3((unsigned)(B * C)), dim3(256), 0, st, xhat, comp, gamma, beta, feats, K1, C, NP,
-                     xhat0);
+                           int K1, int C, int NP, const float* xhat0, hipStream_t st, int x16) {
+  if (x16) hipLaunchKernelGGL(csn_mix_fwd_kernel<true>, dim3((unsigned)(B * C)), dim3(256), 0, st, xhat, comp, gamma, beta, feats, K1, C,
+                              NP, xhat0);
+  else hipLaunchKernelGGL(csn_mix_fwd_kernel<false>, dim3((unsigned)(B * C)), dim3(256), 0, st, xhat, comp, gamma, beta, feats, K1, C,
+                          NP, xhat0);
   return (int)hipGetLastError();
 }
 
 int csn_launch_mix_bwd_f32(const float* dfeats, const float* xhat, const float* comp, const float* gamma, float* dxhat,
                            float* rowdot, float* rowsum, int B, int K1, int C, int NP, const float* xhat0, float* dxhat0,
-                           hipStream_t st) {
-  hipLaunchKernelGGL(csn_mix_bwd_kernel, dim3((unsigned)(B * C)), dim3(256), 0, st, dfeats, xhat, comp, gamma, dxhat, rowdot,
-                     rowsum, K1, C, NP, xhat0, dxhat0);
+                           hipStream_t st, int x16) {
+  if (x16) {
+    if (dxhat || dxhat0) return -1;                                   // 16-bit maps: the linked form (reductions only)
+    hipLaunchKernelGGL(csn_mix_bwd_kernel<true>, dim3((unsigned)(B * C)), dim3(256), 0, st, dfeats, xhat, comp, gamma, dxhat, rowdot,
+                       rowsum, K1, C, NP, xhat0, dxhat0);
+  } else
+    hipLaunchKernelGGL(csn_mix_bwd_kernel<false>, dim3((unsigned)(B * C)), dim3(256), 0, st, dfeats, xhat, comp, gamma, dxhat, rowdot,
+                       rowsum, K1, C, NP, xhat0, dxhat0);
   return (int)hipGetLastError();
 }

@@ -10,6 +10,13 @@ int g_math_mode = CSN_MATH_BF16X3;          // process default (csn_set_math_mod
 thread_local int t_math_mode = -1;          // per-thread override (csn_set_thread_math_mode); -1 = none
 
 inline int mode() { return t_math_mode >= 0 ? t_math_mode : g_math_mode; }
+// 16-bit activation maps between the entry points (csn_set_thread_act16): 0 off, 1 = the forward's maps are bf16 (math mode 2),
+// 2 = they are fp16 (math mode 3 forward; its backward runs in mode 2 and converts them while staging)
+thread_local int t_act16 = 0;
+inline int act16() { return t_act16; }
+// forward entry points: the flag has to name the type of the mode that runs; backward: mode 2 takes either
+inline bool act16_fwd_ok() { return t_act16 == 0 || (t_act16 == 1 && mode() == 2) || (t_act16 == 2 && mode() == 3); }
+inline bool act16_bwd_ok() { return t_act16 == 0 || mode() == 2; }
 inline int planes_of(int m) { return m == 1 ? 2 : 1; }          // tile-plane / split-tensor planes of a 16-bit mode
 
 // the cross-length entry points (fp32 K / V maps) have no single-product kernels: in modes 2 / 3 they run as mode 1
@@ -63,10 +70,10 @@ int wgrad_chunk(int n_maps, int n_points) {
   return (int)c;
 }
 
-// dw[rows][cols] (+)= scale * sum_{z2, n} a[z2][rows][n] * b[z2][cols][n]
+// dw[rows][cols] (+)= scale * sum_{z2, n} a[z2][rows][n] * b[z2][cols][n]      (a_fmt / b_fmt: CSN_FMT_* of the two maps)
 int wgrad(const float* a, long long a_stride, int lda, const float* b, long long b_stride, int ldb, float* dw, int rows,
           int cols, int n_maps, int n_points, float scale, int accumulate, float* ws, long long ws_floats,
-          hipStream_t st) {
+          hipStream_t st, int a_fmt = 0, int b_fmt = 0) {
   const int chunk = wgrad_chunk(n_maps, n_points);
   const int n_chunks = (n_points + chunk - 1) / chunk;
   const long long slabs = (long long)n_maps * n_chunks;
@@ -74,6 +81,7 @@ int wgrad(const float* a, long long a_stride, int lda, const float* b, long long
   CsnGemmArgs g;
   g.A = operand(a, chunk, 0, a_stride, nullptr, lda);
   g.B = operand(b, chunk, 0, b_stride, nullptr, ldb);
+  g.A.fmt = a_fmt; g.B.fmt = b_fmt;
   g.C = operand(ws, (long long)rows * cols, 0, (long long)n_chunks * rows * cols, nullptr, cols);
   g.M = rows; g.N = cols; g.K = n_points;
   g.n0 = n_chunks; g.n1 = 1; g.k_chunk = chunk;
@@ -101,6 +109,12 @@ int csn_set_thread_math_mode(int m) {
 }
 int csn_get_math_mode(void) { return mode(); }
 int csn_get_thread_math_mode(void) { return t_math_mode; }
+int csn_set_thread_act16(int fmt) {
+  if (fmt < 0 || fmt > 2) return CSN_E_ARG;
+  t_act16 = fmt;
+  return 0;
+}
+int csn_get_thread_act16(void) { return t_act16; }
 
 const char* csn_status_string(int status) {
   switch (status) {
@@ -126,7 +140,8 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
                     float* out, long long out_shape_stride, int ld_out, int n_shapes, int n_points, int div_rows,
                     float temperature, int out_split, long long out_plane_stride, void* stream) {
   if (out_split && mode() == 0) return CSN_E_ARG;
-  if (out_split < 0 || out_split > 2) return CSN_E_ARG;
+  if (out_split < 0 || out_split > 3) return CSN_E_ARG;
+  if (out_split == 3 && mode() < 2) return CSN_E_ARG;               // one 16-bit map: the single-product modes
   if (!x || !w || !out || rows <= 0 || channels <= 0 || n_shapes <= 0 || n_points <= 0) return CSN_E_ARG;
   if (out_split == 2) {
     // tile planes: out_plane_stride = points per attention block (<= 512), ld_out = row pitch = n_blocks * 512 * planes
@@ -144,7 +159,7 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
   g.A = operand(w, 0, 0, 0, nullptr, channels);
   g.B = operand(x, 0, 0, x_shape_stride, nullptr, ld_x);
   g.C = operand(out, 0, 0, out_shape_stride, nullptr, ld_out);
-  g.C.planes = out_split; g.C.plane_stride = out_plane_stride;
+  g.C.planes = out_split == 3 ? 1 : out_split; g.C.plane_stride = out_plane_stride;
   g.M = rows; g.N = n_points; g.K = channels;
   g.n0 = 1; g.n1 = 1; g.k_chunk = 0;
   g.alpha = 1.f; g.div_rows = div_rows; g.div_val = temperature; g.accumulate = 0; g.eval_ids = nullptr;
@@ -195,6 +210,10 @@ static int attn_fwd_impl(const float* q, const float* k, const float* v, long lo
   a.dropout_p = dropout_p; a.seed = seed;
   a.r_planes = 0; a.kv_planes = qkv_split; a.r_plane_stride = 0; a.kv_plane_stride = 0; a.sc_tiles = 0;
   a.tq_arr = tq_arr; a.t_arr = t_arr;
+  if (act16()) {                                                     // Qs in, Ctx out: 16-bit maps of the mode's type
+    if (!act16_fwd_ok() || !qkv_split || block_q != 0) return CSN_E_ARG;
+    a.r_fmt = a.out_fmt = act16();
+  }
   return mode() != 0 ? csn_launch_attn_fwd_bf16x3(a, d_head, mode(), (hipStream_t)stream)
                      : csn_launch_attn_fwd_f32(a, d_head, (hipStream_t)stream);
 }
@@ -285,6 +304,10 @@ static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_e
   a.sc_tiles = probs_tiles;
   a.tq_arr = tq_arr; a.t_arr = t_arr;
   a.q2 = q; a.q2_shape_stride = q_shape_stride; a.q2_index = q_index;
+  if (act16()) {                                                     // dO: bf16; O and Qs: the forward's 16-bit type; dQ stays fp32
+    if (!act16_bwd_ok() || !kv_split || block_q != 0) return CSN_E_ARG;
+    a.r_fmt = 1; a.ctx_fmt = act16(); a.q2_fmt = act16();
+  }
   return mode() != 0 ? csn_launch_attn_bwd_bf16x3(a, d_head, mode(), st) : csn_launch_attn_bwd_f32(a, d_head, st);
 }
 
@@ -358,8 +381,10 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   g.n_arr = t_arr; g.k_arr = tq_arr;            // ragged batch: keys (rounded up to 4 by the kernel) / queries of every evaluation
   g.n_last = g.k_last = t_last;                 // the row ends inside the last block
   const int n_batch = group_offsets ? n_groups : n_launch_evals;
+  if (act16() && (!act16_bwd_ok() || !probs_tiles || block_q != 0)) return CSN_E_ARG;
   g.A = operand(dctx, bq, (long long)d_head * ld, dctx_split ? 2 * ctx_eval_stride : ctx_eval_stride, nullptr, ld);
   g.A.planes = dctx_split; g.A.plane_stride = dctx_plane_stride;
+  if (act16()) g.A.fmt = CSN_FMT_16;                                 // dO: a bf16 map
   // tile planes: the same buffers viewed as 16-bit elements (two per float: block strides double).  Two planes (mode 1): a
   // row of 16 tiles [hi | lo] is the fp32 row, pitch 2 * score_pitch, P in `probs`, dS in `dscores`.  One plane (mode 2):
   // compact rows of pitch score_pitch, both in `dscores` — per block [P: bq rows | dS: bq rows] (`probs` is not read)
@@ -375,6 +400,7 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   if (rc) return rc;
   g.A = operand(q, bq, (long long)d_head * ld, q_shape_stride, q_index, ld);
   g.A.planes = q_split; g.A.plane_stride = q_plane_stride;
+  if (act16()) g.A.fmt = act16() == 2 ? CSN_FMT_F16_TO_BF16 : CSN_FMT_16;   // Qs: the forward's 16-bit map
   g.B = operand(ds_src, bm * blk_sc, bm * blk_sc * n_blocks, bm * blk_sc * n_blocks * n_heads, nullptr, ldb);
   g.B.planes = probs_tiles ? 2 : 0;
   g.C = operand(dk, block, (long long)d_head * lk, dkv_slot_stride, dk_index, lk);
@@ -435,6 +461,10 @@ int csn_block_attn_bwd_dkv_flash_f32(const float* dctx, long long ctx_eval_strid
   a.eval_ids = eval_ids; a.grp_off = group_offsets; a.n_groups = group_offsets ? n_groups : n_launch_evals;
   a.ld = ld; a.H = n_heads; a.T = block; a.Tp = score_pitch; a.n_blocks = n_blocks; a.T_last = t_last;
   a.dropout_p = dropout_p; a.seed = seed; a.kv_f16 = kv_f16 != 0;
+  if (act16()) {
+    if (!act16_bwd_ok()) return CSN_E_ARG;
+    a.q_fmt = act16(); a.dctx_fmt = 1;
+  }
   return csn_launch_attn_dkv_flash(a, d_head, mode(), (hipStream_t)stream);
 }
 
@@ -512,6 +542,8 @@ int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const fl
   a.E = n_evals; a.C = d_model; a.D = d_inner; a.ld = ld; a.n_points = n_points; a.eps = eps;
   a.dropout_p = dropout_p; a.seed = seed;
   a.xhat_sum = xhat_sum; a.sum_ws = sum_ws; a.sum_ws_floats = sum_ws ? sum_ws_floats : 0;
+  if (act16() && !act16_fwd_ok()) return CSN_E_ARG;
+  a.act16 = act16();
   return csn_launch_outproj_ln_fwd_f32(a, mode(), (hipStream_t)stream);
 }
 
@@ -540,6 +572,9 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
   l.dropout_p = dropout_p; l.seed = seed;
   l.dxhat_rows = dxhat_rows; l.n_dense = n_dense_evals;
   l.dxhat_scale = dxhat_scale; l.dxhat_group = dxhat_group > 0 ? dxhat_group : 1;
+  const int a16 = act16();
+  if (a16 && (!act16_bwd_ok() || dctx_split)) return CSN_E_ARG;
+  l.act16 = a16;
   int rc = csn_launch_ln_bwd_f32(l, st);
   if (rc) return rc;
   // dctx[e][D][n] = wfc_t[D][c] dz[e][c][n]
@@ -548,6 +583,7 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
   g.B = operand(dz, 0, 0, eval_stride, nullptr, ld);
   g.C = operand(dctx, 0, 0, dctx_split ? 2 * ctx_eval_stride : ctx_eval_stride, nullptr, ld);   // split: [eval][2][D][ld]
   g.C.planes = dctx_split; g.C.plane_stride = dctx_plane_stride;
+  if (a16) { g.B.fmt = CSN_FMT_16; g.C.planes = 1; }                 // dz in, dctx out: bf16 maps
   g.M = d_inner; g.N = n_points; g.K = d_model;
   g.n0 = 1; g.n1 = 1; g.k_chunk = 0;
   g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = 0; g.eval_ids = nullptr;
@@ -555,7 +591,7 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
   if (rc) return rc;
   // dwfc[c][D] (+)= sum_{e,n} dz[e][c][n] ctx[e][D][n]
   return wgrad(dz, eval_stride, ld, ctx, ctx_eval_stride, ld, dwfc, d_model, d_inner, n_evals, n_points, 1.f,
-               accumulate, ws, ws_floats, st);
+               accumulate, ws, ws_floats, st, a16 ? CSN_FMT_16 : 0, a16 == 2 ? CSN_FMT_F16_TO_BF16 : (a16 ? CSN_FMT_16 : 0));
 }
 
 int csn_project_wgrad_f32(const float* dout, long long dout_shape_stride, int ld_dout, const float* x,
@@ -585,7 +621,7 @@ int csn_rowsum_f32(const float* x, float* out, long long rows, int n_points, lon
   if (!x || !out || rows <= 0 || n_points <= 0 || n_points > ld) return CSN_E_ARG;
   if ((n_points & 3) || (ld & 3)) return CSN_E_ALIGN;
   if (mis16(x)) return CSN_E_PTR;
-  return csn_launch_rowsum_f32(x, out, rows, n_points, ld, (hipStream_t)stream);
+  return csn_launch_rowsum_f32(x, out, rows, n_points, ld, (hipStream_t)stream, act16());
 }
 
 int csn_mix_fwd_f32(const float* xhat, const float* comp, const float* gamma, const float* beta, float* feats,
@@ -596,7 +632,7 @@ int csn_mix_fwd_f32(const float* xhat, const float* comp, const float* gamma, co
   if (n_points & 3) return CSN_E_ALIGN;
   if (mis16(xhat) || mis16(feats) || mis16(xhat_self)) return CSN_E_PTR;
   return csn_launch_mix_fwd_f32(xhat, comp, gamma, beta, feats, n_shapes, k1, channels, n_points, xhat_self,
-                                (hipStream_t)stream);
+                                (hipStream_t)stream, act16());
 }
 
 int csn_mix_bwd_f32(const float* dfeats, const float* xhat, const float* comp, const float* gamma, float* dxhat,
@@ -612,8 +648,9 @@ int csn_mix_bwd_f32(const float* dfeats, const float* xhat, const float* comp, c
   if (n_shapes <= 0 || k1 <= 0 || k1 > 8 || channels <= 0 || n_points <= 0) return CSN_E_ARG;
   if (n_points & 3) return CSN_E_ALIGN;
   if (mis16(dfeats) || mis16(xhat) || mis16(dxhat) || mis16(xhat_self) || mis16(dxhat_self)) return CSN_E_PTR;
+  if (act16() && want_maps) return CSN_E_ARG;                         // fp16 maps: the linked form (reductions only)
   return csn_launch_mix_bwd_f32(dfeats, xhat, comp, gamma, dxhat, rowdot, rowsum, n_shapes, k1, channels, n_points, xhat_self,
-                                dxhat_self, (hipStream_t)stream);
+                                dxhat_self, (hipStream_t)stream, act16());
 }
 
 int csn_compat_fwd_f32(const float* pooled, const float* wq_t, const float* bq, const float* wk_t, const float* bk, float* comp,

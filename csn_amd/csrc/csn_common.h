@@ -97,6 +97,11 @@ CSN_DEVINL f32x4 csn_ldg4(const float* __restrict__ row, int c, int clim, bool r
 // Three-level batched operand: element offset = s0*z0 + s1*z1 + s2*(idx2 ? idx2[z2] : z2)
 // `planes` != 0 (bf16x3 kernels only): ptr is the bf16 HIGH plane of a split tensor (x = hi + lo, two bf16 per
 // fp32), the LOW plane starts plane_stride bf16 elements later; strides and ld then count bf16 elements.
+// `fmt` (single-product modes, input operands): CSN_FMT_F32 = fp32 words (split while staged); CSN_FMT_16 = a 16-bit map in the
+// product's own type (bf16, or fp16 in math mode 3), staged by copy; CSN_FMT_F16_TO_BF16 = fp16 bits feeding a bf16 product
+// (a forward tensor of math mode 3 read by its bf16 backward), converted in registers while staged.  Strides and ld count
+// ELEMENTS of the operand's format.  An OUTPUT is a 16-bit map when planes == 1 in a one-plane mode.
+enum { CSN_FMT_F32 = 0, CSN_FMT_16 = 1, CSN_FMT_F16_TO_BF16 = 2 };
 struct CsnOperand {
   float* ptr;
   long long s0, s1, s2;
@@ -104,6 +109,7 @@ struct CsnOperand {
   int ld;
   int planes;
   long long plane_stride;
+  int fmt = CSN_FMT_F32;
 };
 
 // z2 is first mapped through the launch's evaluation list (if any), then through the operand's own slot map
@@ -190,6 +196,15 @@ template <bool H16> CSN_DEVINL f32x4m mfma16(s16x8 a, s16x8 b, f32x4m c) {      
   else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(csn_bf16x8, a), __builtin_bit_cast(csn_bf16x8, b), c, 0, 0, 0);
 }
 CSN_DEVINL s16x8 join8(s16x4 a, s16x4 b) { return s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+// 16-bit activation maps: 8 (4) fp16 values -> the same values as bf16 (round to nearest even); 4 values of either type -> fp32
+CSN_DEVINL f32x4 f16x8_to_bf16x8(const f32x4 v) {
+  s16x8 s = __builtin_bit_cast(s16x8, v);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = to16<false>(from16<true>(s[j]));
+  return __builtin_bit_cast(f32x4, s);
+}
+CSN_DEVINL s16x4 f16x4_to_bf16x4(const s16x4 v) { return to16x4<false>(from16x4<true>(v)); }
+CSN_DEVINL f32x4 act16_to_f32(const s16x4 v, int fmt /* 1: bf16, 2: fp16 */) { return fmt == 2 ? from16x4<true>(v) : from16x4<false>(v); }
 }  // namespace csn_mode
 
 // sum / max across the two 32-lane halves of a wave (lane l <-> lane l ^ 32)

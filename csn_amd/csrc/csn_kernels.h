@@ -73,6 +73,9 @@ struct CsnAttnArgs {
   // forward; q2 == nullptr = the scores are read from `scores` (kept by the forward)
   const float* q2 = nullptr; long long q2_shape_stride = 0; const int* q2_index = nullptr;
   int kv_f16 = 0;                                        // backward, one-plane mode: the K / V tile planes hold fp16 (the forward ran in math mode 3)
+  // 16-bit activation maps (single-product modes): format of the register operand q (forward: Qs; backward: dO), of ctx (O),
+  // of q2 and of out — 0 fp32, 1 bf16, 2 fp16; shape / evaluation strides then count 16-bit elements
+  int r_fmt = 0, ctx_fmt = 0, q2_fmt = 0, out_fmt = 0;
 };
 // score recomputation needs three LDS tile images per stage: one plane at every width, two planes up to d = 128
 constexpr bool csn_attn_recompute_fits(int planes, int dt) { return planes == 1 || dt <= 4; }
@@ -90,6 +93,7 @@ struct CsnAttnDkvArgs {
   int ld, H, T, Tp, n_blocks, T_last;
   float dropout_p;  unsigned long long seed;
   int kv_f16 = 0;                                                         // one-plane mode: k / v hold fp16 (forward of math mode 3)
+  int q_fmt = 0, dctx_fmt = 0;                                            // 16-bit activation maps: 0 fp32, 1 bf16, 2 fp16 (q of a mode-3 forward)
 };
 int csn_launch_attn_dkv_flash(const CsnAttnDkvArgs& a, int d, int mode, hipStream_t st);
 constexpr bool csn_attn_dkv_flash_fits(int dt) { return dt <= 4; }         // K^T, V^T, dK^T, dV^T of 16 keys in one wave's registers
@@ -114,6 +118,8 @@ struct CsnOutProjArgs {
   // The 256 x 256-tile kernel forms per-tile partial sums in its epilogue (sum_ws [e][ceil(n_points/256)][C], reduced by a
   // small second kernel in fp64); the other kernels are followed by the streaming row-sum pass.
   float* xhat_sum; float* sum_ws; long long sum_ws_floats;
+  // 16-bit activation maps (math modes 2 / 3): ctx is a 16-bit map of the mode's type, xhat leaves as fp16; strides in elements
+  int act16 = 0;
 };
 int csn_launch_partial_sums_f32(const float* ws, float* out, long long rows_outer, int tiles, int C, hipStream_t st);
 int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, int mode, hipStream_t st);   // mode 0: fp32, 1..3: 16-bit matrix-core contraction
@@ -133,6 +139,7 @@ struct CsnLnBwdArgs {
   int E, C, ld, n_points;
   float dropout_p;
   unsigned long long seed;
+  int act16 = 0;                                               // xhat is an fp16 map, dz leaves as a bf16 map (dxhat, dz_res stay fp32)
 };
 int csn_launch_ln_bwd_f32(const CsnLnBwdArgs& a, hipStream_t st);
 
@@ -141,12 +148,13 @@ int csn_launch_rowdot_f32(const float* a, const float* b, float* out, const int*
                           int n_points, long long eval_stride, int a_split, long long a_plane_stride, hipStream_t st);
 
 // ---- pooled descriptors / cross-shape mix (combine.hip) ---------------------------------------------
-int csn_launch_rowsum_f32(const float* x, float* out, long long rows, int n, long long ld, hipStream_t st);
+// x16 != 0: the normalised maps (x / xhat / xhat0) are fp16 (16-bit activation maps)
+int csn_launch_rowsum_f32(const float* x, float* out, long long rows, int n, long long ld, hipStream_t st, int x16 = 0);
 int csn_launch_mix_fwd_f32(const float* xhat, const float* comp, const float* gamma, const float* beta, float* feats, int B,
-                           int K1, int C, int NP, const float* xhat0, hipStream_t st);
+                           int K1, int C, int NP, const float* xhat0, hipStream_t st, int x16 = 0);
 int csn_launch_mix_bwd_f32(const float* dfeats, const float* xhat, const float* comp, const float* gamma, float* dxhat,
                            float* rowdot, float* rowsum, int B, int K1, int C, int NP, const float* xhat0, float* dxhat0,
-                           hipStream_t st);
+                           hipStream_t st, int x16 = 0);
 int csn_launch_retrieval_f32(const float* f1, const float* f2, float* out, int s1, int n1, int s2, int n2, int C,
                              float* ws, hipStream_t st);
 

@@ -60,10 +60,17 @@ CSN_DEVINL f32x16 mma32(s16x8 ah, s16x8 al, s16x8 bh, s16x8 bl, f32x16 c) {
 // [hi 32 | lo 32] (B.ld = row pitch in bf16 elements, B strides in bf16 elements; padding columns inside a tile are zero).
 // Its staging is then a plain copy — 16-byte loads, 16-byte LDS stores, no conversion work.  This is how the attention
 // backward hands the probabilities P and the score gradients dS to the dV / dK products.
-template <typename PR, int BM, int BN, bool B_NK, bool BT = false>
+// AF / BF: input formats of A / B in the single-product modes (see the 256 x 256 kernel below)
+template <typename PR, int BM, int BN, bool B_NK, bool BT = false, int AF = 0, int BF = 0>
 __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) {
   constexpr int NPL = PR::NPL;                          // planes per operand: hi (+ lo)
   static_assert(!BT || (!B_NK && BN == 128), "tile-plane B: k-major, 128-column tiles");
+  static_assert((AF == 0 && BF == 0) || PR::NPL == 1, "16-bit operand maps: single-product modes only");
+  static_assert(!(BT && BF) && !((AF == 2 || BF == 2) && PR::HALF), "tile planes carry their own format; fp16 -> bf16 feeds bf16 products");
+  constexpr int AES = AF ? 2 : 4, BES = BF ? 2 : 4;
+  constexpr int A16_PASS = BM / 64, B16_PASS = B_NK ? BN / 64 : 2;    // 16-byte pieces per thread and slab of a 16-bit map
+  constexpr int TPR16 = BN / 8;                         // k-major 16-bit B: threads per k row (16 k rows per pass)
+  static_assert(!BF || B_NK || 256 / TPR16 == 16, "k-major 16-bit B: two passes of 16 k rows");
   constexpr int MT = BM / 64, NT = BN / 64;
   constexpr int A_PASS = BM / 32, B_PASS = BN / 32;
   constexpr int TPR = BN / 4, RPP = 256 / TPR;          // KN staging: threads per k row, k rows per pass
@@ -101,15 +108,18 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   const bool c_pl = p.C.planes != 0;
   const bool c_tiles = p.C.planes == 2;      // "tile planes" for the attention kernels (attn_bf16x3.hip), block = plane_stride points
   const int c_es = c_pl ? 2 : 4;
-  const float* a_base = p.A.ptr + p.A.s0 * z0 + p.A.s1 * z1 + p.A.s2 * (long long)(p.A.idx2 ? p.A.idx2[z2] : z2) + (long long)m0 * lda;
+  const char* a_base = reinterpret_cast<const char*>(p.A.ptr) +
+                       (p.A.s0 * z0 + p.A.s1 * z1 + p.A.s2 * (long long)(p.A.idx2 ? p.A.idx2[z2] : z2) + (long long)m0 * lda) * AES;
   const long long b_el = p.B.s0 * z0 + p.B.s1 * z1 + p.B.s2 * (long long)(p.B.idx2 ? p.B.idx2[z2] : z2);
-  const float* b_base = BT ? reinterpret_cast<const float*>(reinterpret_cast<const short*>(p.B.ptr) + b_el)
-                           : p.B.ptr + b_el + (B_NK ? (long long)n0 * ldb : (long long)n0);
+  const char* b_base = BT ? reinterpret_cast<const char*>(reinterpret_cast<const short*>(p.B.ptr) + b_el)
+                          : reinterpret_cast<const char*>(p.B.ptr) + (b_el + (B_NK ? (long long)n0 * ldb : (long long)n0)) * BES;
   char* c_base = reinterpret_cast<char*>(p.C.ptr) + (p.C.s0 * z0 + p.C.s1 * z1 + p.C.s2 * (long long)(p.C.idx2 ? p.C.idx2[z2] : z2) + (long long)m0 * ldc + (c_tiles ? 0 : n0)) * c_es;
   const long long c_win = (long long)BM * ldc * c_es;
-  const csn_rsrc_t Ar = csn_make_rsrc(a_base, (long long)BM * lda * 4);
+  // (16-bit k-contiguous maps: the window ends with the last valid row's K elements, see the 256 x 256 kernel)
+  const csn_rsrc_t Ar = csn_make_rsrc(a_base, AF ? ((long long)(min(BM, M - m0) - 1) * lda + K) * AES : (long long)BM * lda * AES);
   const csn_rsrc_t Br = csn_make_rsrc(b_base, BT ? (long long)K * ldb * 2
-                                                 : (B_NK ? (long long)BN * ldb * 4 : ((long long)(K - 1) * ldb + (N - n0)) * 4));
+                                                 : (B_NK ? (BF ? ((long long)(min(BN, N - n0) - 1) * ldb + K) * BES : (long long)BN * ldb * BES)
+                                                         : ((long long)(K - 1) * ldb + (N - n0)) * BES));
   const csn_rsrc_t Cr = csn_make_rsrc(c_base, c_win), Crl = csn_make_rsrc(c_base + p.C.plane_stride * 2, c_pl ? c_win : 0);
 
   f32x16 acc[MT][NT];
@@ -125,13 +135,23 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   // tile-plane B: a k row of the tile is B_PASS * NPL / 2 ... contiguous 16-byte units w = (tid & 7) + 8 i of NPL * 64-byte
   // tiles; unit w sits in tile w / (4 NPL), plane (w % (4 NPL)) / 4, keys 8 (w % 4) .. + 7 of the tile
   constexpr int BT_PASS = B_PASS * NPL / 2;             // 16-byte units per thread and slab
+  // 16-bit maps: k-contiguous row pr2 + 64 i, 16-byte unit pu of its 4; k-major B: k row kr2 + 16 i, columns 8 ku .. + 7
+  const int pr2 = tid >> 2, pu = tid & 3;
+  const int kr2 = tid / TPR16, ku = tid % TPR16;
   unsigned a_off[A_PASS], b_off[B_PASS];
   int bt_dst[B_PASS];
 #pragma unroll
-  for (int i = 0; i < A_PASS; ++i) a_off[i] = (m0 + pr + 32 * i) < M ? (unsigned)((pr + 32 * i) * lda + pc) * 4u : CSN_OOB;
+  for (int i = 0; i < A_PASS; ++i) {
+    if (AF) a_off[i] = (i < A16_PASS && (m0 + pr2 + 64 * i) < M) ? (unsigned)((pr2 + 64 * i) * lda + 8 * pu) * 2u : CSN_OOB;
+    else a_off[i] = (m0 + pr + 32 * i) < M ? (unsigned)((pr + 32 * i) * lda + pc) * 4u : CSN_OOB;
+  }
 #pragma unroll
   for (int i = 0; i < B_PASS; ++i) {
-    if (BT) {
+    if (BF) {
+      if (B_NK) b_off[i] = (i < B16_PASS && (n0 + pr2 + 64 * i) < N) ? (unsigned)((pr2 + 64 * i) * ldb + 8 * pu) * 2u : CSN_OOB;
+      else b_off[i] = (i < B16_PASS && (n0 + 8 * ku) < N) ? (unsigned)((kr2 + 16 * i) * ldb + 8 * ku) * 2u : CSN_OOB;
+      bt_dst[i] = 0;
+    } else if (BT) {
       const int w = (tid & 7) + 8 * i, tile = w / (4 * NPL), within = w % (4 * NPL), t_u = within & 3;
       b_off[i] = (i < BT_PASS && (n0 + 32 * tile + 8 * t_u) < N)
                      ? (unsigned)(pr * ldb) * 2u + (unsigned)(n0 >> 5) * (unsigned)(64 * NPL) + (unsigned)w * 16u : CSN_OOB;
@@ -143,9 +163,21 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   f32x4 ra[A_PASS], rb[B_PASS];
   auto load_slab = [&](int k0) {
     const unsigned kp = (k0 + pc) < K ? 0u : CSN_OOB;
+    const unsigned kp16 = (k0 + 8 * pu) < K ? 0u : CSN_OOB;
+    if (AF) {
 #pragma unroll
-    for (int i = 0; i < A_PASS; ++i) ra[i] = csn_bload4(Ar, a_off[i] | kp, (unsigned)k0 * 4u);
-    if (BT) {
+      for (int i = 0; i < A16_PASS; ++i) ra[i] = csn_bload4(Ar, a_off[i] | kp16, (unsigned)k0 * 2u);
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_PASS; ++i) ra[i] = csn_bload4(Ar, a_off[i] | kp, (unsigned)k0 * 4u);
+    }
+    if (BF) {
+#pragma unroll
+      for (int i = 0; i < B16_PASS; ++i) {
+        if (B_NK) rb[i] = csn_bload4(Br, b_off[i] | kp16, (unsigned)k0 * 2u);
+        else rb[i] = csn_bload4(Br, b_off[i] | ((k0 + kr2 + 16 * i) < K ? 0u : CSN_OOB), (unsigned)k0 * (unsigned)ldb * 2u);
+      }
+    } else if (BT) {
       const unsigned kb = (k0 + pr) < K ? 0u : CSN_OOB;               // k row pr of the slab
 #pragma unroll
       for (int i = 0; i < BT_PASS; ++i) rb[i] = csn_bload4(Br, b_off[i] | kb, (unsigned)k0 * (unsigned)ldb * 2u);
@@ -160,13 +192,31 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
       }
     }
   };
-  auto store_slab = [&](int st) {
+  auto unit16 = [&](f32x4 v, int fmt, int k0) {            // (see the 256 x 256 kernel)
+    if (fmt == CSN_FMT_F16_TO_BF16) v = f16x8_to_bf16x8(v);
+    if (k0 + 8 * pu + 8 > K) { v[2] = 0.f; v[3] = 0.f; }
+    return v;
+  };
+  auto store_slab = [&](int st, int k0) {
     s16x4 hi, lo;
+    if (AF) {
 #pragma unroll
-    for (int i = 0; i < A_PASS; ++i) {
-      split4<PR>(ra[i], hi, lo);
-      *reinterpret_cast<s16x4*>(&As[st][0][(pr + 32 * i) * PK + pc]) = hi;
-      if constexpr (NPL == 2) *reinterpret_cast<s16x4*>(&As[st][NPL - 1][(pr + 32 * i) * PK + pc]) = lo;
+      for (int i = 0; i < A16_PASS; ++i) *reinterpret_cast<f32x4*>(&As[st][0][(pr2 + 64 * i) * PK + 8 * pu]) = unit16(ra[i], AF, k0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_PASS; ++i) {
+        split4<PR>(ra[i], hi, lo);
+        *reinterpret_cast<s16x4*>(&As[st][0][(pr + 32 * i) * PK + pc]) = hi;
+        if constexpr (NPL == 2) *reinterpret_cast<s16x4*>(&As[st][NPL - 1][(pr + 32 * i) * PK + pc]) = lo;
+      }
+    }
+    if (BF) {
+#pragma unroll
+      for (int i = 0; i < B16_PASS; ++i) {
+        if (B_NK) *reinterpret_cast<f32x4*>(&Bs[st][0][(pr2 + 64 * i) * PK + 8 * pu]) = unit16(rb[i], BF, k0);
+        else *reinterpret_cast<f32x4*>(&Bs[st][0][(kr2 + 16 * i) * PN + 8 * ku]) = BF == CSN_FMT_F16_TO_BF16 ? f16x8_to_bf16x8(rb[i]) : rb[i];
+      }
+      return;
     }
     if (BT) {
 #pragma unroll
@@ -188,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   const int tr_base = (8 * (grp >> 1) + gq) * PN + 16 * (grp & 1) + 4 * gp;
 
   const int nk = (K + BK - 1) / BK;
-  if (nk > 0) { load_slab(0); store_slab(0); }
+  if (nk > 0) { load_slab(0); store_slab(0, 0); }
   if (nk > 1) load_slab(BK);
   __syncthreads();
   GSTAMP(1);
@@ -237,7 +287,7 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
     // slab kt + 2 starts its trip from HBM
     GIN(0, gt1, gt0);
     if (kt + 1 < nk) {
-      store_slab(cur ^ 1);
+      store_slab(cur ^ 1, (kt + 1) * BK);
       GIN(1, gt0, gt1);
       if (kt + 2 < nk) load_slab((kt + 2) * BK);
     }
@@ -339,11 +389,18 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
 // LN: the out-projection of the attention layer (csa_models.py:114-118) — M = d_model = 256 is exactly one tile, so the
 // epilogue can apply the fc dropout, add the residual and LayerNorm every point over its 256 channels (per-point sums are
 // combined across the four M-waves through LDS) before anything is written: C = xhat, q carries the epilogue's operands.
-template <typename PR, bool B_NK, bool BT, bool LN = false>
+// AF / BF (single-product modes): format of the A / B input (CSN_FMT_*): 16-bit activation maps are staged by copy — 16-byte
+// loads of 8 elements, half the loads and none of the conversion work of the fp32 form (CSN_FMT_F16_TO_BF16: converted in
+// registers).  Contraction counts are multiples of 4: the last 16-byte unit of a k-contiguous row may be half valid, its
+// upper half is then cleared (what lies behind it is the next block's data, not zeros).
+template <typename PR, bool B_NK, bool BT, bool LN = false, int AF = 0, int BF = 0>
 __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs p, CsnOutProjArgs q) {
   static_assert(!BT || !B_NK, "tile-plane B is k-major");
   static_assert(!LN || (!B_NK && !BT), "LayerNorm epilogue: W_fc (MK) x Ctx^T (KN)");
+  static_assert((AF == 0 && BF == 0) || PR::NPL == 1, "16-bit operand maps: single-product modes only");
+  static_assert(!(BT && BF) && !((AF == 2 || BF == 2) && PR::HALF), "tile planes carry their own format; fp16 -> bf16 feeds bf16 products");
   constexpr int NPL = PR::NPL;
+  constexpr int AES = AF ? 2 : 4, BES = BF ? 2 : 4;     // bytes per element of the A / B (non-tile-plane) input
   constexpr int BM = 256, BN = 256, MT = 2, NT = 4;
   constexpr int PN = BN + 32;                           // pitch of the k-major B planes
   constexpr int A_EL = BM * BK, B_EL = B_NK ? BN * BK : BK * PN;
@@ -384,13 +441,17 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
   const int c_es = c_pl ? 2 : 4;
   csn_rsrc_t Ar, Br;
   auto set_item = [&](int zi) {
-    const float* a_base = p.A.ptr + p.A.s0 * z0 + p.A.s1 * z1 + p.A.s2 * (long long)(p.A.idx2 ? p.A.idx2[zi] : zi) + (long long)m0 * lda;
+    const char* a_base = reinterpret_cast<const char*>(p.A.ptr) +
+                         (p.A.s0 * z0 + p.A.s1 * z1 + p.A.s2 * (long long)(p.A.idx2 ? p.A.idx2[zi] : zi) + (long long)m0 * lda) * AES;
     const long long b_el = p.B.s0 * z0 + p.B.s1 * z1 + p.B.s2 * (long long)(p.B.idx2 ? p.B.idx2[zi] : zi);
-    const float* b_base = BT ? reinterpret_cast<const float*>(reinterpret_cast<const short*>(p.B.ptr) + b_el)
-                             : p.B.ptr + b_el + (B_NK ? (long long)n0 * ldb : (long long)n0);
-    Ar = csn_make_rsrc(a_base, (long long)BM * lda * 4);
+    const char* b_base = BT ? reinterpret_cast<const char*>(reinterpret_cast<const short*>(p.B.ptr) + b_el)
+                            : reinterpret_cast<const char*>(p.B.ptr) + (b_el + (B_NK ? (long long)n0 * ldb : (long long)n0)) * BES;
+    // (16-bit k-contiguous maps: the window ends with the last valid row's K elements — a 16-byte unit may straddle the end
+    //  of the contraction, and behind the last row of the last item there is no memory; dwords beyond the window read as 0)
+    Ar = csn_make_rsrc(a_base, AF ? ((long long)(min(BM, M - m0) - 1) * lda + K) * AES : (long long)BM * lda * AES);
     Br = csn_make_rsrc(b_base, BT ? (long long)K * ldb * 2
-                                  : (B_NK ? (long long)BN * ldb * 4 : ((long long)(K - 1) * ldb + (N - n0)) * 4));
+                                  : (B_NK ? (BF ? ((long long)(min(BN, N - n0) - 1) * ldb + K) * BES : (long long)BN * ldb * BES)
+                                          : ((long long)(K - 1) * ldb + (N - n0)) * BES));
   };
   set_item(z2);
   char* c_base = reinterpret_cast<char*>(p.C.ptr) + (p.C.s0 * z0 + p.C.s1 * z1 + p.C.s2 * (long long)(p.C.idx2 ? p.C.idx2[z2] : z2) + (long long)m0 * ldc + (c_tiles ? 0 : n0)) * c_es;
@@ -413,12 +474,22 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
   const int t_kr = (tid >> 3) & 31, t_j = (tid & 7) + 8 * (tid >> 8);
   constexpr int BT_PASS = 2 * NPL;
   const int sw_dst = pr * BK + ((((pc >> 3) ^ ((pr >> 2) & 3)) << 3) | (pc & 4));     // rows 64 apart share the swizzle
+  // 16-bit maps, 2 pieces of 16 bytes (8 elements) per thread and slab.  k-contiguous: row pr2 + 128 i, unit pu of the row's 4;
+  // k-major B: k row kr2 + 16 i, columns 8 ku .. 8 ku + 7
+  const int pr2 = tid >> 2, pu = tid & 3;
+  const int kr2 = tid >> 5, ku = tid & 31;
+  const int sw16 = pr2 * BK + ((pu ^ ((pr2 >> 2) & 3)) << 3);                         // rows 128 apart share the swizzle
   unsigned a_off[4], b_off[4];
   int bt_dst[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    a_off[i] = (m0 + pr + 64 * i) < M ? (unsigned)((pr + 64 * i) * lda + pc) * 4u : CSN_OOB;
-    if (BT) {
+    if (AF) a_off[i] = (i < 2 && (m0 + pr2 + 128 * i) < M) ? (unsigned)((pr2 + 128 * i) * lda + 8 * pu) * 2u : CSN_OOB;
+    else a_off[i] = (m0 + pr + 64 * i) < M ? (unsigned)((pr + 64 * i) * lda + pc) * 4u : CSN_OOB;
+    if (BF) {
+      if (B_NK) b_off[i] = (i < 2 && (n0 + pr2 + 128 * i) < N) ? (unsigned)((pr2 + 128 * i) * ldb + 8 * pu) * 2u : CSN_OOB;
+      else b_off[i] = (i < 2 && (n0 + 8 * ku) < N) ? (unsigned)((kr2 + 16 * i) * ldb + 8 * ku) * 2u : CSN_OOB;
+      bt_dst[i] = 0;
+    } else if (BT) {
       const int w = t_j + 16 * i, tile = w / (4 * NPL), within = w % (4 * NPL), t_u = within & 3;
       b_off[i] = (i < BT_PASS && (n0 + 32 * tile + 8 * t_u) < N)
                      ? (unsigned)(t_kr * ldb) * 2u + (unsigned)(n0 >> 5) * (unsigned)(64 * NPL) + (unsigned)w * 16u : CSN_OOB;
@@ -429,9 +500,21 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
   f32x4 ra[4], rb[4];
   auto load_slab = [&](int k0) {
     const unsigned kp = (k0 + pc) < K ? 0u : CSN_OOB;
+    const unsigned kp16 = (k0 + 8 * pu) < K ? 0u : CSN_OOB;
+    if (AF) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = csn_bload4(Ar, a_off[i] | kp, (unsigned)k0 * 4u);
-    if (BT) {
+      for (int i = 0; i < 2; ++i) ra[i] = csn_bload4(Ar, a_off[i] | kp16, (unsigned)k0 * 2u);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ra[i] = csn_bload4(Ar, a_off[i] | kp, (unsigned)k0 * 4u);
+    }
+    if (BF) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (B_NK) rb[i] = csn_bload4(Br, b_off[i] | kp16, (unsigned)k0 * 2u);
+        else rb[i] = csn_bload4(Br, b_off[i] | ((k0 + kr2 + 16 * i) < K ? 0u : CSN_OOB), (unsigned)k0 * (unsigned)ldb * 2u);
+      }
+    } else if (BT) {
       const unsigned kb = (k0 + t_kr) < K ? 0u : CSN_OOB;
 #pragma unroll
       for (int i = 0; i < BT_PASS; ++i) rb[i] = csn_bload4(Br, b_off[i] | kb, (unsigned)k0 * (unsigned)ldb * 2u);
@@ -446,13 +529,32 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
       }
     }
   };
-  auto store_slab = [&](int st) {
+  // a k-contiguous 16-bit unit of slab k0: converted if need be, its upper half cleared when the contraction ends inside it
+  auto unit16 = [&](f32x4 v, int fmt, int k0) {
+    if (fmt == CSN_FMT_F16_TO_BF16) v = f16x8_to_bf16x8(v);
+    if (k0 + 8 * pu + 8 > K) { v[2] = 0.f; v[3] = 0.f; }
+    return v;
+  };
+  auto store_slab = [&](int st, int k0) {
     s16x4 hi, lo;
+    if (AF) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      split4<PR>(ra[i], hi, lo);
-      *reinterpret_cast<s16x4*>(As(st, 0) + sw_dst + 64 * BK * i) = hi;
-      if constexpr (NPL == 2) *reinterpret_cast<s16x4*>(As(st, 1) + sw_dst + 64 * BK * i) = lo;
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(As(st, 0) + sw16 + 128 * BK * i) = unit16(ra[i], AF, k0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        split4<PR>(ra[i], hi, lo);
+        *reinterpret_cast<s16x4*>(As(st, 0) + sw_dst + 64 * BK * i) = hi;
+        if constexpr (NPL == 2) *reinterpret_cast<s16x4*>(As(st, 1) + sw_dst + 64 * BK * i) = lo;
+      }
+    }
+    if (BF) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if (B_NK) *reinterpret_cast<f32x4*>(Bs(st, 0) + sw16 + 128 * BK * i) = unit16(rb[i], BF, k0);
+        else *reinterpret_cast<f32x4*>(Bs(st, 0) + (kr2 + 16 * i) * PN + 8 * ku) = BF == CSN_FMT_F16_TO_BF16 ? f16x8_to_bf16x8(rb[i]) : rb[i];
+      }
+      return;
     }
     if (BT) {
 #pragma unroll
@@ -480,7 +582,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
     __syncthreads();                                    // the previous item's last slab has been read by every wave
     set_item(item_id(it));
   }
-  if (nk > 0) { load_slab(0); store_slab(0); }
+  if (nk > 0) { load_slab(0); store_slab(0, 0); }
   if (nk > 1) load_slab(BK);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
@@ -516,7 +618,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
       }
     }
     if (kt + 1 < nk) {
-      store_slab(cur ^ 1);
+      store_slab(cur ^ 1, (kt + 1) * BK);
       if (kt + 2 < nk) load_slab((kt + 2) * BK);
     }
     __syncthreads();
@@ -549,7 +651,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int nl = wn0 + 32 * j + l31;
-      voff[j] = (n0 + nl) < N ? (unsigned)(4 * h * ldc + nl) * 4u : CSN_OOB;
+      voff[j] = (n0 + nl) < N ? (unsigned)(4 * h * ldc + nl) * 4u : CSN_OOB;      // (of the fp32 residual; xhat: scaled below)
       float s1 = 0.f;
       unsigned hp = 0;
 #pragma unroll
@@ -598,7 +700,9 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float xh = (acc[i][j][r] - mean[j]) * rstd[j];
-          csn_bstore(xh, Cr, voff[j], (unsigned)(wm0 + 32 * i + csn_acc_row(r, 0)) * (unsigned)ldc * 4u);
+          // xhat as fp32, or (16-bit activation maps) as fp16: |xhat| < sqrt(C), 11 significant bits
+          if (c_pl) csn_bstore16(to16<true>(xh), Cr, voff[j] == CSN_OOB ? CSN_OOB : voff[j] >> 1, (unsigned)(wm0 + 32 * i + csn_acc_row(r, 0)) * (unsigned)ldc * 2u);
+          else csn_bstore(xh, Cr, voff[j], (unsigned)(wm0 + 32 * i + csn_acc_row(r, 0)) * (unsigned)ldc * 4u);
           acc[i][j][r] = pt_ok ? xh : 0.f;
         }
       if (wmi == 0 && h == 0 && pt_ok) q.rstd[(long long)z2 * q.n_points + n0 + nl] = rstd[j];
@@ -700,7 +804,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
   BSTAMP(5);
 }
 
-template <typename PR, bool B_NK, bool BT = false, bool LN = false>
+template <typename PR, bool B_NK, bool BT = false, bool LN = false, int AF = 0, int BF = 0>
 int launch_big(const CsnGemmArgs& a, int batch, hipStream_t st, const CsnOutProjArgs* ln = nullptr) {
   CsnGemmArgs b = a;
   b.batch = batch;
@@ -708,17 +812,17 @@ int launch_big(const CsnGemmArgs& a, int batch, hipStream_t st, const CsnOutProj
   dim3 grid((unsigned)(((batch + 7) / 8) * 8 * tiles));
   CsnOutProjArgs q{};
   if (ln) q = *ln;
-  hipLaunchKernelGGL((csn_gemm_bf16x3_big_kernel<PR, B_NK, BT, LN>), grid, dim3(512), 0, st, b, q);
+  hipLaunchKernelGGL((csn_gemm_bf16x3_big_kernel<PR, B_NK, BT, LN, AF, BF>), grid, dim3(512), 0, st, b, q);
   return (int)hipGetLastError();
 }
 
-template <typename PR, int BM, int BN, bool B_NK, bool BT = false>
+template <typename PR, int BM, int BN, bool B_NK, bool BT = false, int AF = 0, int BF = 0>
 int launch(const CsnGemmArgs& a, int batch, hipStream_t st) {
   CsnGemmArgs b = a;
   b.batch = batch;
   const long long tiles = (long long)((a.N + BN - 1) / BN) * ((a.M + BM - 1) / BM);
   dim3 grid((unsigned)(((batch + 7) / 8) * 8 * tiles));
-  hipLaunchKernelGGL((csn_gemm_bf16x3_kernel<PR, BM, BN, B_NK, BT>), grid, dim3(256), 0, st, b);
+  hipLaunchKernelGGL((csn_gemm_bf16x3_kernel<PR, BM, BN, B_NK, BT, AF, BF>), grid, dim3(256), 0, st, b);
   return (int)hipGetLastError();
 }
 
@@ -734,6 +838,11 @@ int csn_launch_outproj_ln_big(const CsnOutProjArgs& a, int mode, hipStream_t st)
   g.A = CsnOperand{const_cast<float*>(a.wfc), 0, 0, 0, nullptr, a.D, 0, 0};
   g.B = CsnOperand{const_cast<float*>(a.ctx), 0, 0, a.ctx_eval_stride, nullptr, a.ld, 0, 0};
   g.C = CsnOperand{a.xhat, 0, 0, a.xhat_eval_stride, nullptr, a.ld, 0, 0};
+  if (a.act16) {                                        // Ctx^T arrives as a 16-bit map of the mode's type, xhat leaves as fp16
+    if (mode < 2) return -1;
+    g.B.fmt = CSN_FMT_16;
+    g.C.planes = 1;
+  }
   g.M = 256; g.N = a.n_points; g.K = a.D;
   g.n0 = 1; g.n1 = 1; g.k_chunk = 0;
   g.alpha = 1.f; g.div_rows = 0; g.div_val = 1.f; g.accumulate = 0; g.eval_ids = nullptr;
@@ -741,22 +850,61 @@ int csn_launch_outproj_ln_big(const CsnOutProjArgs& a, int mode, hipStream_t st)
   CsnOutProjArgs b = a;
   const bool fused_sums = a.xhat_sum && a.sum_ws && a.sum_ws_floats >= (long long)a.E * tiles_n * 256;
   if (!fused_sums) b.sum_ws = nullptr;
-  int rc = mode == 3   ? launch_big<F16, false, false, true>(g, a.E, st, &b)
+  int rc = a.act16 ? (mode == 3 ? launch_big<F16, false, false, true, 0, 1>(g, a.E, st, &b)
+                                : launch_big<Bf16, false, false, true, 0, 1>(g, a.E, st, &b))
+           : mode == 3 ? launch_big<F16, false, false, true>(g, a.E, st, &b)
            : mode == 2 ? launch_big<Bf16, false, false, true>(g, a.E, st, &b)
                        : launch_big<Bf16x3, false, false, true>(g, a.E, st, &b);
   if (rc || !a.xhat_sum) return rc;
   if (fused_sums) return csn_launch_partial_sums_f32(a.sum_ws, a.xhat_sum, a.E, tiles_n, 256, st);
-  return csn_launch_rowsum_f32(a.xhat, a.xhat_sum, (long long)a.E * a.C, a.n_points, a.ld, st);
+  return csn_launch_rowsum_f32(a.xhat, a.xhat_sum, (long long)a.E * a.C, a.n_points, a.ld, st, a.act16 ? 2 : 0);
 }
 
 int csn_gemm_bf16x3_big_tiles(int M, int N) { return (csn_gemm_big_tiles && M >= 192 && N >= 224) ? 1 : 0; }
 
 namespace {
+// 16-bit activation maps as inputs (single-product modes): the combinations the step uses —
+//   A fp32 (weights) x B 16 k-major      out-projection input, dCtx^T = W_fc^T dZ^T, dx = W^T dqkv
+//   A 16 x B 16 / fp16->bf16 / fp32, NK  weight gradients (dZ Ctx^T; dqkv x^T)
+//   A 16 / fp16->bf16 x tile-plane B     dV^T = dO^T P, dK^T = Qs^T dS
+template <typename PR, int AF, int BF>
+int launch_fmt(const CsnGemmArgs& a, int b_is_nk, int batch, bool big, hipStream_t st) {
+  if (a.B.planes == 2) {
+    if (b_is_nk || (a.B.ld & 7)) return -1;
+    if constexpr (BF == 0 && AF != 0) return big ? launch_big<PR, false, true, false, AF, 0>(a, batch, st) : launch<PR, 128, 128, false, true, AF, 0>(a, batch, st);
+    else return -1;
+  }
+  if (b_is_nk) {
+    if constexpr (AF == 1) {
+      if (big) return launch_big<PR, true, false, false, AF, BF>(a, batch, st);
+      return a.M <= 64 ? launch<PR, 64, 128, true, false, AF, BF>(a, batch, st) : launch<PR, 128, 128, true, false, AF, BF>(a, batch, st);
+    } else return -1;
+  }
+  if constexpr (AF == 0 && BF != 0) {
+    if (big) return launch_big<PR, false, false, false, 0, BF>(a, batch, st);
+    return a.M <= 64 ? launch<PR, 64, 128, false, false, 0, BF>(a, batch, st) : launch<PR, 128, 128, false, false, 0, BF>(a, batch, st);
+  } else return -1;
+}
+
 template <typename PR>
 int launch_mode(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st) {
   // tiles of 256 x 256 where the output is big enough to fill them (a ragged last tile wastes at most ~3 % here)
   const bool big = csn_gemm_big_tiles && a.M >= 192 && a.N >= 224;
   if (a.grp_off && !big) return -1;                                 // grouped accumulation: 256 x 256 kernel only
+  if (a.A.fmt || a.B.fmt) {
+    if constexpr (PR::NPL == 1) {
+      const int af = a.A.fmt, bf = a.B.fmt;
+      if ((af & 1) && (a.A.ld & 3)) return -2;
+      if constexpr (!PR::HALF) {
+        if (af == 1 && bf == 0) return launch_fmt<PR, 1, 0>(a, b_is_nk, batch, big, st);
+        if (af == 2 && bf == 0) return launch_fmt<PR, 2, 0>(a, b_is_nk, batch, big, st);
+        if (af == 1 && bf == 1) return launch_fmt<PR, 1, 1>(a, b_is_nk, batch, big, st);
+        if (af == 1 && bf == 2) return launch_fmt<PR, 1, 2>(a, b_is_nk, batch, big, st);
+      }
+      if (af == 0 && bf == 1) return launch_fmt<PR, 0, 1>(a, b_is_nk, batch, big, st);
+    }
+    return -1;
+  }
   if (a.B.planes == 2) {                                            // tile-plane B: k-major only
     if (b_is_nk || (a.B.ld & 7)) return -1;
     return big ? launch_big<PR, false, true>(a, batch, st) : launch<PR, 128, 128, false, true>(a, batch, st);

@@ -142,9 +142,12 @@ using namespace csn_mode;
 typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
 
 // PR = csn_mode::Bf16x3 / Bf16 / F16 (math modes 1 / 2 / 3): three products of hi / lo planes, or one product of one plane
-template <typename PR, int CT>
+// A16 (single-product modes): Ctx^T arrives as a 16-bit map of the mode's type (staged by copy), xhat leaves as fp16
+template <typename PR, int CT, bool A16 = false>
 __global__ __launch_bounds__(256, 2) void csn_outproj_ln_fwd_bf16x3_kernel(CsnOutProjArgs p) {
+  static_assert(!A16 || PR::NPL == 1, "16-bit activation maps: single-product modes");
   constexpr int NPL = PR::NPL;
+  constexpr int XES = A16 ? 2 : 4;                                // bytes per element of Ctx^T and xhat
   constexpr int C = 32 * CT;
   constexpr int PK = BK + 8;                                      // k-contiguous planes: 80-byte rows (conflict-free b128)
   constexpr int PN = BN + 32;                                     // k-major planes: rows 64 B apart mod 256 (conflict-free tr reads)
@@ -158,9 +161,11 @@ __global__ __launch_bounds__(256, 2) void csn_outproj_ln_fwd_bf16x3_kernel(CsnOu
   const long long rs = p.res_index ? p.res_index[e] : e;
 
   const csn_rsrc_t Wr = csn_make_rsrc(p.wfc, (long long)C * D * 4);
-  const csn_rsrc_t Xr = csn_make_rsrc(p.ctx + (long long)e * p.ctx_eval_stride + n0, ((long long)(D - 1) * ld + (NP - n0)) * 4);
+  const csn_rsrc_t Xr = csn_make_rsrc(reinterpret_cast<const char*>(p.ctx) + ((long long)e * p.ctx_eval_stride + n0) * XES,
+                                      ((long long)(D - 1) * ld + (NP - n0)) * XES);
   const csn_rsrc_t Rr = csn_make_rsrc(p.xres + rs * p.xres_shape_stride + n0, ((long long)(C - 1) * ld + (NP - n0)) * 4);
-  const csn_rsrc_t Hr = csn_make_rsrc(p.xhat + (long long)e * p.xhat_eval_stride + n0, ((long long)(C - 1) * ld + (NP - n0)) * 4);
+  const csn_rsrc_t Hr = csn_make_rsrc(reinterpret_cast<char*>(p.xhat) + ((long long)e * p.xhat_eval_stride + n0) * XES,
+                                      ((long long)(C - 1) * ld + (NP - n0)) * XES);
 
   f32x16 acc[CT];
 #pragma unroll
@@ -170,21 +175,31 @@ __global__ __launch_bounds__(256, 2) void csn_outproj_ln_fwd_bf16x3_kernel(CsnOu
 
   const int pr = tid >> 3, pc = (tid & 7) * 4;        // W slab piece: row pr + 32 i, k piece pc
   const int kr = tid >> 5, kc = (tid & 31) * 4;       // Ctx slab piece: k row kr + 8 i, points kc..kc+3
+  const int kr2 = tid >> 4, ku = tid & 15;            // 16-bit Ctx map: k row kr2 + 16 i, points 8 ku .. 8 ku + 7
   unsigned a_off[CT], b_off[4];
 #pragma unroll
   for (int i = 0; i < CT; ++i) a_off[i] = (unsigned)((pr + 32 * i) * D + pc) * 4u;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) b_off[i] = (n0 + kc) < NP ? (unsigned)((kr + 8 * i) * ld + kc) * 4u : CSN_OOB;
+  for (int i = 0; i < 4; ++i) {
+    if (A16) b_off[i] = (i < 2 && (n0 + 8 * ku) < NP) ? (unsigned)((kr2 + 16 * i) * ld + 8 * ku) * 2u : CSN_OOB;
+    else b_off[i] = (n0 + kc) < NP ? (unsigned)((kr + 8 * i) * ld + kc) * 4u : CSN_OOB;
+  }
 
   f32x4 ra[CT], rb[4];
   auto load_slab = [&](int k0) {
     const unsigned kp = (k0 + pc) < D ? 0u : CSN_OOB;
 #pragma unroll
     for (int i = 0; i < CT; ++i) ra[i] = csn_bload4(Wr, a_off[i] | kp, (unsigned)k0 * 4u);
+    if (A16) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const unsigned kq = (k0 + kr + 8 * i) < D ? 0u : CSN_OOB;
-      rb[i] = csn_bload4(Xr, b_off[i] | kq, (unsigned)k0 * (unsigned)ld * 4u);
+      for (int i = 0; i < 2; ++i)
+        rb[i] = csn_bload4(Xr, b_off[i] | ((k0 + kr2 + 16 * i) < D ? 0u : CSN_OOB), (unsigned)k0 * (unsigned)ld * 2u);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned kq = (k0 + kr + 8 * i) < D ? 0u : CSN_OOB;
+        rb[i] = csn_bload4(Xr, b_off[i] | kq, (unsigned)k0 * (unsigned)ld * 4u);
+      }
     }
   };
   auto store_slab = [&]() {
@@ -194,6 +209,11 @@ __global__ __launch_bounds__(256, 2) void csn_outproj_ln_fwd_bf16x3_kernel(CsnOu
       split4<PR>(ra[i], hi, lo);
       *reinterpret_cast<s16x4*>(&As[0][(pr + 32 * i) * PK + pc]) = hi;
       if constexpr (NPL == 2) *reinterpret_cast<s16x4*>(&As[NPL - 1][(pr + 32 * i) * PK + pc]) = lo;
+    }
+    if (A16) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<f32x4*>(&Bs[0][(kr2 + 16 * i) * PN + 8 * ku]) = rb[i];
+      return;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -278,8 +298,11 @@ __global__ __launch_bounds__(256, 2) void csn_outproj_ln_fwd_bf16x3_kernel(CsnOu
 #pragma unroll
   for (int c = 0; c < CT; ++c)
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      csn_bstore((acc[c][r] - mean) * rstd, Hr, n_off, (unsigned)(c * 32 + csn_acc_row(r, 0)) * (unsigned)ld * 4u);
+    for (int r = 0; r < 16; ++r) {
+      const float xh = (acc[c][r] - mean) * rstd;
+      if constexpr (A16) csn_bstore16(to16<true>(xh), Hr, n_ok ? n_off >> 1 : CSN_OOB, (unsigned)(c * 32 + csn_acc_row(r, 0)) * (unsigned)ld * 2u);
+      else csn_bstore(xh, Hr, n_off, (unsigned)(c * 32 + csn_acc_row(r, 0)) * (unsigned)ld * 4u);
+    }
   if (n_ok && h == 0) p.rstd[(long long)e * NP + n0 + nl] = rstd;
 }
 
@@ -289,7 +312,8 @@ __global__ __launch_bounds__(256, 2) void csn_outproj_ln_fwd_bf16x3_kernel(CsnOu
 // are combined across the 4 waves through LDS, and dz is produced from the registers.
 // dx = dxhat (evaluations below n_dense only) + dxhat_rows[e][c] (constant along the points).  All loads are branch-free
 // (buffer descriptors; an absent dense part is a zero-sized window), so the 2 C/4 loads of a thread are in flight together.
-template <int CPT>
+// A16 (16-bit activation maps): xhat is read as an fp16 map, dz leaves as a bf16 map; dxhat and dz_res stay fp32.
+template <int CPT, bool A16 = false>
 __global__ __launch_bounds__(256) void csn_ln_bwd_kernel(CsnLnBwdArgs p) {
   __shared__ float red[2][4][64];
   const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -301,8 +325,10 @@ __global__ __launch_bounds__(256) void csn_ln_bwd_kernel(CsnLnBwdArgs p) {
   const bool dense = e < p.n_dense;
   const int src = p.dxhat_group > 1 ? e / p.dxhat_group : e;
   const csn_rsrc_t Gr = csn_make_rsrc(dense ? p.dxhat + (long long)src * p.eval_stride : nullptr, dense ? win : 0);
-  const csn_rsrc_t Xr = csn_make_rsrc(p.xhat + (long long)e * p.eval_stride, win);
+  const csn_rsrc_t Xr = A16 ? csn_make_rsrc(reinterpret_cast<const short*>(p.xhat) + (long long)e * p.eval_stride, win / 2)
+                            : csn_make_rsrc(p.xhat + (long long)e * p.eval_stride, win);
   const unsigned voff = ok ? (unsigned)n * 4u : CSN_OOB;
+  const unsigned voff16 = ok ? (unsigned)n * 2u : CSN_OOB;
   const unsigned ldb = (unsigned)p.ld * 4u;
   float gx[CPT], xx[CPT], rw[CPT], sc[CPT];
   if (p.dxhat_scale && dense) {
@@ -324,7 +350,9 @@ __global__ __launch_bounds__(256) void csn_ln_bwd_kernel(CsnLnBwdArgs p) {
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
     gx[i] = csn_bload(Gr, voff, (unsigned)(g * CPT + i) * ldb);
-    xx[i] = csn_bload(Xr, voff, (unsigned)(g * CPT + i) * ldb);
+    if constexpr (A16)
+      xx[i] = csn_mode::from16<true>((short)__builtin_amdgcn_raw_buffer_load_b16(Xr, voff16, (unsigned)(g * CPT + i) * (ldb >> 1), 0));
+    else xx[i] = csn_bload(Xr, voff, (unsigned)(g * CPT + i) * ldb);
   }
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -343,7 +371,8 @@ __global__ __launch_bounds__(256) void csn_ln_bwd_kernel(CsnLnBwdArgs p) {
   const unsigned thr16 = csn_drop_threshold16(p.dropout_p);
   const unsigned salt = drop ? csn_block_salt((unsigned long long)e, p.seed) : 0u;
   const float keep_scale = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
-  const csn_rsrc_t Zr = csn_make_rsrc(p.dz + (long long)e * p.eval_stride, win);
+  const csn_rsrc_t Zr = A16 ? csn_make_rsrc(reinterpret_cast<short*>(p.dz) + (long long)e * p.eval_stride, win / 2)
+                            : csn_make_rsrc(p.dz + (long long)e * p.eval_stride, win);
   const csn_rsrc_t Zres = csn_make_rsrc(p.dz_res ? p.dz_res + (long long)e * p.eval_stride : nullptr, p.dz_res ? win : 0);
 #pragma unroll
   for (int i = 0; i < CPT; ++i) {
@@ -359,7 +388,10 @@ __global__ __launch_bounds__(256) void csn_ln_bwd_kernel(CsnLnBwdArgs p) {
     }
   }
 #pragma unroll
-  for (int i = 0; i < CPT; ++i) csn_bstore(gx[i], Zr, voff, (unsigned)(g * CPT + i) * ldb);
+  for (int i = 0; i < CPT; ++i) {
+    if constexpr (A16) csn_bstore16(csn_mode::to16<false>(gx[i]), Zr, voff16, (unsigned)(g * CPT + i) * (ldb >> 1));
+    else csn_bstore(gx[i], Zr, voff, (unsigned)(g * CPT + i) * ldb);
+  }
 }
 
 // out[e][h][n] = sum_{c < d} a[e][h*d + c][n] * b[e][h*d + c][n]    (delta = rowsum(dO * O) of the softmax backward)
@@ -391,6 +423,12 @@ __global__ __launch_bounds__(256) void csn_rowdot_kernel(const float* __restrict
 template <int CT>
 int launch_fwd(const CsnOutProjArgs& a, int mode, hipStream_t st) {
   dim3 grid((a.n_points + BN - 1) / BN, a.E);
+  if (a.act16) {
+    if (mode == 2) hipLaunchKernelGGL((csn_outproj_ln_fwd_bf16x3_kernel<Bf16, CT, true>), grid, dim3(256), 0, st, a);
+    else if (mode == 3) hipLaunchKernelGGL((csn_outproj_ln_fwd_bf16x3_kernel<F16, CT, true>), grid, dim3(256), 0, st, a);
+    else return -1;
+    return (int)hipGetLastError();
+  }
   if (mode == 1) hipLaunchKernelGGL((csn_outproj_ln_fwd_bf16x3_kernel<Bf16x3, CT>), grid, dim3(256), 0, st, a);
   else if (mode == 2) hipLaunchKernelGGL((csn_outproj_ln_fwd_bf16x3_kernel<Bf16, CT>), grid, dim3(256), 0, st, a);
   else if (mode == 3) hipLaunchKernelGGL((csn_outproj_ln_fwd_bf16x3_kernel<F16, CT>), grid, dim3(256), 0, st, a);
@@ -415,12 +453,23 @@ int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, int mode, hipStream_t
     default: return -5;
   }
   if (rc || !a.xhat_sum) return rc;
-  return csn_launch_rowsum_f32(a.xhat, a.xhat_sum, (long long)a.E * a.C, a.n_points, a.ld, st);   // streaming pass over xhat
+  return csn_launch_rowsum_f32(a.xhat, a.xhat_sum, (long long)a.E * a.C, a.n_points, a.ld, st, a.act16);   // streaming pass over xhat
 }
 
 int csn_launch_ln_bwd_f32(const CsnLnBwdArgs& a, hipStream_t st) {
   if (a.E <= 0 || a.n_points <= 0) return 0;
   dim3 grid((a.n_points + 63) / 64, a.E);
+  if (a.act16) {
+    switch (a.C) {
+      case 32: hipLaunchKernelGGL((csn_ln_bwd_kernel<8, true>), grid, dim3(256), 0, st, a); break;
+      case 64: hipLaunchKernelGGL((csn_ln_bwd_kernel<16, true>), grid, dim3(256), 0, st, a); break;
+      case 96: hipLaunchKernelGGL((csn_ln_bwd_kernel<24, true>), grid, dim3(256), 0, st, a); break;
+      case 128: hipLaunchKernelGGL((csn_ln_bwd_kernel<32, true>), grid, dim3(256), 0, st, a); break;
+      case 256: hipLaunchKernelGGL((csn_ln_bwd_kernel<64, true>), grid, dim3(256), 0, st, a); break;
+      default: return -5;
+    }
+    return (int)hipGetLastError();
+  }
   switch (a.C) {
     case 32: hipLaunchKernelGGL((csn_ln_bwd_kernel<8>), grid, dim3(256), 0, st, a); break;
     case 64: hipLaunchKernelGGL((csn_ln_bwd_kernel<16>), grid, dim3(256), 0, st, a); break;

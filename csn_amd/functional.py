@@ -47,7 +47,7 @@ def _need_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
             raise _lib.CsnError("csn_amd ops need tensors on the MI355X (cuda) device; there is no CPU path")
-        if t is not None and t.dtype not in (torch.float32, torch.int32, torch.bfloat16, torch.float64):
+        if t is not None and t.dtype not in (torch.float32, torch.int32, torch.bfloat16, torch.float16, torch.float64):
             raise _lib.CsnError(f"csn_amd ops are fp32 (got {t.dtype})")
 
 
@@ -206,6 +206,25 @@ class math_mode:
         return False
 
 
+class act16:
+    """``with act16(fmt):`` — the calling thread's library calls exchange their intermediate maps as 16-bit planes inside the
+    block (csn_set_thread_act16; include/csn_hip.h "16-BIT ACTIVATION MAPS"): fmt 1 = the forward's maps are bf16, 2 = fp16,
+    0 = fp32 maps (the default)."""
+
+    def __init__(self, fmt: int):
+        self.fmt = int(fmt)
+
+    def __enter__(self):
+        L = _lib.lib()
+        self.prev = L.csn_get_thread_act16()
+        _lib.check(L.csn_set_thread_act16(self.fmt))
+        return self
+
+    def __exit__(self, *exc):
+        _lib.lib().csn_set_thread_act16(self.prev)
+        return False
+
+
 def _score_flow(mode: int, d: int, T: int) -> int:
     """The attention backward data flow (tuning.KEEP_SCORES / RECOMPUTE_DQ / FLASH) for a forward in `mode` at head width d and
     block T: the configured flow of the mode the BACKWARD runs in, where the library has kernels for it."""
@@ -309,7 +328,12 @@ class _MHAEvals(torch.autograd.Function):
         if mode >= 2 and geo.block > 512:
             mode = 1                                   # the single-product kernels take K / V as tile planes (blocks <= 512 keys)
         ctx.mode = mode
-        with math_mode(mode):
+        # 16-bit activation maps: Qs, Ctx, xhat (and in the backward dZ, dCtx) travel between the launches as one 16-bit plane.
+        # Only where nothing outside this file reads the maps: the linked form (the mix and the pooled sums consume xhat in
+        # kernels, gradients arrive through the link), tile-plane K / V
+        tiles_ok = tuning.current().kv_tiles and geo.block <= 512
+        ctx.a16 = (mode - 1) if (mode >= 2 and tuning.current().act16 and tiles_ok and link is not None and keep_scores) else 0
+        with math_mode(mode), act16(ctx.a16):
             return _MHAEvals._forward(ctx, x_all, w_qs, w_ks, w_vs, w_fc, plan, geo, keep_scores, p_attn, p_fc, n_head_evals,
                                       want_sums, link)
 
@@ -331,7 +355,9 @@ class _MHAEvals(torch.autograd.Function):
         dev = x_all.device
         temperature = geo.temperature or float(d) ** 0.5               # csa_models.py:54
         w_qkv = torch.cat((w_qs, w_ks, w_vs), dim=0).contiguous()      # (3D, C)
-        att = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
+        a16 = ctx.a16
+        fwd16 = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[a16]           # type of the forward's maps Qs, Ctx
+        att = torch.empty((E, D, NP), device=dev, dtype=fwd16)
         lse = torch.empty((E, H, NPP), device=dev, dtype=torch.float32)
         sink = tuning.current().event_sink
         # values may come from a different slot than the keys (slot kv + v_shift): only the generic
@@ -343,14 +369,14 @@ class _MHAEvals(torch.autograd.Function):
             # (pre-scaled) stays fp32
             npl = planes()
             ldp = nb * 512 * npl
-            qkv = torch.empty((S, D, NP), device=dev, dtype=torch.float32)                    # Qs
+            qkv = torch.empty((S, D, NP), device=dev, dtype=fwd16)                            # Qs
             kv_dtype = torch.float16 if ctx.mode == 3 else torch.bfloat16
             # (the projection writes the zero padding of every block's last 32-key tile itself)
             kv = torch.empty((S, 2 * D, ldp), device=dev, dtype=kv_dtype)
             for first, step, count in (plan.q_ranges or [(0, 1, S)]):
                 _lib.check(L.csn_project_f32(x_all.data_ptr() + 4 * first * C * NP, step * C * NP, NP, _ptr(w_qkv), D, C,
-                                             qkv.data_ptr() + 4 * first * D * NP, step * D * NP, NP, count, NP, D, temperature,
-                                             0, 0, _stream()), "csn_project_f32")
+                                             qkv.data_ptr() + qkv.element_size() * first * D * NP, step * D * NP, NP, count, NP, D,
+                                             temperature, 3 if a16 else 0, 0, _stream()), "csn_project_f32")
             for first, step, count in (plan.kv_ranges or [(0, 1, S)]):
                 _lib.check(L.csn_project_f32(x_all.data_ptr() + 4 * first * C * NP, step * C * NP, NP, _ptr(w_qkv[D:]), 2 * D, C,
                                              kv.data_ptr() + 2 * first * 2 * D * ldp, step * 2 * D * ldp, ldp, count, NP, 0, 1.0, 2,
@@ -390,7 +416,7 @@ class _MHAEvals(torch.autograd.Function):
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record()
             sink["fwd"].append((ev0, ev1))
-        xhat = torch.empty((E, C, NP), device=dev, dtype=torch.float32)
+        xhat = torch.empty((E, C, NP), device=dev, dtype=torch.float16 if a16 else torch.float32)
         rstd = torch.empty((E, NP), device=dev, dtype=torch.float32)
         w_fc = w_fc.contiguous()
         # third output (want_sums): sums[e][c] = sum_n xhat[e][c][n], formed in the epilogue of the out-projection (per-tile
@@ -417,11 +443,17 @@ class _MHAEvals(torch.autograd.Function):
         # fourth output: a one-element handle.  A linked mix (csa_mix on LinkedMaps) takes IT as its differentiable input
         # and leaves the gradient of the mixed features in ctx.link instead of returning per-evaluation gradient maps
         handle = x_all.new_zeros(1) if link is not None else None
+        if a16:
+            # fp16 maps are data for the linked mix and nothing else: gradients reach this function through the link, the sums
+            # and the handle, never through the maps
+            head = xhat[:n_head_evals]
+            ctx.mark_non_differentiable(xhat, head)
+            return xhat, head, sums, handle
         return xhat, xhat[:n_head_evals], sums, handle
 
     @staticmethod
     def backward(ctx, dxhat, dhead, dsums=None, dhandle=None):
-        with math_mode(backward_mode(ctx.mode)):
+        with math_mode(backward_mode(ctx.mode)), act16(ctx.a16):
             return _MHAEvals._backward(ctx, dxhat, dhead, dsums, dhandle)
 
     @staticmethod
@@ -467,9 +499,11 @@ class _MHAEvals(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
 
         # ---- LayerNorm + fc backward -------------------------------------------------------------------
-        dz = torch.empty((E, C, NP), device=dev, dtype=torch.float32)
-        dz_res = torch.empty((E, C, NP), device=dev, dtype=torch.float32) if (need_dx and p_fc > 0) else None
-        datt = torch.empty((E, D, NP), device=dev, dtype=torch.float32)
+        a16 = ctx.a16
+        bwd16 = torch.bfloat16 if a16 else torch.float32               # type of the backward's maps dZ, dCtx
+        dz = torch.empty((E, C, NP), device=dev, dtype=bwd16)
+        dz_res = torch.empty((E, C, NP), device=dev, dtype=torch.float32) if (need_dx and (p_fc > 0 or a16)) else None
+        datt = torch.empty((E, D, NP), device=dev, dtype=bwd16)
         dw_fc = torch.empty((C, D), device=dev, dtype=torch.float32)
         ws_n = L.csn_wgrad_workspace_floats(C, D, E, NP)
         ws = torch.empty((ws_n,), device=dev, dtype=torch.float32)
@@ -763,8 +797,11 @@ class _CSAMixLinked(torch.autograd.Function):
         assert xself is None or (xself.is_contiguous() and xself.shape == (B, C, NP))
         comp = comp.contiguous()
         feats = torch.empty((B, C, NP), device=xhat.device, dtype=torch.float32)
-        _lib.check(_lib.lib().csn_mix_fwd_f32(_ptr(xhat), _ptr(comp), _ptr(gamma), _ptr(beta), _ptr(feats), B, K1, C, NP,
-                                              _ptr(xself), _stream()), "csn_mix_fwd_f32")
+        x16 = xhat.dtype == torch.float16                                            # 16-bit activation maps (mha_evals)
+        assert xself is None or (xself.dtype == xhat.dtype)
+        with act16(1 if x16 else 0):
+            _lib.check(_lib.lib().csn_mix_fwd_f32(_ptr(xhat), _ptr(comp), _ptr(gamma), _ptr(beta), _ptr(feats), B, K1, C, NP,
+                                                  _ptr(xself), _stream()), "csn_mix_fwd_f32")
         ctx.save_for_backward(xhat, comp, gamma, beta, xself)
         ctx.dims = (B, K1)
         ctx.links = (maps.link, None if maps_self is None else maps_self.link)
@@ -778,8 +815,9 @@ class _CSAMixLinked(torch.autograd.Function):
         dfeats = dfeats.contiguous()
         rowdot = torch.empty((B, K1, C), device=xhat.device, dtype=torch.float32)
         rowsum = torch.empty((B, C), device=xhat.device, dtype=torch.float32)
-        _lib.check(_lib.lib().csn_mix_bwd_f32(_ptr(dfeats), _ptr(xhat), _ptr(comp), _ptr(gamma), None, _ptr(rowdot),
-                                              _ptr(rowsum), B, K1, C, NP, _ptr(xself), None, _stream()), "csn_mix_bwd_f32")
+        with act16(1 if xhat.dtype == torch.float16 else 0):
+            _lib.check(_lib.lib().csn_mix_bwd_f32(_ptr(dfeats), _ptr(xhat), _ptr(comp), _ptr(gamma), None, _ptr(rowdot),
+                                                  _ptr(rowsum), B, K1, C, NP, _ptr(xself), None, _stream()), "csn_mix_bwd_f32")
         factors = comp[:, :, None] * gamma                                           # (B, K1, C) = comp_k * gamma
         link, link_self = ctx.links
         if link_self is None:

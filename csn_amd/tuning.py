@@ -27,6 +27,7 @@ class Tuning:
     grouped_dkv: bool = True         # False: dK / dV by one read-modify-write launch per colour
     grouped_dq: bool = True          # False: dQ likewise
     fused_compat_head: bool = True   # False: the compatibility head as torch ops (two nn.Linear, normalize, einsum, softmax)
+    act16: bool = True               # bf16 / fp16 modes, linked mix: Qs, Ctx, xhat, dZ, dCtx between the launches as 16-bit maps
     # attention backward data flow by (math mode of the backward: 1 bf16x3, 2 bf16 — fp16 forwards run their backward in 2;
     # head width), or by mode alone; taken where the kernels have an instance for it (csn_attn_bwd_grouping bits 2 / 3),
     # KEEP_SCORES otherwise.  Measured per mode and width, DESIGN.md §4 "data flow A/B": at d = 256 the extra matrix products

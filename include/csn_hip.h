@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSN_ABI_VERSION 13
+#define CSN_ABI_VERSION 14
 
 /* math modes (csn_set_math_mode / csn_set_thread_math_mode) */
 #define CSN_MATH_FP32 0
@@ -79,6 +79,26 @@ int csn_version(void);
  * STATUS: live are csn_project_f32 out_split (1: whole planes, 2: tile planes), csn_outproj_ln_bwd_f32 dctx_split, and the
  * k/v tile planes of csn_block_attn_fwd_f32 / csn_block_attn_bwd_dq_f32; dctx_split / q_split INPUTS are reserved
  * (CSN_E_ARG).  Passing *_split != 0 in math mode 0 returns CSN_E_ARG. */
+/* 16-BIT ACTIVATION MAPS (math modes 2 and 3).  In the single-product modes every matrix operand is rounded to 16 bits when it
+ * is staged, so the maps the entry points hand to each other can travel in that form: half the bytes, and the consumers stage
+ * them by copy.  csn_set_thread_act16(fmt) switches the CALLING THREAD's calls to that exchange format — fmt 1: the forward's
+ * maps are bf16 (a math-mode-2 forward), fmt 2: they are fp16 (a math-mode-3 forward; its backward runs in mode 2 and converts
+ * them in registers while staging), 0: off (the default: everything below is fp32).  With the flag set
+ *   Qs   (csn_project_f32 out_split = 3 writes it; read by (2), by the recomputing calls of (3) and by the dK product)   fwd type
+ *   Ctx  (written by (2); read by (4) forward, by (3)'s delta and by the W_fc gradient of (4) backward)                 fwd type
+ *   xhat (written by (4) forward; read by (4) backward and by (6))                                                      fp16 always (|xhat| < sqrt(C))
+ *   dZ, dCtx (written by (4) backward; read by (3))                                                                     bf16
+ * are ONE plane of 16-bit elements with the shapes documented below; their pointers stay typed float* and every stride and
+ * leading dimension of such a map counts 16-bit ELEMENTS (same numbers as for the fp32 map).  Everything else keeps its type:
+ * the input maps x, the residual, dxhat / dfeats, lse / delta / rstd, every gradient map dQ / dK / dV / dz_res, weights and
+ * weight gradients, the K / V tile planes (already 16-bit).  Products are bit-identical to the fp32 exchange wherever a map is
+ * only a matrix operand (it was rounded to the same 16 bits at staging); delta = sum dO * O, the LayerNorm backward and the mix
+ * see the rounded maps (|xhat| error <= 2^-11 relative).  Requirements: math mode 2 / 3 with K / V tile planes, block mode (no
+ * cross-length entry points), no split tensors, a mix backward without gradient maps (the linked form), evaluation outputs
+ * written once (no accumulate into a 16-bit map).  A forward entry point returns CSN_E_ARG when fmt does not name its mode's
+ * type; backward entry points take either fmt in mode 2. */
+int csn_set_thread_act16(int fmt);
+int csn_get_thread_act16(void);
 int csn_set_math_mode(int mode);
 int csn_set_thread_math_mode(int mode);
 int csn_get_math_mode(void);
@@ -91,7 +111,8 @@ const char* csn_status_string(int status);
  * out[s][r][n] = sum_c w[r][c] * x[s][c][n],  r < rows, n < n_points; rows r < div_rows are then divided
  * by `temperature`.   Replaces w_qs / w_ks / w_vs (nn.Linear, no bias; csa_models.py:49-51,103-105) and the
  * `q / temperature` of csa_models.py:139 (stack W_q|W_k|W_v along rows and pass div_rows = n_head*d_k to
- * project a shape once for all of its evaluations). */
+ * project a shape once for all of its evaluations).  out_split: 0 fp32 maps, 1 / 2 split tensors / tile planes (above), 3 (math
+ * modes 2 / 3): ONE 16-bit map per shape in the mode's type — out_shape_stride and ld_out count 16-bit elements. */
 int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const float* w, int rows, int channels,
                     float* out, long long out_shape_stride, int ld_out, int n_shapes, int n_points, int div_rows,
                     float temperature, int out_split, long long out_plane_stride, void* stream);
