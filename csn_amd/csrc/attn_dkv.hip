@@ -441,13 +441,21 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
         xbuf[row * KW + ((((col >> 2) ^ (4 * ((row >> 2) & 1))) << 2) | (col & 3))] = OUT[c][r];
       }
     __syncthreads();
-    const csn_rsrc_t rs = csn_make_rsrc(base + slot * p.dkv_slot_stride + out_off, owin);
     f32x4 ch[CH_T];
 #pragma unroll
     for (int t = 0; t < CH_T; ++t) {
       const int row = crow + 16 * t;
       ch[t] = *reinterpret_cast<const f32x4*>(&xbuf[row * KW + ((cc ^ (4 * ((row >> 2) & 1))) << 2)]);
     }
+    if (NPL == 1 && p.out_fmt) {                                    // bf16 gradient maps (16-bit activation maps; written once)
+      const csn_rsrc_t r16 = csn_make_rsrc(reinterpret_cast<short*>(base) + slot * p.dkv_slot_stride + out_off, owin / 2);
+#pragma unroll
+      for (int t = 0; t < CH_T; ++t)
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, to16x4<false>(ch[t])), r16, c_off == CSN_OOB ? CSN_OOB : c_off >> 1,
+                                              (unsigned)(16 * t * ld) * 2u, 0);
+      return;
+    }
+    const csn_rsrc_t rs = csn_make_rsrc(base + slot * p.dkv_slot_stride + out_off, owin);
     if (p.accumulate) {
       f32x4 prev[CH_T];
 #pragma unroll
@@ -498,6 +506,7 @@ int csn_launch_attn_dkv_flash(const CsnAttnDkvArgs& a, int d, int mode, hipStrea
   if ((a.q_shape_stride & 3) || (a.ctx_eval_stride & 3) || (a.dkv_slot_stride & 3)) return -4;
   if ((a.q_fmt || a.dctx_fmt) && mode != 2) return -1;              // 16-bit activation maps: the one-plane mode
   if (a.dctx_fmt == 2) return -1;                                   // dO is a backward tensor: bf16
+  if (a.out_fmt && (mode != 2 || a.accumulate)) return -1;
   switch (mode) {
     case 1: return launch_any<Bf16x3>(a, d, st);
     case 2: return launch_any<Bf16>(a, d, st);

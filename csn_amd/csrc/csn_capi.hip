@@ -12,11 +12,13 @@ thread_local int t_math_mode = -1;          // per-thread override (csn_set_thre
 inline int mode() { return t_math_mode >= 0 ? t_math_mode : g_math_mode; }
 // 16-bit activation maps between the entry points (csn_set_thread_act16): 0 off, 1 = the forward's maps are bf16 (math mode 2),
 // 2 = they are fp16 (math mode 3 forward; its backward runs in mode 2 and converts them while staging)
+// + 4: the gradient maps dQ / dK / dV (and what reads them: the projection weight gradients, dx) are bf16 maps too
 thread_local int t_act16 = 0;
-inline int act16() { return t_act16; }
+inline int act16() { return t_act16 & 3; }
+inline bool grad16() { return (t_act16 & 4) != 0; }
 // forward entry points: the flag has to name the type of the mode that runs; backward: mode 2 takes either
-inline bool act16_fwd_ok() { return t_act16 == 0 || (t_act16 == 1 && mode() == 2) || (t_act16 == 2 && mode() == 3); }
-inline bool act16_bwd_ok() { return t_act16 == 0 || mode() == 2; }
+inline bool act16_fwd_ok() { return act16() == 0 || (act16() == 1 && mode() == 2) || (act16() == 2 && mode() == 3); }
+inline bool act16_bwd_ok() { return act16() == 0 || mode() == 2; }
 inline int planes_of(int m) { return m == 1 ? 2 : 1; }          // tile-plane / split-tensor planes of a 16-bit mode
 
 // the cross-length entry points (fp32 K / V maps) have no single-product kernels: in modes 2 / 3 they run as mode 1
@@ -110,7 +112,7 @@ int csn_set_thread_math_mode(int m) {
 int csn_get_math_mode(void) { return mode(); }
 int csn_get_thread_math_mode(void) { return t_math_mode; }
 int csn_set_thread_act16(int fmt) {
-  if (fmt < 0 || fmt > 2) return CSN_E_ARG;
+  if (fmt < 0 || (fmt & 3) == 3 || fmt > 6 || fmt == 4) return CSN_E_ARG;
   t_act16 = fmt;
   return 0;
 }
@@ -139,6 +141,9 @@ long long csn_wgrad_workspace_floats(int rows, int cols, int n_maps, int n_point
 int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const float* w, int rows, int channels,
                     float* out, long long out_shape_stride, int ld_out, int n_shapes, int n_points, int div_rows,
                     float temperature, int out_split, long long out_plane_stride, void* stream) {
+  const int x16 = out_split >= 0 ? (out_split & 16) : 0;             // + 16: x is a bf16 map (math mode 2)
+  if (out_split >= 0) out_split &= ~16;
+  if (x16 && mode() != 2) return CSN_E_ARG;
   if (out_split && mode() == 0) return CSN_E_ARG;
   if (out_split < 0 || out_split > 3) return CSN_E_ARG;
   if (out_split == 3 && mode() < 2) return CSN_E_ARG;               // one 16-bit map: the single-product modes
@@ -158,6 +163,7 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
   CsnGemmArgs g;
   g.A = operand(w, 0, 0, 0, nullptr, channels);
   g.B = operand(x, 0, 0, x_shape_stride, nullptr, ld_x);
+  if (x16) g.B.fmt = CSN_FMT_16;
   g.C = operand(out, 0, 0, out_shape_stride, nullptr, ld_out);
   g.C.planes = out_split == 3 ? 1 : out_split; g.C.plane_stride = out_plane_stride;
   g.M = rows; g.N = n_points; g.K = channels;
@@ -307,6 +313,10 @@ static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_e
   if (act16()) {                                                     // dO: bf16; O and Qs: the forward's 16-bit type; dQ stays fp32
     if (!act16_bwd_ok() || !kv_split || block_q != 0) return CSN_E_ARG;
     a.r_fmt = 1; a.ctx_fmt = act16(); a.q2_fmt = act16();
+    if (grad16()) {
+      if (accumulate) return CSN_E_ARG;                               // a 16-bit gradient map is written once (grouped calls)
+      a.out_fmt = 1;
+    }
   }
   return mode() != 0 ? csn_launch_attn_bwd_bf16x3(a, d_head, mode(), st) : csn_launch_attn_bwd_f32(a, d_head, st);
 }
@@ -395,7 +405,10 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   const float* ds_src = one_plane ? reinterpret_cast<const float*>(reinterpret_cast<const short*>(dscores) + blk_sc) : dscores;
   g.B = operand(p_src, bm * blk_sc, bm * blk_sc * n_blocks, bm * blk_sc * n_blocks * n_heads, nullptr, ldb);
   g.B.planes = probs_tiles ? 2 : 0;
+  const bool g16 = act16() && grad16();
+  if (g16 && accumulate) return CSN_E_ARG;                            // a 16-bit gradient map is written once (grouped calls)
   g.C = operand(dv, block, (long long)d_head * lk, dkv_slot_stride, dv_index, lk);
+  if (g16) g.C.planes = 1;
   int rc = launch_gemm(g, 0, n_blocks * n_heads * n_batch, st);
   if (rc) return rc;
   g.A = operand(q, bq, (long long)d_head * ld, q_shape_stride, q_index, ld);
@@ -404,6 +417,7 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   g.B = operand(ds_src, bm * blk_sc, bm * blk_sc * n_blocks, bm * blk_sc * n_blocks * n_heads, nullptr, ldb);
   g.B.planes = probs_tiles ? 2 : 0;
   g.C = operand(dk, block, (long long)d_head * lk, dkv_slot_stride, dk_index, lk);
+  if (g16) g.C.planes = 1;
   return launch_gemm(g, 0, n_blocks * n_heads * n_batch, st);
 }
 
@@ -464,6 +478,10 @@ int csn_block_attn_bwd_dkv_flash_f32(const float* dctx, long long ctx_eval_strid
   if (act16()) {
     if (!act16_bwd_ok()) return CSN_E_ARG;
     a.q_fmt = act16(); a.dctx_fmt = 1;
+    if (grad16()) {
+      if (accumulate) return CSN_E_ARG;
+      a.out_fmt = 1;
+    }
   }
   return csn_launch_attn_dkv_flash(a, d_head, mode(), (hipStream_t)stream);
 }
@@ -603,8 +621,10 @@ int csn_project_wgrad_f32(const float* dout, long long dout_shape_stride, int ld
   if ((ld_dout & 3) || (ld_x & 3) || (n_points & 3)) return CSN_E_ALIGN;
   if (mis16(dout) || mis16(x) || mis16(dw) || mis16(ws)) return CSN_E_PTR;
   if ((dout_shape_stride & 3) || (x_shape_stride & 3)) return CSN_E_STRIDE;
+  const bool g16 = act16() && grad16();                               // dout: bf16 gradient maps
+  if (g16 && !act16_bwd_ok()) return CSN_E_ARG;
   return wgrad(dout, dout_shape_stride, ld_dout, x, x_shape_stride, ld_x, dw, rows, channels, n_shapes, n_points, scale,
-               accumulate, ws, ws_floats, (hipStream_t)stream);
+               accumulate, ws, ws_floats, (hipStream_t)stream, g16 ? CSN_FMT_16 : 0, 0);
 }
 
 int csn_retrieval_measure_f32(const float* f1, const float* f2, float* out, int s1, int n1, int s2, int n2,

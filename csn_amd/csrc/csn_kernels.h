@@ -94,6 +94,7 @@ struct CsnAttnDkvArgs {
   float dropout_p;  unsigned long long seed;
   int kv_f16 = 0;                                                         // one-plane mode: k / v hold fp16 (forward of math mode 3)
   int q_fmt = 0, dctx_fmt = 0;                                            // 16-bit activation maps: 0 fp32, 1 bf16, 2 fp16 (q of a mode-3 forward)
+  int out_fmt = 0;                                                        // 1: dk / dv leave as bf16 maps (written once: no accumulate)
 };
 int csn_launch_attn_dkv_flash(const CsnAttnDkvArgs& a, int d, int mode, hipStream_t st);
 constexpr bool csn_attn_dkv_flash_fits(int dt) { return dt <= 4; }         // K^T, V^T, dK^T, dV^T of 16 keys in one wave's registers

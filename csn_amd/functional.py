@@ -259,6 +259,8 @@ def project(x: torch.Tensor, w: torch.Tensor, div_rows: int = 0, temperature: fl
     R = w.shape[0]
     npts = N if n_points is None else n_points
     assert x.stride(2) == 1 and x.stride(1) == N and w.is_contiguous()
+    x16 = 16 if x.dtype == torch.bfloat16 else 0                   # a bf16 map as input (math mode 2: the bf16 gradient maps)
+    assert not (split and x16)
     if split:
         out = torch.empty((S, 2, R, npts), device=x.device, dtype=torch.bfloat16)
         _lib.check(_lib.lib().csn_project_f32(_ptr(x), x.stride(0), N, _ptr(w), R, C, _ptr(out), 2 * R * npts, npts, S, npts,
@@ -266,7 +268,7 @@ def project(x: torch.Tensor, w: torch.Tensor, div_rows: int = 0, temperature: fl
         return out
     out = torch.empty((S, R, npts), device=x.device, dtype=torch.float32)
     _lib.check(_lib.lib().csn_project_f32(_ptr(x), x.stride(0), N, _ptr(w), R, C, _ptr(out), R * npts, npts, S, npts,
-                                          div_rows, float(temperature), 0, 0, _stream()), "csn_project_f32")
+                                          div_rows, float(temperature), x16, 0, _stream()), "csn_project_f32")
     return out
 
 
@@ -453,8 +455,18 @@ class _MHAEvals(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dxhat, dhead, dsums=None, dhandle=None):
-        with math_mode(backward_mode(ctx.mode)), act16(ctx.a16):
-            return _MHAEvals._backward(ctx, dxhat, dhead, dsums, dhandle)
+        with math_mode(backward_mode(ctx.mode)):
+            # 16-bit maps: the gradient maps dQ / dK / dV too, where every slot is written once (grouped calls, flash)
+            g16 = 0
+            if ctx.a16:
+                geo, tune = ctx.geo, tuning.current()
+                grouping = _lib.lib().csn_attn_bwd_grouping(geo.d_head, geo.block)
+                dq_once = ctx.flow != tuning.KEEP_SCORES or (tune.grouped_dq and (grouping & 1))
+                dkv_once = ctx.flow == tuning.FLASH or (tune.grouped_dkv and (grouping & 2))
+                g16 = 4 if (dq_once and dkv_once) else 0
+            ctx.g16 = g16
+            with act16(ctx.a16 + g16):
+                return _MHAEvals._backward(ctx, dxhat, dhead, dsums, dhandle)
 
     @staticmethod
     def _backward(ctx, dxhat, dhead, dsums=None, dhandle=None):
@@ -532,7 +544,8 @@ class _MHAEvals(torch.autograd.Function):
             scores = torch.empty(shape, device=dev, dtype=torch.float32) if (travel and planes() == 2) else None
             dscores = torch.empty(shape, device=dev, dtype=torch.float32) if travel else None
         delta = torch.empty((E, H, geo.n_padded), device=dev, dtype=torch.float32)
-        dqkv = torch.empty((S, 3 * D, NP), device=dev, dtype=torch.float32)
+        dqkv = torch.empty((S, 3 * D, NP), device=dev, dtype=torch.bfloat16 if ctx.g16 else torch.float32)
+        ges = dqkv.element_size()
         # the weight gradients contract every slot's gradient maps — or, for a plan with slot ranges (and no input gradients
         # wanted), only the ranges: the maps of the other (slot, projection) pairs are then neither cleared nor read
         ranged = plan.q_ranges is not None and not need_dx
@@ -543,7 +556,7 @@ class _MHAEvals(torch.autograd.Function):
                 dqkv[:, D:2 * D].index_fill_(0, plan.k_unwritten, 0.0)
             if plan.v_unwritten.numel():
                 dqkv[:, 2 * D:].index_fill_(0, plan.v_unwritten, 0.0)
-        slot_stride = 3 * D * NP                                   # of the fp32 gradient maps
+        slot_stride = 3 * D * NP                                   # of the gradient maps, in elements
         q_stride, kv_stride, kv_flag, kv_pitch = ctx.ptrs
         gbase, q_ptr = dqkv.data_ptr(), qkv.data_ptr()
         # fp16 forward / bf16 backward: the forward's K / V planes hold fp16 bits; the attention backward kernels convert every
@@ -599,7 +612,7 @@ class _MHAEvals(torch.autograd.Function):
                 ev0.record()
             _lib.check(L.csn_block_attn_bwd_dkv_flash_f32(_ptr(datt), D * NP, q_ptr, q_stride, _ptr(plan.q_slots), k_ptr, v_ptr,
                                                           kv_stride, _ptr(plan.kv_slots), kv_pitch, kv_f16, NP, _ptr(lse), _ptr(delta),
-                                                          gbase + 4 * D * NP, gbase + 8 * D * NP, slot_stride,
+                                                          gbase + ges * D * NP, gbase + 2 * ges * D * NP, slot_stride,
                                                           _ptr(plan.kv_slots), _ptr(plan.v_slots), 0, _ptr(plan.kv_group_items),
                                                           E, H, d, T, nb, Tp, p_attn, seed_attn, _ptr(plan.kv_group_off),
                                                           plan.n_kv_groups, _stream()), "csn_block_attn_bwd_dkv_flash_f32")
@@ -610,7 +623,7 @@ class _MHAEvals(torch.autograd.Function):
         elif tune.grouped_dkv and (grouping & 2):
             # one call: the evaluations of a key/value slot are contracted one after the other into the same accumulators
             _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, q_ptr, q_stride, _ptr(plan.q_slots), NP,
-                                                    _ptr(scores), _ptr(dscores), gbase + 4 * D * NP, gbase + 8 * D * NP,
+                                                    _ptr(scores), _ptr(dscores), gbase + ges * D * NP, gbase + 2 * ges * D * NP,
                                                     slot_stride, _ptr(plan.kv_slots), _ptr(plan.v_slots), 0,
                                                     _ptr(plan.kv_group_items), E, H, d, T, nb, Tp, 0, 0, 0, 0, pt,
                                                     _ptr(plan.kv_group_off), plan.n_kv_groups, _stream()),
@@ -618,7 +631,7 @@ class _MHAEvals(torch.autograd.Function):
         else:
             for ci, ids in enumerate(plan.dkv_colors):
                 _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, q_ptr, q_stride, _ptr(plan.q_slots), NP,
-                                                        _ptr(scores), _ptr(dscores), gbase + 4 * D * NP, gbase + 8 * D * NP,
+                                                        _ptr(scores), _ptr(dscores), gbase + ges * D * NP, gbase + 2 * ges * D * NP,
                                                         slot_stride, _ptr(plan.kv_slots), _ptr(plan.v_slots),
                                                         0 if ci == 0 else 1, _ptr(ids),
                                                         ids.numel(), H, d, T, nb, Tp, 0, 0, 0, 0, pt, None, 0, _stream()),
@@ -632,7 +645,7 @@ class _MHAEvals(torch.autograd.Function):
                 for i, (first, step, count) in enumerate(ranges):
                     ws_n = L.csn_wgrad_workspace_floats(nrows, C, count, NP)
                     ws = torch.empty((ws_n,), device=dev, dtype=torch.float32)
-                    _lib.check(L.csn_project_wgrad_f32(dqkv.data_ptr() + 4 * (first * 3 * D + rows0) * NP, step * 3 * D * NP, NP,
+                    _lib.check(L.csn_project_wgrad_f32(dqkv.data_ptr() + ges * (first * 3 * D + rows0) * NP, step * 3 * D * NP, NP,
                                                        x_all.data_ptr() + 4 * first * C * NP, step * C * NP, NP,
                                                        dw_qkv.data_ptr() + 4 * rows0 * C, nrows, C, count, NP, 1.0,
                                                        0 if i == 0 else 1, _ptr(ws), ws_n, _stream()), "csn_project_wgrad_f32")
@@ -645,7 +658,7 @@ class _MHAEvals(torch.autograd.Function):
         if need_dx:
             # residual path + the three projections (not needed by the reference's training: inputs are constants)
             dqkv[:, :D] /= temperature
-            dx_all = project(dqkv, w_qkv.t().contiguous())
+            dx_all = project(dqkv, w_qkv.t().contiguous())                   # (bf16 gradient maps: read as such)
             dx_all.index_add_(0, plan.q_slots.long(), dz if dz_res is None else dz_res)
         return dx_all, dw_q, dw_k, dw_v, dw_fc, None, None, None, None, None, None, None, None
 

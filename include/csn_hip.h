@@ -88,6 +88,7 @@ int csn_version(void);
  *   Ctx  (written by (2); read by (4) forward, by (3)'s delta and by the W_fc gradient of (4) backward)                 fwd type
  *   xhat (written by (4) forward; read by (4) backward and by (6))                                                      fp16 always (|xhat| < sqrt(C))
  *   dZ, dCtx (written by (4) backward; read by (3))                                                                     bf16
+ *   dQ, dK, dV (fmt + 4 only: written by (3), read by csn_project_wgrad_f32 and, as x, by csn_project_f32 out_split + 16)    bf16
  * are ONE plane of 16-bit elements with the shapes documented below; their pointers stay typed float* and every stride and
  * leading dimension of such a map counts 16-bit ELEMENTS (same numbers as for the fp32 map).  Everything else keeps its type:
  * the input maps x, the residual, dxhat / dfeats, lse / delta / rstd, every gradient map dQ / dK / dV / dz_res, weights and
@@ -96,7 +97,9 @@ int csn_version(void);
  * see the rounded maps (|xhat| error <= 2^-11 relative).  Requirements: math mode 2 / 3 with K / V tile planes, block mode (no
  * cross-length entry points), no split tensors, a mix backward without gradient maps (the linked form), evaluation outputs
  * written once (no accumulate into a 16-bit map).  A forward entry point returns CSN_E_ARG when fmt does not name its mode's
- * type; backward entry points take either fmt in mode 2. */
+ * type; backward entry points take either fmt in mode 2.  fmt + 4 (5 or 6) also makes the gradient maps dQ / dK / dV bf16:
+ * they are then written once per slot (grouped calls; accumulate != 0 returns CSN_E_ARG), and what contracts them rounds them to
+ * bf16 anyway — the weight gradients are the same bits. */
 int csn_set_thread_act16(int fmt);
 int csn_get_thread_act16(void);
 int csn_set_math_mode(int mode);
@@ -112,7 +115,8 @@ const char* csn_status_string(int status);
  * by `temperature`.   Replaces w_qs / w_ks / w_vs (nn.Linear, no bias; csa_models.py:49-51,103-105) and the
  * `q / temperature` of csa_models.py:139 (stack W_q|W_k|W_v along rows and pass div_rows = n_head*d_k to
  * project a shape once for all of its evaluations).  out_split: 0 fp32 maps, 1 / 2 split tensors / tile planes (above), 3 (math
- * modes 2 / 3): ONE 16-bit map per shape in the mode's type — out_shape_stride and ld_out count 16-bit elements. */
+ * modes 2 / 3): ONE 16-bit map per shape in the mode's type — out_shape_stride and ld_out count 16-bit elements.  out_split + 16
+ * (math mode 2): x itself is a bf16 map (x_shape_stride, ld_x in elements) — the input gradient W^T dqkv from bf16 gradient maps. */
 int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const float* w, int rows, int channels,
                     float* out, long long out_shape_stride, int ld_out, int n_shapes, int n_points, int div_rows,
                     float temperature, int out_split, long long out_plane_stride, void* stream);

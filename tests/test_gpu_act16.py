@@ -68,6 +68,31 @@ def test_module_step_with_16bit_maps(L, mode, geo, train):
         assert err <= 3e-2 * gs, (n, err, gs)
 
 
+def test_input_gradients_with_16bit_maps(L):
+    """The same step with the neighbour stack requiring a gradient: dx = W^T dqkv reads the bf16 gradient maps, the residual
+    branch stays fp32."""
+    from csn_amd import tuning
+    from csn_amd.csa_models import get_model
+    from oracle import csa_oracle as orc
+    rng = np.random.default_rng(32)
+    B, K, n_cls, C, N = 2, 2, 5, 128, 300
+    torch.manual_seed(6)
+    model = get_model("csa", n_cls, 1, K, d_model=C, d_k=128, d_v=128, block=100, n_blocks=3).cuda().train(True)
+    L.check(L.lib().csn_set_math_mode(2))
+    nb0 = torch.from_numpy(rng.standard_normal((B, K + 1, C, N, 1)).astype(np.float32)).cuda()
+    lab = torch.from_numpy(rng.integers(0, n_cls, size=(B, N))).cuda()
+    grads = []
+    for on in (False, True):
+        nbf = nb0.clone().requires_grad_(True)
+        with tuning.override(act16=on):
+            torch.manual_seed(3)
+            loss = orc.masked_ce_loss(model(nbf[:, 0], "train", nbf), lab)
+            loss.backward()
+        grads.append(nbf.grad.clone())
+    scale = grads[0].abs().max().item()
+    assert scale > 0 and (grads[0] - grads[1]).abs().max().item() <= 3e-2 * scale
+
+
 def test_switch_is_scoped_to_the_thread(L):
     lib = L.lib()
     assert lib.csn_get_thread_act16() == 0
@@ -78,7 +103,8 @@ def test_switch_is_scoped_to_the_thread(L):
     t = threading.Thread(target=lambda: seen.append(lib.csn_get_thread_act16()))
     t.start(); t.join()
     assert seen == [0]
-    assert lib.csn_set_thread_act16(3) == -1
+    assert lib.csn_set_thread_act16(3) == -1 and lib.csn_set_thread_act16(4) == -1 and lib.csn_set_thread_act16(7) == -1
+    L.check(lib.csn_set_thread_act16(5))
     L.check(lib.csn_set_thread_act16(0))
 
 
