@@ -395,15 +395,25 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
     const int nv = T - q0;                                          // valid queries among them (only the last tile has fewer than 8)
     const bool last_tile = c_qt == nqt - 1;
     float pd[8], ds[8];
+    // One mixer round decides the two keys of a pair (low / high 16 bits), and the two keys of a pair sit on NEIGHBOURING lanes
+    // here: the even lane hashes queries 0..3, the odd lane 4..7, and a quad swap hands each the other's four — half the
+    // quarter-rate multiplies of the pointwise segment for four full-rate moves.
+    unsigned hsh[8];
+    if (drop) {
+      unsigned mine[4], theirs[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mine[j] = csn_pair_hash(pw_key + (unsigned)(q0 + (key_odd ? 4 : 0) + j), salt);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) theirs[j] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine[j], 0xB1, 0xf, 0xf, false);   // lane ^ 1
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { hsh[j] = key_odd ? theirs[j] : mine[j]; hsh[4 + j] = key_odd ? mine[j] : theirs[j]; }
+    }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       float pv = __builtin_amdgcn_exp2f(fmaf(sv[r], LOG2E, -lse2[r]));       // softmax probability (csa_models.py:141)
       if (last_tile) pv = r < nv ? pv : 0.f;                                 // queries beyond the block end (wave-uniform branch)
       bool keep = true;
-      if (drop) {
-        const unsigned h = csn_pair_hash(pw_key + (unsigned)(q0 + r), salt);
-        keep = (key_odd ? (h >> 16) : (h & 0xffffu)) >= thr16;
-      }
+      if (drop) keep = (key_odd ? (hsh[r] >> 16) : (hsh[r] & 0xffffu)) >= thr16;
       const float md = keep ? keep_scale : 0.f;                              // d P_drop / d P
       pd[r] = pv * md;                                                       // what dV contracts: the dropped probabilities
       ds[r] = pv * (dp[r] * md - dlt[r]);                                    // d softmax

@@ -93,6 +93,44 @@ def test_input_gradients_with_16bit_maps(L):
     assert scale > 0 and (grads[0] - grads[1]).abs().max().item() <= 3e-2 * scale
 
 
+class _Ready:
+    """stands in for csn_amd.sharding.PendingStack with the exchange already complete"""
+
+    def __init__(self, stack):
+        self.stack = stack
+
+    def wait(self):
+        return self.stack
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp16"])
+def test_overlapped_path_with_16bit_maps(L, mode):
+    """The multi-GPU form of the step (own shapes first, the rest after the exchange: two evaluation batches whose fp16 maps
+    meet in one mix) on the 16-bit exchange against the single call on fp32 maps."""
+    from csn_amd import tuning
+    from csn_amd.csa_models import get_model
+    from oracle import csa_oracle as orc
+    rng = np.random.default_rng(33)
+    B, K, H, n_cls = 2, 3, 1, 7
+    p, x, nb, lab = orc.conditioned_csa_case(rng, B, K, H, n_cls, 4.0, 3.0, 1.0)
+    x, nb, lab = x.cuda(), nb.cuda().contiguous(), lab.cuda()
+    outs = []
+    for overlapped, on in ((False, False), (True, True)):
+        m = get_model("csa", n_cls, H, K, math=mode)
+        m.load_state_dict(p, strict=False)
+        m = m.cuda().eval()
+        with tuning.override(act16=on):
+            logits = m(x, "test", _Ready(nb) if overlapped else nb)
+            loss = orc.masked_ce_loss(logits, lab)
+            loss.backward()
+        outs.append((logits.detach(), loss.item(), {n: q.grad.clone() for n, q in m.named_parameters() if q.grad is not None}))
+    (l0, s0, g0), (l1, s1, g1) = outs
+    assert (l0 - l1).abs().max().item() <= 2e-3 * l0.abs().max().item() and abs(s0 - s1) <= 1e-3 * abs(s0)
+    assert set(g0) == set(g1) and len(g0) == 11
+    for n in g0:
+        assert (g0[n] - g1[n]).abs().max().item() <= 3e-2 * g0[n].abs().max().item(), n
+
+
 def test_switch_is_scoped_to_the_thread(L):
     lib = L.lib()
     assert lib.csn_get_thread_act16() == 0

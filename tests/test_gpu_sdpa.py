@@ -93,3 +93,31 @@ def test_unequal_and_odd_head_widths(math_mode):
     for got, want in ((qd.grad, q64.grad), (kd.grad, k64.grad), (vd.grad, v64.grad)):
         assert got.shape == want.shape
         assert ((got.cpu().double() - want).abs().max() / want.abs().max()).item() < 1e-4
+
+
+def test_backward_runs_in_the_mode_of_its_forward():
+    """A forward under a THREAD override (``CF.math_mode('fp32')`` while the process default is bf16x3) gets its backward —
+    which autograd runs on its own worker thread — in the same arithmetic: the gradients are the bits of a run whose
+    process default is fp32, not those of the bf16x3 default."""
+    from csn_amd import _lib, functional as CF
+    from csn_amd.csa_models import ScaledDotProductAttention
+    rng = np.random.default_rng(11)
+    B, H, T, d = 1, 2, 96, 32
+    q0, k0, v0 = (torch.from_numpy(rng.standard_normal((B, H, T, d)).astype(np.float32)).cuda() for _ in range(3))
+    w = torch.from_numpy(rng.standard_normal((B, H, T, d)).astype(np.float32)).cuda()
+    m = ScaledDotProductAttention(temperature=d ** 0.5).eval()
+
+    def grads(process_mode, override):
+        _lib.check(_lib.lib().csn_set_math_mode(process_mode))
+        q, k, v = (t.clone().requires_grad_(True) for t in (q0, k0, v0))
+        with CF.math_mode(override):
+            o, _ = m(q, k, v)
+        (o * w).sum().backward()                       # outside the block: the worker thread has no override of its own
+        torch.cuda.synchronize()
+        return [t.grad.clone() for t in (q, k, v)]
+
+    exact = grads(0, None)
+    scoped = grads(1, "fp32")
+    fast = grads(1, None)
+    assert all(torch.equal(a, b) for a, b in zip(exact, scoped))
+    assert any(not torch.equal(a, b) for a, b in zip(exact, fast))
