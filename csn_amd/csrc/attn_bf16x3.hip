@@ -77,8 +77,18 @@ CSN_DEVINL f32x4v mma16(s16x8 ah, s16x8 al, s16x8 bh, s16x8 bl, f32x4v c) {
 // query slot) and a third LDS image (the K tile in the k-major form of tileA) — instead of being read back from the forward's
 // saved copy: no score loads, and with sc_tiles == 0 no P / dS stores either (the key-stationary dK / dV kernel of
 // attn_dkv.hip recomputes them for itself).  One more matrix product per tile; LDS holds three images per stage.
+// Waves per SIMD (the second launch bound).  Two everywhere — 256 registers a wave — except the narrow instances, whose tile
+// images leave room for a second work-group on the CU: one plane up to d = 96, two planes up to d = 64.  There the bound is
+// four (128 registers), which costs the recomputing dQ instances 13-18 spilled registers and still pays: a second work-group
+// hides what a latency-bound loop cannot (config-5 geometry, bf16: dQ 3.53 -> 2.69 ms; bf16x3 at d = 64: 2.43 -> 1.75 ms).
+// Measured and NOT taken (scripts/dev/ab_attn.sh): one plane at d = 128 (+-0), two planes at d = 96 / 128 (38-82 spilled
+// registers inside the loop: forward 3.8 -> 6.6 ms), the key-stationary dK / dV kernel (96 spills: 4.2 -> 15.5 ms).
+#ifndef CSN_LB_NARROW
+#define CSN_LB_NARROW 4
+#endif
+constexpr int csn_attn_waves(int npl, int dt) { return (npl == 1 ? dt <= 3 : dt <= 2) ? CSN_LB_NARROW : 2; }
 template <typename PR, int DT, bool BWD, bool KVP, bool RC = false>
-__global__ __launch_bounds__(512, 2) void csn_attn_bf16x3_kernel(CsnAttnArgs p) {
+__global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT)) void csn_attn_bf16x3_kernel(CsnAttnArgs p) {
   static_assert(PR::NT == 3 || KVP, "single-product modes take K / V as tile planes");
   static_assert(!RC || (BWD && KVP), "score recomputation: backward kernel on tile-plane K / V");
   constexpr int NPL = PR::NPL;                          // planes: hi (+ lo)

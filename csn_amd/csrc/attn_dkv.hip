@@ -60,6 +60,7 @@ CSN_DEVINL f32x4v mma16(s16x8 ah, s16x8 al, s16x8 bh, s16x8 bl, f32x4v c) {
 // QF (one-plane mode): 0 = Qs and dO are fp32 maps; 1 / 2 = 16-bit activation maps, Qs in bf16 / fp16 (a math-mode-3 forward:
 // converted to bf16 at the commit) and dO in bf16 — a compile-time property: a format branch inside the tile loop costs the
 // kernel its schedule (measured: 3.7 -> 5.2 ms at config-5 geometry)
+// (two waves per SIMD at every width: with four, the d = 96 instance spills 96 registers — 4.2 -> 15.5 ms, scripts/dev/ab_attn.sh)
 template <typename PR, int DT, int QF = 0>
 __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) {
   static_assert(QF == 0 || PR::NPL == 1, "16-bit activation maps: the one-plane mode");
