@@ -22,7 +22,7 @@
 namespace {
 
 constexpr int QT = 32;               // queries per streamed tile
-constexpr int KW = 128;              // keys per work-group (8 waves x 16)
+// keys per work-group = 16 per wave: 128 (8 waves), or 64 (4 waves) where three such work-groups fit a CU (csn_dkv_waves)
 constexpr float LOG2E = 1.4426950408889634f;
 
 using namespace csn_mode;
@@ -60,16 +60,27 @@ CSN_DEVINL f32x4v mma16(s16x8 ah, s16x8 al, s16x8 bh, s16x8 bl, f32x4v c) {
 // QF (one-plane mode): 0 = Qs and dO are fp32 maps; 1 / 2 = 16-bit activation maps, Qs in bf16 / fp16 (a math-mode-3 forward:
 // converted to bf16 at the commit) and dO in bf16 — a compile-time property: a format branch inside the tile loop costs the
 // kernel its schedule (measured: 3.7 -> 5.2 ms at config-5 geometry)
-// (two waves per SIMD at every width: with four, the d = 96 instance spills 96 registers — 4.2 -> 15.5 ms, scripts/dev/ab_attn.sh)
-template <typename PR, int DT, int QF = 0>
-__global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) {
+// Occupancy.  At d = 96 one plane the kernel needs ~175 registers: two waves per SIMD, ONE work-group of 8 waves per CU.  Both
+// ways to more resident waves were built and measured at config-5 geometry (scripts/dev/ab_attn.sh, ab_step.sh) and lose:
+// the register bound of four waves per SIMD spills 96 registers (4.2 -> 15.5 ms); work-groups of four waves / 64 keys
+// (-DCSN_DKV_NW=4: three per CU under a bound of 168 registers) stage every tile for half as many keys and still spill 32
+// registers (3.7 -> 6.0 ms).  The default stays 8 waves, two per SIMD.
+#ifndef CSN_DKV_NW
+#define CSN_DKV_NW 8
+#endif
+constexpr int csn_dkv_waves(int npl, int dt) { return (npl == 1 && dt <= 3) ? CSN_DKV_NW : 8; }
+template <typename PR, int DT, int QF = 0, int NW = 8>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) {
   static_assert(QF == 0 || PR::NPL == 1, "16-bit activation maps: the one-plane mode");
+  static_assert(NW == 8 || NW == 4, "work-groups of 8 or 4 waves");
+  constexpr int NT = 64 * NW;                           // threads
+  constexpr int KW = 16 * NW;                           // keys per work-group
   constexpr int NPL = PR::NPL;
   constexpr int D = 32 * DT;
   constexpr int PLANE = D * QT + 32;                    // hi and lo planes 64 bytes out of phase (store banks, attn_bf16x3.hip)
-  constexpr int NP_T = (D * 8 + 511) / 512;             // 16-byte pieces of a [D][32] fp32 tile per thread
+  constexpr int NP_T = (D * 8 + NT - 1) / NT;           // 16-byte pieces of a [D][32] fp32 tile per thread
   constexpr int IMG_EL = 4 * 2 * NPL * PLANE;           // [image: QA, OA, QB, OB][stage][plane]
-  constexpr int STAGE_EL = D * KW * 2;                  // prologue / epilogue: a [D][128 keys] fp32 block
+  constexpr int STAGE_EL = D * KW * 2;                  // prologue / epilogue: a [D][KW keys] fp32 block
   constexpr int BUF_EL = IMG_EL > STAGE_EL ? IMG_EL : STAGE_EL;
   static_assert(2 * BUF_EL + 3 * 64 * 4 <= 160 * 1024, "LDS budget of one CU");
   __shared__ __attribute__((aligned(16))) short tiles[BUF_EL + 3 * 64 * 2];
@@ -95,42 +106,42 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
   const long long kslot = p.kv_index ? p.kv_index[e_first] : e_first;
   const int nqt = (T + QT - 1) / QT;
   const int n_steps = (it1 - it0) * nqt;
-  const bool late = __builtin_amdgcn_readfirstlane(wave) >= 4;
+  const bool late = __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
   const int col = 16 * wave + lq;                                   // this lane's key inside the chunk of 128
   const int key = kc * KW + col;                                    // ... inside the block
 
   // ---- register operands K^T, V^T [d][16 keys] from the tile planes -----------------------------------------------
   // The chunk's 128 keys are 4 tiles of [hi 32 | lo 32] (one plane: [32]) per row: 256 NPL bytes.  The work-group fetches the
   // [D][4 tiles] block with 16-byte loads into LDS (the tile buffers are idle) and every lane picks its 16-bit values.
-  constexpr int RPC = 16 * NPL;                                     // 16-byte pieces per row of the block
-  constexpr int CH_K = (D * RPC + 511) / 512;
+  constexpr int RPC = (KW / 8) * NPL;                               // 16-byte pieces per row of the block
+  constexpr int CH_K = (D * RPC + NT - 1) / NT;
   s16x8 Kh[DT], Kl[DT], Vh[DT], Vl[DT];
   {
     const int kld = p.kv_ld;
-    const int cc = tid % RPC, crow = tid / RPC;                     // piece column, first row (rows + 512 / RPC per pass)
-    constexpr int RPS = 512 / RPC;
-    short* sbuf = tiles;                                            // [row][piece ^ swizzle][8 shorts], row pitch 128 NPL shorts
+    const int cc = tid % RPC, crow = tid / RPC;                     // piece column, first row (rows + NT / RPC per pass)
+    constexpr int RPS = NT / RPC;
+    short* sbuf = tiles;                                            // [row][piece ^ swizzle][8 shorts], row pitch KW NPL shorts
     auto stage_planes = [&](const short* base) {
-      const long long off = kslot * p.kv_shape_stride + (long long)hd * D * kld + (long long)blk * (512 * NPL) + (long long)kc * (128 * NPL);
-      const csn_rsrc_t rs = csn_make_rsrc(base + off, ((long long)(D - 1) * kld + 128 * NPL) * 2);
+      const long long off = kslot * p.kv_shape_stride + (long long)hd * D * kld + (long long)blk * (512 * NPL) + (long long)kc * (KW * NPL);
+      const csn_rsrc_t rs = csn_make_rsrc(base + off, ((long long)(D - 1) * kld + KW * NPL) * 2);
       f32x4 ch[CH_K];
 #pragma unroll
       for (int t = 0; t < CH_K; ++t) {
         const int row = crow + RPS * t;
         // (only the tiles that hold keys of this block: the projection writes nothing beyond the block's last 32-key tile)
-        const bool ok = row < D && (kc * 4 + cc / (4 * NPL)) < (T + 31) / 32;
+        const bool ok = row < D && (kc * (KW / 32) + cc / (4 * NPL)) < (T + 31) / 32;
         ch[t] = csn_bload4(rs, ok ? (unsigned)(row * kld * 2 + cc * 16) : CSN_OOB);
       }
 #pragma unroll
       for (int t = 0; t < CH_K; ++t) {
         const int row = crow + RPS * t;
-        if (row < D) *reinterpret_cast<f32x4*>(&sbuf[row * (128 * NPL) + ((cc ^ (2 * ((row >> 3) & 3))) << 3)]) = ch[t];
+        if (row < D) *reinterpret_cast<f32x4*>(&sbuf[row * (KW * NPL) + ((cc ^ (2 * ((row >> 3) & 3))) << 3)]) = ch[t];
       }
     };
     // element (row, local key kl): tile kl >> 5, position kl & 31 -> piece (kl >> 5) * 4 NPL + plane * 4 + ((kl & 31) >> 3)
     auto pick = [&](int row, int plane) {
       const int piece = (col >> 5) * (4 * NPL) + plane * 4 + ((col & 31) >> 3);
-      return sbuf[row * (128 * NPL) + (((piece ^ (2 * ((row >> 3) & 3))) << 3) | (col & 7))];
+      return sbuf[row * (KW * NPL) + (((piece ^ (2 * ((row >> 3) & 3))) << 3) | (col & 7))];
     };
     stage_planes(reinterpret_cast<const short*>(p.k));
     __syncthreads();
@@ -177,9 +188,10 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
   const bool key_odd = key & 1;
 
   // ---- streamed tiles: fp32 [d][32 queries] -> bf16 hi / lo -> LDS, in both forms (the fp32 staging of attn_bf16x3.hip) ----
-  const int t_c = tid & 7, t_row = tid >> 3;                        // 16-byte piece of the row (queries 4 c ..), first row (+ 64 i)
+  const int t_c = tid & 7, t_row = tid >> 3;                        // 16-byte piece of the row (queries 4 c ..), first row (+ RPT i)
   const int t_sw = ((t_row >> 3) ^ t_row) & 1, t_swz = (-((t_row >> 2) & 3)) & 3;
-  const bool t_last_ok = ((D * 8) % 512 == 0) || (tid + 512 * (NP_T - 1) < D * 8);
+  constexpr int RPT = NT / 8;                                       // tile rows per pass of the work-group's threads
+  const bool t_last_ok = ((D * 8) % NT == 0) || (tid + NT * (NP_T - 1) < D * 8);
   const int a_dst = t_row * QT + 4 * (t_c ^ t_sw);
   const int b_dst = t_row * QT + 8 * ((t_c >> 1) ^ t_swz) + 4 * (t_c & 1);
   // The pieces of a tile are split into bf16 hi / lo ONCE, when they are committed to the k-major image (segment 1), and wait
@@ -220,10 +232,10 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
 #pragma unroll
     for (int i = 0; i < NP_T; ++i) {
       const unsigned o = (i == NP_T - 1 && !t_last_ok) ? CSN_OOB : off;
-      if constexpr (q_fmt != 0) hQ[i] = csn_bload2(Qr, o == CSN_OOB ? o : o * 2u, (unsigned)(64 * i * ld) * 2u);
-      else gQ[i] = csn_bload4(Qr, o == CSN_OOB ? o : o * 4u, (unsigned)(64 * i * ld) * 4u);
-      if constexpr (o_fmt != 0) hO[i] = csn_bload2(Or, o == CSN_OOB ? o : o * 2u, (unsigned)(64 * i * ld) * 2u);
-      else gO[i] = csn_bload4(Or, o == CSN_OOB ? o : o * 4u, (unsigned)(64 * i * ld) * 4u);
+      if constexpr (q_fmt != 0) hQ[i] = csn_bload2(Qr, o == CSN_OOB ? o : o * 2u, (unsigned)(RPT * i * ld) * 2u);
+      else gQ[i] = csn_bload4(Qr, o == CSN_OOB ? o : o * 4u, (unsigned)(RPT * i * ld) * 4u);
+      if constexpr (o_fmt != 0) hO[i] = csn_bload2(Or, o == CSN_OOB ? o : o * 2u, (unsigned)(RPT * i * ld) * 2u);
+      else gO[i] = csn_bload4(Or, o == CSN_OOB ? o : o * 4u, (unsigned)(RPT * i * ld) * 4u);
     }
     if (wave0) {
       const long long rwin = (nq < QT ? nq : QT) * 4;
@@ -249,11 +261,11 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
           cOh[i] = __builtin_bit_cast(s16x4, moved(hO[i]));
           cOl[i] = cOh[i];
         } else split4<PR>(gO[i], cOh[i], cOl[i]);
-        *reinterpret_cast<s16x4*>(image(0, st, 0) + a_dst + 64 * QT * i) = cQh[i];
-        *reinterpret_cast<s16x4*>(image(1, st, 0) + a_dst + 64 * QT * i) = cOh[i];
+        *reinterpret_cast<s16x4*>(image(0, st, 0) + a_dst + RPT * QT * i) = cQh[i];
+        *reinterpret_cast<s16x4*>(image(1, st, 0) + a_dst + RPT * QT * i) = cOh[i];
         if constexpr (NPL == 2) {
-          *reinterpret_cast<s16x4*>(image(0, st, 1) + a_dst + 64 * QT * i) = cQl[i];
-          *reinterpret_cast<s16x4*>(image(1, st, 1) + a_dst + 64 * QT * i) = cOl[i];
+          *reinterpret_cast<s16x4*>(image(0, st, 1) + a_dst + RPT * QT * i) = cQl[i];
+          *reinterpret_cast<s16x4*>(image(1, st, 1) + a_dst + RPT * QT * i) = cOl[i];
         }
       }
   };
@@ -261,11 +273,11 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
 #pragma unroll
     for (int i = 0; i < NP_T; ++i)
       if (i < NP_T - 1 || t_last_ok) {
-        *reinterpret_cast<s16x4*>(image(2, st, 0) + b_dst + 64 * QT * i) = cQh[i];
-        *reinterpret_cast<s16x4*>(image(3, st, 0) + b_dst + 64 * QT * i) = cOh[i];
+        *reinterpret_cast<s16x4*>(image(2, st, 0) + b_dst + RPT * QT * i) = cQh[i];
+        *reinterpret_cast<s16x4*>(image(3, st, 0) + b_dst + RPT * QT * i) = cOh[i];
         if constexpr (NPL == 2) {
-          *reinterpret_cast<s16x4*>(image(2, st, 1) + b_dst + 64 * QT * i) = cQl[i];
-          *reinterpret_cast<s16x4*>(image(3, st, 1) + b_dst + 64 * QT * i) = cOl[i];
+          *reinterpret_cast<s16x4*>(image(2, st, 1) + b_dst + RPT * QT * i) = cQl[i];
+          *reinterpret_cast<s16x4*>(image(3, st, 1) + b_dst + RPT * QT * i) = cOl[i];
         }
       }
   };
@@ -436,7 +448,7 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
   if (!late) __syncthreads();                                       // pairs with the last barrier of the late half
 
   // ---- epilogue: dK^T, dV^T [d][128 keys] leave as 16-byte rows through an LDS transpose ---------------------------------
-  const int cc = tid & 31, crow = tid >> 5;
+  const int cc = tid & (KW / 4 - 1), crow = tid / (KW / 4);       // 4-key chunk of the row, first row (+ 16 t: NT / (KW / 4) = 16)
   constexpr int CH_T = D / 16;
   const long long okslot = p.dk_index ? p.dk_index[e_first] : e_first, ovslot = p.dv_index ? p.dv_index[e_first] : e_first;
   const long long out_off = (long long)hd * D * ld + (long long)blk * p.T + kc * KW;
@@ -484,17 +496,18 @@ __global__ __launch_bounds__(512, 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) 
 
 template <typename PR, int DT>
 int launch_dt(const CsnAttnDkvArgs& a, hipStream_t st) {
+  constexpr int NW = csn_dkv_waves(PR::NPL, DT);
   const long long units = (long long)a.n_blocks * a.H * a.n_groups;
-  const int KC = (a.T + KW - 1) / KW;
+  const int KC = (a.T + 16 * NW - 1) / (16 * NW);
   dim3 grid((unsigned)(((units + 7) / 8) * 8 * KC));
   if (a.q_fmt || a.dctx_fmt) {
     if constexpr (PR::NPL == 1) {
       if (a.dctx_fmt != 1) return -1;
-      if (a.q_fmt == 1) hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 1>), grid, dim3(512), 0, st, a);
-      else if (a.q_fmt == 2) hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 2>), grid, dim3(512), 0, st, a);
+      if (a.q_fmt == 1) hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 1, NW>), grid, dim3(64 * NW), 0, st, a);
+      else if (a.q_fmt == 2) hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 2, NW>), grid, dim3(64 * NW), 0, st, a);
       else return -1;
     } else return -1;
-  } else hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT>), grid, dim3(512), 0, st, a);
+  } else hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 0, NW>), grid, dim3(64 * NW), 0, st, a);
   return (int)hipGetLastError();
 }
 
