@@ -3,7 +3,8 @@
 # profiles/ under the round's names and refresh profiles/attn_hbm_traffic.json (what bench.py reports as roofline.traffic)
 tag=$1
 cd "$(dirname "$0")/../.." || exit 1
-for d in gpurun_out/${tag}_*; do
+for d in gpurun_out/${tag}_c*/; do
+  d=${d%/}
   name=${d#gpurun_out/${tag}_}
   cp $d/stats.csv profiles/${tag}_kernel_stats_${name}.csv
   cp $d/hbm.txt profiles/${tag}_pmc_hbm_traffic_${name}.txt
