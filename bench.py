@@ -145,10 +145,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n_ranks_seen = 1
-    if world > 1:
+    # CSN_BENCH_GROUP_OF_ONE=1 (development aid, one GPU): the multi-GPU code path — process group, sharded step, exchange,
+    # gradient all-reduce, max-over-ranks timing — in a world of ONE rank over RCCL: what a one-GPU box can rehearse of it
+    grouped = world > 1 or os.environ.get("CSN_BENCH_GROUP_OF_ONE") == "1"
+    if grouped:
         # the process group comes up BEFORE anything touches the GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            for k, v in (("MASTER_PORT", "29581"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+                os.environ.setdefault(k, v)
         # CSN_BENCH_BACKEND=gloo + CSN_BENCH_ONE_GPU=1 rehearse the N > 1 code path with all ranks on one GPU (no RCCL)
         backend = os.environ.get("CSN_BENCH_BACKEND", "nccl")
         if os.environ.get("CSN_BENCH_ONE_GPU") == "1":
@@ -193,7 +199,7 @@ def main():
     # resident in HBM before the timed region.  (N > 1: only the same-work reference run below uses it.)
     x_nb_resident = torch.empty((B, K + 1, C, N, 1), device=dev, dtype=torch.float32)
     x_nb_resident[:, 0, :, :, 0] = feats
-    if world == 1:
+    if not grouped:
         for k in range(K):
             x_nb_resident[:, k + 1, :, :, 0] = torch.from_numpy(rng.standard_normal(size=(B, C, N)).astype(np.float32)).to(dev)
     else:
@@ -204,7 +210,7 @@ def main():
     # CSN_BENCH_HOST_NB=1 (N = 1, development aid): the neighbour stack stays in pinned HOST memory and crosses PCIe inside
     # every step, the way csa_training.py:198-202 hands it over — the PCIe-inclusive rate DESIGN.md quotes; never `value`
     x_nb_host = None
-    if world == 1 and os.environ.get("CSN_BENCH_HOST_NB") == "1":
+    if not grouped and os.environ.get("CSN_BENCH_HOST_NB") == "1":
         x_nb_host = x_nb_resident.cpu().pin_memory()
 
     attn_events = {"fwd": [], "bwd": [], "dkv": []}      # dkv: the key-stationary dK / dV launch of the score-recomputing flow
@@ -213,7 +219,7 @@ def main():
 
     # CSN_BENCH_SPLIT=1 (N = 1, development aid): run the two-phase evaluation order of the multi-GPU path with the stack
     # already complete, to price its extra work against the single call
-    split_probe = world == 1 and os.environ.get("CSN_BENCH_SPLIT") == "1"
+    split_probe = not grouped and os.environ.get("CSN_BENCH_SPLIT") == "1"
 
     class _ReadyStack:
         """stands in for csn_amd.sharding.PendingStack with the exchange already complete (development aids below)"""
@@ -234,10 +240,10 @@ def main():
     # the reference runs.  N = 1: selected by --same-work.  N > 1: every rank times it before the group step, so that the
     # scaling line carries its own like-for-like single-GPU reference (config.n1_same_work_ms_per_step).
     from csn_amd.sharding import regular_graph as _regular_graph
-    local_graph = torch.from_numpy(_regular_graph(B, K)).to(dev) if (args.same_work or world > 1) else None
+    local_graph = torch.from_numpy(_regular_graph(B, K)).to(dev) if (args.same_work or grouped) else None
     if local_graph is not None:
         x_nb_resident[:, 1:, :, :, 0] = feats[local_graph]
-    same_work_n1 = world == 1 and args.same_work
+    same_work_n1 = not grouped and args.same_work
 
     def step(record=False, local=False):
         """local: the same-work step on this rank's own shapes (no exchange, no gradient all-reduce)"""
@@ -275,7 +281,7 @@ def main():
         torch.manual_seed(1)
         for v in attn_events.values():
             v.clear()
-        group = world > 1 and not local
+        group = grouped and not local
         for _ in range(args.warmup):
             step(local=local)
         torch.cuda.synchronize()
@@ -310,7 +316,7 @@ def main():
     # headline mode, and the same train-mode step in the other arithmetic mode
     other = "fp32" if args.math != "fp32" else "bf16x3"
     same_work_ms = None
-    if world > 1:
+    if grouped:
         # the like-for-like single-GPU reference of this line: the same K+2 evaluations per shape on this rank's own shapes
         _, _, _, _, sw = timed(True, local=True)
         same_work_ms = float(np.median(sw))
@@ -320,7 +326,7 @@ def main():
         set_math(other)
         elapsed_other, loss_other, attn_ms_other, gnorm_other, step_ms_other = timed(True)
         set_math(args.math)
-    reuse = (world > 1 and overlap and os.environ.get("CSN_REUSE", "1") != "0") or same_work_n1
+    reuse = (grouped and overlap and os.environ.get("CSN_REUSE", "1") != "0") or same_work_n1
     # train mode: the pooled and the mixed self evaluation differ (2K+2 per shape); with descriptor reuse (N > 1) the K
     # neighbour self-attention evaluations per shape are their owners' work: K+2 per shape
     n_evals = B * ((K + 2) if reuse else (2 * K + 2))
@@ -396,12 +402,12 @@ def main():
                        "evaluations_per_shape": n_evals // B,
                        "shapes_total": S, "K": K,
                        "parallelism": (f"shape-graph sharded x{world}, exchange {exchange_mode}" + (" overlapped" if overlap else "")
-                                       + (", descriptor reuse" if reuse else "")) if world > 1 else "single GPU",
+                                       + (", descriptor reuse" if reuse else "")) if grouped else "single GPU",
                        "loss": loss_val, "grad_norm": gnorm,
                        "step_tflops_algorithmic": 3 * algorithmic_flops_fwd(S, K, N, C, D, T) / (med_ms * 1e-3) / 1e12},
             "roofline": dominant, "roofline_other": second,
         }
-        if world > 1:
+        if grouped:
             out["config"]["n1_same_work_ms_per_step"] = same_work_ms
             out["config"]["scaling_note"] = (
                 f"this line runs K+2 = {K + 2} evaluations per shape (descriptor reuse: a neighbour's pooled SSA descriptor is its "
@@ -431,11 +437,11 @@ def main():
             if not ok:
                 print(f"bench: WARNING the {args.math} step disagrees with the {other} step beyond {tol}: "
                       f"loss {loss_val} vs {loss_other}, |grad| {gnorm} vs {gnorm_other}", file=sys.stderr, flush=True)
-        if world == 1 and not args.no_cpu_baseline:
+        if not grouped and not args.no_cpu_baseline:
             cores = min(len(os.sched_getaffinity(0)), 16)          # the GPU box gives one GPU a 16-core share
             out["cpu_baseline"] = cpu_baseline(cfg, 4 if args.config == 3 else (2 if args.config == 2 else 1), cores)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.destroy_process_group()
 
 

@@ -100,8 +100,8 @@ class ShapeGraphShard:
         whole collection to every rank (RCCL's stock all-gather), kept as the fallback.
         reuse_descriptors: the pending object also offers ``gather_pooled`` (see PendingStack), with which the model takes
         the neighbours' pooled SSA descriptors from their owners instead of recomputing SSA(x_k) for every use."""
-        if self.world == 1:
-            raise ValueError("exchange_async needs world > 1")
+        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
+            raise ValueError("exchange_async needs a process group (world > 1, or a world of one rank for rehearsals)")
         feats = feats.contiguous()
         if mode == "allgather":
             if self._gathered is None or self._gathered.shape[1:] != feats.shape[1:]:
@@ -146,7 +146,7 @@ class ShapeGraphShard:
     # -- gradient reduction ------------------------------------------------------------------------------------
     def allreduce_grads(self, params: Iterable[torch.nn.Parameter], average: bool = True) -> None:
         """Sum (or average) the weight gradients over ranks in ONE bucket (≈0.4 M parameters: latency-bound)."""
-        if self.world == 1:
+        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
             return
         plist: List[torch.nn.Parameter] = [p for p in params if p.grad is not None]
         flat = torch.cat([p.grad.reshape(-1) for p in plist])

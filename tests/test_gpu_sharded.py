@@ -1,5 +1,6 @@
 """Multi-process pieces on the MI355X: two ranks share the one GPU of the test box (gloo carries the collectives; RCCL
-needs one GPU per rank and is exercised by the driver's multi-GPU bench only)."""
+needs one GPU per rank: here it runs as a world of ONE rank — the same calls on the device, no peer — and at world > 1 in
+the driver's multi-GPU bench only)."""
 import os
 import socket
 
@@ -65,11 +66,11 @@ CSA_B, CSA_K, CSA_N, CSA_CLS = 2, 2, 400, 6
 CSA_GEO = dict(block=100, n_blocks=4)
 
 
-def _csa_collection(world):
+def _csa_collection(world, B=None):
     """A small collection with per-shape channel offsets (well-conditioned compatibility gradients, see
     oracle.conditioned_csa_case) + one set of weights."""
     rng = np.random.default_rng(23)
-    S = CSA_B * world
+    S = (B or CSA_B) * world
     p = orc.make_params(rng, 1, n_cls=CSA_CLS, csa=True)
     p["attention.fc.weight"] = p["attention.fc.weight"] * 4.0
     feats = orc.synth_points(rng, (S, 256, CSA_N)) + orc.synth_points(rng, (S, 256, 1))
@@ -77,18 +78,22 @@ def _csa_collection(world):
     return p, feats, labels
 
 
-def _csa_worker(rank, world, port, out_dir, mode):
+def _csa_worker(rank, world, port, out_dir, mode, backend="gloo", B=None):
+    B = B or CSA_B
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from csn_amd import _lib
     from csn_amd.csa_models import get_model
     from csn_amd.sharding import ShapeGraphShard, regular_graph
     _lib.check(_lib.lib().csn_set_math_mode(mode))
-    p, feats, labels = _csa_collection(world)
-    shard = ShapeGraphShard(regular_graph(CSA_B * world, CSA_K), CSA_B, rank, world, torch.device("cuda"))
-    lo, hi = shard.first, shard.first + CSA_B
+    p, feats, labels = _csa_collection(world, B)
+    shard = ShapeGraphShard(regular_graph(B * world, CSA_K), B, rank, world, torch.device("cuda"))
+    lo, hi = shard.first, shard.first + B
     mine, lab = feats[lo:hi].cuda(), labels[lo:hi].cuda()
     out = {}
     for tag, kw in (("reuse", dict(mode="alltoall", reuse_descriptors=True)),
@@ -150,3 +155,33 @@ def test_sharded_csa_step_with_descriptor_reuse_equals_single_process(tmp_path, 
                     assert (got["grads"][n] - g).abs().max().item() <= 2e-4 * g.abs().max().item(), (tag, n)
     finally:
         _lib.lib().csn_set_math_mode(1)
+
+
+def test_sharded_step_over_rccl_world_of_one(tmp_path):
+    """The sharded step with backend "nccl" (= RCCL) in a world of one rank: every collective of the path — the neighbour
+    all_to_all_single with explicit splits, the all-gather fallback, the descriptor gather and its gradient, the one-bucket
+    gradient all-reduce — is issued on the device through RCCL as the multi-GPU job issues it, and the step equals the plain
+    module.  (What a one-GPU box can check of the RCCL path: call forms, dtypes, contiguity, stream hand-over.)"""
+    from csn_amd import _lib
+    from csn_amd.csa_models import get_model
+    from csn_amd.sharding import ShapeGraphShard, regular_graph
+    world, mode, B = 1, 1, 4
+    mp.spawn(_csa_worker, args=(world, _free_port(), str(tmp_path), mode, "nccl", B), nprocs=world, join=True)
+    res = torch.load(os.path.join(tmp_path, "csa0.pt"))
+    _lib.check(_lib.lib().csn_set_math_mode(mode))
+    p, feats, labels = _csa_collection(world, B)
+    model = get_model("csa", CSA_CLS, 1, CSA_K, **CSA_GEO)
+    model.load_state_dict(p, strict=False)
+    model = model.cuda().eval()
+    sh = ShapeGraphShard(regular_graph(B, CSA_K), B, 0, 1, torch.device("cpu"))
+    stack = sh.neighbour_stack(feats, feats)
+    logits = model(feats.cuda().unsqueeze(-1), "test", stack.cuda())
+    loss = orc.masked_ce_loss(logits, labels.cuda())
+    loss.backward()
+    ref = {n: q.grad.cpu() for n, q in model.named_parameters() if q.grad is not None}
+    for tag in ("reuse", "a2a", "gather"):
+        got = res[tag]
+        assert (got["logits"] - logits.detach().cpu()).abs().max().item() < 2e-5, tag
+        assert abs(got["loss"] - loss.item()) < 1e-5, tag
+        for n, g in ref.items():
+            assert (got["grads"][n] - g).abs().max().item() <= 2e-4 * g.abs().max().item(), (tag, n)
