@@ -106,7 +106,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void csn_attn_dkv_kernel(
   const long long kslot = p.kv_index ? p.kv_index[e_first] : e_first;
   const int nqt = (T + QT - 1) / QT;
   const int n_steps = (it1 - it0) * nqt;
-  const bool late = __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
+#ifndef CSN_DKV_LOCKSTEP
+#define CSN_DKV_LOCKSTEP 0
+#endif
+#ifndef CSN_DKV_ABL        // timing-only ablations (WRONG results): 1 no tile loads, 2 no pointwise, 4 no phase 2, 8 no phase 1
+#define CSN_DKV_ABL 0
+#endif
+  // (-DCSN_DKV_LOCKSTEP=1, measured: all waves in step, ONE barrier per tile instead of two and no stagger)
+  const bool late = !CSN_DKV_LOCKSTEP && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
   const int col = 16 * wave + lq;                                   // this lane's key inside the chunk of 128
   const int key = kc * KW + col;                                    // ... inside the block
 
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void csn_attn_dkv_kernel(
     const unsigned off = (4 * t_c) < nq ? (unsigned)(t_row * ld + 4 * t_c) : CSN_OOB;      // (elements) T % 4 == 0: a piece is all in or all out
 #pragma unroll
     for (int i = 0; i < NP_T; ++i) {
-      const unsigned o = (i == NP_T - 1 && !t_last_ok) ? CSN_OOB : off;
+      const unsigned o = ((CSN_DKV_ABL & 1) || (i == NP_T - 1 && !t_last_ok)) ? CSN_OOB : off;
       if constexpr (q_fmt != 0) hQ[i] = csn_bload2(Qr, o == CSN_OOB ? o : o * 2u, (unsigned)(RPT * i * ld) * 2u);
       else gQ[i] = csn_bload4(Qr, o == CSN_OOB ? o : o * 4u, (unsigned)(RPT * i * ld) * 4u);
       if constexpr (o_fmt != 0) hO[i] = csn_bload2(Or, o == CSN_OOB ? o : o * 2u, (unsigned)(RPT * i * ld) * 2u);
@@ -389,13 +396,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void csn_attn_dkv_kernel(
       const int e = p.eval_ids ? p.eval_ids[c_it] : c_it;
       salt = csn_block_salt((unsigned long long)(((long long)e * p.H + hd) * p.n_blocks + blk), p.seed);
     }
-    phase1(cur, S0, S1, P0, P1);                                    // S = Qs K^T (the forward's product, roles transposed), dP = dO V^T
+    if (!(CSN_DKV_ABL & 8)) phase1(cur, S0, S1, P0, P1);                                    // S = Qs K^T (the forward's product, roles transposed), dP = dO V^T
     if (more) {
       commit_kmajor(nxt);                                           // (splits the pieces: the fp32 registers are free again)
       commit_rowc(rc_nxt);
       if (step + 2 < n_steps) fetch();                              // a whole tile ahead of its first use
     }
-    __syncthreads();
+    if (!CSN_DKV_LOCKSTEP) __syncthreads();
     phase2_ahead(cur);
     // ---- pointwise: this lane's key against queries qt * 32 + 8 kq .. + 7 --------------------------------------------
     const f32x4 l0 = *reinterpret_cast<const f32x4*>(&rowc[rc_cur * 64 + 8 * kq]), l1 = *reinterpret_cast<const f32x4*>(&rowc[rc_cur * 64 + 8 * kq + 4]);
@@ -412,7 +419,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void csn_attn_dkv_kernel(
     // here: the even lane hashes queries 0..3, the odd lane 4..7, and a quad swap hands each the other's four — half the
     // quarter-rate multiplies of the pointwise segment for four full-rate moves.
     unsigned hsh[8];
-    if (drop) {
+    if (drop && !(CSN_DKV_ABL & 2)) {
       unsigned mine[4], theirs[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) mine[j] = csn_pair_hash(pw_key + (unsigned)(q0 + (key_odd ? 4 : 0) + j), salt);
@@ -423,6 +430,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void csn_attn_dkv_kernel(
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
+      if (CSN_DKV_ABL & 2) { pd[r] = sv[r]; ds[r] = dp[r]; continue; }
       float pv = __builtin_amdgcn_exp2f(fmaf(sv[r], LOG2E, -lse2[r]));       // softmax probability (csa_models.py:141)
       if (last_tile) pv = r < nv ? pv : 0.f;                                 // queries beyond the block end (wave-uniform branch)
       bool keep = true;
@@ -439,7 +447,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void csn_attn_dkv_kernel(
       dh[r] = to16<PR::HALF>(ds[r]);
       dl[r] = PR::NT == 3 ? to16<PR::HALF>(ds[r] - from16<PR::HALF>(dh[r])) : dh[r];
     }
-    phase2(ph, pl, dh, dl);                                         // dV^T += dO^T P_drop,  dK^T += Qs^T dS
+    if (!(CSN_DKV_ABL & 4)) phase2(ph, pl, dh, dl);                                         // dV^T += dO^T P_drop,  dK^T += Qs^T dS
+    else { dV[0][0] += from16<PR::HALF>(ph[0]) + from16<PR::HALF>(ph[7]); dK[0][0] += from16<PR::HALF>(dh[0]) + from16<PR::HALF>(dh[7]); }
     if (more) commit_contig(nxt);
     if (++c_qt == nqt) { c_qt = 0; ++c_it; }
     rc_cur = rc_nxt;
