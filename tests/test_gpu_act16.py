@@ -159,3 +159,42 @@ def test_forward_refuses_a_type_that_is_not_its_modes(L):
                                     torch.cuda.current_stream().cuda_stream)
     L.check(lib.csn_set_thread_act16(0))
     assert rc == -1
+
+
+@pytest.mark.parametrize("S,R,C,NP", [(3, 40, 36, 300), (2, 256, 256, 1004), (1, 96, 96, 236), (2, 288, 96, 520)])
+def test_projection_entry_points_on_16bit_maps(L, S, R, C, NP):
+    """csn_project_f32 writing a bf16 map (out_split = 3) and reading one (+ 16), csn_project_wgrad_f32 contracting bf16
+    gradient maps (flag 5), against float64 on the SAME rounded operands: sizes whose rows and contraction lengths end inside
+    a 16-byte unit (NP % 8 == 4, C % 8 == 4), small and 256 x 256 tiles."""
+    lib = L.lib()
+    L.check(lib.csn_set_math_mode(2))
+    rng = np.random.default_rng(S * 1000 + NP)
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.from_numpy(rng.standard_normal((S, C, NP)).astype(np.float32)).cuda()
+    w = torch.from_numpy((rng.standard_normal((R, C)) / np.sqrt(C)).astype(np.float32)).cuda()
+    bf = lambda t: t.bfloat16().double()
+    # (a) out = w @ x as a bf16 map
+    out16 = torch.full((S, R, NP), float("nan"), device="cuda", dtype=torch.bfloat16)
+    L.check(lib.csn_project_f32(x.data_ptr(), C * NP, NP, w.data_ptr(), R, C, out16.data_ptr(), R * NP, NP, S, NP, 0, 1.0, 3, 0, st))
+    ref = torch.einsum("rc,scn->srn", bf(w), bf(x))
+    assert torch.isfinite(out16.float()).all()
+    assert (out16.double() - ref).abs().max().item() <= 2.0 ** -8 * ref.abs().max().item()          # one bf16 rounding of the result
+    # (b) dx = w^T @ g with g a bf16 map as INPUT (out_split + 16), fp32 result
+    g16 = torch.from_numpy(rng.standard_normal((S, R, NP)).astype(np.float32)).cuda().bfloat16()
+    wt = w.t().contiguous()
+    dx = torch.full((S, C, NP), float("nan"), device="cuda")
+    L.check(lib.csn_project_f32(g16.data_ptr(), R * NP, NP, wt.data_ptr(), C, R, dx.data_ptr(), C * NP, NP, S, NP, 0, 1.0, 16, 0, st))
+    ref = torch.einsum("cr,srn->scn", bf(wt), g16.double())
+    assert (dx.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    # (c) dw = sum_s g[s] @ x[s]^T with g a bf16 map (flag 5), x fp32 (rounded to bf16 while staged)
+    L.check(lib.csn_set_thread_act16(5))
+    try:
+        ws_n = lib.csn_wgrad_workspace_floats(R, C, S, NP)
+        ws = torch.empty((ws_n,), device="cuda")
+        dw = torch.full((R, C), float("nan"), device="cuda")
+        L.check(lib.csn_project_wgrad_f32(g16.data_ptr(), R * NP, NP, x.data_ptr(), C * NP, NP, dw.data_ptr(), R, C, S, NP, 1.0, 0,
+                                          ws.data_ptr(), ws_n, st))
+    finally:
+        L.check(lib.csn_set_thread_act16(0))
+    ref = torch.einsum("srn,scn->rc", g16.double(), bf(x))
+    assert (dw.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
