@@ -9,3 +9,4 @@ timeout -k 10 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_W
 timeout -k 10 200 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS -d $OUT/b -- python3 "$@" > $OUT/b.log 2>&1 &&
 timeout -k 10 200 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE -d $OUT/c -- python3 "$@" > $OUT/c.log 2>&1
 python3 scripts/pmc_summary.py $OUT "$FLT" > $OUT/summary.txt 2>&1
+rm -rf $OUT/a $OUT/b $OUT/c          # the raw traces are large: only the summary travels back
