@@ -32,10 +32,12 @@ def _step(model, x, nbf, lab, seed):
 
 
 GEOS = [dict(), dict(d_model=128, d_k=128, d_v=128, block=100, n_blocks=3), dict(d_model=96, d_k=96, d_v=96, block=500, n_blocks=2),
-        dict(d_model=64, d_k=32, d_v=32, n_head=2, block=52, n_blocks=3)]
+        dict(d_model=64, d_k=32, d_v=32, n_head=2, block=52, n_blocks=3),
+        dict(d_model=128, d_k=128, d_v=128, block=100, n_blocks=None, n_pts=236),       # the row ends inside the last block (36 points)
+        dict(d_model=256, d_k=32, d_v=32, n_head=8, block=300, n_blocks=None, n_pts=444)]   # 8 heads, short last block, 256 x 256 GEMM tiles
 
 
-@pytest.mark.parametrize("geo", GEOS, ids=["d256", "d128", "d96", "2heads-d32-ragged-tiles"])
+@pytest.mark.parametrize("geo", GEOS, ids=["d256", "d128", "d96", "2heads-d32-ragged-tiles", "d128-short-last-block", "8heads-short-last-block"])
 @pytest.mark.parametrize("mode", ["bf16", "fp16"])
 @pytest.mark.parametrize("train", [False, True], ids=["eval", "train"])
 def test_module_step_with_16bit_maps(L, mode, geo, train):
@@ -45,9 +47,9 @@ def test_module_step_with_16bit_maps(L, mode, geo, train):
     rng = np.random.default_rng(31)
     B, K, n_cls = 2, 2, 7
     C = geo.get("d_model", 256)
-    N = geo.get("block", 500) * geo.get("n_blocks", 20)
+    N = geo.get("n_pts") or geo.get("block", 500) * geo.get("n_blocks", 20)
     torch.manual_seed(5)
-    model = get_model("csa", n_cls, geo.get("n_head", 1), K, **{k: v for k, v in geo.items() if k != "n_head"}).cuda().train(train)
+    model = get_model("csa", n_cls, geo.get("n_head", 1), K, **{k: v for k, v in geo.items() if k not in ("n_head", "n_pts")}).cuda().train(train)
     L.check(L.lib().csn_set_math_mode({"bf16": 2, "fp16": 3}[mode]))
     off = torch.from_numpy(rng.standard_normal((B, K + 1, C, 1, 1)).astype(np.float32))
     nbf = (torch.from_numpy(rng.standard_normal((B, K + 1, C, N, 1)).astype(np.float32)) + 2.0 * off).cuda()
