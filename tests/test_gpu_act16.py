@@ -200,3 +200,28 @@ def test_projection_entry_points_on_16bit_maps(L, S, R, C, NP):
         L.check(lib.csn_set_thread_act16(0))
     ref = torch.einsum("srn,scn->rc", g16.double(), bf(x))
     assert (dw.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("switch", ["fused_point_sums", "grouped_dq", "grouped_dkv", "link_mix", "keep_flow"])
+def test_16bit_maps_with_each_data_flow_switch_off(L, switch):
+    """The exchange under every other data-flow switch of csn_amd.tuning turned off: pooled sums by the streaming pass over the
+    fp16 maps, dQ / dK / dV by one read-modify-write launch per colour (fp32 gradient maps then), an unlinked mix (no 16-bit maps at
+    all: the switch must fall back, not fail), kept scores at a width that would take the flash flow."""
+    from csn_amd import tuning
+    from csn_amd.csa_models import get_model
+    rng = np.random.default_rng(41)
+    B, K, n_cls, C, N = 2, 2, 5, 128, 300
+    torch.manual_seed(8)
+    model = get_model("csa", n_cls, 1, K, d_model=C, d_k=128, d_v=128, block=100, n_blocks=3).cuda().train(True)
+    L.check(L.lib().csn_set_math_mode(2))
+    nbf = torch.from_numpy(rng.standard_normal((B, K + 1, C, N, 1)).astype(np.float32)).cuda()
+    x = nbf[:, 0].contiguous()
+    lab = torch.from_numpy(rng.integers(0, n_cls, size=(B, N))).cuda()
+    off = {"keep_flow": dict(score_flow={1: tuning.KEEP_SCORES, 2: tuning.KEEP_SCORES})}.get(switch, {switch: False})
+    with tuning.override(act16=False, **off):
+        l0, s0, g0 = _step(model, x, nbf, lab, 4)
+    with tuning.override(act16=True, **off):
+        l1, s1, g1 = _step(model, x, nbf, lab, 4)
+    assert (l0 - l1).abs().max().item() <= 2e-3 * l0.abs().max().item() and abs(s0 - s1) <= 1e-3 * abs(s0)
+    for n in g0:
+        assert (g0[n] - g1[n]).abs().max().item() <= 3e-2 * g0[n].abs().max().item(), n
