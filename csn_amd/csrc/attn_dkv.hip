@@ -64,13 +64,20 @@ CSN_DEVINL f32x4v mma16(s16x8 ah, s16x8 al, s16x8 bh, s16x8 bl, f32x4v c) {
 // ways to more resident waves were built and measured at config-5 geometry (scripts/dev/ab_attn.sh, ab_step.sh) and lose:
 // the register bound of four waves per SIMD spills 96 registers (4.2 -> 15.5 ms); work-groups of four waves / 64 keys
 // (-DCSN_DKV_NW=4: three per CU under a bound of 168 registers) stage every tile for half as many keys and still spill 32
-// registers (3.7 -> 6.0 ms).  The default stays 8 waves, two per SIMD.
+// registers (3.7 -> 6.0 ms).  The default stays 8 waves, two per SIMD.  NARROW (one plane, d <= 64): there the kernel does fit
+// 128 registers without spills once the fragment rings are one deep and the phase-2 reads follow the pointwise segment, so
+// these instances run under the four-wave bound: two work-groups per CU.
 #ifndef CSN_DKV_NW
 #define CSN_DKV_NW 8
 #endif
+#ifndef CSN_DKV_NARROW
+#define CSN_DKV_NARROW 1
+#endif
 constexpr int csn_dkv_waves(int npl, int dt) { return (npl == 1 && dt <= 3) ? CSN_DKV_NW : 8; }
+constexpr bool csn_dkv_narrow(int npl, int dt) { return CSN_DKV_NARROW && npl == 1 && dt <= 2; }
 template <typename PR, int DT, int QF = 0, int NW = 8>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) {
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT) ? 4 : 2)) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) {
+  constexpr bool NARROW = csn_dkv_narrow(PR::NPL, DT);
   static_assert(QF == 0 || PR::NPL == 1, "16-bit activation maps: the one-plane mode");
   static_assert(NW == 8 || NW == 4, "work-groups of 8 or 4 waves");
   constexpr int NT = 64 * NW;                           // threads
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void csn_attn_dkv_kernel(
   // fragment reads of the two images run PD steps ahead of the matrix instructions in one register ring each, and a phase
   // pays the LDS latency once.  At the narrow head widths a phase is only 2 x D/16 matrix instructions, so what a tile costs
   // is the number of such exposed latencies, not the matrix work.
-  constexpr int PD = 2;
+  constexpr int PD = NARROW ? 1 : 2;
   // phase 1: S[q][key] = sum_d Qs^T[d][q] K^T[d][key]  and  dP[q][key] = sum_d dO^T[d][q] V^T[d][key]   (images 0 and 1)
   auto phase1 = [&](int st, f32x4v& S0, f32x4v& S1, f32x4v& P0, f32x4v& P1) {
     S0 = f32x4v{0.f, 0.f, 0.f, 0.f}; S1 = S0; P0 = S0; P1 = S0;
@@ -403,7 +410,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void csn_attn_dkv_kernel(
       if (step + 2 < n_steps) fetch();                              // a whole tile ahead of its first use
     }
     if (!CSN_DKV_LOCKSTEP) __syncthreads();
-    phase2_ahead(cur);
+    if constexpr (!NARROW) phase2_ahead(cur);
     // ---- pointwise: this lane's key against queries qt * 32 + 8 kq .. + 7 --------------------------------------------
     const f32x4 l0 = *reinterpret_cast<const f32x4*>(&rowc[rc_cur * 64 + 8 * kq]), l1 = *reinterpret_cast<const f32x4*>(&rowc[rc_cur * 64 + 8 * kq + 4]);
     const f32x4 d0 = *reinterpret_cast<const f32x4*>(&rowc[rc_cur * 64 + 32 + 8 * kq]), d1 = *reinterpret_cast<const f32x4*>(&rowc[rc_cur * 64 + 32 + 8 * kq + 4]);
@@ -447,6 +454,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 2) void csn_attn_dkv_kernel(
       dh[r] = to16<PR::HALF>(ds[r]);
       dl[r] = PR::NT == 3 ? to16<PR::HALF>(ds[r] - from16<PR::HALF>(dh[r])) : dh[r];
     }
+    if constexpr (NARROW) phase2_ahead(cur);                         // (register diet: nothing of phase 2 lives across the pointwise segment)
     if (!(CSN_DKV_ABL & 4)) phase2(ph, pl, dh, dl);                                         // dV^T += dO^T P_drop,  dK^T += Qs^T dS
     else { dV[0][0] += from16<PR::HALF>(ph[0]) + from16<PR::HALF>(ph[7]); dK[0][0] += from16<PR::HALF>(dh[0]) + from16<PR::HALF>(dh[7]); }
     if (more) commit_contig(nxt);
