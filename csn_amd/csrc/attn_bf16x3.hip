@@ -81,14 +81,21 @@ CSN_DEVINL f32x4v mma16(s16x8 ah, s16x8 al, s16x8 bh, s16x8 bl, f32x4v c) {
 // images leave room for a second work-group on the CU: one plane up to d = 96, two planes up to d = 64.  There the bound is
 // four (128 registers), which costs the recomputing dQ instances 13-18 spilled registers and still pays: a second work-group
 // hides what a latency-bound loop cannot (config-5 geometry, bf16: dQ 3.53 -> 2.69 ms; bf16x3 at d = 64: 2.43 -> 1.75 ms).
-// Measured and NOT taken (scripts/dev/ab_attn.sh): one plane at d = 128 (+-0), two planes at d = 96 / 128 (38-82 spilled
-// registers inside the loop: forward 3.8 -> 6.6 ms), the key-stationary dK / dV kernel (96 spills: 4.2 -> 15.5 ms).
+// Measured and NOT taken (scripts/dev/ab_attn.sh): one plane at d = 128 (+-0), two planes at d = 96 / 128 with the default
+// ring depth (38-82 spilled registers inside the loop: forward 3.8 -> 6.6 ms; the d = 96 forward with a ring of two: below).
 #ifndef CSN_LB_NARROW
 #define CSN_LB_NARROW 4
 #endif
-constexpr int csn_attn_waves(int npl, int dt) { return (npl == 1 ? dt <= 3 : dt <= 2) ? CSN_LB_NARROW : 2; }
+#ifndef CSN_LB_X3FWD96
+#define CSN_LB_X3FWD96 1
+#endif
+// (two planes, d = 96, FORWARD: with a fragment ring two deep instead of four it fits 128 registers with 4 spills)
+constexpr bool csn_attn_x3fwd96(int npl, int dt, bool bwd) { return CSN_LB_X3FWD96 && npl == 2 && dt == 3 && !bwd; }
+constexpr int csn_attn_waves(int npl, int dt, bool bwd) {
+  return ((npl == 1 ? dt <= 3 : dt <= 2) || csn_attn_x3fwd96(npl, dt, bwd)) ? CSN_LB_NARROW : 2;
+}
 template <typename PR, int DT, bool BWD, bool KVP, bool RC = false>
-__global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT)) void csn_attn_bf16x3_kernel(CsnAttnArgs p) {
+__global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_attn_bf16x3_kernel(CsnAttnArgs p) {
   static_assert(PR::NT == 3 || KVP, "single-product modes take K / V as tile planes");
   static_assert(!RC || (BWD && KVP), "score recomputation: backward kernel on tile-plane K / V");
   constexpr int NPL = PR::NPL;                          // planes: hi (+ lo)
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT)) void csn_attn_bf1
 #endif
   // LDS fragment reads run CSN_PD steps ahead of the matrix instructions that consume them (explicit register ring):
   // with two waves per SIMD nothing else hides the ~150-cycle LDS latency, and a step is only 48 matrix-pipe cycles.
-  constexpr int PD = CSN_PD;
+  constexpr int PD = csn_attn_x3fwd96(NPL, DT, BWD) ? 2 : CSN_PD;
   f32x4v Z0, Z1;                                        // RC: the recomputed scores of this lane's 8 keys (S0 / S1 hold dP)
   auto phase1_on = [&](const short* __restrict__ tAh, const short* __restrict__ tAl, const s16x8* Rh, const s16x8* Rl,
                        f32x4v& S0, f32x4v& S1) {
