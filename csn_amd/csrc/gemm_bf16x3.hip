@@ -298,21 +298,29 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
 
   GSTAMP(2);
   const float alpha = p.alpha;
-  unsigned c_off[MT][NT][16];
+  // output positions: the lane's part (its column, its half's 4-row shift; columns beyond N switched off) in cv[j], the row of
+  // accumulator (i, r) as a scalar offset c_so(i, r), rows beyond M cut off by the window Cw — no per-element offset registers
+  // (64 of them used to live here, which alone kept the 128 x 128 instances at two waves per SIMD)
+  unsigned cv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int nl = wn0 + 32 * j + l31;
+    cv[j] = (n0 + nl) < N ? (unsigned)(4 * h * ldc + nl) * (unsigned)c_es : CSN_OOB;
+  }
+  auto c_so = [&](int i, int r) { return (unsigned)((wm0 + 32 * i + csn_acc_row(r, 0)) * ldc) * (unsigned)c_es; };
+  const long long c_rows = min(BM, M - m0);
+  const csn_rsrc_t Cw = csn_make_rsrc(c_base, c_rows * ldc * c_es), Cwl = csn_make_rsrc(c_base + p.C.plane_stride * 2, c_pl ? c_rows * ldc * c_es : 0);
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int nl = wn0 + 32 * j + l31;
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ml = wm0 + 32 * i + csn_acc_row(r, h);
-        c_off[i][j][r] = ((m0 + ml) < M && (n0 + nl) < N) ? (unsigned)(ml * ldc + nl) * (unsigned)c_es : CSN_OOB;
         float v = acc[i][j][r] * alpha;
         if ((m0 + ml) < p.div_rows) v = v / p.div_val;
         acc[i][j][r] = v;
       }
-    }
   if (c_tiles) {
     // column n of the map -> block n / Tb, key k = n % Tb -> tile k / 32, position k % 32; a row holds, per block, 16 tiles
     // of [hi: 32 | lo: 32] bf16 (block pitch 1024; the padding keys of a block's last tile are written as zeros)
@@ -350,8 +358,8 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const short hi = to16<PR::HALF>(acc[i][j][r]);
-          csn_bstore16(hi, Cr, c_off[i][j][r]);
-          if constexpr (NPL == 2) csn_bstore16(to16<PR::HALF>(acc[i][j][r] - from16<PR::HALF>(hi)), Crl, c_off[i][j][r]);
+          csn_bstore16(hi, Cw, cv[j], c_so(i, r));
+          if constexpr (NPL == 2) csn_bstore16(to16<PR::HALF>(acc[i][j][r] - from16<PR::HALF>(hi)), Cwl, cv[j], c_so(i, r));
         }
     return;
   }
@@ -362,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
       for (int j = 0; j < NT; ++j) {
         f32x16 prev;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) prev[r] = csn_bload(Cr, c_off[i][j][r]);
+        for (int r = 0; r < 16; ++r) prev[r] = csn_bload(Cw, cv[j], c_so(i, r));
         acc[i][j] += prev;
       }
   }
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) csn_bstore(acc[i][j][r], Cr, c_off[i][j][r]);
+      for (int r = 0; r < 16; ++r) csn_bstore(acc[i][j][r], Cw, cv[j], c_so(i, r));
 #ifdef CSN_STAMPS
   __builtin_amdgcn_s_waitcnt(0);
   GSTAMP(3);
