@@ -49,7 +49,11 @@ def _maxerr(got, ref):
 
 # ---------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("S,C,N,R,div_rows", [(2, 256, 1000, 768, 256), (3, 96, 500, 96, 0), (1, 128, 2048, 384, 128),
-                                              (1, 32, 36, 32, 0)])
+                                              (1, 32, 36, 32, 0),
+                                              # 256 x 256 tiles with ragged edges in every direction: 200 / 460 rows (one and two
+                                              # row tiles, the last one short), 236 / 1004 points, contraction lengths that end
+                                              # inside a 32-wide slab, the scaled rows ending inside a tile
+                                              (9, 260, 236, 200, 100), (2, 100, 1004, 460, 300), (11, 36, 520, 256, 0)])
 def test_project(L, S, C, N, R, div_rows):
     from csn_amd import functional as CF
     rng = np.random.default_rng(1)
@@ -687,3 +691,24 @@ def test_compat_head(L, math_mode, B, K1, C, ref_layout):
     again = [t.detach().clone().requires_grad_(True) for t in a32]                 # sums over shapes in a fixed order: bitwise repeatable
     CF.compat_head(*again, reference_layout=ref_layout).backward(dcomp.cuda())
     assert all(torch.equal(x.grad, y.grad) for x, y in zip(a32, again))
+
+
+@pytest.mark.parametrize("S,C,N,R,div_rows", [(9, 260, 236, 200, 100), (2, 100, 1004, 460, 300), (3, 256, 10000, 256, 256)])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_sixteen_wave_gemm_equals_the_eight_wave_one(L, mode, S, C, N, R, div_rows):
+    """The plain 256 x 256 products run on the 16-wave kernel in the bf16x3 mode (and in the one-plane modes under the
+    development switch): the same bits as the 8-wave kernel — same slabs, same products in the same order — on ragged tiles."""
+    from csn_amd import functional as CF
+    lib = L.lib()
+    L.check(lib.csn_set_math_mode(mode))
+    rng = np.random.default_rng(3)
+    x, w = _rand(rng, S, C, N).cuda(), (_rand(rng, R, C) / math.sqrt(C)).cuda()
+    try:
+        outs = []
+        for wide in (0, 2):
+            lib.csn_debug_set_wide_gemm(wide)
+            outs.append(CF.project(x, w, div_rows=div_rows, temperature=16.0).clone())
+        assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
+    finally:
+        lib.csn_debug_set_wide_gemm(1)
+        lib.csn_set_math_mode(1)
