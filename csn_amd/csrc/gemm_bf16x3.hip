@@ -815,23 +815,26 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
 // ---- 256 x 256 x 32 tiles on SIXTEEN waves ---------------------------------------------------------------------------
 // The same tile as the kernel above with twice the waves: 4 (M) x 4 (N) waves of 64 x 64 accumulators (64 registers instead
 // of 128), 1024 threads, two staging pieces per thread and operand instead of four — four waves per SIMD if a wave stays within
-// 128 registers.  Plain products only (A = fp32 weights, k-contiguous; B k-major, fp32 or a 16-bit map; C fp32 or a 16-bit map
+// 128 registers.  A fp32, k-contiguous; B k-major (fp32, a 16-bit map, or tile planes with the grouped item loop) or
+// k-contiguous fp32; C fp32 (optionally accumulated into) or a 16-bit map
 // through the per-wave LDS transpose).  Measured (scripts/dev/wide_gemm_probe.py, same bits as the 8-wave kernel): the
-// projection of 128 slots 0.79 -> 0.71 ms in bf16x3, 0.61 -> 0.57 ms in bf16; in the step only Q and dCtx qualify (-0.07 ms at
-// config 3), so it serves the bf16x3 mode's plain products and stays a probe for the rest of the family (grouped tile-plane
-// products, weight gradients, the LayerNorm epilogue would each need their 16-wave form).
-template <typename PR, int BF>
+// projection of 128 slots 0.79 -> 0.71 ms in bf16x3, 0.61 -> 0.57 ms in bf16.  It serves the bf16x3 mode: the plain products
+// (Q, dCtx), the grouped tile-plane products dV / dK (B_NK = false, BT) and the weight gradients (B_NK) — config-3 step 28.09 ->
+// 27.70 ms, gradients bit for bit those of the 8-wave kernel (scripts/dev/wide_ab_step.py); the LayerNorm epilogue and the
+// 16-bit operand forms of the one-plane modes stay on the 8-wave kernel (measured there: +-0).
+template <typename PR, bool B_NK, bool BT, int BF>
 __global__ __launch_bounds__(1024, 4) void csn_gemm_bf16x3_wide_kernel(CsnGemmArgs p) {
-  static_assert(BF == 0 || PR::NPL == 1, "16-bit operand maps: single-product modes only");
+  static_assert(BF == 0 || (PR::NPL == 1 && !B_NK && !BT), "16-bit operand maps: single-product modes, k-major B");
+  static_assert(!BT || !B_NK, "tile-plane B is k-major");
   constexpr int NPL = PR::NPL;
   constexpr int BM = 256, BN = 256, MT = 2, NT = 2;
   constexpr int PN = BN + 32;
-  constexpr int A_EL = BM * BK, B_EL = BK * PN;
+  constexpr int A_EL = BM * BK, B_EL = B_NK ? BN * BK : BK * PN;
   constexpr int BES = BF ? 2 : 4;
   // (each array also serves 8 waves as their 8 KB epilogue blocks: never less than 64 KB)
   constexpr int A_ALL = 2 * NPL * A_EL > 32768 ? 2 * NPL * A_EL : 32768, B_ALL = 2 * NPL * B_EL > 32768 ? 2 * NPL * B_EL : 32768;
   __shared__ __attribute__((aligned(16))) short As_raw[A_ALL];   // [stage][plane][row][k ^ swizzle]
-  __shared__ __attribute__((aligned(16))) short Bs_raw[B_ALL];   // [stage][plane][k][col]
+  __shared__ __attribute__((aligned(16))) short Bs_raw[B_ALL];   // NK: like A   KN: [stage][plane][k][col]
   auto As = [&](int st, int pl) -> short* { return As_raw + (st * NPL + pl) * A_EL; };
   auto Bs = [&](int st, int pl) -> short* { return Bs_raw + (st * NPL + pl) * B_EL; };
 
@@ -846,19 +849,30 @@ __global__ __launch_bounds__(1024, 4) void csn_gemm_bf16x3_wide_kernel(CsnGemmAr
   const int tile_m = tile / tiles_n, tile_n = tile % tiles_n;
   const int z0 = z % p.n0; z /= p.n0;
   const int z1 = z % p.n1;
-  const int z2 = p.eval_ids ? p.eval_ids[z / p.n1] : z / p.n1;
+  const int zz = z / p.n1;
+  const int it0 = p.grp_off ? p.grp_off[zz] : zz, it1 = p.grp_off ? p.grp_off[zz + 1] : zz + 1;   // items contracted by this tile
+  auto item_id = [&](int it) { return p.grp_off ? p.grp_items[it] : (p.eval_ids ? p.eval_ids[it] : it); };
+  const int z2 = item_id(it0);
   const int lda = p.A.ld, ldb = p.B.ld, ldc = p.C.ld;
-  const int M = p.M, N = p.N, K = p.K;
+  const int M = p.M, N = (p.n_last > 0 && z0 == p.n0 - 1) ? p.n_last : (p.n_arr ? ((p.n_arr[z2] + 3) & ~3) : p.N);
+  int K = (p.k_last > 0 && z0 == p.n0 - 1) ? p.k_last : (p.k_arr ? p.k_arr[z2] : p.K);
+  if (p.k_chunk > 0) { K = min(p.k_chunk, p.K - z0 * p.k_chunk); }
   if (tile_n * BN >= N) return;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const bool c_pl = p.C.planes != 0;
   const int c_es = c_pl ? 2 : 4;
-  const float* a_base = p.A.ptr + p.A.s0 * z0 + p.A.s1 * z1 + p.A.s2 * (long long)(p.A.idx2 ? p.A.idx2[z2] : z2) + (long long)m0 * lda;
-  const char* b_base = reinterpret_cast<const char*>(p.B.ptr) +
-                       (p.B.s0 * z0 + p.B.s1 * z1 + p.B.s2 * (long long)(p.B.idx2 ? p.B.idx2[z2] : z2) + n0) * BES;
+  csn_rsrc_t Ar, Br;
+  auto set_item = [&](int zi) {
+    const float* a_base = p.A.ptr + p.A.s0 * z0 + p.A.s1 * z1 + p.A.s2 * (long long)(p.A.idx2 ? p.A.idx2[zi] : zi) + (long long)m0 * lda;
+    const long long b_el = p.B.s0 * z0 + p.B.s1 * z1 + p.B.s2 * (long long)(p.B.idx2 ? p.B.idx2[zi] : zi);
+    const char* b_base = BT ? reinterpret_cast<const char*>(reinterpret_cast<const short*>(p.B.ptr) + b_el)
+                            : reinterpret_cast<const char*>(p.B.ptr) + (b_el + (B_NK ? (long long)n0 * ldb : (long long)n0)) * BES;
+    Ar = csn_make_rsrc(a_base, (long long)BM * lda * 4);
+    Br = csn_make_rsrc(b_base, BT ? (long long)K * ldb * 2
+                                  : (B_NK ? (long long)BN * ldb * BES : ((long long)(K - 1) * ldb + (N - n0)) * BES));
+  };
+  set_item(z2);
   char* c_base = reinterpret_cast<char*>(p.C.ptr) + (p.C.s0 * z0 + p.C.s1 * z1 + p.C.s2 * (long long)(p.C.idx2 ? p.C.idx2[z2] : z2) + (long long)m0 * ldc + n0) * c_es;
-  const csn_rsrc_t Ar = csn_make_rsrc(a_base, (long long)BM * lda * 4);
-  const csn_rsrc_t Br = csn_make_rsrc(b_base, ((long long)(K - 1) * ldb + (N - n0)) * BES);
   const csn_rsrc_t Cw = csn_make_rsrc(c_base, (long long)min(BM, M - m0) * ldc * c_es);
 
   f32x16 acc[MT][NT];
@@ -869,17 +883,27 @@ __global__ __launch_bounds__(1024, 4) void csn_gemm_bf16x3_wide_kernel(CsnGemmAr
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // staging: 2 A pieces (row pr + 128 i, k = pc .. pc + 3) and 2 B pieces (fp32: k row kr + 16 i, columns kc .. kc + 3;
-  // 16-bit map: ONE piece, k row kr2, columns 8 ku .. 8 ku + 7) per thread and slab
+  // staging, two 16-byte pieces per thread, operand and slab: k-contiguous operands row pr + 128 i, k = pc .. pc + 3; k-major
+  // fp32 B k row kr + 16 i, columns kc .. kc + 3; a 16-bit B map ONE piece (k row kr2, columns 8 ku .. + 7); tile-plane B: k row
+  // t_kr, its 256 columns are 32 NPL contiguous units, unit w = t_j + 32 i -> tile w / (4 NPL), plane, 8 keys
   const int pr = tid >> 3, pc = (tid & 7) * 4;
   const int kr = tid >> 6, kc = (tid & 63) * 4;
   const int kr2 = tid >> 5, ku = tid & 31;
+  const int t_kr = tid >> 5, t_j = tid & 31;
   const int sw_dst = pr * BK + ((((pc >> 3) ^ ((pr >> 2) & 3)) << 3) | (pc & 4));     // rows 128 apart share the swizzle
   unsigned a_off[2], b_off[2];
+  int bt_dst[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     a_off[i] = (m0 + pr + 128 * i) < M ? (unsigned)((pr + 128 * i) * lda + pc) * 4u : CSN_OOB;
-    if (BF) b_off[i] = (i == 0 && (n0 + 8 * ku) < N) ? (unsigned)(kr2 * ldb + 8 * ku) * 2u : CSN_OOB;
+    bt_dst[i] = 0;
+    if (BT) {
+      const int w = t_j + 32 * i, tl = w / (4 * NPL), within = w % (4 * NPL), t_u = within & 3;
+      b_off[i] = (i < NPL && (n0 + 32 * tl + 8 * t_u) < N)
+                     ? (unsigned)(t_kr * ldb) * 2u + (unsigned)(n0 >> 5) * (unsigned)(64 * NPL) + (unsigned)w * 16u : CSN_OOB;
+      bt_dst[i] = (within >> 2) * B_EL + t_kr * PN + 32 * tl + 8 * t_u;
+    } else if (BF) b_off[i] = (i == 0 && (n0 + 8 * ku) < N) ? (unsigned)(kr2 * ldb + 8 * ku) * 2u : CSN_OOB;
+    else if (B_NK) b_off[i] = (n0 + pr + 128 * i) < N ? (unsigned)((pr + 128 * i) * ldb + pc) * 4u : CSN_OOB;
     else b_off[i] = (n0 + kc) < N ? (unsigned)((kr + 16 * i) * ldb + kc) * 4u : CSN_OOB;
   }
   f32x4 ra[2], rb[2];
@@ -887,8 +911,15 @@ __global__ __launch_bounds__(1024, 4) void csn_gemm_bf16x3_wide_kernel(CsnGemmAr
     const unsigned kp = (k0 + pc) < K ? 0u : CSN_OOB;
 #pragma unroll
     for (int i = 0; i < 2; ++i) ra[i] = csn_bload4(Ar, a_off[i] | kp, (unsigned)k0 * 4u);
-    if (BF) rb[0] = csn_bload4(Br, b_off[0] | ((k0 + kr2) < K ? 0u : CSN_OOB), (unsigned)k0 * (unsigned)ldb * 2u);
-    else {
+    if (BT) {
+      const unsigned kb = (k0 + t_kr) < K ? 0u : CSN_OOB;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) rb[i] = csn_bload4(Br, b_off[i] | kb, (unsigned)k0 * (unsigned)ldb * 2u);
+    } else if (BF) rb[0] = csn_bload4(Br, b_off[0] | ((k0 + kr2) < K ? 0u : CSN_OOB), (unsigned)k0 * (unsigned)ldb * 2u);
+    else if (B_NK) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) rb[i] = csn_bload4(Br, b_off[i] | kp, (unsigned)k0 * 4u);
+    } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i) rb[i] = csn_bload4(Br, b_off[i] | ((k0 + kr + 16 * i) < K ? 0u : CSN_OOB), (unsigned)k0 * (unsigned)ldb * 4u);
     }
@@ -901,18 +932,29 @@ __global__ __launch_bounds__(1024, 4) void csn_gemm_bf16x3_wide_kernel(CsnGemmAr
       *reinterpret_cast<s16x4*>(As(st, 0) + sw_dst + 128 * BK * i) = hi;
       if constexpr (NPL == 2) *reinterpret_cast<s16x4*>(As(st, 1) + sw_dst + 128 * BK * i) = lo;
     }
+    if (BT) {
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) *reinterpret_cast<f32x4*>(Bs(st, 0) + bt_dst[i]) = rb[i];
+      return;
+    }
     if (BF) { *reinterpret_cast<f32x4*>(Bs(st, 0) + kr2 * PN + 8 * ku) = rb[0]; return; }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       split4<PR>(rb[i], hi, lo);
-      *reinterpret_cast<s16x4*>(Bs(st, 0) + (kr + 16 * i) * PN + kc) = hi;
-      if constexpr (NPL == 2) *reinterpret_cast<s16x4*>(Bs(st, 1) + (kr + 16 * i) * PN + kc) = lo;
+      const int dst = B_NK ? sw_dst + 128 * BK * i : (kr + 16 * i) * PN + kc;
+      *reinterpret_cast<s16x4*>(Bs(st, 0) + dst) = hi;
+      if constexpr (NPL == 2) *reinterpret_cast<s16x4*>(Bs(st, 1) + dst) = lo;
     }
   };
   const int fr_sw = (l31 >> 2) & 3;
   const int grp = lane >> 4, gq = (lane >> 2) & 3, gp = lane & 3;
   const int tr_base = (8 * (grp >> 1) + gq) * PN + 16 * (grp & 1) + 4 * gp;
   const int nk = (K + BK - 1) / BK;
+  for (int it = it0; it < it1; ++it) {
+  if (it > it0) {
+    __syncthreads();                                    // the previous item's last slab has been read by every wave
+    set_item(item_id(it));
+  }
   if (nk > 0) { load_slab(0); store_slab(0); }
   if (nk > 1) load_slab(BK);
   __syncthreads();
@@ -929,14 +971,21 @@ __global__ __launch_bounds__(1024, 4) void csn_gemm_bf16x3_wide_kernel(CsnGemmAr
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const int o = tr_base + (16 * s) * PN + wn0 + 32 * j;
-        typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
-        s16x8 bh = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Bs(cur, 0) + o)),
-                         __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Bs(cur, 0) + o + 4 * PN)));
-        s16x8 bl = bh;
-        if constexpr (NPL == 2)
-          bl = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Bs(cur, 1) + o)),
-                     __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Bs(cur, 1) + o + 4 * PN)));
+        s16x8 bh, bl;
+        if (B_NK) {
+          const int o = (wn0 + 32 * j + l31) * BK + (((2 * s + h) ^ fr_sw) << 3);
+          bh = *reinterpret_cast<const s16x8*>(Bs(cur, 0) + o);
+          bl = *reinterpret_cast<const s16x8*>(Bs(cur, NPL - 1) + o);
+        } else {
+          const int o = tr_base + (16 * s) * PN + wn0 + 32 * j;
+          typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+          bh = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Bs(cur, 0) + o)),
+                     __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Bs(cur, 0) + o + 4 * PN)));
+          if constexpr (NPL == 2)
+            bl = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Bs(cur, 1) + o)),
+                       __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Bs(cur, 1) + o + 4 * PN)));
+          else bl = bh;
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i) acc[i][j] = mma32<PR>(ah[i], al[i], bh, bl, acc[i][j]);
       }
@@ -946,6 +995,7 @@ __global__ __launch_bounds__(1024, 4) void csn_gemm_bf16x3_wide_kernel(CsnGemmAr
       if (kt + 2 < nk) load_slab((kt + 2) * BK);
     }
     __syncthreads();
+  }
   }
   // epilogue: every wave transposes its 64 x 64 block through its own 8 KB of LDS, 32 rows at a time (the tile loop is over),
   // and writes 16 contiguous bytes per lane (8 in a 16-bit map): 16 stores instead of 64.  Column halves of rows with
@@ -980,7 +1030,10 @@ __global__ __launch_bounds__(1024, 4) void csn_gemm_bf16x3_wide_kernel(CsnGemmAr
         s16x4 hi, lo;
         split4<PR>(vals[t], hi, lo);
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), Cw, off, 0, 0);
-      } else csn_bstore4(vals[t], Cw, off);
+      } else {
+        if (p.accumulate) vals[t] += csn_bload4(Cw, off);
+        csn_bstore4(vals[t], Cw, off);
+      }
     }
   }
 }
@@ -1012,16 +1065,18 @@ int launch(const CsnGemmArgs& a, int batch, hipStream_t st) {
 int csn_gemm_big_tiles = 1;      // development switch (csn_debug_set_big_tiles)
 extern "C" void csn_debug_set_big_tiles(int on) { csn_gemm_big_tiles = on; }
 int csn_gemm_wide = 1;           // plain 256 x 256 products of the bf16x3 mode on the 16-wave kernel (csn_debug_set_wide_gemm: 0 off, 2 = the one-plane modes too)
+int csn_gemm_wide_set = 7;       // which product forms take it: 1 plain k-major B, 2 tile-plane B (grouped dV / dK), 4 k-contiguous B (weight gradients)
 extern "C" void csn_debug_set_wide_gemm(int on) { csn_gemm_wide = on; }
+extern "C" void csn_debug_set_wide_gemm_forms(int set) { csn_gemm_wide_set = set; }
 
 namespace {
-template <typename PR, int BF>
+template <typename PR, bool B_NK, bool BT, int BF>
 int launch_wide(const CsnGemmArgs& a, int batch, hipStream_t st) {
   CsnGemmArgs b = a;
   b.batch = batch;
   const long long tiles = (long long)((a.N + 255) / 256) * ((a.M + 255) / 256);
   dim3 grid((unsigned)(((batch + 7) / 8) * 8 * tiles));
-  hipLaunchKernelGGL((csn_gemm_bf16x3_wide_kernel<PR, BF>), grid, dim3(1024), 0, st, b);
+  hipLaunchKernelGGL((csn_gemm_bf16x3_wide_kernel<PR, B_NK, BT, BF>), grid, dim3(1024), 0, st, b);
   return (int)hipGetLastError();
 }
 }  // namespace
@@ -1086,10 +1141,17 @@ int launch_mode(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st) {
   // tiles of 256 x 256 where the output is big enough to fill them (a ragged last tile wastes at most ~3 % here)
   const bool big = csn_gemm_big_tiles && a.M >= 192 && a.N >= 224;
   if (a.grp_off && !big) return -1;                                 // grouped accumulation: 256 x 256 kernel only
-  if (csn_gemm_wide && (PR::NPL == 2 || csn_gemm_wide == 2) && big && !b_is_nk && a.B.planes != 2 && !a.grp_off && !a.accumulate && a.C.planes != 2 && !a.A.fmt &&
-      !a.n_arr && !a.k_arr && !a.n_last && !a.k_last && !a.k_chunk && (a.C.planes == 0 || PR::NPL == 1)) {
-    if (a.B.fmt == 0) return launch_wide<PR, 0>(a, batch, st);
-    if constexpr (PR::NPL == 1) { if (a.B.fmt == 1) return launch_wide<PR, 1>(a, batch, st); }
+  // the 16-wave form of the 256 x 256 tiles: A fp32, C fp32 (or a 16-bit map in the accumulating-free plain case)
+  if (csn_gemm_wide && (PR::NPL == 2 || csn_gemm_wide == 2) && big && a.C.planes != 2 && !a.A.fmt && (a.C.planes == 0 || PR::NPL == 1) &&
+      !(a.C.planes && a.accumulate)) {
+    if (a.B.planes == 2) {
+      if (!b_is_nk && !(a.B.ld & 7) && (csn_gemm_wide_set & 2)) return launch_wide<PR, false, true, 0>(a, batch, st);
+    } else if (b_is_nk) {
+      if (a.B.fmt == 0 && !a.grp_off && (csn_gemm_wide_set & 4)) return launch_wide<PR, true, false, 0>(a, batch, st);
+    } else if (!a.grp_off && (csn_gemm_wide_set & 1)) {
+      if (a.B.fmt == 0) return launch_wide<PR, false, false, 0>(a, batch, st);
+      if constexpr (PR::NPL == 1) { if (a.B.fmt == 1) return launch_wide<PR, false, false, 1>(a, batch, st); }
+    }
   }
   if (a.A.fmt || a.B.fmt) {
     if constexpr (PR::NPL == 1) {

@@ -11,7 +11,8 @@ CONFIGS = {2: dict(B=4, K=2, N=10000, C=256, nb=20), 3: dict(B=32, K=3, N=10000,
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", type=int, default=3)
 ap.add_argument("--math", default="bf16x3")
-ap.add_argument("--rounds", type=int, default=4)
+ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--forms", default="0,1,3,7", help="sets of product forms on the 16-wave kernel (bits: 1 plain, 2 tile-plane B, 4 weight gradients)")
 a = ap.parse_args()
 c = CONFIGS[a.config]
 B, K, N, C, nb = c["B"], c["K"], c["N"], c["C"], c["nb"]
@@ -33,18 +34,23 @@ def step():
     loss.backward()
     return loss.item()
 
-res, losses = {0: [], 2: []}, {}
+forms = [int(v) for v in a.forms.split(",")]
+L.csn_debug_set_wide_gemm(1 if a.math == "bf16x3" else 2)
+res, losses, grads = {f: [] for f in forms}, {}, {}
 for r in range(a.rounds):
-    for on in (0, 2):
-        L.csn_debug_set_wide_gemm(on)
+    for f in forms:
+        L.csn_debug_set_wide_gemm_forms(f)
         for _ in range(2):
-            losses[on] = step()
+            losses[f] = step()
+        grads[f] = [p.grad.clone() for p in model.parameters() if p.grad is not None]
         torch.cuda.synchronize()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
         for i in range(5):
             ev[i].record(); step()
         ev[5].record(); torch.cuda.synchronize()
-        res[on].append(float(np.median([ev[i].elapsed_time(ev[i + 1]) for i in range(5)])))
+        res[f].append(float(np.median([ev[i].elapsed_time(ev[i + 1]) for i in range(5)])))
+L.csn_debug_set_wide_gemm_forms(1)
 L.csn_debug_set_wide_gemm(1)
-for on in (0, 2):
-    print(f"config {a.config} {a.math:7s} 16-wave GEMM {'on ' if on else 'off'}: median {np.median(res[on]):7.3f} ms/step  ({' '.join(f'{v:.2f}' for v in res[on])})  loss {losses[on]:.6f}", flush=True)
+for f in forms:
+    same = all(torch.equal(x, y) for x, y in zip(grads[f], grads[forms[0]]))
+    print(f"config {a.config} {a.math:7s} 16-wave forms {f}: median {np.median(res[f]):7.3f} ms/step  ({' '.join(f'{v:.2f}' for v in res[f])})  loss {losses[f]:.6f}  gradients equal to forms {forms[0]}: {same}", flush=True)

@@ -712,3 +712,33 @@ def test_sixteen_wave_gemm_equals_the_eight_wave_one(L, mode, S, C, N, R, div_ro
     finally:
         lib.csn_debug_set_wide_gemm(1)
         lib.csn_set_math_mode(1)
+
+
+def test_sixteen_wave_forms_leave_the_step_bit_for_bit(L):
+    """The whole module step in bf16x3 with the 16-wave GEMM forms (plain, grouped tile-plane dV / dK, weight gradients) against
+    the 8-wave kernel: logits and all 11 gradients bit for bit (same slabs, same products, same order; train mode, same masks)."""
+    from csn_amd.csa_models import get_model
+    from oracle import csa_oracle as orc
+    lib = L.lib()
+    L.check(lib.csn_set_math_mode(1))
+    rng = np.random.default_rng(61)
+    B, K, n_cls, C, N = 2, 2, 7, 256, 1500
+    torch.manual_seed(2)
+    model = get_model("csa", n_cls, 1, K, block=500, n_blocks=3).cuda().train()
+    nbf = torch.from_numpy(rng.standard_normal((B, K + 1, C, N, 1)).astype(np.float32)).cuda()
+    x = nbf[:, 0].contiguous()
+    lab = torch.from_numpy(rng.integers(0, n_cls, size=(B, N))).cuda()
+    outs = []
+    try:
+        for forms in (0, 7):
+            lib.csn_debug_set_wide_gemm_forms(forms)
+            for prm in model.parameters():
+                prm.grad = None
+            torch.manual_seed(4)
+            logits = model(x, "train", nbf)
+            orc.masked_ce_loss(logits, lab).backward()
+            outs.append((logits.detach().clone(), [p.grad.clone() for p in model.parameters() if p.grad is not None]))
+    finally:
+        lib.csn_debug_set_wide_gemm_forms(7)
+    assert torch.equal(outs[0][0], outs[1][0]) and len(outs[0][1]) == 11
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
