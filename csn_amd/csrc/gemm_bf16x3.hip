@@ -1100,6 +1100,8 @@ int csn_launch_outproj_ln_big(const CsnOutProjArgs& a, int mode, hipStream_t st)
   CsnOutProjArgs b = a;
   const bool fused_sums = a.xhat_sum && a.sum_ws && a.sum_ws_floats >= (long long)a.E * tiles_n * 256;
   if (!fused_sums) b.sum_ws = nullptr;
+  // (the 16-wave form of this kernel was built too — same xhat / rstd bits — and measured slower: its epilogue holds the 64
+  //  accumulators beside the residual loads in flight under a 128-register bound, 46-48 spills: step 28.36 -> 29.26 ms)
   int rc = a.act16 ? (mode == 3 ? launch_big<F16, false, false, true, 0, 1>(g, a.E, st, &b)
                                 : launch_big<Bf16, false, false, true, 0, 1>(g, a.E, st, &b))
            : mode == 3 ? launch_big<F16, false, false, true>(g, a.E, st, &b)
