@@ -16,7 +16,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libcsn_hip.so")
-SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "attn_f32.hip", "attn_bf16x3.hip", "attn_dkv.hip", "outproj_ln.hip", "retrieval.hip", "combine.hip", "compat.hip", "csn_capi.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "wx_stream.hip", "attn_f32.hip", "attn_bf16x3.hip", "attn_dkv.hip", "outproj_ln.hip", "retrieval.hip", "combine.hip", "compat.hip", "csn_capi.hip"]
 HEADERS = ["csn_common.h", "csn_kernels.h", os.path.join("..", "..", "include", "csn_hip.h")]
 ARCH = "gfx950"
 BUILD_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared"]
@@ -117,6 +117,8 @@ _SIGNATURES = {
     "csn_set_thread_act16": (c_int, [c_int]),
     "csn_get_thread_act16": (c_int, []),
     "csn_status_string": (c_char_p, [c_int]),
+    "csn_dev_set": (c_int, [c_int, c_int]),
+    "csn_dev_get": (c_int, [c_int]),
     "csn_wgrad_workspace_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
     "csn_project_f32": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_int, c_int, c_void_p, c_longlong, c_int,
                                 c_int, c_int, c_int, c_float, c_int, c_longlong, c_void_p]),
@@ -178,6 +180,8 @@ _SIGNATURES = {
 }
 
 EXPORTS = tuple(_SIGNATURES)
+# keys of csn_dev_set / csn_dev_get (include/csn_hip.h, development section)
+DEV_BIG_TILES, DEV_WIDE_GEMM, DEV_WIDE_FORMS, DEV_WX = 0, 1, 2, 3
 
 
 def lib() -> ctypes.CDLL:
@@ -193,7 +197,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.csn_version() != 14:
+        if handle.csn_version() != 15:
             raise CsnError("libcsn_hip.so ABI version mismatch")
         _lib = handle
     return _lib

@@ -2,6 +2,7 @@
 // decomposition of each domain-level call into kernel launches live here; no allocation, no sync.
 #include "../../include/csn_hip.h"
 #include "csn_kernels.h"
+#include <cmath>
 
 namespace {
 
@@ -39,6 +40,20 @@ int launch_gemm(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st) {
 }
 
 inline bool mis16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) != 0; }
+
+// K = 256 weight products of the bf16x3 mode on the weight-stationary streaming kernel (wx_stream.hip)
+int launch_wx(const float* w, const float* x, long long x_stride, int ldx, void* out, long long out_stride, int ldo, int rows,
+              int n_items, int n_points, int div_rows, float div_val, int out_mode, int tb, hipStream_t st) {
+  CsnWxArgs a;
+  a.w = w; a.x = x; a.x_item_stride = x_stride; a.ldx = ldx;
+  a.out = out; a.out_item_stride = out_stride; a.ldo = ldo;
+  a.n_items = n_items; a.n_points = n_points; a.n_sets = rows / 256;
+  a.div_rows = div_rows; a.div_val = div_val; a.div_rcp = 1.f / div_val;
+  int ex = 0;
+  a.div_exact = (std::frexp(div_val, &ex) == 0.5f && div_val > 0.f) ? 1 : 0;     // a power of two: v * (1 / t) == v / t bit for bit
+  a.tb = tb;
+  return csn_launch_wx(a, out_mode, st);
+}
 
 // Block mode, n_blocks * block > ld: the row of ld points ends inside the last block, which then holds
 // ld - (n_blocks - 1) * block points (a multiple of 4).  Returns that count, 0 for full blocks, or a negative status.
@@ -98,6 +113,27 @@ int wgrad(const float* a, long long a_stride, int lda, const float* b, long long
 extern "C" {
 
 int csn_version(void) { return CSN_ABI_VERSION; }
+
+int csn_dev_get(int key) {
+  switch (key) {
+    case CSN_DEV_BIG_TILES: return csn_gemm_big_tiles;
+    case CSN_DEV_WIDE_GEMM: return csn_gemm_wide;
+    case CSN_DEV_WIDE_FORMS: return csn_gemm_wide_set;
+    case CSN_DEV_WX: return csn_dev_wx;
+    default: return CSN_E_ARG;
+  }
+}
+int csn_dev_set(int key, int value) {
+  const int prev = csn_dev_get(key);
+  switch (key) {
+    case CSN_DEV_BIG_TILES: csn_gemm_big_tiles = value; break;
+    case CSN_DEV_WIDE_GEMM: csn_gemm_wide = value; break;
+    case CSN_DEV_WIDE_FORMS: csn_gemm_wide_set = value; break;
+    case CSN_DEV_WX: csn_dev_wx = value; break;
+    default: return CSN_E_ARG;
+  }
+  return prev;
+}
 
 int csn_set_math_mode(int m) {
   if (m < 0 || m > 3) return CSN_E_ARG;
@@ -160,6 +196,9 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
   if ((ld_x & 3) || (ld_out & 3) || (n_points & 3) || (channels & 3)) return CSN_E_ALIGN;
   if (mis16(x) || mis16(w) || mis16(out)) return CSN_E_PTR;
   if ((x_shape_stride & 3) || (out_shape_stride & 3)) return CSN_E_STRIDE;
+  if (mode() == 1 && !x16 && (out_split == 0 || out_split == 2) && !(div_rows & 31) && csn_wx_takes(rows, channels))
+    return launch_wx(w, x, x_shape_stride, ld_x, out, out_shape_stride, ld_out, rows, n_shapes, n_points, div_rows, temperature,
+                     out_split, (int)out_plane_stride, (hipStream_t)stream);
   CsnGemmArgs g;
   g.A = operand(w, 0, 0, 0, nullptr, channels);
   g.B = operand(x, 0, 0, x_shape_stride, nullptr, ld_x);
@@ -596,6 +635,12 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
   int rc = csn_launch_ln_bwd_f32(l, st);
   if (rc) return rc;
   // dctx[e][D][n] = wfc_t[D][c] dz[e][c][n]
+  if (mode() == 1 && !a16 && !dctx_split && csn_wx_takes(d_inner, d_model)) {
+    rc = launch_wx(wfc_t, dz, eval_stride, ld, dctx, ctx_eval_stride, ld, d_inner, n_evals, n_points, 0, 1.f, 0, 0, st);
+    if (rc) return rc;
+    return wgrad(dz, eval_stride, ld, ctx, ctx_eval_stride, ld, dwfc, d_model, d_inner, n_evals, n_points, 1.f, accumulate, ws,
+                 ws_floats, st, 0, 0);
+  }
   CsnGemmArgs g;
   g.A = operand(wfc_t, 0, 0, 0, nullptr, d_model);
   g.B = operand(dz, 0, 0, eval_stride, nullptr, ld);

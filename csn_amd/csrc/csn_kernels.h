@@ -34,6 +34,19 @@ int csn_gemm_bf16x3_big_tiles(int M, int N);          // 1: an M x N output take
 int csn_launch_slab_reduce(const float* slab, float* out, int n_slabs, long long n, float alpha, int accumulate,
                            hipStream_t st);
 
+// ---- weight-stationary streaming products, K = 256, bf16x3 (wx_stream.hip) ---------------------------------
+struct CsnWxArgs {
+  const float* w;                                         // [n_sets * 256][256] row-major
+  const float* x;  long long x_item_stride;  int ldx;     // [item][256][ldx] fp32
+  void* out;  long long out_item_stride;  int ldo;        // fp32 [item][n_sets * 256][ldo], or bf16 tile planes (strides in 16-bit elements)
+  int n_items, n_points, n_sets;
+  int div_rows;  float div_val;  float div_rcp;  int div_exact;   // rows < div_rows are divided by div_val (exact as * div_rcp when it is a power of two)
+  int tb;                                                 // tile planes: points per attention block
+};
+extern int csn_gemm_big_tiles, csn_gemm_wide, csn_gemm_wide_set, csn_dev_wx;   // development switches (csn_dev_set)
+bool csn_wx_takes(int rows, int k);                       // this product shape runs on the streaming kernel
+int csn_launch_wx(const CsnWxArgs& a, int out_mode /* 0 fp32, 2 tile planes */, hipStream_t st);
+
 // ---- fused block attention (attn_f32.hip) -----------------------------------------------------
 struct CsnAttnArgs {
   // channel-major projected features, one slab of [H*d][ld] per shape

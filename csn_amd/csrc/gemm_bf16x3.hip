@@ -1062,12 +1062,10 @@ int launch(const CsnGemmArgs& a, int batch, hipStream_t st) {
 
 }  // namespace
 
-int csn_gemm_big_tiles = 1;      // development switch (csn_debug_set_big_tiles)
-extern "C" void csn_debug_set_big_tiles(int on) { csn_gemm_big_tiles = on; }
-int csn_gemm_wide = 1;           // plain 256 x 256 products of the bf16x3 mode on the 16-wave kernel (csn_debug_set_wide_gemm: 0 off, 2 = the one-plane modes too)
+// development switches (csn_dev_set, include/csn_hip.h "DEVELOPMENT SECTION")
+int csn_gemm_big_tiles = 1;
+int csn_gemm_wide = 1;           // plain 256 x 256 products of the bf16x3 mode on the 16-wave kernel (0 off, 2 = the one-plane modes too)
 int csn_gemm_wide_set = 7;       // which product forms take it: 1 plain k-major B, 2 tile-plane B (grouped dV / dK), 4 k-contiguous B (weight gradients)
-extern "C" void csn_debug_set_wide_gemm(int on) { csn_gemm_wide = on; }
-extern "C" void csn_debug_set_wide_gemm_forms(int set) { csn_gemm_wide_set = set; }
 
 namespace {
 template <typename PR, bool B_NK, bool BT, int BF>

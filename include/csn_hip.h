@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSN_ABI_VERSION 14
+#define CSN_ABI_VERSION 15
 
 /* math modes (csn_set_math_mode / csn_set_thread_math_mode) */
 #define CSN_MATH_FP32 0
@@ -375,6 +375,22 @@ int csn_compat_fwd_f32(const float* pooled, const float* wq_t, const float* bq, 
 int csn_compat_bwd_f32(const float* dcomp, const float* comp, const double* save_u, const double* save_norm, const float* pooled,
                        const float* wq, const float* wk, double* ws, long long ws_doubles, float* dpooled, float* dwq, float* dbq,
                        float* dwk, float* dbk, int n_shapes, int k1, int channels, int reference_layout, void* stream);
+
+/* ---- DEVELOPMENT SECTION -------------------------------------------------------------------------------------------------
+ * Kernel-selection switches for A/B timing and for the equality tests between two kernel forms of one product.  They are
+ * PROCESS-wide, not thread-safe, change no result beyond fp32 rounding and are not part of the drop-in surface: a product
+ * build leaves every key at its default.  csn_dev_set returns the previous value (CSN_E_ARG for an unknown key).
+ *   CSN_DEV_BIG_TILES   1   256 x 256 GEMM tiles where the output fills them (0: 128 x 128 tiles everywhere)
+ *   CSN_DEV_WIDE_GEMM   1   sixteen-wave form of the 256 x 256 tiles in the bf16x3 mode (0 off, 2: the one-plane modes too)
+ *   CSN_DEV_WIDE_FORMS  7   bit set of the product forms that take it: 1 plain, 2 tile-plane B (dV / dK), 4 weight gradients
+ *   CSN_DEV_WX          1   K = 256 weight products (projections, dCtx, out-projection + LayerNorm) of the bf16x3 mode on the
+ *                           weight-stationary streaming kernel (0: on the tiled GEMM kernels) */
+#define CSN_DEV_BIG_TILES 0
+#define CSN_DEV_WIDE_GEMM 1
+#define CSN_DEV_WIDE_FORMS 2
+#define CSN_DEV_WX 3
+int csn_dev_set(int key, int value);
+int csn_dev_get(int key);
 
 #ifdef __cplusplus
 }

@@ -33,7 +33,7 @@ def step():
 res = {0: [], 1: []}
 for r in range(a.rounds):
     for on in (1, 0):
-        L.csn_debug_set_big_tiles(on)
+        L.csn_dev_set(0, on)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
@@ -42,6 +42,6 @@ for r in range(a.rounds):
             ev[i].record(); step()
         ev[5].record(); torch.cuda.synchronize()
         res[on].append(float(np.median([ev[i].elapsed_time(ev[i + 1]) for i in range(5)])))
-L.csn_debug_set_big_tiles(1)
+L.csn_dev_set(0, 1)
 for on in (1, 0):
     print(f"config {a.config} {a.math:7s} 256x256 tiles {'on ' if on else 'off'}: median {np.median(res[on]):7.3f} ms/step  ({' '.join(f'{v:.2f}' for v in res[on])})", flush=True)

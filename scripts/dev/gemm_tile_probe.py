@@ -25,11 +25,11 @@ def main():
     w = torch.randn((R, C), device="cuda") / 16
     for rep in range(2):
         for big in (1, 0):
-            L.csn_debug_set_big_tiles(big)
+            L.csn_dev_set(0, big)
             t = timeit(lambda: CF.project(x, w))
             print(f"big_tiles={big}: project {S} x ({R} x {C}) x {N}: {t:.3f} ms  {2 * S * R * C * N / t / 1e9:.1f} TF/s "
                   f"{(S * C * N * 4 + S * R * N * 4) / t / 1e9:.2f} TB/s algorithmic", flush=True)
-    L.csn_debug_set_big_tiles(1)
+    L.csn_dev_set(0, 1)
 
 
 if __name__ == "__main__":

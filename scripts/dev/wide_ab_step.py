@@ -35,11 +35,11 @@ def step():
     return loss.item()
 
 forms = [int(v) for v in a.forms.split(",")]
-L.csn_debug_set_wide_gemm(1 if a.math == "bf16x3" else 2)
+L.csn_dev_set(1, 1 if a.math == "bf16x3" else 2)
 res, losses, grads = {f: [] for f in forms}, {}, {}
 for r in range(a.rounds):
     for f in forms:
-        L.csn_debug_set_wide_gemm_forms(f)
+        L.csn_dev_set(2, f)
         for _ in range(2):
             losses[f] = step()
         grads[f] = [p.grad.clone() for p in model.parameters() if p.grad is not None]
@@ -49,8 +49,8 @@ for r in range(a.rounds):
             ev[i].record(); step()
         ev[5].record(); torch.cuda.synchronize()
         res[f].append(float(np.median([ev[i].elapsed_time(ev[i + 1]) for i in range(5)])))
-L.csn_debug_set_wide_gemm_forms(1)
-L.csn_debug_set_wide_gemm(1)
+L.csn_dev_set(2, 1)
+L.csn_dev_set(1, 1)
 for f in forms:
     same = all(torch.equal(x, y) for x, y in zip(grads[f], grads[forms[0]]))
     print(f"config {a.config} {a.math:7s} 16-wave forms {f}: median {np.median(res[f]):7.3f} ms/step  ({' '.join(f'{v:.2f}' for v in res[f])})  loss {losses[f]:.6f}  gradients equal to forms {forms[0]}: {same}", flush=True)

@@ -32,10 +32,10 @@ for mode, name in ((1, "bf16x3"), (2, "bf16")):
         res, t = {}, {}
         for rep in range(2):
             for wide in (0, 2):
-                L.csn_debug_set_wide_gemm(wide)
+                L.csn_dev_set(1, wide)
                 res[wide] = fn().clone()
                 t.setdefault(wide, []).append(timeit(fn))
-        L.csn_debug_set_wide_gemm(1)
+        L.csn_dev_set(1, 1)
         same = torch.equal(res[0], res[2])
         d = (res[0].float() - res[1].float()).abs().max().item()
         print(f"{name:7s} {label}: 8 waves {min(t[0]):6.3f} ms   16 waves {min(t[2]):6.3f} ms   equal {same} (max diff {d:.2e})", flush=True)

@@ -9,7 +9,7 @@ S, C, N, R = 32, 256, 10000, 768
 for name, x, w in (("random", torch.randn((S, C, N), device="cuda"), torch.randn((R, C), device="cuda") / 16),
                    ("zeros", torch.zeros((S, C, N), device="cuda"), torch.zeros((R, C), device="cuda"))):
     for big in (1, 0):
-        L.csn_debug_set_big_tiles(big)
+        L.csn_dev_set(0, big)
         t = timeit(lambda: CF.project(x, w), n=9)
         print(f"{name:7s} big_tiles={big}: {t:6.3f} ms  {2 * S * R * C * N / t / 1e9:6.1f} TF/s", flush=True)
-L.csn_debug_set_big_tiles(1)
+L.csn_dev_set(0, 1)

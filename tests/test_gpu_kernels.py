@@ -706,11 +706,13 @@ def test_sixteen_wave_gemm_equals_the_eight_wave_one(L, mode, S, C, N, R, div_ro
     try:
         outs = []
         for wide in (0, 2):
-            lib.csn_debug_set_wide_gemm(wide)
+            lib.csn_dev_set(L.DEV_WX, 0)
+            lib.csn_dev_set(L.DEV_WIDE_GEMM, wide)
             outs.append(CF.project(x, w, div_rows=div_rows, temperature=16.0).clone())
         assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
     finally:
-        lib.csn_debug_set_wide_gemm(1)
+        lib.csn_dev_set(L.DEV_WIDE_GEMM, 1)
+        lib.csn_dev_set(L.DEV_WX, 1)
         lib.csn_set_math_mode(1)
 
 
@@ -730,8 +732,9 @@ def test_sixteen_wave_forms_leave_the_step_bit_for_bit(L):
     lab = torch.from_numpy(rng.integers(0, n_cls, size=(B, N))).cuda()
     outs = []
     try:
+        lib.csn_dev_set(L.DEV_WX, 0)          # (the streaming kernel sums in another order: compared against the oracle, not bitwise)
         for forms in (0, 7):
-            lib.csn_debug_set_wide_gemm_forms(forms)
+            lib.csn_dev_set(L.DEV_WIDE_FORMS, forms)
             for prm in model.parameters():
                 prm.grad = None
             torch.manual_seed(4)
@@ -739,6 +742,7 @@ def test_sixteen_wave_forms_leave_the_step_bit_for_bit(L):
             orc.masked_ce_loss(logits, lab).backward()
             outs.append((logits.detach().clone(), [p.grad.clone() for p in model.parameters() if p.grad is not None]))
     finally:
-        lib.csn_debug_set_wide_gemm_forms(7)
+        lib.csn_dev_set(L.DEV_WIDE_FORMS, 7)
+        lib.csn_dev_set(L.DEV_WX, 1)
     assert torch.equal(outs[0][0], outs[1][0]) and len(outs[0][1]) == 11
     assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))

@@ -1,0 +1,145 @@
+"""The weight-stationary streaming kernel (csn_amd/csrc/wx_stream.hip) behind csn_project_f32 and the dCtx product of
+csn_outproj_ln_bwd_f32 in the bf16x3 mode, K = 256 (MID-FC/csa_models.py:103-105, 115): against float64 on the host, against the
+tiled GEMM kernels it replaces (switch CSN_DEV_WX), on ragged point counts, strided slots, several row sets, and with the
+output carved to end exactly where its allocation ends."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from csn_amd import _lib
+    _lib.build()
+    lib = _lib.lib()
+    _lib.check(lib.csn_set_math_mode(1))
+    assert lib.csn_dev_get(_lib.DEV_WX) == 1
+    return _lib
+
+
+def _rand(rng, *shape):
+    return torch.from_numpy(rng.standard_normal(size=shape).astype(np.float32))
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rel(got, ref):
+    return ((got.double().cpu() - ref).abs().max() / ref.abs().max()).item()
+
+
+@pytest.mark.parametrize("S,N,ld,R,div_rows,temp", [
+    (2, 1000, 1000, 256, 256, 16.0),        # 31 chunks + a short one of 8 points
+    (3, 36, 40, 512, 0, 1.0),               # two chunks per slot, row pitch above the point count
+    (1, 10000, 10000, 768, 256, 16.0),      # the reference's geometry, Q | K | V rows in one call (three row sets)
+    (5, 500, 512, 256, 256, math.sqrt(96)), # a temperature that is not a power of two: true division
+    (300, 64, 64, 256, 0, 1.0),             # more slots than streams
+    (1, 4, 4, 2048, 1024, 16.0),            # eight row sets (H = 8), one chunk of 4 points
+])
+def test_projection_against_float64_and_the_tiled_kernel(L, S, N, ld, R, div_rows, temp):
+    lib = L.lib()
+    rng = np.random.default_rng(5)
+    C = 256
+    x = torch.zeros((S, C, ld))
+    x[:, :, :N] = _rand(rng, S, C, N)
+    w = _rand(rng, R, C) / math.sqrt(C)
+    xd, wd = x.cuda(), w.cuda()
+    ref = torch.einsum("rc,scn->srn", w.double(), x[:, :, :N].double())
+    ref[:, :div_rows] /= temp
+    outs = []
+    for wx in (1, 0):
+        lib.csn_dev_set(L.DEV_WX, wx)
+        try:
+            out = torch.full((S, R, ld), float("nan"), device="cuda")
+            L.check(lib.csn_project_f32(xd.data_ptr(), C * ld, ld, wd.data_ptr(), R, C, out.data_ptr(), R * ld, ld, S, N, div_rows,
+                                        temp, 0, 0, _stream()))
+            outs.append(out.cpu())
+        finally:
+            lib.csn_dev_set(L.DEV_WX, 1)
+    for out in outs:
+        assert _rel(out[:, :, :N], ref) < 2e-5
+        assert torch.isnan(out[:, :, N:]).all()                       # nothing beyond the points of a row is written
+    assert _rel(outs[0][:, :, :N], outs[1][:, :, :N].double()) < 1e-5   # (another summation order, same products)
+
+
+@pytest.mark.parametrize("S,T,nb,N,R", [(2, 500, 2, 1000, 512), (1, 100, 3, 300, 256), (3, 36, 2, 72, 512), (1, 500, 3, 1300, 512)])
+def test_tile_planes_against_float64_and_the_tiled_kernel(L, S, T, nb, N, R):
+    """K / V leave as bf16 tile planes: per row and block 16 tiles of [hi 32 | lo 32]; padding keys of the block's last tile are
+    zeros, tiles beyond it stay untouched; a row that ends inside the last block (N < nb * T)."""
+    lib = L.lib()
+    rng = np.random.default_rng(6)
+    C = 256
+    x, w = _rand(rng, S, C, N), _rand(rng, R, C) / math.sqrt(C)
+    xd, wd = x.cuda(), w.cuda()
+    ldp = nb * 1024
+    ref = torch.einsum("rc,scn->srn", w.double(), x.double())
+    outs = []
+    for wx in (1, 0):
+        lib.csn_dev_set(L.DEV_WX, wx)
+        try:
+            kv = torch.full((S, R, ldp), float("nan"), device="cuda", dtype=torch.bfloat16)
+            L.check(lib.csn_project_f32(xd.data_ptr(), C * N, N, wd.data_ptr(), R, C, kv.data_ptr(), R * ldp, ldp, S, N, 0, 1.0, 2, T,
+                                        _stream()))
+            outs.append(kv.view(S, R, nb, 16, 2, 32).float().cpu())
+        finally:
+            lib.csn_dev_set(L.DEV_WX, 1)
+    assert torch.equal(torch.isnan(outs[0]), torch.isnan(outs[1]))     # the same elements are written by both kernels
+    for t in outs:
+        got = (t[..., 0, :] + t[..., 1, :]).reshape(S, R, nb, 512)
+        for b in range(nb):
+            n_b = min(T, N - b * T)                                    # points of this block (the last one may be short)
+            assert _rel(got[:, :, b, :n_b], ref[:, :, b * T:b * T + n_b]) < 3e-5
+            last = (n_b + 31) // 32 * 32
+            assert (got[:, :, b, n_b:last] == 0).all()
+            assert torch.isnan(got[:, :, b, last:]).all()
+
+
+def test_strided_slots_and_an_output_that_ends_its_allocation(L):
+    """Slot ranges (first, step, count) as the sharded plans pass them, and the output map carved so that its last row ends the
+    tensor's storage, followed by a poisoned guard: not one byte of the guard may change (buffer windows, not luck)."""
+    lib = L.lib()
+    rng = np.random.default_rng(7)
+    C, N, R, S, step = 256, 100, 256, 7, 2
+    x, w = _rand(rng, S, C, N), _rand(rng, R, C) / math.sqrt(C)
+    xd, wd = x.cuda(), w.cuda()
+    count = (S + step - 1) // step
+    pool = torch.full((count * R * N + 4096,), float("nan"), device="cuda")     # output map + guard in ONE allocation
+    out, guard = pool[:count * R * N].view(count, R, N), pool[count * R * N:]
+    L.check(lib.csn_project_f32(xd.data_ptr(), step * C * N, N, wd.data_ptr(), R, C, out.data_ptr(), R * N, N, count, N, 0, 1.0, 0, 0,
+                                _stream()))
+    ref = torch.einsum("rc,scn->srn", w.double(), x[::step].double())
+    assert _rel(out, ref) < 2e-5
+    assert torch.isnan(guard).all()
+
+
+def test_dctx_product_inside_the_layer_norm_backward(L):
+    """csn_outproj_ln_bwd_f32: dCtx = W_fc^T dZ on the streaming kernel equals the tiled kernel's to fp32 rounding (dZ and the
+    weight gradient are the same launches in both)."""
+    lib = L.lib()
+    rng = np.random.default_rng(8)
+    E, C, D, NP = 3, 256, 256, 520
+    dxhat, xhat = _rand(rng, E, C, NP).cuda(), _rand(rng, E, C, NP).cuda()
+    rstd = (torch.rand(E, NP) + 0.5).cuda()
+    ctx = _rand(rng, E, D, NP).cuda()
+    wfc_t = (_rand(rng, D, C) / 16).cuda()
+    res = []
+    for wx in (1, 0):
+        lib.csn_dev_set(L.DEV_WX, wx)
+        try:
+            dz, dctx, dw = torch.empty((E, C, NP), device="cuda"), torch.full((E, D, NP), float("nan"), device="cuda"), torch.empty((C, D), device="cuda")
+            ws_n = lib.csn_wgrad_workspace_floats(C, D, E, NP)
+            ws = torch.empty((ws_n,), device="cuda")
+            L.check(lib.csn_outproj_ln_bwd_f32(dxhat.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), C * NP, ctx.data_ptr(), D * NP,
+                                               wfc_t.data_ptr(), dz.data_ptr(), None, dctx.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws_n,
+                                               E, C, D, NP, NP, 0, 0.0, 0, 0, 0, None, E, None, 1, _stream()))
+            res.append((dz.cpu(), dctx.cpu(), dw.cpu()))
+        finally:
+            lib.csn_dev_set(L.DEV_WX, 1)
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])
+    ref = torch.einsum("dc,ecn->edn", wfc_t.double().cpu(), res[0][0].double())
+    assert _rel(res[0][1], ref) < 2e-5 and _rel(res[1][1], ref) < 2e-5
