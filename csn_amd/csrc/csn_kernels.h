@@ -42,6 +42,8 @@ struct CsnWxArgs {
   int n_items, n_points, n_sets;
   int div_rows;  float div_val;  float div_rcp;  int div_exact;   // rows < div_rows are divided by div_val (exact as * div_rcp when it is a power of two)
   int tb;                                                 // tile planes: points per attention block
+  int stagger = 0;                                        // waves 4..7 half an iteration behind waves 0..3 (development; filled in by the launcher)
+  int ablate = 0;                                         // development: timing-only ablations (bits 4..7 of CSN_DEV_WX)
 };
 extern int csn_gemm_big_tiles, csn_gemm_wide, csn_gemm_wide_set, csn_dev_wx;   // development switches (csn_dev_set)
 bool csn_wx_takes(int rows, int k);                       // this product shape runs on the streaming kernel

@@ -18,6 +18,7 @@
 // L2 (speed only); the sets of one stream sit on such work-groups and walk the same chunks, so X leaves HBM once.
 #include "csn_common.h"
 #include "csn_kernels.h"
+#include <type_traits>
 
 namespace {
 
@@ -37,6 +38,24 @@ CSN_DEVINL f32x16 wx_mma(s16x8 ah, s16x8 al, s16x8 bh, s16x8 bl, f32x16 c) {
   return mfma32<false>(ah, bh, c);
 }
 
+// The chunk requests are hidden from the compiler (inline asm) and waited for by hand.  hipcc's wait-count model for gfx950
+// does not count STORES in vmcnt, the hardware does: with compiler-visible loads every commit waited "all but 4..7" —
+// which, with this chunk's 4 stores behind them, drained the request made at the top of the same iteration as well (one chunk
+// in flight instead of two: 4.1 TB/s).  An asm load's destination is untouched by the compiler until the wait statement that
+// names it "+v"; the counts below are the stores and requests issued after the request being waited for, all unconditional.
+CSN_DEVINL void wx_request(f32x4& dst, u32x4 rsrc, unsigned voff, unsigned soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+template <int N>
+CSN_DEVINL void wx_arrived(f32x4* R) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]) : "n"(N) : "memory");
+}
+CSN_DEVINL u32x4 wx_rsrc(const void* base, long long bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  const unsigned nb = bytes > 0x7fffffffLL ? 0x7fffffffu : (bytes < 0 ? 0u : (unsigned)bytes);
+  return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, nb, 0x00020000u};
+}
+
 // OUT 0: fp32 map [item][rows][ldo];  OUT 2: bf16 tile planes (attn_bf16x3.hip): per row and block of tb points 16 tiles of
 // [hi 32 | lo 32], block pitch 1024, row pitch ldo 16-bit elements, the padding keys of a block's last tile written as zeros
 template <int OUT>
@@ -53,7 +72,12 @@ __global__ __launch_bounds__(512, 2) void csn_wx_kernel(CsnWxArgs p) {
   if (j >= spx * p.n_sets) return;
   const int set = j % p.n_sets, n_streams = spx * 8;
   const int stream = (j / p.n_sets) * 8 + xcd;
-  const unsigned cpi = (unsigned)(p.n_points + WX_CH - 1) / WX_CH;
+  // chunk map.  fp32 output: chunk = 32 consecutive points of an item.  Tile planes: chunk = one 32-key tile of an attention
+  // block (blocks of tb points start anywhere mod 32): a chunk then writes whole [hi 32 | lo 32] lines — chunks that straddle
+  // two tiles left every 128-byte line to two work-groups, each with a partial write (K/V projection 1.98 ms against 1.63 tiled)
+  const unsigned blen = OUT == 2 ? (unsigned)p.tb : (unsigned)p.n_points;          // points per chunked block
+  const unsigned cpb = (blen + WX_CH - 1) / WX_CH;                                 // chunks per block
+  const unsigned cpi = cpb * ((unsigned)(p.n_points + (int)blen - 1) / blen);        // chunks per item
   const int n_chunks = p.n_items * (int)cpi;                  // (the launcher keeps it below 2^31)
   if (stream >= n_chunks) return;
   // rows < div_rows are divided by div_val; a wave's 32 rows are all in or all out (div_rows % 32 == 0)
@@ -79,17 +103,50 @@ __global__ __launch_bounds__(512, 2) void csn_wx_kernel(CsnWxArgs p) {
   // staging: a chunk is 256 k rows x 8 pieces of 16 bytes; thread -> k row tid / 8 + 64 i, piece tid % 8
   const int krow = tid >> 3, c4 = tid & 7;
   const unsigned x_voff = (unsigned)(krow * p.ldx + 4 * c4) * 4u;
-  auto issue = [&](int q, f32x4* R) {
-    if (q >= n_chunks) return;
-    const unsigned item = (unsigned)q / cpi;
-    const int col0 = (int)((unsigned)q - item * cpi) * WX_CH, valid = min(WX_CH, p.n_points - col0);
-    const csn_rsrc_t Xr = csn_make_rsrc(p.x + (long long)item * p.x_item_stride + col0, ((long long)(WX_K - 1) * p.ldx + valid) * 4);
+  // chunk q -> item, block, tile; first point, valid points (<= 0: a tile beyond a short last block).  A cursor walks the
+  // stream's chunks with adds and compares (two 32-bit divisions per chunk and use site were a sixth of the loop's skeleton)
+  struct Cursor { int q; unsigned item, blk, tile; };
+  const unsigned bpi = cpi / cpb;                                                // blocks per item
+  auto cursor_at = [&](int q) {
+    Cursor c;
+    c.q = q;
+    c.item = (unsigned)q / cpi;
+    const unsigned r = (unsigned)q - c.item * cpi;
+    c.blk = r / cpb;
+    c.tile = r - c.blk * cpb;
+    return c;
+  };
+  const unsigned st_item = (unsigned)n_streams / cpi, st_r = (unsigned)n_streams - st_item * cpi;    // one step = n_streams chunks
+  const unsigned st_blk = st_r / cpb, st_tile = st_r - st_blk * cpb;
+  auto advance = [&](Cursor& c) {
+    c.q += n_streams;
+    c.tile += st_tile;
+    if (c.tile >= cpb) { c.tile -= cpb; ++c.blk; }
+    c.blk += st_blk;
+    if (c.blk >= bpi) { c.blk -= bpi; ++c.item; }
+    c.item += st_item;
+  };
+  auto locate = [&](const Cursor& c, int& col0, int& valid) {
+    col0 = (int)(c.blk * blen + c.tile * WX_CH);
+    valid = min(min(WX_CH, (int)blen - (int)(c.tile * WX_CH)), p.n_points - col0);
+  };
+  // (request and commit are unconditional — a chunk beyond the stream's last one is requested with every lane switched off and
+  //  committed as zeros: with a branch around either, the compiler can no longer pair a request with its commit and drains
+  //  the whole memory queue, this chunk's stores and the next request included, before it touches a staging register:
+  //  s_waitcnt vmcnt(0) at the top of every iteration, 0.64 ms for the Q projection instead of 0.4x)
+  auto issue = [&](const Cursor& cu, f32x4* R) {
+    const bool exists = cu.q < n_chunks;
+    int col0, valid;
+    locate(cu, col0, valid);
+    if (valid < 0 || !exists || (p.ablate & 4)) valid = 0;
+    const unsigned item = exists ? cu.item : 0u;
+    if (!exists) col0 = 0;
+    const u32x4 Xr = wx_rsrc(p.x + (long long)item * p.x_item_stride + col0, ((long long)(WX_K - 1) * p.ldx + valid) * 4);
     const unsigned off = 4 * c4 < valid ? x_voff : CSN_OOB;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) R[i] = csn_bload4(Xr, off, (unsigned)(64 * i * p.ldx) * 4u);
+    for (int i = 0; i < 4; ++i) wx_request(R[i], Xr, off, (unsigned)(64 * i * p.ldx) * 4u);
   };
-  auto commit = [&](int q, int stage, const f32x4* R) {
-    if (q >= n_chunks) return;
+  auto commit = [&](int stage, const f32x4* R) {
     short* dst = xs + stage * WX_STAGE + krow * WX_CH + 4 * c4;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -119,6 +176,10 @@ __global__ __launch_bounds__(512, 2) void csn_wx_kernel(CsnWxArgs p) {
       fl = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + WX_PLANE)),
                  __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(a + WX_PLANE + 4 * WX_CH)));
     };
+    if (p.ablate & 1) {
+      acc[0] = __builtin_bit_cast(float, (int)xh[0]);
+      return acc;
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < WX_PD; ++s) rd(s, bh[s], bl[s]);
@@ -137,88 +198,115 @@ __global__ __launch_bounds__(512, 2) void csn_wx_kernel(CsnWxArgs p) {
   // epilogue: the wave's 32 x 32 block through its private LDS block (row-major, 128-byte rows) and out as 16-byte rows:
   // lane -> row lane / 8 + 8 t, points 4 (lane % 8) .. + 3
   const int erow = lane >> 3, c8 = lane & 7;
-  auto epilogue = [&](int q, f32x16 acc) {
-    const unsigned item = (unsigned)q / cpi;
-    const int col0 = (int)((unsigned)q - item * cpi) * WX_CH;
+  auto epilogue = [&](const Cursor& cu, f32x16 acc) {
+    const unsigned item = cu.item, blk = cu.blk, tile = cu.tile;
+    int col0, valid;
+    locate(cu, col0, valid);
     const int n = col0 + 4 * c8;
-    const bool n_ok = n < p.n_points;
+    if (p.ablate & 2) valid = 0;
+    const bool n_ok = 4 * c8 < valid;                                  // (a tile beyond a short last block: no lane stores)
     if (true_div) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = acc[r] / p.div_val;
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) eb[csn_acc_row(r, h) * 32 + l31] = acc[r] * dscale;
-    f32x4 vals[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) vals[t] = *reinterpret_cast<const f32x4*>(&eb[(erow + 8 * t) * 32 + 4 * c8]);
     if constexpr (OUT == 0) {
+      f32x4 vals[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) vals[t] = *reinterpret_cast<const f32x4*>(&eb[(erow + 8 * t) * 32 + 4 * c8]);
       const csn_rsrc_t Or = csn_make_rsrc(reinterpret_cast<float*>(p.out) + (long long)item * p.out_item_stride + (long long)(256 * set) * p.ldo,
                                           (long long)256 * p.ldo * 4);
       const unsigned off = n_ok ? (unsigned)((32 * wave + erow) * p.ldo + n) * 4u : CSN_OOB;
 #pragma unroll
       for (int t = 0; t < 4; ++t) csn_bstore4(vals[t], Or, off, (unsigned)(8 * t * p.ldo) * 4u);
     } else {
+      // the tile's 32 keys leave whole, 8 keys = 16 bytes per lane and plane (lane -> row lane / 4 + 16 t, keys 8 (lane % 4) ..):
+      // points beyond the block's (or the row's) end were never loaded, their sums are zeros — exactly the padding the
+      // attention kernels expect behind a block's last key
+      const int prow = lane >> 2, c4k = lane & 3;
       const csn_rsrc_t Or = csn_make_rsrc(reinterpret_cast<short*>(p.out) + (long long)item * p.out_item_stride + (long long)(256 * set) * p.ldo,
                                           (long long)256 * p.ldo * 2);
-      const int blk = n / p.tb, kib = n - blk * p.tb;                  // tb % 4 == 0: the 4 points share block and tile
-      const unsigned tcol = (unsigned)(blk * 1024 + (kib >> 5) * 64 + (kib & 31));
-      const unsigned off = n_ok ? ((unsigned)((32 * wave + erow) * p.ldo) + tcol) * 2u : CSN_OOB;
-      int tpad = 0;                                                    // 4-key groups of zero padding behind this lane's points
-      if (n_ok && (kib + 4 == p.tb || n + 4 == p.n_points)) tpad = ((32 - ((kib + 4) & 31)) & 31) >> 2;
+      const unsigned tcol = blk * 1024u + tile * 64u + 8u * (unsigned)c4k;
+      const unsigned off = valid > 0 ? ((unsigned)((32 * wave + prow) * p.ldo) + tcol) * 2u : CSN_OOB;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        s16x4 hi, lo;
-        split4<Bf16x3>(vals[t], hi, lo);
-        const unsigned so = (unsigned)(8 * t * p.ldo) * 2u;
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), Or, off, so, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), Or, off, so + 64u, 0);
-      }
-      if (tpad > 0) {
-        const u32x2 z2 = {0u, 0u};
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-          for (int g = 1; g <= tpad; ++g) {
-            const unsigned so = (unsigned)(8 * t * p.ldo) * 2u;
-            __builtin_amdgcn_raw_buffer_store_b64(z2, Or, off + 8u * (unsigned)g, so, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(z2, Or, off + 8u * (unsigned)g, so + 64u, 0);
-          }
+      for (int t = 0; t < 2; ++t) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(&eb[(prow + 16 * t) * 32 + 8 * c4k]);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(&eb[(prow + 16 * t) * 32 + 8 * c4k + 4]);
+        s16x4 h0, l0, h1, l1;
+        split4<Bf16x3>(v0, h0, l0);
+        split4<Bf16x3>(v1, h1, l1);
+        const unsigned so = (unsigned)(16 * t * p.ldo) * 2u;
+        csn_bstore4(__builtin_bit_cast(f32x4, join8(h0, h1)), Or, off, so);
+        csn_bstore4(__builtin_bit_cast(f32x4, join8(l0, l1)), Or, off, so + 64u);
       }
     }
   };
 
-  // chunk i of this stream is q(i) = stream + n_streams * i.  Iteration c: request chunk c + 3 (register set (c + 1) & 1),
-  // contract chunk c (stage c % 3), store it, commit chunk c + 2 (requested in iteration c - 1) to stage (c + 2) % 3 — last
-  // read in iteration c - 1, which every wave has left through the barrier — and meet at the barrier.
-  f32x4 R0[4], R1[4];
-  auto qi = [&](int i) { return stream + n_streams * i; };
-  issue(qi(0), R0);
-  issue(qi(1), R1);
-  commit(qi(0), 0, R0);
-  commit(qi(1), 1, R1);
-  issue(qi(2), R0);
+  // Chunk i of this stream is stream + n_streams * i.  Iteration c: request chunk c + 3 (register set (c + 1) & 1),
+  // contract chunk c (stage c % 3) | store it, commit chunk c + 2 (requested in iteration c - 1) to stage (c + 2) % 3.
+  // Staggered halves (p.stagger; measured: no gain — the CU's memory pipe, not the overlap of the parts, sets the pace — and
+  // off by default): a barrier between the two parts, and waves 4..7 — the SIMD partners of waves 0..3 — run one
+  // part behind (one extra barrier in front of their loop, one behind the loop of the others): a SIMD then always has one wave
+  // in its matrix part beside one in its memory part, instead of eight waves in lock step leaving each pipe idle in turn.
+  // Hazards (barrier intervals; waves 0..3 contract chunk c in 2c and commit in 2c + 1, waves 4..7 in 2c + 1 and 2c + 2):
+  // chunk c lands in stage c % 3 in intervals 2c - 3 / 2c - 2 and is first read in 2c; the stage's previous chunk c - 3 was
+  // last read in 2c - 5.  Without the stagger: one barrier per iteration, written in c - 2, read in c, previous read in c - 3.
+  // (p.ablate, development timing only: 1 no matrix instructions, 2 every store lane off, 4 every request lane off)
+  // THREE chunks in flight: chunk k travels in register set k % 3 and lands in LDS stage k % 3.  Iteration c requests chunk
+  // c + 4, contracts and stores chunk c, then commits chunk c + 2 — requested at the top of iteration c - 2, so a request has
+  // two whole iterations (and a store three) to complete: 96 KB of loads and 96 KB of stores per CU in flight.  (With two
+  // sets — 64 KB — loads-only and stores-only timings added up to the kernel's time: each was bound by its own queue depth
+  // times the memory latency, ~3 us under load.)
+  f32x4 R0[4], R1[4], R2[4];
+  const bool stag = p.stagger != 0, late = stag && wave >= 4;
+  constexpr int NST = 4;                               // stores of one epilogue (always issued; switched-off lanes still count)
+  constexpr int BEHIND = 3 * NST + 8;                  // issued behind a request when its commit waits for it: three epilogues' stores, two requests
+  Cursor ci = cursor_at(stream), ce = ci;              // request cursor (runs four chunks ahead), contraction / store cursor
+  // the loop waits for a request by counting what was issued behind it.  In front of the first iterations there are no
+  // epilogues yet: NST stores through an empty window (dropped by the range check, counted like any other) stand in for each,
+  // so that ONE count holds for every iteration (two wait statements on two branches made the compiler copy the in-flight
+  // registers between them)
+  auto standin = [&]() {
+    const u32x4 none = wx_rsrc(nullptr, 0);
+    const unsigned oob = CSN_OOB;
+#pragma unroll
+    for (int i = 0; i < NST; ++i)                            // (asm: identical stores through a builtin are merged into one)
+      asm volatile("buffer_store_dword %0, %0, %1, 0 offen" :: "v"(oob), "s"(none) : "memory");
+  };
+  issue(ci, R0); advance(ci);
+  issue(ci, R1); advance(ci);
+  wx_arrived<0>(R0);
+  wx_arrived<0>(R1);
+  commit(0, R0);
+  commit(1, R1);
+  issue(ci, R2); advance(ci);                          // chunk 2
+  standin();
+  issue(ci, R0); advance(ci);                          // chunk 3
+  standin();
   __syncthreads();
-  int st = 0;
-  for (int c = 0; qi(c) < n_chunks; c += 2) {
-    {
-      issue(qi(c + 3), R1);
-      const f32x16 acc = compute(st);
-      epilogue(qi(c), acc);
-      const int s2 = st == 0 ? 2 : st - 1;
-      commit(qi(c + 2), s2, R0);
-      st = st == 2 ? 0 : st + 1;
-      __syncthreads();
-    }
-    if (qi(c + 1) >= n_chunks) break;
-    {
-      issue(qi(c + 4), R0);
-      const f32x16 acc = compute(st);
-      epilogue(qi(c + 1), acc);
-      const int s2 = st == 0 ? 2 : st - 1;
-      commit(qi(c + 3), s2, R1);
-      st = st == 2 ? 0 : st + 1;
-      __syncthreads();
-    }
+  if (late) __syncthreads();
+  // one iteration: ST = c % 3 (compile time: the loop is unrolled by three), RQ the set chunk c + 4 goes to, RC the set of chunk c + 2
+  auto iteration = [&](auto st_c, f32x4* RQ, f32x4* RC) {
+    constexpr int ST = decltype(st_c)::value;
+    issue(ci, RQ); advance(ci);
+    const f32x16 acc = compute(ST);
+    if (stag) __syncthreads();
+    epilogue(ce, acc); advance(ce);
+    wx_arrived<BEHIND>(RC);
+    commit((ST + 2) % 3, RC);
+    __syncthreads();
+  };
+  while (true) {
+    if (ce.q >= n_chunks) break;
+    iteration(std::integral_constant<int, 0>{}, R1, R2);
+    if (ce.q >= n_chunks) break;
+    iteration(std::integral_constant<int, 1>{}, R2, R0);
+    if (ce.q >= n_chunks) break;
+    iteration(std::integral_constant<int, 2>{}, R0, R1);
   }
+  if (stag && !late) __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (requests beyond the last chunk: every lane off, nothing fetched)
 }
 
 int wx_grid() {
@@ -236,18 +324,21 @@ int wx_grid() {
 
 int csn_dev_wx = 1;      // development switch (csn_dev_set): 0 = these products on the tiled kernels of gemm_bf16x3.hip
 
-bool csn_wx_takes(int rows, int k) { return csn_dev_wx != 0 && k == WX_K && rows > 0 && rows % 256 == 0 && rows / 256 <= 32; }
+bool csn_wx_takes(int rows, int k) { return (csn_dev_wx & 1) != 0 && k == WX_K && rows > 0 && rows % 256 == 0 && rows / 256 <= 32; }
 
 
 int csn_launch_wx(const CsnWxArgs& a, int out_mode, hipStream_t st) {
   if (a.n_items <= 0 || a.n_points <= 0) return 0;
   if ((a.ldx & 3) || (a.ldo & 3) || (a.n_points & 3)) return -2;
   if (out_mode == 2 && (a.tb <= 0 || (a.tb & 3))) return -2;
-  if ((a.div_rows & 31) || (long long)a.n_items * ((a.n_points + WX_CH - 1) / WX_CH) + 4ll * wx_grid() >= (1ll << 31)) return -1;
+  if ((a.div_rows & 31) || ((long long)a.n_items * ((a.n_points + WX_CH - 1) / WX_CH + 16) + 4ll * wx_grid()) * 2 >= (1ll << 31)) return -1;
   const int grid = wx_grid();
   if ((grid >> 3) < a.n_sets) return -1;
-  if (out_mode == 0) hipLaunchKernelGGL((csn_wx_kernel<0>), dim3(grid), dim3(512), 0, st, a);
-  else if (out_mode == 2) hipLaunchKernelGGL((csn_wx_kernel<2>), dim3(grid), dim3(512), 0, st, a);
+  CsnWxArgs b = a;
+  b.stagger = (csn_dev_wx & 2) ? 1 : 0;
+  b.ablate = (csn_dev_wx >> 4) & 15;
+  if (out_mode == 0) hipLaunchKernelGGL((csn_wx_kernel<0>), dim3(grid), dim3(512), 0, st, b);
+  else if (out_mode == 2) hipLaunchKernelGGL((csn_wx_kernel<2>), dim3(grid), dim3(512), 0, st, b);
   else return -1;
   return (int)hipGetLastError();
 }

@@ -384,7 +384,8 @@ int csn_compat_bwd_f32(const float* dcomp, const float* comp, const double* save
  *   CSN_DEV_WIDE_GEMM   1   sixteen-wave form of the 256 x 256 tiles in the bf16x3 mode (0 off, 2: the one-plane modes too)
  *   CSN_DEV_WIDE_FORMS  7   bit set of the product forms that take it: 1 plain, 2 tile-plane B (dV / dK), 4 weight gradients
  *   CSN_DEV_WX          1   K = 256 weight products (projections, dCtx, out-projection + LayerNorm) of the bf16x3 mode on the
- *                           weight-stationary streaming kernel (0: on the tiled GEMM kernels) */
+ *                           weight-stationary streaming kernel (0: on the tiled GEMM kernels; 3: streaming with the two
+ *                           wave halves staggered; bits 4..6: timing-only ablations, results wrong) */
 #define CSN_DEV_BIG_TILES 0
 #define CSN_DEV_WIDE_GEMM 1
 #define CSN_DEV_WIDE_FORMS 2
