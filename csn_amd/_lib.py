@@ -116,6 +116,8 @@ _SIGNATURES = {
     "csn_get_thread_math_mode": (c_int, []),
     "csn_set_thread_act16": (c_int, [c_int]),
     "csn_get_thread_act16": (c_int, []),
+    "csn_set_thread_score_layout": (c_int, [c_int]),
+    "csn_get_thread_score_layout": (c_int, []),
     "csn_status_string": (c_char_p, [c_int]),
     "csn_dev_set": (c_int, [c_int, c_int]),
     "csn_dev_get": (c_int, [c_int]),

@@ -297,7 +297,10 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
   }
   // score positions of this lane: the scores of a block are stored [query][key] (pitch Tp), so the 8 consecutive keys
   // kt*32 + 8 kq .. + 7 of this lane's query are two 16-byte runs (half j = keys + 4 j .. + 3: all in or all out, T % 4 == 0)
-  const unsigned s_base = (unsigned)(qrow * Tp + 8 * kq) * 4u;
+  // (tile-major storage: tile kt of the block is [query][32 keys], Tq * 128 bytes per tile)
+  const bool tile_major = p.sc_layout != 0;
+  const unsigned s_base = tile_major ? (unsigned)(qrow * KT + 8 * kq) * 4u : (unsigned)(qrow * Tp + 8 * kq) * 4u;
+  const unsigned s_tile = tile_major ? (unsigned)Tq * (KT * 4u) : KT * 4u;      // bytes from one key tile to the next
 
   // ---- streamed tiles: global -> registers -> LDS (swizzled) ---------------------------------------
   // piece idx = tid + 512 i  ->  row tid / UPR + RPP i.  fp32 input: keys 4 c .. 4 c + 3, c = tid % 8.  Tile planes: 16-byte
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       j_ok[j] = kt * KT + 8 * kq + 4 * j < T;
-      s_voff[j] = (q_ok && j_ok[j]) ? s_base + (unsigned)(kt * KT + 4 * j) * 4u : CSN_OOB;
+      s_voff[j] = (q_ok && j_ok[j]) ? s_base + (unsigned)kt * s_tile + (unsigned)(16 * j) : CSN_OOB;
     }
   };
   auto load_sv = [&](int kt) {                          // backward: request the saved scores of tile kt early
@@ -565,7 +568,9 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
       if constexpr (NPL == 2) {
         // two planes: a row of 16 tiles is exactly the bytes of the fp32 score row — P overwrites the scores of this tile
         // (already consumed by this wave) in place, dS takes the same place in `dscores`
-        const unsigned tv = q_ok ? (unsigned)(qrow * Tp) * 4u + (unsigned)(kt * 128 + 16 * kq) : CSN_OOB;
+        const unsigned tv = !q_ok ? CSN_OOB
+                            : tile_major ? (unsigned)(kt * Tq + qrow) * 128u + (unsigned)(16 * kq)
+                                         : (unsigned)(qrow * Tp) * 4u + (unsigned)(kt * 128 + 16 * kq);
         csn_bstore4_stream(__builtin_bit_cast(f32x4, qh), Sr, tv);
         csn_bstore4_stream(__builtin_bit_cast(f32x4, ql), Sr, tv, 64u);
         csn_bstore4_stream(__builtin_bit_cast(f32x4, ph), dSr, tv);
@@ -784,6 +789,8 @@ int launch_any(const CsnAttnArgs& a, int d, bool bwd, hipStream_t st) {
   if ((a.T & 3) && a.kv_planes) return -2;                          // ragged key counts: fp32 K/V maps only
   if ((a.q_shape_stride & 3) || (a.kv_shape_stride & 3)) return -4;
   if (a.sc_tiles && a.Tp < (a.T + 31) / 32 * 32) return -2;
+  if (a.sc_layout && (PR::NPL != 2 || !a.kv_planes || a.Tq > 0 || a.tq_arr || a.t_arr || a.Tp < (a.T + 31) / 32 * 32 || (bwd && !a.sc_tiles)))
+    return -1;                                                      // tile-major scores: block mode, two planes, tile-plane K / V
   if (a.q2 && (!bwd || !a.kv_planes || (a.q2_shape_stride & 3))) return -1;
   if ((a.r_fmt || a.ctx_fmt || a.q2_fmt || a.out_fmt) && (PR::NPL != 1 || !a.kv_planes)) return -1;   // 16-bit maps: single-product modes
   if (a.out_fmt && a.accumulate) return -1;

@@ -20,6 +20,8 @@ inline bool grad16() { return (t_act16 & 4) != 0; }
 // forward entry points: the flag has to name the type of the mode that runs; backward: mode 2 takes either
 inline bool act16_fwd_ok() { return act16() == 0 || (act16() == 1 && mode() == 2) || (act16() == 2 && mode() == 3); }
 inline bool act16_bwd_ok() { return act16() == 0 || mode() == 2; }
+// score storage of the block-attention entry points (csn_set_thread_score_layout): 0 = [query][key] rows, 1 = tile-major
+thread_local int t_score_layout = 0;
 inline int planes_of(int m) { return m == 1 ? 2 : 1; }          // tile-plane / split-tensor planes of a 16-bit mode
 
 // the cross-length entry points (fp32 K / V maps) have no single-product kernels: in modes 2 / 3 they run as mode 1
@@ -153,6 +155,12 @@ int csn_set_thread_act16(int fmt) {
   return 0;
 }
 int csn_get_thread_act16(void) { return t_act16; }
+int csn_set_thread_score_layout(int layout) {
+  if (layout < 0 || layout > 1) return CSN_E_ARG;
+  t_score_layout = layout;
+  return 0;
+}
+int csn_get_thread_score_layout(void) { return t_score_layout; }
 
 const char* csn_status_string(int status) {
   switch (status) {
@@ -259,6 +267,10 @@ static int attn_fwd_impl(const float* q, const float* k, const float* v, long lo
     if (!act16_fwd_ok() || !qkv_split || block_q != 0) return CSN_E_ARG;
     a.r_fmt = a.out_fmt = act16();
   }
+  if (t_score_layout && scores) {                                    // tile-major scores: block mode, bf16x3, tile-plane K / V
+    if (mode() != 1 || !qkv_split || block_q != 0 || tq_arr || t_arr || score_pitch < (block + 31) / 32 * 32) return CSN_E_ARG;
+    a.sc_layout = 1;
+  }
   return mode() != 0 ? csn_launch_attn_fwd_bf16x3(a, d_head, mode(), (hipStream_t)stream)
                      : csn_launch_attn_fwd_f32(a, d_head, (hipStream_t)stream);
 }
@@ -349,6 +361,10 @@ static int attn_bwd_dq_impl(const float* dctx, const float* ctx, long long ctx_e
   a.sc_tiles = probs_tiles;
   a.tq_arr = tq_arr; a.t_arr = t_arr;
   a.q2 = q; a.q2_shape_stride = q_shape_stride; a.q2_index = q_index;
+  if (t_score_layout) {                                              // tile-major scores in, tile-major P / dS planes out
+    if (mode() != 1 || !kv_split || block_q != 0 || tq_arr || t_arr || !probs_tiles) return CSN_E_ARG;
+    a.sc_layout = 1;
+  }
   if (act16()) {                                                     // dO: bf16; O and Qs: the forward's 16-bit type; dQ stays fp32
     if (!act16_bwd_ok() || !kv_split || block_q != 0) return CSN_E_ARG;
     a.r_fmt = 1; a.ctx_fmt = act16(); a.q2_fmt = act16();
@@ -442,8 +458,12 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   const int ldb = one_plane ? score_pitch : bm * score_pitch;
   const float* p_src = one_plane ? dscores : probs;
   const float* ds_src = one_plane ? reinterpret_cast<const float*>(reinterpret_cast<const short*>(dscores) + blk_sc) : dscores;
+  // tile-major P / dS planes (csn_set_thread_score_layout): where the dV / dK products run on the 16-wave 256 x 256 kernel
+  const bool tile_major = t_score_layout != 0;
+  if (tile_major && (mode() != 1 || !probs_tiles || block_q != 0 || tq_arr || t_arr || !csn_gemm_tile_major_planes(d_head, bk4)))
+    return CSN_E_ARG;
   g.B = operand(p_src, bm * blk_sc, bm * blk_sc * n_blocks, bm * blk_sc * n_blocks * n_heads, nullptr, ldb);
-  g.B.planes = probs_tiles ? 2 : 0;
+  g.B.planes = probs_tiles ? (tile_major ? 3 : 2) : 0;
   const bool g16 = act16() && grad16();
   if (g16 && accumulate) return CSN_E_ARG;                            // a 16-bit gradient map is written once (grouped calls)
   g.C = operand(dv, block, (long long)d_head * lk, dkv_slot_stride, dv_index, lk);
@@ -454,7 +474,7 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   g.A.planes = q_split; g.A.plane_stride = q_plane_stride;
   if (act16()) g.A.fmt = act16() == 2 ? CSN_FMT_F16_TO_BF16 : CSN_FMT_16;   // Qs: the forward's 16-bit map
   g.B = operand(ds_src, bm * blk_sc, bm * blk_sc * n_blocks, bm * blk_sc * n_blocks * n_heads, nullptr, ldb);
-  g.B.planes = probs_tiles ? 2 : 0;
+  g.B.planes = probs_tiles ? (tile_major ? 3 : 2) : 0;
   g.C = operand(dk, block, (long long)d_head * lk, dkv_slot_stride, dk_index, lk);
   if (g16) g.C.planes = 1;
   return launch_gemm(g, 0, n_blocks * n_heads * n_batch, st);
@@ -478,7 +498,8 @@ int csn_attn_bwd_grouping(int d_head, int block) {
   const bool tiles_ok = mode() != 3 && block <= 512 && !(block & 3) && dim_ok(d_head);
   const bool recompute = tiles_ok && csn_attn_recompute_fits(planes_of(mode()), d_head / 32);
   const bool flash = recompute && csn_attn_dkv_flash_fits(d_head / 32);
-  return 1 | (csn_gemm_bf16x3_big_tiles(d_head, (block + 3) / 4 * 4) ? 2 : 0) | (recompute ? 4 : 0) | (flash ? 8 : 0);
+  const bool tm = mode() == 1 && tiles_ok && csn_gemm_tile_major_planes(d_head, (block + 3) / 4 * 4);
+  return 1 | (csn_gemm_bf16x3_big_tiles(d_head, (block + 3) / 4 * 4) ? 2 : 0) | (recompute ? 4 : 0) | (flash ? 8 : 0) | (tm ? 16 : 0);
 }
 
 int csn_block_attn_bwd_dkv_flash_f32(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,

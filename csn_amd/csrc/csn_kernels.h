@@ -30,6 +30,7 @@ struct CsnGemmArgs {
 
 int csn_launch_gemm_f32(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st);
 int csn_launch_gemm_bf16x3(const CsnGemmArgs& a, int b_is_nk, int batch, int mode, hipStream_t st);   // gemm_bf16x3.hip; mode 1 bf16x3, 2 bf16, 3 fp16
+int csn_gemm_tile_major_planes(int M, int N);         // 1: B.planes == 3 (tile-major tile planes, CsnAttnArgs::sc_layout) is available for an M x N output
 int csn_gemm_bf16x3_big_tiles(int M, int N);          // 1: an M x N output takes the 256 x 256 kernel (grouped accumulation available)
 int csn_launch_slab_reduce(const float* slab, float* out, int n_slabs, long long n, float alpha, int accumulate,
                            hipStream_t st);
@@ -91,6 +92,10 @@ struct CsnAttnArgs {
   // 16-bit activation maps (single-product modes): format of the register operand q (forward: Qs; backward: dO), of ctx (O),
   // of q2 and of out — 0 fp32, 1 bf16, 2 fp16; shape / evaluation strides then count 16-bit elements
   int r_fmt = 0, ctx_fmt = 0, q2_fmt = 0, out_fmt = 0;
+  // score storage (block mode, two planes, tile-plane K / V): 0 = [query][key] rows of pitch Tp; 1 = TILE-MAJOR, per block
+  // [key tile kt][query][32 keys] (the 128 bytes of a query's tile, fp32 scores or [hi 32 | lo 32] planes): what a wave stores
+  // or loads per instruction is then one contiguous run instead of sixteen 64-byte pieces 2 KB apart
+  int sc_layout = 0;
 };
 // score recomputation needs three LDS tile images per stage: one plane at every width, two planes up to d = 128
 constexpr bool csn_attn_recompute_fits(int planes, int dt) { return planes == 1 || dt <= 4; }

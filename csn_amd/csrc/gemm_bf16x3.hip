@@ -868,7 +868,7 @@ __global__ __launch_bounds__(1024, 4) void csn_gemm_bf16x3_wide_kernel(CsnGemmAr
     const char* b_base = BT ? reinterpret_cast<const char*>(reinterpret_cast<const short*>(p.B.ptr) + b_el)
                             : reinterpret_cast<const char*>(p.B.ptr) + (b_el + (B_NK ? (long long)n0 * ldb : (long long)n0)) * BES;
     Ar = csn_make_rsrc(a_base, (long long)BM * lda * 4);
-    Br = csn_make_rsrc(b_base, BT ? (long long)K * ldb * 2
+    Br = csn_make_rsrc(b_base, BT ? (long long)(p.B.planes == 3 ? p.K : K) * ldb * 2
                                   : (B_NK ? (long long)BN * ldb * BES : ((long long)(K - 1) * ldb + (N - n0)) * BES));
   };
   set_item(z2);
@@ -892,16 +892,30 @@ __global__ __launch_bounds__(1024, 4) void csn_gemm_bf16x3_wide_kernel(CsnGemmAr
   const int t_kr = tid >> 5, t_j = tid & 31;
   const int sw_dst = pr * BK + ((((pc >> 3) ^ ((pr >> 2) & 3)) << 3) | (pc & 4));     // rows 128 apart share the swizzle
   unsigned a_off[2], b_off[2];
-  int bt_dst[2];
+  int bt_dst[2], bt_row[2];
+  const bool b_tm = BT && p.B.planes == 3;              // tile-major tile planes (CsnAttnArgs::sc_layout)
+  const unsigned bt_kstep = b_tm ? (unsigned)(64 * NPL) : (unsigned)ldb * 2u;      // bytes from one k row to the next
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     a_off[i] = (m0 + pr + 128 * i) < M ? (unsigned)((pr + 128 * i) * lda + pc) * 4u : CSN_OOB;
-    bt_dst[i] = 0;
+    bt_dst[i] = 0; bt_row[i] = 0;
     if (BT) {
-      const int w = t_j + 32 * i, tl = w / (4 * NPL), within = w % (4 * NPL), t_u = within & 3;
-      b_off[i] = (i < NPL && (n0 + 32 * tl + 8 * t_u) < N)
-                     ? (unsigned)(t_kr * ldb) * 2u + (unsigned)(n0 >> 5) * (unsigned)(64 * NPL) + (unsigned)w * 16u : CSN_OOB;
-      bt_dst[i] = (within >> 2) * B_EL + t_kr * PN + 32 * tl + 8 * t_u;
+      if (b_tm) {
+        // tile-major planes: per block [key tile][k row = query][hi 32 | lo 32].  Unit u = tid + 1024 i of the slab's 32 rows x 8
+        // tiles x 4 NPL units: within the row's tile (u % (4 NPL)), row (next 5 bits), tile — a wave reads 8 rows of one tile,
+        // 1 KB in one piece
+        const int u = tid + 1024 * i, within = u % (4 * NPL), t_u = within & 3, q = (u / (4 * NPL)) & 31, tl = u / (128 * NPL);
+        b_off[i] = (i < NPL && (n0 + 32 * tl + 8 * t_u) < N)
+                       ? (unsigned)(((n0 >> 5) + tl) * p.K + q) * (unsigned)(64 * NPL) + (unsigned)within * 16u : CSN_OOB;
+        bt_dst[i] = (within >> 2) * B_EL + q * PN + 32 * tl + 8 * t_u;
+        bt_row[i] = q;
+      } else {
+        const int w = t_j + 32 * i, tl = w / (4 * NPL), within = w % (4 * NPL), t_u = within & 3;
+        b_off[i] = (i < NPL && (n0 + 32 * tl + 8 * t_u) < N)
+                       ? (unsigned)(t_kr * ldb) * 2u + (unsigned)(n0 >> 5) * (unsigned)(64 * NPL) + (unsigned)w * 16u : CSN_OOB;
+        bt_dst[i] = (within >> 2) * B_EL + t_kr * PN + 32 * tl + 8 * t_u;
+        bt_row[i] = t_kr;
+      }
     } else if (BF) b_off[i] = (i == 0 && (n0 + 8 * ku) < N) ? (unsigned)(kr2 * ldb + 8 * ku) * 2u : CSN_OOB;
     else if (B_NK) b_off[i] = (n0 + pr + 128 * i) < N ? (unsigned)((pr + 128 * i) * ldb + pc) * 4u : CSN_OOB;
     else b_off[i] = (n0 + kc) < N ? (unsigned)((kr + 16 * i) * ldb + kc) * 4u : CSN_OOB;
@@ -912,9 +926,8 @@ __global__ __launch_bounds__(1024, 4) void csn_gemm_bf16x3_wide_kernel(CsnGemmAr
 #pragma unroll
     for (int i = 0; i < 2; ++i) ra[i] = csn_bload4(Ar, a_off[i] | kp, (unsigned)k0 * 4u);
     if (BT) {
-      const unsigned kb = (k0 + t_kr) < K ? 0u : CSN_OOB;
 #pragma unroll
-      for (int i = 0; i < NPL; ++i) rb[i] = csn_bload4(Br, b_off[i] | kb, (unsigned)k0 * (unsigned)ldb * 2u);
+      for (int i = 0; i < NPL; ++i) rb[i] = csn_bload4(Br, b_off[i] | ((k0 + bt_row[i]) < K ? 0u : CSN_OOB), (unsigned)k0 * bt_kstep);
     } else if (BF) rb[0] = csn_bload4(Br, b_off[0] | ((k0 + kr2) < K ? 0u : CSN_OOB), (unsigned)k0 * (unsigned)ldb * 2u);
     else if (B_NK) {
 #pragma unroll
@@ -1111,6 +1124,8 @@ int csn_launch_outproj_ln_big(const CsnOutProjArgs& a, int mode, hipStream_t st)
 }
 
 int csn_gemm_bf16x3_big_tiles(int M, int N) { return (csn_gemm_big_tiles && M >= 192 && N >= 224) ? 1 : 0; }
+// 1: a dV / dK product of this shape can take its P / dS operand as TILE-MAJOR tile planes (bf16x3, 16-wave kernel)
+int csn_gemm_tile_major_planes(int M, int N) { return (csn_gemm_bf16x3_big_tiles(M, N) && csn_gemm_wide) ? 1 : 0; }
 
 namespace {
 // 16-bit activation maps as inputs (single-product modes): the combinations the step uses —
@@ -1144,8 +1159,8 @@ int launch_mode(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st) {
   // the 16-wave form of the 256 x 256 tiles: A fp32, C fp32 (or a 16-bit map in the accumulating-free plain case)
   if (csn_gemm_wide && (PR::NPL == 2 || csn_gemm_wide == 2) && big && a.C.planes != 2 && !a.A.fmt && (a.C.planes == 0 || PR::NPL == 1) &&
       !(a.C.planes && a.accumulate)) {
-    if (a.B.planes == 2) {
-      if (!b_is_nk && !(a.B.ld & 7) && (csn_gemm_wide_set & 2)) return launch_wide<PR, false, true, 0>(a, batch, st);
+    if (a.B.planes >= 2) {
+      if (!b_is_nk && !(a.B.ld & 7) && ((csn_gemm_wide_set & 2) || a.B.planes == 3)) return launch_wide<PR, false, true, 0>(a, batch, st);
     } else if (b_is_nk) {
       if (a.B.fmt == 0 && !a.grp_off && (csn_gemm_wide_set & 4)) return launch_wide<PR, true, false, 0>(a, batch, st);
     } else if (!a.grp_off && (csn_gemm_wide_set & 1)) {
@@ -1153,6 +1168,7 @@ int launch_mode(const CsnGemmArgs& a, int b_is_nk, int batch, hipStream_t st) {
       if constexpr (PR::NPL == 1) { if (a.B.fmt == 1) return launch_wide<PR, false, false, 1>(a, batch, st); }
     }
   }
+  if (a.B.planes == 3) return -1;                                   // tile-major planes: the 16-wave kernel only (csn_gemm_tile_major_planes)
   if (a.A.fmt || a.B.fmt) {
     if constexpr (PR::NPL == 1) {
       const int af = a.A.fmt, bf = a.B.fmt;

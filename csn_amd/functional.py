@@ -225,6 +225,23 @@ class act16:
         return False
 
 
+class score_layout:
+    """Bracket: the block-attention calls inside store their scores / P / dS planes tile-major (csn_set_thread_score_layout)."""
+
+    def __init__(self, layout: int):
+        self.layout = layout
+
+    def __enter__(self):
+        L = _lib.lib()
+        self.prev = L.csn_get_thread_score_layout()
+        _lib.check(L.csn_set_thread_score_layout(self.layout))
+        return self
+
+    def __exit__(self, *exc):
+        _lib.lib().csn_set_thread_score_layout(self.prev)
+        return False
+
+
 def _score_flow(mode: int, d: int, T: int) -> int:
     """The attention backward data flow (tuning.KEEP_SCORES / RECOMPUTE_DQ / FLASH) for a forward in `mode` at head width d and
     block T: the configured flow of the mode the BACKWARD runs in, where the library has kernels for it."""
@@ -406,14 +423,20 @@ class _MHAEvals(torch.autograd.Function):
         # attention backward data flow: keep the raw scores for it, or only lse (the backward then rebuilds S from Qs and K)
         flow = _score_flow(ctx.mode, d, T) if (keep_scores and tiles) else tuning.KEEP_SCORES
         scores = torch.empty((E, H, nb, T, Tp), device=dev, dtype=torch.float32) if (keep_scores and flow == tuning.KEEP_SCORES) else None
+        # score storage: tile-major where the whole chain (forward, grouped dQ call, grouped dK / dV products on the 256 x 256
+        # tiles) takes it — bf16x3 at d = 256 with kept scores; nothing outside this function reads the buffer
+        tune = tuning.current()
+        ctx.sc_layout = 1 if (scores is not None and tiles and ctx.mode == 1 and tune.tile_major_scores and tune.grouped_dq and
+                              tune.grouped_dkv and Tp >= (T + 31) // 32 * 32 and (L.csn_attn_bwd_grouping(d, T) & 19) == 19) else 0
         if sink is not None:
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record()
-        _lib.check(L.csn_block_attn_fwd_f32(q_ptr, k_ptr, v_ptr, q_stride, kv_stride,
-                                            _ptr(q_slots), _ptr(kv_slots), NP, _ptr(att), D * NP, _ptr(scores),
-                                            _ptr(lse), E, H, d, T, nb, Tp, RESCALE_THRESHOLD, p_attn, seed_attn,
-                                            kv_flag, kv_pitch, _stream()),
-                   "csn_block_attn_fwd_f32")
+        with score_layout(ctx.sc_layout):
+            _lib.check(L.csn_block_attn_fwd_f32(q_ptr, k_ptr, v_ptr, q_stride, kv_stride,
+                                                _ptr(q_slots), _ptr(kv_slots), NP, _ptr(att), D * NP, _ptr(scores),
+                                                _ptr(lse), E, H, d, T, nb, Tp, RESCALE_THRESHOLD, p_attn, seed_attn,
+                                                kv_flag, kv_pitch, _stream()),
+                       "csn_block_attn_fwd_f32")
         if sink is not None:
             ev1 = torch.cuda.Event(enable_timing=True)
             ev1.record()
@@ -465,7 +488,7 @@ class _MHAEvals(torch.autograd.Function):
                 dkv_once = ctx.flow == tuning.FLASH or (tune.grouped_dkv and (grouping & 2))
                 g16 = 4 if (dq_once and dkv_once) else 0
             ctx.g16 = g16
-            with act16(ctx.a16 + g16):
+            with act16(ctx.a16 + g16), score_layout(getattr(ctx, "sc_layout", 0)):
                 return _MHAEvals._backward(ctx, dxhat, dhead, dsums, dhandle)
 
     @staticmethod

@@ -28,6 +28,11 @@ class Tuning:
     grouped_dq: bool = True          # False: dQ likewise
     fused_compat_head: bool = True   # False: the compatibility head as torch ops (two nn.Linear, normalize, einsum, softmax)
     act16: bool = True               # bf16 / fp16 modes, linked mix: Qs, Ctx, xhat, dZ, dCtx between the launches as 16-bit maps
+    # bf16x3, kept scores: S and the P / dS planes stored [key tile][query][32 keys], so that every wave instruction that touches
+    # them moves 1 KB in one piece.  Measured +-0 over the config-3 step (27.69 vs 27.68 ms, profiles/r4k_ab_score_layout.txt):
+    # the 16-byte pieces 2 KB apart were not what the dQ kernel or the dV / dK products wait for.  Off; kept as the measured
+    # form (tests/test_gpu_score_layout.py holds it to the row-major step bit for bit)
+    tile_major_scores: bool = False
     # attention backward data flow by (math mode of the backward: 1 bf16x3, 2 bf16 — fp16 forwards run their backward in 2;
     # head width), or by mode alone; taken where the kernels have an instance for it (csn_attn_bwd_grouping bits 2 / 3),
     # KEEP_SCORES otherwise.  Measured per mode and width, DESIGN.md §4 "data flow A/B": at d = 256 the extra matrix products

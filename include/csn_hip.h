@@ -102,6 +102,15 @@ int csn_version(void);
  * bf16 anyway — the weight gradients are the same bits. */
 int csn_set_thread_act16(int fmt);
 int csn_get_thread_act16(void);
+/* SCORE STORAGE of the block-attention entry points (3), (3c), per calling thread.  0 (default): the scores of a block are
+ * [query][key] rows of pitch score_pitch — what a caller that reads probabilities expects.  1: TILE-MAJOR — per block
+ * [key tile of 32][query][32 keys]: the forward's scores, and the P / dS tile planes the backward hands from its dQ call to its
+ * dK / dV call, are then written and read in contiguous runs (a wave instruction moves 1 KB in one piece instead of sixteen
+ * 64-byte pieces 2 KB apart).  Same arithmetic, same buffer sizes; only meaningful when the three calls of one evaluation batch
+ * agree.  Taken where csn_attn_bwd_grouping reports bit 4 (bf16x3 mode, block mode, tile-plane K / V, probs_tiles = 1, the dK / dV
+ * products on the 256 x 256 tiles); CSN_E_ARG otherwise.  csn_amd sets it around the training step's three calls. */
+int csn_set_thread_score_layout(int layout);
+int csn_get_thread_score_layout(void);
 int csn_set_math_mode(int mode);
 int csn_set_thread_math_mode(int mode);
 int csn_get_math_mode(void);
@@ -171,7 +180,7 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
  * results are accumulated in registers and its slot is written once — one call for all evaluations instead of one
  * read-modify-write pass per colour.  csn_attn_bwd_grouping() says where that is available in the current math mode:
  * bit 0 = the dq call, bit 1 = the dkv call, bit 2 = csn_block_attn_bwd_dq_recompute_f32, bit 3 =
- * csn_block_attn_bwd_dkv_flash_f32 (both below).
+ * csn_block_attn_bwd_dkv_flash_f32 (both below), bit 4 = tile-major score storage (csn_set_thread_score_layout).
  *
  * csn_block_attn_bwd_dq_recompute_f32 — the dq call WITHOUT saved scores ("flash" data flow; math modes 1 and 2, K / V as tile
  * planes, block mode): the forward is run with scores = NULL (only lse is kept) and this call rebuilds S = Qs K^T tile by tile

@@ -2,7 +2,8 @@
 """The whole training step (forward + masked cross-entropy + backward, train mode) under several settings of the library's
 development switches (csn_dev_set, include/csn_hip.h), interleaved in one process: median ms per step per variant, the loss, and
 whether the gradients equal those of the first variant bit for bit.
-    python scripts/ab_step.py --config 3 --math bf16x3 --variants "tiled:3=0;streaming:3=1"      (3 = CSN_DEV_WX)"""
+    python scripts/ab_step.py --config 3 --math bf16x3 --variants "tiled:3=0;streaming:3=1"      (3 = CSN_DEV_WX)
+A setting `name=value` with a non-numeric name flips a switch of csn_amd.tuning instead ("rows:tile_major_scores=0;tiles:")."""
 import argparse
 import os
 import sys
@@ -46,11 +47,14 @@ def step():
 variants = []
 for spec in a.variants.split(";"):
     name, _, kv = spec.partition(":")
-    variants.append((name, [tuple(int(v) for v in item.split("=")) for item in kv.split(",") if item]))
-defaults = {k: L.csn_dev_get(k) for _, kvs in variants for k, _ in kvs}
-res, losses, grads = {n: [] for n, _ in variants}, {}, {}
+    items = [item.split("=") for item in kv.split(",") if item]
+    variants.append((name, [(int(k), int(v)) for k, v in items if k.isdigit()], {k: bool(int(v)) for k, v in items if not k.isdigit()}))
+defaults = {k: L.csn_dev_get(k) for _, kvs, _ in variants for k, _ in kvs}
+from csn_amd import tuning  # noqa: E402
+res, losses, grads = {n: [] for n, _, _ in variants}, {}, {}
 for r in range(a.rounds):
-    for name, kvs in variants:
+  for name, kvs, tun in variants:
+    with tuning.override(**tun):
         for k, v in defaults.items():
             L.csn_dev_set(k, v)
         for k, v in kvs:
@@ -69,7 +73,7 @@ for r in range(a.rounds):
 for k, v in defaults.items():
     L.csn_dev_set(k, v)
 first = variants[0][0]
-for name, _ in variants:
+for name, _, _ in variants:
     same = all(torch.equal(g, h) for g, h in zip(grads[name], grads[first]))
     worst = max(((g - h).abs().max() / h.abs().max().clamp_min(1e-30)).item() for g, h in zip(grads[name], grads[first]))
     print(f"config {a.config} {a.math:7s} {name:>16s}: median {np.median(res[name]):7.3f} ms/step  ({' '.join(f'{v:.2f}' for v in res[name])})  "
