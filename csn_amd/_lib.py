@@ -58,7 +58,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # several ranks may import the package at once (mp.spawn in the tests, torchrun): one of them builds, the others wait
     # on the lock and find the library current when they get it
     import fcntl
-    with open(os.path.join(_HERE, ".build.lock"), "w") as lock:
+    import tempfile
+    lock_path = os.path.join(_HERE, ".build.lock")                 # (git-ignored; opened for append: nothing is truncated)
+    if not os.access(_HERE, os.W_OK):
+        lock_path = os.path.join(tempfile.gettempdir(), "csn_amd_build_" + hashlib.sha256(_HERE.encode()).hexdigest()[:16] + ".lock")
+    with open(lock_path, "a") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
             if not force and not _stale():

@@ -420,7 +420,9 @@ class CrossShapeAt(nn.Module):
         descriptors are concatenated neighbour-major (rows k*B + b, :213,:220) and then re-viewed as
         (B, K+1, C) (:227).  ``"per_shape"`` scores every shape against its own neighbours."""
         B, K1, C = pooled.shape
-        if pooled.is_cuda and tuning.current().fused_compat_head and C <= 256 and K1 <= 8:
+        f32 = all(t.dtype == torch.float32 for t in (pooled, self.compatibility_q.weight, self.compatibility_q.bias,
+                                                     self.compatibility_k.weight, self.compatibility_k.bias))
+        if pooled.is_cuda and f32 and tuning.current().fused_compat_head and C <= 256 and K1 <= 8:
             # one launch forward, two backward (csn_compat_fwd_f32 / _bwd_f32) instead of ~45 small library launches per step
             return CF.compat_head(pooled, self.compatibility_q.weight, self.compatibility_q.bias, self.compatibility_k.weight,
                                   self.compatibility_k.bias, self.compat_layout == "reference")

@@ -167,10 +167,15 @@ class DeviceFeatureCache:
         return self.feats.shape[0]
 
     def _local(self, ids) -> torch.Tensor:
-        ids = torch.as_tensor(ids, dtype=torch.int64, device=self.device).reshape(-1)
-        if ids.numel() and (int(ids.min()) < self.first or int(ids.max()) >= self.first + len(self)):
+        """Cache-local row numbers of global shape ids, on the device.  The range check runs on the HOST copy of the ids (numpy /
+        lists / CPU tensors: every caller in this package) — reading min / max of a device tensor would stall the launch thread
+        once per step, under the exchange it is meant to overlap; ids that already live on the device are taken as checked."""
+        if isinstance(ids, torch.Tensor) and ids.is_cuda:
+            return ids.reshape(-1).to(torch.int64) - self.first
+        host = np.asarray(ids.cpu() if isinstance(ids, torch.Tensor) else ids, dtype=np.int64).reshape(-1)
+        if host.size and (host.min() < self.first or host.max() >= self.first + len(self)):
             raise IndexError("shape id outside this cache's owned range: fetch it through the exchange of csn_amd.sharding")
-        return ids - self.first
+        return torch.from_numpy(host - self.first).to(self.device)
 
     def batch(self, ids):
         """(feats (B, C, N, 1), labels (B, N)) of the given shape ids — what FeaturesDataset / the first two items of

@@ -43,12 +43,21 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _need_cuda(*ts):
+def _need_f32(*ts, also=()):
+    for t in ts:
+        if t is not None and t.dtype not in (torch.float32, torch.int32) and t.dtype not in also:
+            raise _lib.CsnError(f"csn_amd ops take fp32 tensors (got {t.dtype}): convert with .float() — nothing here casts silently")
+
+
+def _need_cuda(*ts, also=()):
+    """The one gate in front of the raw-pointer calls: fp32 (int32 for index arrays) tensors on the device, nothing else — the
+    library reads its operands as fp32 words, so a half or double tensor would be reinterpreted, not converted (and a half
+    buffer read as fp32 runs past its allocation).  ``also``: the 16-bit map types a call site legitimately hands over
+    (bf16 gradient maps, fp16 normalised maps of the 16-bit exchange).  Types are checked before devices."""
+    _need_f32(*ts, also=also)
     for t in ts:
         if t is not None and not t.is_cuda:
             raise _lib.CsnError("csn_amd ops need tensors on the MI355X (cuda) device; there is no CPU path")
-        if t is not None and t.dtype not in (torch.float32, torch.int32, torch.bfloat16, torch.float16, torch.float64):
-            raise _lib.CsnError(f"csn_amd ops are fp32 (got {t.dtype})")
 
 
 KERNEL_HEAD_WIDTHS = (32, 64, 96, 128, 256)        # instances of the fused attention kernels (csrc/csn_capi.hip dim_ok)
@@ -271,7 +280,9 @@ def project(x: torch.Tensor, w: torch.Tensor, div_rows: int = 0, temperature: fl
             n_points: Optional[int] = None, split: bool = False) -> torch.Tensor:
     """x (S, C, N), w (R, C)  ->  (S, R, n_points) = w @ x[s]; rows < div_rows divided by temperature.
     split=True (fast math only): the result is returned as bf16 planes (S, 2, R, n_points), x = hi + lo."""
-    _need_cuda(x, w)
+    _need_f32(w)
+    _need_cuda(x, also=(torch.bfloat16,))                          # (a bf16 gradient map of math mode 2)
+    _need_cuda(w)
     S, C, N = x.shape
     R = w.shape[0]
     npts = N if n_points is None else n_points
@@ -291,7 +302,9 @@ def project(x: torch.Tensor, w: torch.Tensor, div_rows: int = 0, temperature: fl
 
 def project_wgrad(dout: torch.Tensor, x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     """dout (S, R, NP), x (S, C, N>=NP) -> dw (R, C) = scale * sum_s dout[s] @ x[s][:, :NP]^T."""
-    _need_cuda(dout, x)
+    _need_f32(x)
+    _need_cuda(dout, also=(torch.bfloat16,))                       # (bf16 gradient maps of the 16-bit exchange)
+    _need_cuda(x)
     S, R, NP = dout.shape
     C, N = x.shape[1], x.shape[2]
     assert dout.is_contiguous() and x.stride(2) == 1 and x.stride(1) == N
@@ -347,6 +360,9 @@ class _MHAEvals(torch.autograd.Function):
         if mode >= 2 and geo.block > 512:
             mode = 1                                   # the single-product kernels take K / V as tile planes (blocks <= 512 keys)
         ctx.mode = mode
+        # the switches as they stand NOW: the backward (another thread, possibly after an override() block has ended) reads this
+        # snapshot, never the live object — forward and backward of one step always agree (tuning.override is not thread-safe)
+        ctx.tune = tuning.current()
         # 16-bit activation maps: Qs, Ctx, xhat (and in the backward dZ, dCtx) travel between the launches as one 16-bit plane.
         # Only where nothing outside this file reads the maps: the linked form (the mix and the pooled sums consume xhat in
         # kernels, gradients arrive through the link), tile-plane K / V
@@ -482,7 +498,7 @@ class _MHAEvals(torch.autograd.Function):
             # 16-bit maps: the gradient maps dQ / dK / dV too, where every slot is written once (grouped calls, flash)
             g16 = 0
             if ctx.a16:
-                geo, tune = ctx.geo, tuning.current()
+                geo, tune = ctx.geo, ctx.tune
                 grouping = _lib.lib().csn_attn_bwd_grouping(geo.d_head, geo.block)
                 dq_once = ctx.flow != tuning.KEEP_SCORES or (tune.grouped_dq and (grouping & 1))
                 dkv_once = ctx.flow == tuning.FLASH or (tune.grouped_dkv and (grouping & 2))
@@ -592,8 +608,8 @@ class _MHAEvals(torch.autograd.Function):
             k_ptr = q_ptr + 4 * D * NP
             v_ptr = q_ptr + 4 * (2 * D * NP + plan.v_shift * kv_stride)
         grouping = L.csn_attn_bwd_grouping(d, T)
-        tune = tuning.current()
-        sink = tune.event_sink
+        tune = ctx.tune                                              # the forward's snapshot
+        sink = tuning.current().event_sink
         if sink is not None:
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record()
@@ -827,7 +843,9 @@ class _CSAMixLinked(torch.autograd.Function):
     def forward(ctx, handle, handle_self, comp, gamma, beta, B: int, K1: int, maps: LinkedMaps, maps_self):
         xhat = maps.maps
         xself = None if maps_self is None else maps_self.maps
-        _need_cuda(xhat, comp, gamma, beta, xself)
+        _need_f32(comp, gamma, beta)
+        _need_cuda(xhat, xself, also=(torch.float16,))                               # (fp16 normalised maps of the 16-bit exchange)
+        _need_cuda(comp, gamma, beta)
         E, C, NP = xhat.shape
         assert xhat.is_contiguous() and E == B * (K1 if xself is None else K1 - 1)
         assert xself is None or (xself.is_contiguous() and xself.shape == (B, C, NP))

@@ -211,7 +211,7 @@ class BatchExchangePlan:
     """What one training step of one rank moves: the rank's batch (global shape ids), the owned shapes it sends to each other
     rank, what it receives, and where every slot of its (B, K+1) neighbour stack comes from — the rank's own cache or the
     receive pool.  A pure function of (the step's batches of ALL ranks, the neighbour table, the ownership ranges)."""
-    __slots__ = ("ids", "send_local", "send_splits", "recv_splits", "n_recv", "rows_local", "src_local", "rows_remote",
+    __slots__ = ("ids", "ids_local", "send_local", "send_splits", "recv_splits", "n_recv", "rows_local", "src_local", "rows_remote",
                  "src_remote", "B", "K")
 
 
@@ -285,7 +285,10 @@ class ResidentCollection:
         """The steps of one epoch: a list of steps, each a list over ranks of B global shape ids owned by that rank.  Every rank
         walks ITS shapes (in a permutation drawn from (seed, epoch, rank) when shuffling); the number of steps is that of the
         rank with the most shapes, ranks with fewer wrap around — every rank runs every step (the collectives line up) with a
-        full batch."""
+        full batch.  Consequences, stated rather than hidden: ownership differs by at most one shape per rank (split_bounds), so
+        a rank with fewer shapes revisits at most batch_size - 1 + 1 of them in the epoch's last step, and the value
+        train_layers_sharded returns is the mean over this rank's STEPS, not over distinct shapes.  batch_size above the smallest
+        ownership makes that rank's batches repeat shapes INSIDE a batch: allowed, with a warning."""
         per_rank = []
         for r in range(self.world):
             own = np.arange(self.bounds[r], self.bounds[r + 1])
@@ -294,6 +297,14 @@ class ResidentCollection:
             if shuffle:
                 own = np.random.default_rng([seed, epoch, r]).permutation(own)
             per_rank.append(own)
+        short = [r for r, o in enumerate(per_rank) if o.size < batch_size]
+        if short and not getattr(self, "_warned_short", False):
+            # a wrap-around inside ONE batch puts the same shape into it more than once: legal (the collectives still line up,
+            # the replicas stay identical) but that rank's loss and gradient weigh the repeated shapes more — say so, once
+            import warnings
+            warnings.warn(f"batch_size {batch_size} exceeds the {min(o.size for o in per_rank)} shapes rank {short[0]} owns: its "
+                          "batches repeat shapes (loss and gradients of that rank weigh them accordingly)", stacklevel=2)
+            self._warned_short = True
         n_steps = max((o.size + batch_size - 1) // batch_size for o in per_rank)
         steps = []
         for t in range(n_steps):
@@ -321,6 +332,7 @@ class ResidentCollection:
         p = BatchExchangePlan()
         ids = np.asarray(batches[me], dtype=np.int64)
         p.ids, p.B, p.K = ids, int(ids.size), self.K
+        p.ids_local = torch.from_numpy(ids - lo).to(self.device)           # validated above on the host: batch() needs no sync
         p.send_local = torch.from_numpy(np.concatenate([need[r][me] - lo for r in range(self.world)])).to(self.device)
         p.send_splits = [int(need[r][me].size) for r in range(self.world)]
         p.recv_splits = [int(need[me][src].size) for src in range(self.world)]
@@ -342,7 +354,10 @@ class ResidentCollection:
 
     def batch(self, plan: BatchExchangePlan):
         """(feats (B, C, N, 1), labels (B, N)) of the rank's batch — what the model and the loss take."""
-        return self.cache.batch(plan.ids)
+        loc = getattr(plan, "ids_local", None)
+        if loc is None:
+            return self.cache.batch(plan.ids)
+        return self.cache.feats.index_select(0, loc).unsqueeze(-1), self.cache.labels.index_select(0, loc)
 
     def exchange_async(self, plan: BatchExchangePlan) -> PendingBatchStack:
         """Start the step's neighbour-only all-to-all (uneven per-step splits) and return at once."""
@@ -375,14 +390,20 @@ class ResidentCollection:
         """The weight gradients summed (or averaged) over the ranks in one bucket, as ShapeGraphShard.allreduce_grads."""
         if self.world == 1:
             return
-        plist = [p for p in params if p.grad is not None]
-        flat = torch.cat([p.grad.reshape(-1) for p in plist])
+        # the bucket covers EVERY parameter handed in, a missing gradient as zeros: its size is then the same on every rank by
+        # construction (a bucket of "whoever has a grad" hangs or corrupts the collective the day the sets differ)
+        plist = list(params)
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in plist])
         dist.all_reduce(flat, group=self.group)
         if average:
             flat /= self.world
         off = 0
         for p in plist:
-            p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
+            piece = flat[off:off + p.numel()].view_as(p)
+            if p.grad is None:
+                p.grad = piece.clone()
+            else:
+                p.grad.copy_(piece)
             off += p.numel()
 
 

@@ -126,14 +126,16 @@ def train_layers(model, dataloader: Iterable, optimizer, num_class: int, device,
 
 
 def train_layers_sharded(model, collection, optimizer, num_class: int, batch_size: int, epoch: int = 0, shuffle: bool = True,
-                         seed: int = 0, max_steps: Optional[int] = None, steps=None) -> float:
+                         seed: int = 0, max_steps: Optional[int] = None, steps=None, reference_semantics: bool = True) -> float:
     """One epoch of ``train_layers`` (csa_training.py:191-222, one optimizer step per batch) over a collection that is resident
     across the ranks of a torch.distributed job (csn_amd.sharding.ResidentCollection): every rank trains on mini-batches of
     ``batch_size`` shapes it owns, the batch's neighbour features arrive through the step's neighbour-only exchange — in
     flight under the self-attention of the batch's own shapes — and the weight gradients are averaged over the ranks before
     the optimizer step, so all replicas stay identical.  With world = 1 this is the single-process loop over the same
     batches.  ``steps``: an explicit list of steps (each a list over ranks of shape ids) instead of the epoch's sampler.
-    Returns the mean loss of this rank's batches (accumulated on the device, read back once)."""
+    Returns the mean loss of this rank's batches (accumulated on the device, read back once; NaN losses are left out of it, as in
+    train_layers).  ``reference_semantics`` as in train_layers: True reproduces the reference's NaN "guard" as written (the NaN
+    reaches the gradients — and through the all-reduce every rank), False zeroes the gradients of a NaN batch on its rank."""
     model.train()
     steps = collection.epoch_batches(batch_size, epoch, shuffle, seed) if steps is None else steps
     if max_steps is not None:
@@ -147,10 +149,19 @@ def train_layers_sharded(model, collection, optimizer, num_class: int, batch_siz
         optimizer.zero_grad()
         out = model(feats, "train", pending)                   # own-shape self-attention first, then pending.wait()
         loss, _ = loss_functions_seg(out, label, num_class)
-        loss.backward()
+        bad = torch.isnan(loss)
+        total += torch.where(bad, torch.zeros_like(loss), loss).detach().double()     # the running loss skips NaN (:206-209)
+        if reference_semantics:
+            torch.where(bad, loss * 0.0, loss).backward()      # :206-207 as written: NaN * 0 is NaN — the step is poisoned, as there
+        else:
+            # repaired: a NaN batch contributes a zero gradient on its rank (decided on the device: every rank still runs the
+            # backward and the collective, so the ranks stay in step)
+            torch.where(bad, torch.zeros_like(loss), loss).backward()
+            for p in params:
+                if p.grad is not None:
+                    p.grad.nan_to_num_(nan=0.0, posinf=0.0, neginf=0.0)
         collection.allreduce_grads(params, average=True)
         optimizer.step()
-        total += loss.detach().double()
     return float(total.item()) / max(len(steps), 1)
 
 

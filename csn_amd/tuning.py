@@ -58,7 +58,9 @@ def current() -> Tuning:
 
 @contextlib.contextmanager
 def override(**changes):
-    """``with tuning.override(grouped_dq=False): ...`` — the switches inside the block, the previous ones after it."""
+    """``with tuning.override(grouped_dq=False): ...`` — the switches inside the block, the previous ones after it.
+    NOT thread-safe: the object is process-wide and swapped without a lock.  A step is safe against it all the same — every
+    forward snapshots the switches into its autograd context and its backward reads only that snapshot."""
     global _current
     names = {f.name for f in fields(Tuning)}
     unknown = set(changes) - names

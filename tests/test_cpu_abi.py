@@ -114,3 +114,25 @@ def test_eval_plan_colours_and_groups_cover_the_same_sharing():
         assert all(len(s) == 1 for s in group_slots)                                 # one slot per group ...
         assert len(set.union(*group_slots)) == n == len(set(slots.tolist()))         # ... and one group per slot
     assert plan.n_q_groups == B * K1 and int(np.diff(plan.q_group_off.numpy()).max()) == K1 + 1    # own slots: K+2 evaluations
+
+
+def test_half_and_double_tensors_are_refused_before_any_pointer_is_taken():
+    """The library reads its operands as fp32 words: a half or double tensor must be refused, not reinterpreted (a half buffer
+    read as fp32 runs past its allocation).  The gate checks the type before the device, so this runs without a GPU."""
+    from csn_amd import CsnError
+    from csn_amd import functional as CF
+    for bad in (torch.float16, torch.float64, torch.bfloat16, torch.int64):
+        with pytest.raises(CsnError, match="fp32"):
+            CF._need_cuda(torch.zeros(4, dtype=bad))
+    with pytest.raises(CsnError, match="fp32"):
+        CF.project(torch.zeros(1, 4, 4, dtype=torch.float64), torch.zeros(4, 4))
+    with pytest.raises(CsnError, match="fp32"):
+        CF.project(torch.zeros(1, 4, 4), torch.zeros(4, 4, dtype=torch.float16))
+    with pytest.raises(CsnError, match="fp32"):
+        CF.compat_head(torch.zeros(1, 2, 4, dtype=torch.float64), torch.zeros(4, 4), torch.zeros(4), torch.zeros(4, 4), torch.zeros(4))
+    # the call sites that carry 16-bit maps by design name the type they take, and only that one
+    CF._need_cuda(None)
+    with pytest.raises(CsnError, match="cuda"):
+        CF._need_cuda(torch.zeros(4, dtype=torch.bfloat16), also=(torch.bfloat16,))      # type accepted, device refused
+    with pytest.raises(CsnError, match="fp32"):
+        CF._need_cuda(torch.zeros(4, dtype=torch.float16), also=(torch.bfloat16,))
