@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libcsn_hip.so")
 SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "wx_stream.hip", "attn_f32.hip", "attn_bf16x3.hip", "attn_dkv.hip", "outproj_ln.hip", "retrieval.hip", "combine.hip", "compat.hip", "csn_capi.hip"]
-HEADERS = ["csn_common.h", "csn_kernels.h", os.path.join("..", "..", "include", "csn_hip.h")]
+HEADERS = ["csn_common.h", "csn_kernels.h", "csn_window.h", os.path.join("..", "..", "include", "csn_hip.h")]
 ARCH = "gfx950"
 BUILD_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared"]
 

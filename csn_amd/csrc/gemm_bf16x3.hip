@@ -25,6 +25,7 @@
 // 32 elements (block pitch 512 instead of 1024).  Template parameter PR = csn_mode::{Bf16x3, Bf16, F16} (csn_common.h).
 #include "csn_common.h"
 #include "csn_kernels.h"
+#include "csn_window.h"
 
 // -DCSN_STAMPS: development build that records s_memtime after the prologue, the main loop and the epilogue of every
 // work-group (scripts/gemm_stamps.py)
@@ -116,9 +117,9 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   char* c_base = reinterpret_cast<char*>(p.C.ptr) + (p.C.s0 * z0 + p.C.s1 * z1 + p.C.s2 * (long long)(p.C.idx2 ? p.C.idx2[z2] : z2) + (long long)m0 * ldc + (c_tiles ? 0 : n0)) * c_es;
   const long long c_win = (long long)BM * ldc * c_es;
   // (16-bit k-contiguous maps: the window ends with the last valid row's K elements, see the 256 x 256 kernel)
-  const csn_rsrc_t Ar = csn_make_rsrc(a_base, AF ? ((long long)(min(BM, M - m0) - 1) * lda + K) * AES : (long long)BM * lda * AES);
+  const csn_rsrc_t Ar = csn_make_rsrc(a_base, AF ? csn_kwin_bytes(min(BM, M - m0), lda, K, AES) : (long long)BM * lda * AES);
   const csn_rsrc_t Br = csn_make_rsrc(b_base, BT ? (long long)K * ldb * 2
-                                                 : (B_NK ? (BF ? ((long long)(min(BN, N - n0) - 1) * ldb + K) * BES : (long long)BN * ldb * BES)
+                                                 : (B_NK ? (BF ? csn_kwin_bytes(min(BN, N - n0), ldb, K, BES) : (long long)BN * ldb * BES)
                                                          : ((long long)(K - 1) * ldb + (N - n0)) * BES));
   const csn_rsrc_t Cr = csn_make_rsrc(c_base, c_win), Crl = csn_make_rsrc(c_base + p.C.plane_stride * 2, c_pl ? c_win : 0);
 
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   f32x4 ra[A_PASS], rb[B_PASS];
   auto load_slab = [&](int k0) {
     const unsigned kp = (k0 + pc) < K ? 0u : CSN_OOB;
-    const unsigned kp16 = (k0 + 8 * pu) < K ? 0u : CSN_OOB;
+    const unsigned kp16 = csn_unit_starts_inside(k0 + 8 * pu, K) ? 0u : CSN_OOB;
     if (AF) {
 #pragma unroll
       for (int i = 0; i < A16_PASS; ++i) ra[i] = csn_bload4(Ar, a_off[i] | kp16, (unsigned)k0 * 2u);
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void csn_gemm_bf16x3_kernel(CsnGemmArgs p) 
   };
   auto unit16 = [&](f32x4 v, int fmt, int k0) {            // (see the 256 x 256 kernel)
     if (fmt == CSN_FMT_F16_TO_BF16) v = f16x8_to_bf16x8(v);
-    if (k0 + 8 * pu + 8 > K) { v[2] = 0.f; v[3] = 0.f; }
+    if (csn_unit_upper_half_beyond(k0 + 8 * pu, K)) { v[2] = 0.f; v[3] = 0.f; }
     return v;
   };
   auto store_slab = [&](int st, int k0) {
@@ -456,9 +457,9 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
                             : reinterpret_cast<const char*>(p.B.ptr) + (b_el + (B_NK ? (long long)n0 * ldb : (long long)n0)) * BES;
     // (16-bit k-contiguous maps: the window ends with the last valid row's K elements — a 16-byte unit may straddle the end
     //  of the contraction, and behind the last row of the last item there is no memory; dwords beyond the window read as 0)
-    Ar = csn_make_rsrc(a_base, AF ? ((long long)(min(BM, M - m0) - 1) * lda + K) * AES : (long long)BM * lda * AES);
+    Ar = csn_make_rsrc(a_base, AF ? csn_kwin_bytes(min(BM, M - m0), lda, K, AES) : (long long)BM * lda * AES);
     Br = csn_make_rsrc(b_base, BT ? (long long)K * ldb * 2
-                                  : (B_NK ? (BF ? ((long long)(min(BN, N - n0) - 1) * ldb + K) * BES : (long long)BN * ldb * BES)
+                                  : (B_NK ? (BF ? csn_kwin_bytes(min(BN, N - n0), ldb, K, BES) : (long long)BN * ldb * BES)
                                           : ((long long)(K - 1) * ldb + (N - n0)) * BES));
   };
   set_item(z2);
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
   f32x4 ra[4], rb[4];
   auto load_slab = [&](int k0) {
     const unsigned kp = (k0 + pc) < K ? 0u : CSN_OOB;
-    const unsigned kp16 = (k0 + 8 * pu) < K ? 0u : CSN_OOB;
+    const unsigned kp16 = csn_unit_starts_inside(k0 + 8 * pu, K) ? 0u : CSN_OOB;
     if (AF) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) ra[i] = csn_bload4(Ar, a_off[i] | kp16, (unsigned)k0 * 2u);
@@ -540,7 +541,7 @@ __global__ __launch_bounds__(512, 2) void csn_gemm_bf16x3_big_kernel(CsnGemmArgs
   // a k-contiguous 16-bit unit of slab k0: converted if need be, its upper half cleared when the contraction ends inside it
   auto unit16 = [&](f32x4 v, int fmt, int k0) {
     if (fmt == CSN_FMT_F16_TO_BF16) v = f16x8_to_bf16x8(v);
-    if (k0 + 8 * pu + 8 > K) { v[2] = 0.f; v[3] = 0.f; }
+    if (csn_unit_upper_half_beyond(k0 + 8 * pu, K)) { v[2] = 0.f; v[3] = 0.f; }
     return v;
   };
   auto store_slab = [&](int st, int k0) {

@@ -43,7 +43,9 @@ def main():
     fwd = a.pairs * (2 * C * D * (a.lq + 2 * a.lk) + 4 * a.lq * a.lk * D + 2 * a.lq * D * C)
     print(f"mode {'bf16x3' if a.mode else 'fp32'}: {a.pairs} pairs, {a.lq} x {a.lk} points, H={H}, d_model={C}: {ms:7.3f} ms per fwd+bwd "
           f"(train mode, gradients to q, k, v and weights) = {a.pairs * a.lq / ms / 1e3:6.2f} M query points/s, "
-          f"{3 * fwd / ms / 1e9:6.1f} TFLOP/s algorithmic (3 x forward matmul FLOPs)")
+          f"{3 * fwd / ms / 1e9:6.1f} TFLOP/s algorithmic (3 x forward matmul FLOPs) = {3 * fwd / ms / 1e9 / (2500.0 if a.mode else 157.3):.4f} of the "
+          f"{'2.5 PFLOP/s bf16 matrix peak (the pipe sees 3 x that: three products per FLOP)' if a.mode else '157.3 TFLOP/s fp32 matrix peak'}; "
+          f"attention products alone (4 Lq Lk d per pair and pass, x 3 passes): {3 * a.pairs * 4.0 * a.lq * a.lk * D / ms / 1e9:6.1f} TFLOP/s")
     _lib.lib().csn_set_math_mode(0)
 
 

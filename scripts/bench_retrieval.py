@@ -15,5 +15,6 @@ for _ in range(3):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / 3 * 1e3
 fl = 2.0 * S * S * N * N * C
-print(f"retrieval measure {S} x {S} shapes of {N} points: {ms:8.2f} ms = {S * S / ms * 1e3:7.1f} shape pairs/s, {fl / ms / 1e9:6.1f} TFLOP/s "
-      f"(fp32 matrix peak 157.3), diag {r.diag().mean().item():.6f}")
+tf = fl / ms / 1e9
+print(f"retrieval measure {S} x {S} shapes of {N} points: {ms:8.2f} ms = {S * S / ms * 1e3:7.1f} shape pairs/s, {tf:6.1f} TFLOP/s algorithmic "
+      f"(2 N^2 C = {2.0 * N * N * C / 1e9:.1f} GFLOP per pair) = {tf / 157.3:.3f} of the 157.3 TFLOP/s fp32 matrix peak, diag {r.diag().mean().item():.6f}")

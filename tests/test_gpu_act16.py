@@ -225,3 +225,37 @@ def test_16bit_maps_with_each_data_flow_switch_off(L, switch):
     assert (l0 - l1).abs().max().item() <= 2e-3 * l0.abs().max().item() and abs(s0 - s1) <= 1e-3 * abs(s0)
     for n in g0:
         assert (g0[n] - g1[n]).abs().max().item() <= 3e-2 * g0[n].abs().max().item(), n
+
+
+@pytest.mark.parametrize("S,R,C,NP", [(3, 256, 256, 500), (2, 256, 256, 1004), (5, 96, 96, 36), (1, 260, 256, 10004)])
+def test_16bit_operand_at_the_very_end_of_its_allocation(L, S, R, C, NP):
+    """The fault of round 3 where it bit: a k-contiguous bf16 operand whose last row ends its allocation, contraction lengths
+    with NP % 8 == 4 (the last 16-byte unit of every row straddles the end of the contraction).  The gradient maps are carved
+    out of ONE pool so that they end exactly where a guard of bf16 NaNs begins: a unit fetched past the operand's window, or an
+    upper half that is not cleared, puts a NaN into the product (NaN x 0 is NaN) — the result must be finite and right.  The
+    window arithmetic itself is tested on the host (tests/test_cpu_window.py)."""
+    lib = L.lib()
+    L.check(lib.csn_set_math_mode(2))
+    rng = np.random.default_rng(S * 7 + NP)
+    st = torch.cuda.current_stream().cuda_stream
+    n_el = S * R * NP
+    pool = torch.full((n_el + 4096,), float("nan"), device="cuda", dtype=torch.bfloat16)      # operand + guard, one allocation
+    g16 = pool[:n_el].view(S, R, NP)
+    g16.copy_(torch.from_numpy(rng.standard_normal((S, R, NP)).astype(np.float32)).cuda())
+    assert torch.isnan(pool[n_el:]).all() and g16.data_ptr() + 2 * n_el == pool[n_el:].data_ptr()
+    x = torch.from_numpy(rng.standard_normal((S, C, NP)).astype(np.float32)).cuda()
+    L.check(lib.csn_set_thread_act16(5))
+    try:
+        ws_n = lib.csn_wgrad_workspace_floats(R, C, S, NP)
+        ws = torch.empty((ws_n,), device="cuda")
+        dw = torch.full((R, C), float("nan"), device="cuda")
+        L.check(lib.csn_project_wgrad_f32(g16.data_ptr(), R * NP, NP, x.data_ptr(), C * NP, NP, dw.data_ptr(), R, C, S, NP, 1.0, 0,
+                                          ws.data_ptr(), ws_n, st))
+    finally:
+        L.check(lib.csn_set_thread_act16(0))
+        L.check(lib.csn_set_math_mode(1))
+    torch.cuda.synchronize()
+    assert torch.isfinite(dw).all()                                    # no guard byte reached a product
+    ref = torch.einsum("srn,scn->rc", g16.double(), x.bfloat16().double())
+    assert (dw.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    assert torch.isnan(pool[n_el:]).all()                              # and nothing was written there either

@@ -77,3 +77,38 @@ def test_big_category_graph_maps_candidate_ids_back():
     assert len(centres) <= 2                                          # 20 // 10 k-means centres (csa_models.py:321)
     assert tr.shape == (20, 2) and te.shape == (2, 2)
     assert set(tr.reshape(-1).tolist()) <= centres and set(te.reshape(-1).tolist()) <= centres
+
+
+def test_save_knn_graph_cli_writes_the_files_csa_training_reads(tmp_path):
+    """``python -m csn_amd.save_knn_graph`` — the script MID-FC/run_save_knn.py:50 launches and the reference does not ship — run
+    through its main(): feature files on disk in the O-CNN layout (fc_1/*.npy (1, 256, n, 1), point_labels/*.npy), a saved SSA
+    checkpoint, and out come train.npy / test.npy as int64 (S, K+1) tables (csa_training.py:286-290 reads them) that equal what
+    update_knn_graphs builds from the same loaders."""
+    from csn_amd import save_knn_graph
+    from csn_amd.csa_models import get_model
+    rng = np.random.default_rng(9)
+    n_cls, K, part = 4, 2, "Bottle"
+    root = tmp_path / "data"
+    sizes = {"train": [10000, 7000, 10000, 5100, 10000], "test": [10000, 6000]}          # short shapes are wrap-around padded
+    for split, ns in sizes.items():
+        d = root / f"{part}_{split}_feats"
+        (d / "fc_1").mkdir(parents=True)
+        (d / "point_labels").mkdir()
+        for i, n in enumerate(ns):
+            np.save(d / "fc_1" / f"shape_{i:02d}.npy", (rng.standard_normal((1, 256, n, 1)) + 0.3 * i).astype(np.float32))
+            np.save(d / "point_labels" / f"shape_{i:02d}.npy", rng.integers(0, n_cls, size=n))
+    torch.manual_seed(1)
+    ssa = get_model("ssa", n_cls, 1).cuda().eval()
+    logs = tmp_path / "ssa_logs"
+    logs.mkdir()
+    torch.save(ssa.state_dict(), logs / "trained_layers.pth")                            # csa_training.py:324-326
+    graphs = tmp_path / "graphs"
+    save_knn_graph.main(["--ssa_logs_dir", str(logs), "--graphs_dir", str(graphs), "--partname", part, "--dataroot", str(root),
+                         "--num_classes", str(n_cls), "--K", str(K)])
+    tr, te = np.load(graphs / "train.npy"), np.load(graphs / "test.npy")
+    assert tr.dtype == np.int64 and te.dtype == np.int64 and tr.shape == (5, K + 1) and te.shape == (2, K + 1)
+    assert (tr[:, 0] == np.arange(5)).all() and tr.min() >= 0 and tr.max() < 5 and te.max() < 5
+    train_ld = DataLoader(D.FeaturesDataset(str(root / f"{part}_train_feats")), 1, shuffle=False)
+    test_ld = DataLoader(D.FeaturesDataset(str(root / f"{part}_test_feats")), 1, shuffle=False)
+    tr2, te2 = T.update_knn_graphs(ssa, train_ld, test_ld, K, torch.device("cuda"))
+    assert np.array_equal(tr, tr2) and np.array_equal(te, te2)
