@@ -20,9 +20,10 @@ Workloads (`--config`, numbering of SURVEY.md §8d = BASELINE.json configs[i-1])
   5            8 query shapes x 50000 points x 96 channels (d_k = d_v = 96), K = 4, 100 blocks of 500.
 n_heads = 1 (csa_training.py:37 default), 39 classes (PartNet Chair), train mode (dropout 0.1 live, csa_training.py:192).
 
-Prints ONE JSON line (rank 0).  `roofline` describes the DOMINANT kernel of the step — the longer of the two fused
-block-attention launches (forward: S = Q K^T, softmax, P V; backward: dP = dO V^T, dS, dQ = dS K), each timed live with HIP
-events on the launch stream, mean over the timed steps; the other launch is reported beside it (`roofline_other`).
+Prints ONE JSON line (rank 0).  EVERY launching entry point of the C ABI is bracketed by HIP events on the launch stream in
+every timed step (csn_amd._lib.set_call_hook); `launches` lists them (mean ms per step), `roofline` describes the longest one
+WHATEVER it is — today a fused block-attention launch (forward: S = Q K^T, softmax, P V; backward: dP = dO V^T, dS, dQ = dS K)
+— and `roofline_other` the next attention launch.
 `cpu_baseline` is the oracle's faithful op-for-op port of the reference timed on the host cores over a bounded sample.
 """
 import argparse
@@ -210,11 +211,28 @@ def main():
     # CSN_BENCH_HOST_NB=1 (N = 1, development aid): the neighbour stack stays in pinned HOST memory and crosses PCIe inside
     # every step, the way csa_training.py:198-202 hands it over — the PCIe-inclusive rate DESIGN.md quotes; never `value`
     x_nb_host = None
-    if not grouped and os.environ.get("CSN_BENCH_HOST_NB") == "1":
-        x_nb_host = x_nb_resident.cpu().pin_memory()
+    if not grouped and os.environ.get("CSN_BENCH_HOST_NB") in ("1", "2"):
+        x_nb_host = x_nb_resident.cpu()                                   # "2": pageable, as the reference's DataLoader hands it over
+        if os.environ["CSN_BENCH_HOST_NB"] == "1":
+            x_nb_host = x_nb_host.pin_memory()
 
-    attn_events = {"fwd": [], "bwd": [], "dkv": []}      # dkv: the key-stationary dK / dV launch of the score-recomputing flow
+    # HIP events around every launching C-ABI call of the timed steps: entry point -> [(start, end), ...]
+    call_events = {}
+    ATTN_CALLS = {"csn_block_attn_fwd_f32": "fwd", "csn_block_attn_bwd_dq_f32": "bwd", "csn_block_attn_bwd_dq_recompute_f32": "bwd",
+                  "csn_block_attn_bwd_dkv_flash_f32": "dkv"}  # dkv: the key-stationary dK / dV launch of the score-recomputing flow
+    _open = {}
+
+    def call_hook(name, phase):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if phase == "begin":
+            _open[name] = ev
+        else:
+            call_events.setdefault(name, []).append((_open.pop(name), ev))
     exchange_mode = os.environ.get("CSN_EXCHANGE", "alltoall")           # "allgather": the whole collection to every rank
+    # --math bf16 / fp16: the neighbour features cross xGMI as bf16 (the consumers round them to 16 bits anyway): config 4 as
+    # SURVEY.md §8(e) sizes it; the parity modes exchange the fp32 maps
+    payload_dtype = torch.bfloat16 if args.math in ("bf16", "fp16") else None
     overlap = os.environ.get("CSN_OVERLAP", "1") != "0"                  # exchange in flight under the self-attention evaluations
 
     # CSN_BENCH_SPLIT=1 (N = 1, development aid): run the two-phase evaluation order of the multi-GPU path with the stack
@@ -252,7 +270,8 @@ def main():
         if shard is not None and not local:
             if overlap:
                 x_nb = shard.exchange_async(feats, mode=exchange_mode,   # the model overlaps its self-attention with it
-                                            reuse_descriptors=os.environ.get("CSN_REUSE", "1") != "0")
+                                            reuse_descriptors=os.environ.get("CSN_REUSE", "1") != "0",
+                                            payload_dtype=payload_dtype if exchange_mode == "alltoall" else None)
             elif exchange_mode == "alltoall":
                 x_nb = shard.exchange_neighbours(feats)                  # neighbour-only all-to-all
             else:
@@ -263,10 +282,13 @@ def main():
                 x_nb = _ReadyStack(x_nb)
             elif local or same_work_n1:
                 x_nb = _ReadyStack(x_nb_resident, local_graph)
-        with tuning.override(event_sink=attn_events if record else None):   # HIP events around the fused attention launches
+        csn_amd._lib.set_call_hook(call_hook if record else None)       # HIP events around every launch of the layer
+        try:
             logits = model(feats.unsqueeze(-1), "train", x_nb)
             loss = masked_ce(logits, label)
             loss.backward()
+        finally:
+            csn_amd._lib.set_call_hook(None)
         if shard is not None and not local:
             shard.allreduce_grads(params)                                # one 1.6 MB bucket
         return loss
@@ -279,8 +301,7 @@ def main():
         value is quoted on their MEDIAN, the mean of the bracketed time beside it."""
         model.train(train_mode)                                          # train: dropout p = 0.1 live (csa_training.py:192)
         torch.manual_seed(1)
-        for v in attn_events.values():
-            v.clear()
+        call_events.clear()
         group = grouped and not local
         for _ in range(args.warmup):
             step(local=local)
@@ -308,7 +329,11 @@ def main():
         step_ms = step_ms.cpu().numpy()
         # per STEP: the attention launches of one step summed (N = 1: one forward and one backward launch; the overlapped
         # multi-GPU path: two of each — own shapes first, the evaluations that need neighbour data after the exchange)
-        ms = {k: (float(np.sum([a.elapsed_time(b) for a, b in v])) / args.steps if v else float("nan")) for k, v in attn_events.items()}
+        per_call = {k: float(np.sum([a.elapsed_time(b) for a, b in v])) / args.steps for k, v in call_events.items()}
+        ms = {"fwd": float("nan"), "bwd": float("nan"), "dkv": float("nan"), "calls": per_call}
+        for name, which in ATTN_CALLS.items():
+            if name in per_call:
+                ms[which] = per_call[name] if np.isnan(ms[which]) else ms[which] + per_call[name]
         gnorm = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params if p.grad is not None)).item())
         return el, float(loss.item()), ms, gnorm, step_ms
 
@@ -373,9 +398,34 @@ def main():
                             "note": "measured traffic / this run's launch time"}
             return r
 
+        # algorithmic matmul FLOPs per step of the other launching entry points (what a non-attention launch would be priced on)
+        E_all, S_all = n_evals, B * (K + 1)
+        OTHER_FLOPS = {
+            "csn_block_attn_bwd_dkv_f32": (launch_flops, "dV = P^T dO and dK = dS^T Qs on the P / dS planes: 4*T*d per query point and evaluation"),
+            "csn_project_f32": (2.0 * 3 * D * C * N * S_all, "Q / K / V projections of every slot (+ the logit layer)"),
+            "csn_outproj_ln_fwd_f32": (2.0 * C * D * N * E_all, "out-projection of every evaluation (+ residual + LayerNorm)"),
+            "csn_outproj_ln_bwd_f32": (2.0 * 2 * C * D * N * E_all, "LayerNorm backward, dCtx = W_fc^T dZ and the W_fc gradient"),
+            "csn_project_wgrad_f32": (2.0 * 3 * D * C * N * S_all, "projection weight gradients (+ the logit layer's)"),
+        }
+
+        def roof_other_call(math, name, ms):
+            fl, what = OTHER_FLOPS.get(name, (None, "no FLOP model for this entry point"))
+            r = {"bound": "mfma", "kernel": f"{name} (C-ABI entry point: {what})", "launch_ms": ms,
+                 "launch_ms_is": f"mean over {args.steps} timed steps of the step's calls of this entry point (HIP events on the launch stream)",
+                 "achieved": None, "peak": PEAK_TFLOPS[math], "unit": "TFLOP/s", "frac": None, "traffic": None, "flops_per_launch": fl,
+                 "note": "NOT an attention launch: the longest launch of the step has changed — re-profile (scripts/run_profile.sh)"}
+            if fl:
+                r["achieved"] = fl / (ms * 1e-3) / 1e12
+                r["frac"] = r["achieved"] / PEAK_TFLOPS[math]
+            return r
+
         def roofs(math, ms):
-            # the dominant of the step's fused attention launches (NaN = did not run), then the next one
-            ran = sorted((k for k in ms if not np.isnan(ms[k])), key=lambda k: -ms[k]) or ["bwd", "fwd"]
+            # the longest launching entry point of the step, whatever it is; beside it the longest (other) attention launch
+            ran = sorted((k for k in ("fwd", "bwd", "dkv") if not np.isnan(ms[k])), key=lambda k: -ms[k]) or ["bwd", "fwd"]
+            calls = ms.get("calls", {})
+            top = max(calls, key=calls.get) if calls else None
+            if top is not None and top not in ATTN_CALLS:
+                return roof_other_call(math, top, calls[top]), roof(math, ran[0], ms)
             dom, oth = ran[0], (ran[1] if len(ran) > 1 else ran[0])
             return roof(math, dom, ms), roof(math, oth, ms)
 
@@ -406,8 +456,15 @@ def main():
                        "loss": loss_val, "grad_norm": gnorm,
                        "step_tflops_algorithmic": 3 * algorithmic_flops_fwd(S, K, N, C, D, T) / (med_ms * 1e-3) / 1e12},
             "roofline": dominant, "roofline_other": second,
+            # every launching entry point of the step, mean ms per step (HIP events around the C-ABI calls; a call may be several
+            # kernels: csn_outproj_ln_bwd_f32 = LayerNorm backward + dCtx + W_fc gradient, csn_block_attn_bwd_dkv_f32 = dV + dK)
+            "launches": {k: round(v, 4) for k, v in sorted(attn_ms.get("calls", {}).items(), key=lambda kv: -kv[1])},
         }
         if grouped:
+            sent, recvd = getattr(shard, "payload_bytes", (None, None))
+            out["config"]["exchange"] = {"mode": exchange_mode, "payload_dtype": str(payload_dtype or torch.float32).replace("torch.", ""),
+                                         "bytes_sent_per_rank": sent, "bytes_received_per_rank": recvd,
+                                         "note": "rank 0's neighbour-only all-to-all of one step (None: the all-gather fallback moves the whole collection)"}
             out["config"]["n1_same_work_ms_per_step"] = same_work_ms
             out["config"]["scaling_note"] = (
                 f"this line runs K+2 = {K + 2} evaluations per shape (descriptor reuse: a neighbour's pooled SSA descriptor is its "

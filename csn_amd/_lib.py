@@ -205,8 +205,43 @@ def lib() -> ctypes.CDLL:
             fn.argtypes = args
         if handle.csn_version() != 15:
             raise CsnError("libcsn_hip.so ABI version mismatch")
-        _lib = handle
+        _lib = _Hooked(handle)
     return _lib
+
+
+# Every C-ABI call can be bracketed by a caller-supplied hook (bench.py: HIP events on the launch stream around EVERY entry
+# point of the step, so that the roofline names the longest launch whatever it is).  None (the default) costs one comparison.
+_call_hook = None
+
+
+def set_call_hook(fn) -> None:
+    """fn(name, phase) with phase "begin" / "end" around every call that takes a stream (i.e. launches kernels); None removes it."""
+    global _call_hook
+    _call_hook = fn
+
+
+class _Hooked:
+    """The loaded library with its launching entry points wrapped for the call hook."""
+
+    def __init__(self, handle):
+        self._handle = handle
+        for name, (_, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            launches = bool(args) and args[-1] is c_void_p and name not in ("csn_status_string",)
+            setattr(self, name, self._wrap(name, fn) if launches else fn)
+
+    @staticmethod
+    def _wrap(name, fn):
+        def call(*a):
+            hook = _call_hook
+            if hook is None:
+                return fn(*a)
+            hook(name, "begin")
+            try:
+                return fn(*a)
+            finally:
+                hook(name, "end")
+        return call
 
 
 def check(status: int, what: str = "") -> None:

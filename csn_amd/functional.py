@@ -394,7 +394,6 @@ class _MHAEvals(torch.autograd.Function):
         fwd16 = {0: torch.float32, 1: torch.bfloat16, 2: torch.float16}[a16]           # type of the forward's maps Qs, Ctx
         att = torch.empty((E, D, NP), device=dev, dtype=fwd16)
         lse = torch.empty((E, H, NPP), device=dev, dtype=torch.float32)
-        sink = tuning.current().event_sink
         # values may come from a different slot than the keys (slot kv + v_shift): only the generic
         # MultiHeadAttention.forward(Q, K, V) with three distinct inputs uses that
         tiles = fast_math() and tuning.current().kv_tiles and T <= 512
@@ -444,19 +443,12 @@ class _MHAEvals(torch.autograd.Function):
         tune = tuning.current()
         ctx.sc_layout = 1 if (scores is not None and tiles and ctx.mode == 1 and tune.tile_major_scores and tune.grouped_dq and
                               tune.grouped_dkv and Tp >= (T + 31) // 32 * 32 and (L.csn_attn_bwd_grouping(d, T) & 19) == 19) else 0
-        if sink is not None:
-            ev0 = torch.cuda.Event(enable_timing=True)
-            ev0.record()
         with score_layout(ctx.sc_layout):
             _lib.check(L.csn_block_attn_fwd_f32(q_ptr, k_ptr, v_ptr, q_stride, kv_stride,
                                                 _ptr(q_slots), _ptr(kv_slots), NP, _ptr(att), D * NP, _ptr(scores),
                                                 _ptr(lse), E, H, d, T, nb, Tp, RESCALE_THRESHOLD, p_attn, seed_attn,
                                                 kv_flag, kv_pitch, _stream()),
                        "csn_block_attn_fwd_f32")
-        if sink is not None:
-            ev1 = torch.cuda.Event(enable_timing=True)
-            ev1.record()
-            sink["fwd"].append((ev0, ev1))
         xhat = torch.empty((E, C, NP), device=dev, dtype=torch.float16 if a16 else torch.float32)
         rstd = torch.empty((E, NP), device=dev, dtype=torch.float32)
         w_fc = w_fc.contiguous()
@@ -609,10 +601,6 @@ class _MHAEvals(torch.autograd.Function):
             v_ptr = q_ptr + 4 * (2 * D * NP + plan.v_shift * kv_stride)
         grouping = L.csn_attn_bwd_grouping(d, T)
         tune = ctx.tune                                              # the forward's snapshot
-        sink = tuning.current().event_sink
-        if sink is not None:
-            ev0 = torch.cuda.Event(enable_timing=True)
-            ev0.record()
         if flow != tuning.KEEP_SCORES:
             # one grouped call, scores rebuilt from the pre-scaled queries of the evaluation's query slot
             _lib.check(L.csn_block_attn_bwd_dq_recompute_f32(_ptr(datt), _ptr(att), D * NP, q_ptr, q_stride, _ptr(plan.q_slots),
@@ -639,26 +627,15 @@ class _MHAEvals(torch.autograd.Function):
                                                        ids.numel(), H, d, T, nb, Tp, p_attn, seed_attn, 0, 0, kv_flag + kv_f16,
                                                        kv_pitch, pt, None, 0, _stream()),
                            "csn_block_attn_bwd_dq_f32")
-        if sink is not None:
-            ev1 = torch.cuda.Event(enable_timing=True)
-            ev1.record()
-            sink["bwd"].append((ev0, ev1))
         if flow == tuning.FLASH:
             # key-stationary kernel: P and dS are rebuilt per (key/value slot, head, block, 128 keys) from lse, delta and the
             # masks' seed; the evaluations of a key/value slot accumulate in registers (grouped) — no score-sized tensor exists
-            if sink is not None:
-                ev0 = torch.cuda.Event(enable_timing=True)
-                ev0.record()
             _lib.check(L.csn_block_attn_bwd_dkv_flash_f32(_ptr(datt), D * NP, q_ptr, q_stride, _ptr(plan.q_slots), k_ptr, v_ptr,
                                                           kv_stride, _ptr(plan.kv_slots), kv_pitch, kv_f16, NP, _ptr(lse), _ptr(delta),
                                                           gbase + ges * D * NP, gbase + 2 * ges * D * NP, slot_stride,
                                                           _ptr(plan.kv_slots), _ptr(plan.v_slots), 0, _ptr(plan.kv_group_items),
                                                           E, H, d, T, nb, Tp, p_attn, seed_attn, _ptr(plan.kv_group_off),
                                                           plan.n_kv_groups, _stream()), "csn_block_attn_bwd_dkv_flash_f32")
-            if sink is not None:
-                ev1 = torch.cuda.Event(enable_timing=True)
-                ev1.record()
-                sink.setdefault("dkv", []).append((ev0, ev1))
         elif tune.grouped_dkv and (grouping & 2):
             # one call: the evaluations of a key/value slot are contracted one after the other into the same accumulators
             _lib.check(L.csn_block_attn_bwd_dkv_f32(_ptr(datt), D * NP, q_ptr, q_stride, _ptr(plan.q_slots), NP,

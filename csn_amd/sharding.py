@@ -91,7 +91,8 @@ class ShapeGraphShard:
         self._start_alltoall(feats.contiguous()).wait()
         return self._finish_alltoall(feats)
 
-    def exchange_async(self, feats: torch.Tensor, mode: str = "alltoall", reuse_descriptors: bool = True) -> "PendingStack":
+    def exchange_async(self, feats: torch.Tensor, mode: str = "alltoall", reuse_descriptors: bool = True,
+                       payload_dtype: Optional[torch.dtype] = None) -> "PendingStack":
         """Start the exchange and return at once: ``wait()`` on the result yields the neighbour stack.  A model that is handed
         the pending object (CrossShapeAt accepts it in place of the neighbour tensor) runs the evaluations that need no
         neighbour data — the self-attention of its own shapes — while the exchange is in flight.
@@ -99,7 +100,11 @@ class ShapeGraphShard:
         all_to_all_single with uneven splits; at 8 ranks and K = 3 at most 96 of the 224 remote shapes); "allgather": the
         whole collection to every rank (RCCL's stock all-gather), kept as the fallback.
         reuse_descriptors: the pending object also offers ``gather_pooled`` (see PendingStack), with which the model takes
-        the neighbours' pooled SSA descriptors from their owners instead of recomputing SSA(x_k) for every use."""
+        the neighbours' pooled SSA descriptors from their owners instead of recomputing SSA(x_k) for every use.
+        payload_dtype (mode "alltoall"): the type the features cross xGMI in — torch.bfloat16 halves the bytes (164 MB per rank
+        and 32 shapes instead of 328 MB, what SURVEY.md §8(e) budgets for config 4); the received shapes are widened back to the
+        features' own type, which is exact for a consumer that rounds its operands to bf16 anyway (math mode ``bf16``) and a
+        2^-9 relative perturbation of the neighbour features otherwise."""
         if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
             raise ValueError("exchange_async needs a process group (world > 1, or a world of one rank for rehearsals)")
         feats = feats.contiguous()
@@ -108,20 +113,28 @@ class ShapeGraphShard:
                 self._gathered = torch.empty((self.S,) + tuple(feats.shape[1:]), device=feats.device, dtype=feats.dtype)
             work = dist.all_gather_into_tensor(self._gathered, feats, async_op=True)
         elif mode == "alltoall":
-            work = self._start_alltoall(feats)
+            work = self._start_alltoall(feats, payload_dtype)
         else:
             raise ValueError(f"unknown exchange mode {mode!r}")
         return PendingStack(self, feats, work, mode, reuse_descriptors)
 
-    def _start_alltoall(self, feats: torch.Tensor):
+    def _start_alltoall(self, feats: torch.Tensor, payload_dtype: Optional[torch.dtype] = None):
         tail = tuple(feats.shape[1:])
         if self._pool is None or self._pool.shape[1:] != tail or self._pool.dtype != feats.dtype:
             self._pool = torch.empty((self._n_recv + self.B,) + tail, device=feats.device, dtype=feats.dtype)
         self._send = (feats.index_select(0, self._send_ids) if self._send_ids.numel() else feats[:0]).contiguous()
-        return dist.all_to_all_single(self._pool[:self._n_recv], self._send, self._recv_splits, self._send_splits, async_op=True)
+        self._recv_narrow = None
+        recv = self._pool[:self._n_recv]
+        if payload_dtype is not None and payload_dtype != feats.dtype:
+            self._send = self._send.to(payload_dtype)
+            recv = self._recv_narrow = torch.empty((self._n_recv,) + tail, device=feats.device, dtype=payload_dtype)
+        self.payload_bytes = (self._send.numel() * self._send.element_size(), recv.numel() * recv.element_size())   # (sent, received)
+        return dist.all_to_all_single(recv, self._send, self._recv_splits, self._send_splits, async_op=True)
 
     def _finish_alltoall(self, feats: torch.Tensor) -> torch.Tensor:
         tail = tuple(feats.shape[1:])
+        if getattr(self, "_recv_narrow", None) is not None:
+            self._pool[:self._n_recv].copy_(self._recv_narrow)             # widened to the features' type
         self._pool[self._n_recv:].copy_(feats)
         shape = (self.B * (self.K + 1),) + tail
         if self._stack is None or self._stack.shape != shape or self._stack.dtype != feats.dtype:
@@ -148,14 +161,19 @@ class ShapeGraphShard:
         """Sum (or average) the weight gradients over ranks in ONE bucket (≈0.4 M parameters: latency-bound)."""
         if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
             return
-        plist: List[torch.nn.Parameter] = [p for p in params if p.grad is not None]
-        flat = torch.cat([p.grad.reshape(-1) for p in plist])
+        # (every parameter handed in, a missing gradient as zeros: the bucket has the same size on every rank by construction)
+        plist: List[torch.nn.Parameter] = list(params)
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in plist])
         dist.all_reduce(flat)
         if average:
             flat /= self.world
         off = 0
         for p in plist:
-            p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
+            piece = flat[off:off + p.numel()].view_as(p)
+            if p.grad is None:
+                p.grad = piece.clone()
+            else:
+                p.grad.copy_(piece)
             off += p.numel()
 
 

@@ -3,8 +3,8 @@
 Every switch selects between two forms of the SAME arithmetic (a fused pass and the plain pass it replaced, or two data
 flows of the attention backward); the defaults are the measured-faster forms.  Nothing here changes results
 beyond fp32 rounding; `tests/test_gpu_module.py::test_fused_data_flow_equals_the_unfused_one` and
-`tests/test_gpu_flash.py` flip them through ``override`` to check one form against the other, `bench.py` hangs its HIP-event
-sink here.  The state is process-wide on purpose: autograd runs the backward on its own threads, and a step must see the
+`tests/test_gpu_flash.py` flip them through ``override`` to check one form against the other (`bench.py` times the launches
+through csn_amd._lib.set_call_hook, not through anything here).  The state is process-wide on purpose: autograd runs the backward on its own threads, and a step must see the
 same switches in both passes.
 """
 from __future__ import annotations
@@ -45,8 +45,6 @@ class Tuning:
 
     def flow_for(self, mode: int, d_head: int) -> int:
         return self.score_flow.get((mode, d_head), self.score_flow.get(mode, KEEP_SCORES))
-    # bench.py: {"fwd": [], "bwd": []} collects (start, end) HIP-event pairs around the fused attention launches
-    event_sink: Optional[dict] = None
 
 
 _current = Tuning()

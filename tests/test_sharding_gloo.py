@@ -122,10 +122,31 @@ def _a2a_worker(rank, world, port):
     shard = ShapeGraphShard(graph, B, rank, world, torch.device("cpu"))
     mine = feats[shard.first:shard.first + B].clone()
     for _ in range(2):                                                      # buffers are reused between steps
-        stack = shard.exchange_neighbours(mine)
+        stack = shard.exchange_neighbours(mine).clone()                     # (both calls fill the shard's one stack buffer)
         ref = shard.neighbour_stack(mine, feats)
         assert torch.equal(stack, ref)
     assert sum(shard._recv_splits) <= min(B * Kn, S - B)
+    # the same exchange with a bf16 payload (bench.py --math bf16): half the bytes on the wire, remote slots arrive rounded to
+    # bf16 and widened again, own slots (never sent) stay exact; a gradient-free parameter joins the bucket as zeros
+    feats2 = feats * 1.001 + 0.37                                              # (values that bf16 does not hold exactly)
+    mine2 = feats2[shard.first:shard.first + B].clone()
+    pend = shard.exchange_async(mine2, payload_dtype=torch.bfloat16, reuse_descriptors=False)
+    stack = pend.wait().clone()
+    ref = shard.neighbour_stack(mine2, feats2)
+    own = torch.from_numpy((graph[shard.first:shard.first + B] >= shard.first) & (graph[shard.first:shard.first + B] < shard.first + B))
+    assert stack.dtype == torch.float32 and torch.equal(stack[:, 0], ref[:, 0])
+    for b in range(B):
+        for k in range(Kn):
+            want = ref[b, k + 1] if own[b, k] else ref[b, k + 1].bfloat16().float()
+            assert torch.equal(stack[b, k + 1], want)
+    sent, recvd = shard.payload_bytes
+    assert sent == sum(shard._send_splits) * 4 * 5 * 2 and recvd == sum(shard._recv_splits) * 4 * 5 * 2
+    pa, pb = torch.nn.Parameter(torch.zeros(2)), torch.nn.Parameter(torch.zeros(3))
+    pa.grad = torch.full((2,), float(rank + 1))
+    if rank == 0:
+        pb.grad = torch.ones(3)                                                # only rank 0 has a gradient for pb
+    shard.allreduce_grads([pa, pb], average=False)
+    assert torch.equal(pa.grad, torch.full((2,), float(sum(range(1, world + 1))))) and torch.equal(pb.grad, torch.ones(3))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -153,7 +174,7 @@ def _a2a8_worker(rank, world, port):
         table.sum().backward()
         uses = torch.from_numpy((graph.reshape(-1)[None, :] == torch.arange(shard.first, shard.first + B).numpy()[:, None]).sum(axis=1))
         assert torch.equal(own.grad, uses.float()[:, None].expand(B, C))       # one unit of gradient per use, from every rank
-        stack = pending.wait()
+        stack = pending.wait().clone()
         assert torch.equal(stack, shard.neighbour_stack(mine, feats))
     assert sum(shard._recv_splits) <= B * Kn
     g = [torch.nn.Parameter(torch.zeros(3))]
