@@ -816,5 +816,8 @@ int launch_mode(const CsnAttnArgs& a, int d, int mode, bool bwd, hipStream_t st)
 
 }  // namespace
 
-int csn_launch_attn_fwd_bf16x3(const CsnAttnArgs& a, int d, int mode, hipStream_t st) { return launch_mode(a, d, mode, false, st); }
+int csn_launch_attn_fwd_bf16x3(const CsnAttnArgs& a, int d, int mode, hipStream_t st) {
+  if (csn_attn_fwd_x4_takes(a, d, mode)) return csn_launch_attn_fwd_x4(a, st);      // d = 256, bf16x3: four 32-query waves
+  return launch_mode(a, d, mode, false, st);
+}
 int csn_launch_attn_bwd_bf16x3(const CsnAttnArgs& a, int d, int mode, hipStream_t st) { return launch_mode(a, d, mode, true, st); }

@@ -122,6 +122,7 @@ int csn_dev_get(int key) {
     case CSN_DEV_WIDE_GEMM: return csn_gemm_wide;
     case CSN_DEV_WIDE_FORMS: return csn_gemm_wide_set;
     case CSN_DEV_WX: return csn_dev_wx;
+    case CSN_DEV_ATTN_X4: return csn_dev_attn_x4;
     default: return CSN_E_ARG;
   }
 }
@@ -132,6 +133,7 @@ int csn_dev_set(int key, int value) {
     case CSN_DEV_WIDE_GEMM: csn_gemm_wide = value; break;
     case CSN_DEV_WIDE_FORMS: csn_gemm_wide_set = value; break;
     case CSN_DEV_WX: csn_dev_wx = value; break;
+    case CSN_DEV_ATTN_X4: csn_dev_attn_x4 = value; break;
     default: return CSN_E_ARG;
   }
   return prev;

@@ -119,6 +119,11 @@ struct CsnAttnDkvArgs {
 int csn_launch_attn_dkv_flash(const CsnAttnDkvArgs& a, int d, int mode, hipStream_t st);
 constexpr bool csn_attn_dkv_flash_fits(int dt) { return dt <= 4; }         // K^T, V^T, dK^T, dV^T of 16 keys in one wave's registers
 
+// forward at d = 256 in bf16x3 on four 32-query waves (attn_fwd_x4.hip)
+extern int csn_dev_attn_x4;
+bool csn_attn_fwd_x4_takes(const CsnAttnArgs& a, int d, int mode);
+int csn_launch_attn_fwd_x4(const CsnAttnArgs& a, hipStream_t st);
+
 int csn_launch_attn_fwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
 int csn_launch_attn_bwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
 int csn_launch_attn_fwd_bf16x3(const CsnAttnArgs& a, int d, int mode, hipStream_t st);     // attn_bf16x3.hip; mode 1..3 (2, 3: tile-plane K/V only)

@@ -399,6 +399,8 @@ int csn_compat_bwd_f32(const float* dcomp, const float* comp, const double* save
 #define CSN_DEV_WIDE_GEMM 1
 #define CSN_DEV_WIDE_FORMS 2
 #define CSN_DEV_WX 3
+#define CSN_DEV_ATTN_X4 4   /* default 0; 1: the attention forward at d = 256 in bf16x3 on four 32-query waves
+                               (v_mfma_f32_32x32x16_bf16, one wave per SIMD) — built, measured 25 % slower, kept as the measured form */
 int csn_dev_set(int key, int value);
 int csn_dev_get(int key);
 

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--only", default="fwd,dq,dkv")
     ap.add_argument("--d", type=int, default=256)
     ap.add_argument("--nb", type=int, default=20)
+    ap.add_argument("--dev", default="", help="development switches for the timed runs, key=value,... (csn_dev_set; 4=0: forward on the 8-wave kernel)")
     ap.add_argument("--recompute", type=int, default=0, help="1: dq rebuilds the scores, P / dS planes still written; 2: nothing written")
     a = ap.parse_args()
     L = _lib.lib()
@@ -108,6 +109,10 @@ def main():
 
     flops = 4.0 * T * d * NP * E * H
     L.csn_set_math_mode(a.mode)
+    for item in a.dev.split(","):
+        if item:
+            k, v = item.split("=")
+            L.csn_dev_set(int(k), int(v))
     ref = {}
     if a.check:
         L.csn_set_math_mode(0)
