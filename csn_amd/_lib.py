@@ -163,6 +163,7 @@ _SIGNATURES = {
                                         c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_longlong, c_longlong, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                         c_float, c_ulonglong, c_void_p]),
+    "csn_outproj_ln_workspace_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
     "csn_outproj_ln_fwd_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p,
                                        c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
                                        c_ulonglong, c_void_p, c_void_p, c_longlong, c_void_p]),
@@ -203,7 +204,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.csn_version() != 15:
+        if handle.csn_version() != 16:
             raise CsnError("libcsn_hip.so ABI version mismatch")
         _lib = _Hooked(handle)
     return _lib

@@ -602,6 +602,13 @@ int csn_varlen_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_e
                            max_queries, ld_kv, nullptr, 0, stream, n_queries, n_keys);
 }
 
+long long csn_outproj_ln_workspace_floats(int n_evals, int d_model, int d_inner, int n_points) {
+  if (n_evals <= 0 || d_model <= 0 || d_inner <= 0 || n_points <= 0) return 0;
+  const long long tiled = (long long)n_evals * ((n_points + 255) / 256) * d_model;
+  const long long stream = d_model == 256 && d_inner == 256 ? (long long)n_evals * csn_wx_ln_sum_slots(n_evals, n_points) * 256 : 0;
+  return tiled > stream ? tiled : stream;
+}
+
 int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const float* wfc, const float* xres,
                            long long xres_shape_stride, const int* res_index, float* xhat,
                            long long xhat_eval_stride, float* rstd, int n_evals, int d_model, int d_inner, int ld,

@@ -45,10 +45,17 @@ struct CsnWxArgs {
   int tb;                                                 // tile planes: points per attention block
   int stagger = 0;                                        // waves 4..7 half an iteration behind waves 0..3 (development; filled in by the launcher)
   int ablate = 0;                                         // development: timing-only ablations (bits 4..7 of CSN_DEV_WX)
+  // out_mode 3 — out-projection + fc dropout + residual + LayerNorm (csa_models.py:115-118): x = Ctx^T, w = W_fc, out = xhat
+  const float* res = nullptr;  long long res_shape_stride = 0;  const int* res_index = nullptr;   // residual x[shape][256][ldo]
+  float* rstd = nullptr;                                  // [item][n_points]
+  float eps = 0.f, dropout_p = 0.f;  unsigned long long seed = 0;
+  float* sum_ws = nullptr;  int sum_slots = 0;            // optional [item][sum_slots][256]: per-stream sums over points of xhat
 };
 extern int csn_gemm_big_tiles, csn_gemm_wide, csn_gemm_wide_set, csn_dev_wx;   // development switches (csn_dev_set)
 bool csn_wx_takes(int rows, int k);                       // this product shape runs on the streaming kernel
-int csn_launch_wx(const CsnWxArgs& a, int out_mode /* 0 fp32, 2 tile planes */, hipStream_t st);
+int csn_launch_wx(const CsnWxArgs& a, int out_mode /* 0 fp32, 2 tile planes, 3 LayerNorm */, hipStream_t st);
+int csn_wx_ln_sum_slots(int n_items, int n_points);      // out_mode 3: sum_slots the launch will use (sum_ws = n_items * slots * 256 floats)
+int csn_launch_wx_ln_sums(const float* ws, float* out, int n_items, int n_points, hipStream_t st);   // out[item][256] from sum_ws
 
 // ---- fused block attention (attn_f32.hip) -----------------------------------------------------
 struct CsnAttnArgs {

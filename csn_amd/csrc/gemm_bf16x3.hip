@@ -1096,6 +1096,26 @@ int launch_wide(const CsnGemmArgs& a, int batch, hipStream_t st) {
 // out-projection + residual + LayerNorm for d_model = 256 on the 256 x 256 tiles (math modes 1..3): xhat = LN(W_fc Ctx^T (+drop) + x)
 int csn_launch_outproj_ln_big(const CsnOutProjArgs& a, int mode, hipStream_t st) {
   if (a.C != 256 || (a.D & 3) || (a.ld & 3) || (a.n_points & 3)) return -5;
+  // bf16x3 with fp32 maps and D = 256: the weight-stationary streaming kernel (wx_stream.hip; CSN_DEV_WX bit 2 switches it off)
+  if (mode == 1 && !a.act16 && !(csn_dev_wx & 4) && csn_wx_takes(256, a.D)) {
+    CsnWxArgs w{};
+    w.w = a.wfc;
+    w.x = a.ctx; w.x_item_stride = a.ctx_eval_stride; w.ldx = a.ld;
+    w.out = a.xhat; w.out_item_stride = a.xhat_eval_stride; w.ldo = a.ld;
+    w.n_items = a.E; w.n_points = a.n_points; w.n_sets = 1;
+    w.div_rows = 0; w.div_val = 1.f; w.div_rcp = 1.f; w.div_exact = 1; w.tb = 0;
+    w.res = a.xres; w.res_shape_stride = a.xres_shape_stride; w.res_index = a.res_index;
+    w.rstd = a.rstd; w.eps = a.eps; w.dropout_p = a.dropout_p; w.seed = a.seed;
+    const int slots = csn_wx_ln_sum_slots(a.E, a.n_points);
+    const bool fused = a.xhat_sum && a.sum_ws && a.sum_ws_floats >= (long long)a.E * slots * 256;
+    if (fused) { w.sum_ws = a.sum_ws; w.sum_slots = slots; }
+    const int rc = csn_launch_wx(w, 3, st);
+    if (rc != -1) {                                      // (-1: a geometry the streaming kernel does not take)
+      if (rc || !a.xhat_sum) return rc;
+      if (fused) return csn_launch_wx_ln_sums(a.sum_ws, a.xhat_sum, a.E, a.n_points, st);
+      return csn_launch_rowsum_f32(a.xhat, a.xhat_sum, (long long)a.E * a.C, a.n_points, a.ld, st, 0);
+    }
+  }
   CsnGemmArgs g;
   g.A = CsnOperand{const_cast<float*>(a.wfc), 0, 0, 0, nullptr, a.D, 0, 0};
   g.B = CsnOperand{const_cast<float*>(a.ctx), 0, 0, a.ctx_eval_stride, nullptr, a.ld, 0, 0};

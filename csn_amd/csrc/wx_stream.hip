@@ -44,27 +44,63 @@ CSN_DEVINL f32x16 wx_mma(s16x8 ah, s16x8 al, s16x8 bh, s16x8 bl, f32x16 c) {
 // in flight instead of two: 4.1 TB/s).  An asm load's destination is untouched by the compiler until the wait statement that
 // names it "+v"; the counts below are the stores and requests issued after the request being waited for, all unconditional.
 CSN_DEVINL void wx_request(f32x4& dst, u32x4 rsrc, unsigned voff, unsigned soff) {
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
 }
 template <int N>
 CSN_DEVINL void wx_arrived(f32x4* R) {
   asm volatile("s_waitcnt vmcnt(%4)" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]) : "n"(N) : "memory");
 }
+// a residual chunk goes from memory straight to the wave's LDS block (no registers): lane l's 16 bytes land at m0 + 16 l
+CSN_DEVINL void wx_dma(unsigned lds_addr, u32x4 rsrc, unsigned voff, unsigned soff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
+}
+// 16-byte store whose data registers may be rewritten by the very next instruction.  Measured on gfx950: after
+//   buffer_store_dwordx4 v[0:3], v10, s[44:47], s64 offen ;  v_add_f32 v0, v0, v1
+// lanes 12..15 (mod 16) of the second wave of a SIMD stored the SUM in the first dword now and then.  hipcc separates the two
+// with s_nop when the store's soffset is an immediate and not when it is a register; the hardware needs it in both cases.
+CSN_DEVINL void wx_store4(f32x4 v, u32x4 rsrc, unsigned voff, unsigned soff) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" :: "v"(v), "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
+}
+// a wave-uniform int through the scalar cache (left to the compiler this became a vector load and a vmcnt(0) — which drains
+// every chunk request in flight)
+CSN_DEVINL int wx_sload(const int* ptr) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const unsigned long long u = ((unsigned long long)hi << 32) | lo;
+  int v;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(u) : "memory");
+  return v;
+}
 CSN_DEVINL u32x4 wx_rsrc(const void* base, long long bytes) {
   const unsigned long long a = reinterpret_cast<unsigned long long>(base);
   const unsigned nb = bytes > 0x7fffffffLL ? 0x7fffffffu : (bytes < 0 ? 0u : (unsigned)bytes);
-  return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, nb, 0x00020000u};
+  // (wave-uniform by construction; said so to the compiler, which must keep the words in scalar registers for the asm operands)
+  return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu)),
+               (unsigned)__builtin_amdgcn_readfirstlane((int)nb), 0x00020000u};
 }
 
 // OUT 0: fp32 map [item][rows][ldo];  OUT 2: bf16 tile planes (attn_bf16x3.hip): per row and block of tb points 16 tiles of
 // [hi 32 | lo 32], block pitch 1024, row pitch ldo 16-bit elements, the padding keys of a block's last tile written as zeros
-template <int OUT>
+// OUT 3: xhat = LayerNorm over the 256 rows of (drop(W X) + residual), no affine (csa_models.py:115-118; the affine is applied
+// where xhat is used), rstd per point, and per-stream sums of xhat over points (the pooled descriptor, csa_models.py:211-212).
+// Streams take CONTIGUOUS runs of chunks here, so that the sums of an item stay in registers until the run leaves the item.
+template <int OUT, bool DROP = false>
 __global__ __launch_bounds__(512, 2) void csn_wx_kernel(CsnWxArgs p) {
-  __shared__ __attribute__((aligned(16))) short smem[WX_NS * WX_STAGE + 8 * WX_EB * 2];      // 96 KB + 32 KB
-  short* xs = smem;
+  constexpr bool LN = OUT == 3;
+  constexpr int WX_RES = LN ? 8 * WX_EB * 2 : 0;            // LN: the waves' residual blocks, 32 rows x 32 points fp32 each (32 KB)
+  constexpr int WX_EBW = LN ? WX_EB / 2 : WX_EB;            // floats of a wave's epilogue block (LN: two passes of 16 rows)
+  // 96 KB of stages + 32 KB of epilogue blocks; LN: 32 KB residual + 96 KB + 16 KB + 2 KB of per-wave point statistics
+  // and 8 KB of running sums (one cell per lane and row group: the sums cost 6 registers at the kernel's tightest point)
+  __shared__ __attribute__((aligned(16))) short smem[WX_RES + WX_NS * WX_STAGE + 8 * WX_EBW * 2 + (LN ? 1024 + 4096 : 0)];
+  short* xs = smem + WX_RES;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, h = lane >> 5;
-  float* eb = reinterpret_cast<float*>(smem + WX_NS * WX_STAGE) + wave * WX_EB;
+  float* eb = reinterpret_cast<float*>(smem + WX_RES + WX_NS * WX_STAGE) + wave * WX_EBW;
+  float* red = reinterpret_cast<float*>(smem + WX_RES + WX_NS * WX_STAGE + 8 * WX_EBW * 2);    // LN: [wave][point][sum, m2]
+  const float* resb = reinterpret_cast<const float*>(smem) + wave * WX_EB;                       // LN: the wave's residual block
+  float* ps = red + 512 + wave * 256 + lane;                                                     // LN: this lane's cells ps[64 i], i < 4
 
   // streams: work-group b sits on XCD label b % 8; its place j = b / 8 there is (stream lane, row set)
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
@@ -79,7 +115,12 @@ __global__ __launch_bounds__(512, 2) void csn_wx_kernel(CsnWxArgs p) {
   const unsigned cpb = (blen + WX_CH - 1) / WX_CH;                                 // chunks per block
   const unsigned cpi = cpb * ((unsigned)(p.n_points + (int)blen - 1) / blen);        // chunks per item
   const int n_chunks = p.n_items * (int)cpi;                  // (the launcher keeps it below 2^31)
-  if (stream >= n_chunks) return;
+  // chunks of this stream: q0, q0 + q_step, ... < q_end
+  const int run = LN ? (n_chunks + n_streams - 1) / n_streams : 0;
+  const int q_step = LN ? 1 : n_streams;
+  const int q0 = LN ? stream * run : stream;
+  const int q_end = LN ? min(q0 + run, n_chunks) : n_chunks;
+  if (q0 >= q_end) return;
   // rows < div_rows are divided by div_val; a wave's 32 rows are all in or all out (div_rows % 32 == 0)
   const bool dv = 256 * set + 32 * wave < p.div_rows;
   const float dscale = (dv && p.div_exact) ? p.div_rcp : 1.f;
@@ -116,10 +157,10 @@ __global__ __launch_bounds__(512, 2) void csn_wx_kernel(CsnWxArgs p) {
     c.tile = r - c.blk * cpb;
     return c;
   };
-  const unsigned st_item = (unsigned)n_streams / cpi, st_r = (unsigned)n_streams - st_item * cpi;    // one step = n_streams chunks
+  const unsigned st_item = (unsigned)q_step / cpi, st_r = (unsigned)q_step - st_item * cpi;          // one step = q_step chunks
   const unsigned st_blk = st_r / cpb, st_tile = st_r - st_blk * cpb;
   auto advance = [&](Cursor& c) {
-    c.q += n_streams;
+    c.q += q_step;
     c.tile += st_tile;
     if (c.tile >= cpb) { c.tile -= cpb; ++c.blk; }
     c.blk += st_blk;
@@ -135,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void csn_wx_kernel(CsnWxArgs p) {
   //  the whole memory queue, this chunk's stores and the next request included, before it touches a staging register:
   //  s_waitcnt vmcnt(0) at the top of every iteration, 0.64 ms for the Q projection instead of 0.4x)
   auto issue = [&](const Cursor& cu, f32x4* R) {
-    const bool exists = cu.q < n_chunks;
+    const bool exists = cu.q < q_end;
     int col0, valid;
     locate(cu, col0, valid);
     if (valid < 0 || !exists || (p.ablate & 4)) valid = 0;
@@ -243,6 +284,131 @@ __global__ __launch_bounds__(512, 2) void csn_wx_kernel(CsnWxArgs p) {
     }
   };
 
+  // ---- LayerNorm epilogue (OUT 3) --------------------------------------------------------------------------------------
+  // residual of a chunk: the wave's 32 rows x 32 points, 4 requests of 8 rows (lane -> row lane / 8, piece lane % 8) that land
+  // row-major in the wave's residual block one iteration after they were asked for
+  const unsigned res_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)((short __attribute__((address_space(3)))*)smem))
+                           + (unsigned)wave * (WX_EB * 4u);
+  auto issue_res = [&](const Cursor& cu) __attribute__((always_inline)) {
+    const bool exists = cu.q < q_end;
+    int col0, valid;
+    locate(cu, col0, valid);
+    if (valid < 0 || !exists || (p.ablate & 4)) valid = 0;
+    const unsigned item = __builtin_amdgcn_readfirstlane(exists ? cu.item : 0u);
+    if (!exists) col0 = 0;
+    const long long rs = p.res_index ? (long long)wx_sload(p.res_index + item) : (long long)item;
+    const u32x4 Rr = wx_rsrc(p.res + rs * p.res_shape_stride + (long long)(32 * wave) * p.ldo + col0, ((long long)31 * p.ldo + valid) * 4);
+    const unsigned off = 4 * c8 < valid ? (unsigned)(erow * p.ldo + 4 * c8) * 4u : CSN_OOB;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (the block's previous chunk has been read)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wx_dma(res_lds + 1024u * t, Rr, off, (unsigned)(8 * t * p.ldo) * 4u);
+  };
+  constexpr int NST = LN ? 5 : 4;                      // stores of one epilogue (always issued; switched-off lanes still count)
+  const unsigned thr16 = csn_drop_threshold16(p.dropout_p);
+  const float keep_scale = DROP ? 1.f / (1.f - p.dropout_p) : 1.f;
+  // sums of xhat over the points of the item the run is in: lane partials (row lane / 8 + 8 t + 16 half, points 4 (lane % 8)..)
+  if constexpr (LN) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ps[64 * i] = 0.f;
+  }
+  unsigned sum_item = 0;
+  auto flush_sums = [&]() __attribute__((always_inline)) {
+    if (!p.sum_ws) return;
+    const unsigned slot = (unsigned)stream - (sum_item * cpi) / (unsigned)run;
+    float* dst = p.sum_ws + ((long long)sum_item * p.sum_slots + slot) * 256 + 32 * wave + erow;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = ps[64 * i];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      if (c8 == 0) dst[16 * (i >> 1) + 8 * (i & 1)] = v;
+      ps[64 * i] = 0.f;
+    }
+  };
+  auto epilogue_ln = [&](const Cursor& cu, f32x16 acc) __attribute__((always_inline)) {
+    int col0, valid;
+    locate(cu, col0, valid);
+    if (p.ablate & 2) valid = 0;
+    const bool pt_ok = l31 < valid;
+    if (cu.item != sum_item) {                          // (work-group uniform)
+      flush_sums();
+      sum_item = cu.item;
+    }
+    // fc dropout in the accumulator layout: rows r, r + 1 (r even) are one channel pair of point col0 + l31 — one hash
+    if constexpr (DROP) {
+      const unsigned salt = csn_block_salt((unsigned long long)cu.item, p.seed);
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const unsigned hp = csn_fc_pair(32 * wave + csn_acc_row(r, h), (unsigned)p.ldo, (unsigned)(col0 + l31), salt);
+        acc[r] = csn_keep16(hp, 0, thr16) ? acc[r] * keep_scale : 0.f;
+        acc[r + 1] = csn_keep16(hp, 1, thr16) ? acc[r + 1] * keep_scale : 0.f;
+        if (r & 2) __builtin_amdgcn_sched_barrier(0);   // (two hashes at a time: eight at once cost nine more registers)
+      }
+    }
+    // + residual: requested one iteration ago; behind that request only the stores of that iteration and this one's chunk request
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NST + 4) : "memory");
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                       // (in fours: sixteen reads in flight at once cost sixteen more registers)
+#pragma unroll
+      for (int r = 4 * g; r < 4 * g + 4; ++r) acc[r] += resb[csn_acc_row(r, h) * 32 + l31];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // statistics of the point over the wave's 32 rows (sum, squares about the wave's mean), combined over the 8 waves below
+    float s1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s1 += acc[r];
+    s1 += csn_xhalf(s1);
+    const float mw = s1 * (1.f / 32.f);
+    float m2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m2 += (acc[r] - mw) * (acc[r] - mw);
+    m2 += csn_xhalf(m2);
+    if (h == 0) *reinterpret_cast<float2*>(&red[(wave * 32 + l31) * 2]) = make_float2(s1, m2);
+    {
+      Cursor cn = cu;
+      advance(cn);
+      issue_res(cn);                                    // the next chunk's residual (the block's reads are done: values in use)
+    }
+    __syncthreads();
+    // (Chan's combination of the waves' (sum, squares about own mean); two sweeps over the 8 entries keep 16 registers free)
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) tot += red[(w * 32 + l31) * 2];
+    const float mean = tot * (1.f / 256.f);
+    float var = 0.f;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+      const float2 sw = *reinterpret_cast<const float2*>(&red[(w * 32 + l31) * 2]);
+      const float dm = sw.x * (1.f / 32.f) - mean;
+      var += sw.y + 32.f * dm * dm;
+    }
+    const float rstd = 1.f / sqrtf(var * (1.f / 256.f) + p.eps);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = pt_ok ? (acc[r] - mean) * rstd : 0.f;
+    {
+      const csn_rsrc_t Sr = csn_make_rsrc(p.rstd + (long long)cu.item * p.n_points, (long long)p.n_points * 4);
+      csn_bstore(rstd, Sr, (wave == 0 && h == 0 && pt_ok) ? (unsigned)(col0 + l31) * 4u : CSN_OOB);
+    }
+    // out through the wave's block in two passes of 16 rows, 16-byte row stores
+    const int n = col0 + 4 * c8;
+    const bool n_ok = 4 * c8 < valid;
+    const u32x4 Or = wx_rsrc(reinterpret_cast<float*>(p.out) + (long long)cu.item * p.out_item_stride, (long long)256 * p.ldo * 4);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) eb[csn_acc_row(rr, h) * 32 + l31] = acc[8 * half + rr];
+      const unsigned off = n_ok ? (unsigned)((32 * wave + 16 * half + erow) * p.ldo + n) * 4u : CSN_OOB;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&eb[(erow + 8 * t) * 32 + 4 * c8]);
+        wx_store4(v, Or, off, (unsigned)(8 * t * p.ldo) * 4u);
+        ps[64 * (2 * half + t)] += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+    }
+  };
+
   // Chunk i of this stream is stream + n_streams * i.  Iteration c: request chunk c + 3 (register set (c + 1) & 1),
   // contract chunk c (stage c % 3) | store it, commit chunk c + 2 (requested in iteration c - 1) to stage (c + 2) % 3.
   // Staggered halves (p.stagger; measured: no gain — the CU's memory pipe, not the overlap of the parts, sets the pace — and
@@ -260,18 +426,18 @@ __global__ __launch_bounds__(512, 2) void csn_wx_kernel(CsnWxArgs p) {
   // times the memory latency, ~3 us under load.)
   f32x4 R0[4], R1[4], R2[4];
   const bool stag = p.stagger != 0, late = stag && wave >= 4;
-  constexpr int NST = 4;                               // stores of one epilogue (always issued; switched-off lanes still count)
-  constexpr int BEHIND = 3 * NST + 8;                  // issued behind a request when its commit waits for it: three epilogues' stores, two requests
-  Cursor ci = cursor_at(stream), ce = ci;              // request cursor (runs four chunks ahead), contraction / store cursor
+  // issued behind a request when its commit waits for it: three epilogues' stores, two requests (LN: three residual requests)
+  constexpr int BEHIND = 3 * NST + 8 + (LN ? 12 : 0);
+  Cursor ci = cursor_at(q0), ce = ci;              // request cursor (runs four chunks ahead), contraction / store cursor
   // the loop waits for a request by counting what was issued behind it.  In front of the first iterations there are no
   // epilogues yet: NST stores through an empty window (dropped by the range check, counted like any other) stand in for each,
   // so that ONE count holds for every iteration (two wait statements on two branches made the compiler copy the in-flight
   // registers between them)
-  auto standin = [&]() {
+  auto standin = [&](auto count) {
     const u32x4 none = wx_rsrc(nullptr, 0);
     const unsigned oob = CSN_OOB;
 #pragma unroll
-    for (int i = 0; i < NST; ++i)                            // (asm: identical stores through a builtin are merged into one)
+    for (int i = 0; i < decltype(count)::value; ++i)         // (asm: identical stores through a builtin are merged into one)
       asm volatile("buffer_store_dword %0, %0, %1, 0 offen" :: "v"(oob), "s"(none) : "memory");
   };
   issue(ci, R0); advance(ci);
@@ -281,9 +447,13 @@ __global__ __launch_bounds__(512, 2) void csn_wx_kernel(CsnWxArgs p) {
   commit(0, R0);
   commit(1, R1);
   issue(ci, R2); advance(ci);                          // chunk 2
-  standin();
+  standin(std::integral_constant<int, NST + (LN ? 4 : 0)>{});          // (LN: a residual request sits in front of each epilogue's stores)
   issue(ci, R0); advance(ci);                          // chunk 3
-  standin();
+  if constexpr (LN) {
+    sum_item = ce.item;
+    issue_res(ce);                                     // residual of chunk 0
+  }
+  standin(std::integral_constant<int, NST>{});
   __syncthreads();
   if (late) __syncthreads();
   // one iteration: ST = c % 3 (compile time: the loop is unrolled by three), RQ the set chunk c + 4 goes to, RC the set of chunk c + 2
@@ -292,19 +462,22 @@ __global__ __launch_bounds__(512, 2) void csn_wx_kernel(CsnWxArgs p) {
     issue(ci, RQ); advance(ci);
     const f32x16 acc = compute(ST);
     if (stag) __syncthreads();
-    epilogue(ce, acc); advance(ce);
+    if constexpr (LN) epilogue_ln(ce, acc);
+    else epilogue(ce, acc);
+    advance(ce);
     wx_arrived<BEHIND>(RC);
     commit((ST + 2) % 3, RC);
     __syncthreads();
   };
   while (true) {
-    if (ce.q >= n_chunks) break;
+    if (ce.q >= q_end) break;
     iteration(std::integral_constant<int, 0>{}, R1, R2);
-    if (ce.q >= n_chunks) break;
+    if (ce.q >= q_end) break;
     iteration(std::integral_constant<int, 1>{}, R2, R0);
-    if (ce.q >= n_chunks) break;
+    if (ce.q >= q_end) break;
     iteration(std::integral_constant<int, 2>{}, R0, R1);
   }
+  if constexpr (LN) flush_sums();
   if (stag && !late) __syncthreads();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (requests beyond the last chunk: every lane off, nothing fetched)
 }
@@ -320,12 +493,44 @@ int wx_grid() {
   return cus;
 }
 
+// out[item][c] = sum of the item's slots of sum_ws[item][slots][256] (fp64 accumulation; the slots the launch geometry wrote)
+__global__ void csn_wx_ln_sums_kernel(const float* __restrict__ ws, float* __restrict__ out, int cpi, int run, int slots) {
+  const long long e = blockIdx.x;
+  const int first = (int)((e * cpi) / run), last = (int)(((e + 1) * cpi - 1) / run);
+  const float* src = ws + e * slots * 256 + threadIdx.x;
+  double s = 0.0;
+  for (int k = 0; k <= last - first; ++k) s += (double)src[k * 256];
+  out[e * 256 + threadIdx.x] = (float)s;
+}
+
+void wx_ln_geometry(int n_items, int n_points, int& cpi, int& run, int& slots) {
+  cpi = (n_points + WX_CH - 1) / WX_CH;
+  const long long n_chunks = (long long)n_items * cpi;
+  run = (int)((n_chunks + wx_grid() - 1) / wx_grid());
+  if (run < 1) run = 1;
+  slots = (cpi + run - 1) / run + 1;
+}
+
 }  // namespace
 
 int csn_dev_wx = 1;      // development switch (csn_dev_set): 0 = these products on the tiled kernels of gemm_bf16x3.hip
 
 bool csn_wx_takes(int rows, int k) { return (csn_dev_wx & 1) != 0 && k == WX_K && rows > 0 && rows % 256 == 0 && rows / 256 <= 32; }
 
+
+int csn_wx_ln_sum_slots(int n_items, int n_points) {
+  int cpi, run, slots;
+  wx_ln_geometry(n_items, n_points, cpi, run, slots);
+  return slots;
+}
+
+int csn_launch_wx_ln_sums(const float* ws, float* out, int n_items, int n_points, hipStream_t st) {
+  if (n_items <= 0) return 0;
+  int cpi, run, slots;
+  wx_ln_geometry(n_items, n_points, cpi, run, slots);
+  hipLaunchKernelGGL(csn_wx_ln_sums_kernel, dim3(n_items), dim3(256), 0, st, ws, out, cpi, run, slots);
+  return (int)hipGetLastError();
+}
 
 int csn_launch_wx(const CsnWxArgs& a, int out_mode, hipStream_t st) {
   if (a.n_items <= 0 || a.n_points <= 0) return 0;
@@ -337,7 +542,13 @@ int csn_launch_wx(const CsnWxArgs& a, int out_mode, hipStream_t st) {
   CsnWxArgs b = a;
   b.stagger = (csn_dev_wx & 2) ? 1 : 0;
   b.ablate = (csn_dev_wx >> 4) & 15;
-  if (out_mode == 0) hipLaunchKernelGGL((csn_wx_kernel<0>), dim3(grid), dim3(512), 0, st, b);
+  if (out_mode == 3) {
+    if (a.n_sets != 1 || !a.res || !a.rstd || a.div_rows) return -2;
+    b.stagger = 0;
+    if (a.sum_ws && a.sum_slots != csn_wx_ln_sum_slots(a.n_items, a.n_points)) return -2;
+    if (a.dropout_p > 0.f) hipLaunchKernelGGL((csn_wx_kernel<3, true>), dim3(grid), dim3(512), 0, st, b);
+    else hipLaunchKernelGGL((csn_wx_kernel<3, false>), dim3(grid), dim3(512), 0, st, b);
+  } else if (out_mode == 0) hipLaunchKernelGGL((csn_wx_kernel<0>), dim3(grid), dim3(512), 0, st, b);
   else if (out_mode == 2) hipLaunchKernelGGL((csn_wx_kernel<2>), dim3(grid), dim3(512), 0, st, b);
   else return -1;
   return (int)hipGetLastError();

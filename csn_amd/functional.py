@@ -455,7 +455,7 @@ class _MHAEvals(torch.autograd.Function):
         # third output (want_sums): sums[e][c] = sum_n xhat[e][c][n], formed in the epilogue of the out-projection (per-tile
         # partials in sum_ws) instead of a separate streaming pass over the 2.6 GB of maps
         sums = torch.empty((E, C), device=dev, dtype=torch.float32) if want_sums else None
-        sum_ws_n = E * ((NP + 255) // 256) * C if (want_sums and tuning.current().fused_point_sums) else 0
+        sum_ws_n = int(L.csn_outproj_ln_workspace_floats(E, C, D, NP)) if (want_sums and tuning.current().fused_point_sums) else 0
         sum_ws = torch.empty((sum_ws_n,), device=dev, dtype=torch.float32) if sum_ws_n else None
         _lib.check(L.csn_outproj_ln_fwd_f32(_ptr(att), D * NP, _ptr(w_fc), _ptr(x_all), C * NP, _ptr(q_slots),
                                             _ptr(xhat), C * NP, _ptr(rstd), E, C, D, NP, NP, LN_EPS, p_fc, seed_fc,

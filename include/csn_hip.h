@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSN_ABI_VERSION 15
+#define CSN_ABI_VERSION 16
 
 /* math modes (csn_set_math_mode / csn_set_thread_math_mode) */
 #define CSN_MATH_FP32 0
@@ -297,7 +297,11 @@ int csn_varlen_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_e
  * mean_n SSA(x) of csa_models.py:211-212, 218-219 before the affine.  With a workspace sum_ws of
  * n_evals * ceil(n_points / 256) * d_model floats (sum_ws_floats says how many there are) the 256-channel bf16x3 kernel forms
  * per-tile partial sums in its epilogue and a small kernel adds them in a fixed order; without one, or on the other kernels,
- * a streaming pass over xhat follows (dense maps only: xhat_eval_stride == d_model * ld). */
+ * a streaming pass over xhat follows (dense maps only: xhat_eval_stride == d_model * ld).
+ * csn_outproj_ln_workspace_floats: the sum_ws size with which the fused sums are taken on every kernel that has them (the
+ * streaming kernel of the bf16x3 mode keeps one partial per work-group and evaluation it touches; a smaller workspace is
+ * never an error — the streaming pass runs instead). */
+long long csn_outproj_ln_workspace_floats(int n_evals, int d_model, int d_inner, int n_points);
 int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const float* wfc, const float* xres,
                            long long xres_shape_stride, const int* res_index, float* xhat,
                            long long xhat_eval_stride, float* rstd, int n_evals, int d_model, int d_inner, int ld,

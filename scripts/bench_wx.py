@@ -17,6 +17,7 @@ ap.add_argument("--slots", type=int, default=128)
 ap.add_argument("--evals", type=int, default=256)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--ld", type=int, default=10000, help="row pitch of the fp32 maps (>= 10000 points): 10016 makes every row start on a 128-byte line")
+ap.add_argument("--ln", action="store_true", help="time the out-projection + LayerNorm instead")
 a = ap.parse_args()
 _lib.build()
 L = _lib.lib()
@@ -51,6 +52,33 @@ cases = [("Q projection, BLOCKED layout (128 slots x 312 blocks of 32 points)", 
          ("Q projection (128 slots, fp32 out)", lambda: q_proj(a.slots), a.slots * (C + 256) * NP * 4),
          ("K/V projection (128 slots, tile planes out)", lambda: kv_proj(a.slots), a.slots * (C * NP * 4 + 512 * ldp * 2)),
          ("dCtx-shaped product (256 evaluations, fp32 out)", lambda: q_proj(a.evals), a.evals * (C + 256) * NP * 4)]
+if a.ln:
+    # out-projection + residual + LayerNorm + pooled sums (csn_outproj_ln_fwd_f32): 256 x 256 tiles (CSN_DEV_WX = 5) against the stream
+    E = a.evals
+    xres = torch.randn((a.slots, C, LD), device="cuda", generator=g)
+    rid = (torch.arange(E, device="cuda", dtype=torch.int32) % a.slots).contiguous()
+    xhat, rstd, sums = torch.empty((E, C, LD), device="cuda"), torch.empty((E, NP), device="cuda"), torch.empty((E, C), device="cuda")
+    ws_n = L.csn_outproj_ln_workspace_floats(E, C, C, NP)
+    ws = torch.empty((ws_n,), device="cuda")
+    nbytes = E * C * NP * 4 * 3 + E * NP * 4
+    for p_fc in (0.0, 0.1):
+        times = {5: [], 1: []}
+        for rep in range(a.reps + 2):
+            for wx in (5, 1):
+                L.csn_dev_set(_lib.DEV_WX, wx)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _lib.check(L.csn_outproj_ln_fwd_f32(x.data_ptr(), C * LD, w.data_ptr(), xres.data_ptr(), C * LD, rid.data_ptr(), xhat.data_ptr(),
+                                                    C * LD, rstd.data_ptr(), E, C, C, LD, NP, 1e-6, p_fc, 77, sums.data_ptr(), ws.data_ptr(), ws_n, st))
+                e1.record()
+                torch.cuda.synchronize()
+                if rep >= 2:
+                    times[wx].append(e0.elapsed_time(e1))
+        L.csn_dev_set(_lib.DEV_WX, 1)
+        t0, t1 = float(np.median(times[5])), float(np.median(times[1]))
+        print(f"out-projection + LayerNorm + sums ({E} evaluations, fc dropout {p_fc}): tiled {t0:.3f} ms ({nbytes / t0 / 1e9:.2f} TB/s of its own bytes)   "
+              f"streaming {t1:.3f} ms ({nbytes / t1 / 1e9:.2f} TB/s)   min {min(times[5]):.3f} / {min(times[1]):.3f}", flush=True)
+    sys.exit(0)
 ap2 = os.environ.get("WX_ABLATE")
 if ap2:
     # timing-only ablations of the streaming kernel (outputs are wrong): CSN_DEV_WX value = 1 | 2 (lock step) | bits << 4

@@ -145,3 +145,60 @@ def test_dctx_product_inside_the_layer_norm_backward(L):
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])
     ref = torch.einsum("dc,ecn->edn", wfc_t.double().cpu(), res[0][0].double())
     assert _rel(res[0][1], ref) < 2e-5 and torch.equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("E,S,NP,ld,p,indexed", [
+    (3, 2, 520, 520, 0.0, True),            # 17 chunks per evaluation (the last of 8 points), evaluations sharing residual slots
+    (2, 2, 1000, 1000, 0.1, False),         # fc dropout: the mask of the tiled kernel, bit for bit, or xhat is nowhere near
+    (300, 7, 64, 64, 0.0, True),            # more evaluations than streams: runs that cross several evaluations
+    (1, 1, 10000, 10000, 0.25, False),      # the reference's point count: one evaluation shared by all the streams
+    (5, 5, 36, 40, 0.0, False),             # row pitch above the point count
+])
+def test_out_projection_layer_norm_on_the_stream(L, E, S, NP, ld, p, indexed):
+    """csn_outproj_ln_fwd_f32 (csa_models.py:115-118) on the streaming kernel: xhat, rstd and the pooled sums against float64 and
+    against the 256 x 256-tile kernel it replaces (CSN_DEV_WX bit 2 switches the route off); nothing written outside the maps."""
+    lib = L.lib()
+    rng = np.random.default_rng(17)
+    C = D = 256
+    seed = 0x1234_5678_9abc_def0
+    ctx = torch.zeros((E, D, ld))
+    ctx[:, :, :NP] = _rand(rng, E, D, NP)
+    x = torch.zeros((S, C, ld))
+    x[:, :, :NP] = _rand(rng, S, C, NP)
+    wfc = _rand(rng, C, D) / math.sqrt(D)
+    rid = torch.from_numpy(rng.integers(0, S, size=E).astype(np.int32)) if indexed else None
+    cd, xd, wd = ctx.cuda(), x.cuda(), wfc.cuda()
+    ridd = rid.cuda() if indexed else None
+    ws_n = lib.csn_outproj_ln_workspace_floats(E, C, D, NP)
+    assert ws_n >= E * ((NP + 255) // 256) * C
+    res = []
+    for wx, fused in ((1, True), (5, True), (1, False)):
+        lib.csn_dev_set(L.DEV_WX, wx)
+        try:
+            pool = torch.full((E * C * ld + 4096,), float("nan"), device="cuda")
+            xhat, guard = pool[:E * C * ld].view(E, C, ld), pool[E * C * ld:]
+            rstd = torch.full((E * NP + 1024,), float("nan"), device="cuda")
+            sums = torch.full((E, C), float("nan"), device="cuda")
+            ws = torch.full((ws_n,), float("nan"), device="cuda") if fused else None
+            L.check(lib.csn_outproj_ln_fwd_f32(cd.data_ptr(), D * ld, wd.data_ptr(), xd.data_ptr(), C * ld,
+                                               ridd.data_ptr() if indexed else None, xhat.data_ptr(), C * ld, rstd.data_ptr(), E, C, D,
+                                               ld, NP, 1e-6, p, seed, sums.data_ptr(), ws.data_ptr() if fused else None,
+                                               ws_n if fused else 0, _stream()))
+            torch.cuda.synchronize()
+            assert torch.isnan(guard).all() and torch.isnan(rstd[E * NP:]).all()
+            if ld > NP:
+                assert torch.isnan(xhat[:, :, NP:]).all()
+            res.append((xhat[:, :, :NP].cpu(), rstd[:E * NP].view(E, NP).cpu(), sums.cpu()))
+        finally:
+            lib.csn_dev_set(L.DEV_WX, 1)
+    (xh, rs, sm), (xh_t, rs_t, sm_t), (xh_n, rs_n, sm_n) = res
+    assert torch.equal(xh, xh_n) and torch.equal(rs, rs_n)         # with or without the fused sums: the same maps
+    assert (xh - xh_t).abs().max() < 2e-5 and ((rs - rs_t).abs() / rs_t).max() < 2e-5
+    tol = 2e-5 * math.sqrt(NP) * 4
+    assert (sm - sm_t).abs().max() < tol and (sm - sm_n).abs().max() < tol
+    assert (sm.double() - xh.double().sum(dim=2)).abs().max() < tol
+    if p == 0.0:
+        z = torch.einsum("cd,edn->ecn", wfc.double(), ctx[:, :, :NP].double()) + (x[rid.long()] if indexed else x)[:, :, :NP].double()
+        ref = (z - z.mean(dim=1, keepdim=True)) / torch.sqrt(z.var(dim=1, unbiased=False, keepdim=True) + 1e-6)
+        assert _rel(xh, ref) < 5e-6
+        assert ((rs.double() - 1 / torch.sqrt(z.var(dim=1, unbiased=False) + 1e-6)).abs() * torch.sqrt(z.var(dim=1, unbiased=False))).max() < 1e-5
