@@ -67,7 +67,8 @@ def algorithmic_flops_fwd(B, K, N, C, D, T):
 def masked_ce(logits, label):
     """csa_training.py:94-108 restated: mean cross-entropy over the points with label > 0 (label 0 = unlabelled is
     ignored; class-major logits are consumed in place instead of being transposed and gathered)."""
-    return torch.nn.functional.cross_entropy(logits.squeeze(-1), label, ignore_index=0)
+    from csn_amd.functional import masked_cross_entropy
+    return masked_cross_entropy(logits, label, 0)[0]
 
 
 def cpu_model_name():

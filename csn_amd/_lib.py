@@ -16,7 +16,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libcsn_hip.so")
-SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "wx_stream.hip", "attn_fwd_x4.hip", "attn_f32.hip", "attn_bf16x3.hip", "attn_dkv.hip", "outproj_ln.hip", "retrieval.hip", "combine.hip", "compat.hip", "csn_capi.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "wx_stream.hip", "loss.hip", "attn_fwd_x4.hip", "attn_f32.hip", "attn_bf16x3.hip", "attn_dkv.hip", "outproj_ln.hip", "retrieval.hip", "combine.hip", "compat.hip", "csn_capi.hip"]
 HEADERS = ["csn_common.h", "csn_kernels.h", "csn_window.h", os.path.join("..", "..", "include", "csn_hip.h")]
 ARCH = "gfx950"
 BUILD_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared"]
@@ -164,6 +164,11 @@ _SIGNATURES = {
                                         c_longlong, c_longlong, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                         c_float, c_ulonglong, c_void_p]),
     "csn_outproj_ln_workspace_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
+    "csn_masked_ce_workspace_bytes": (c_longlong, [c_int, c_int]),
+    "csn_masked_ce_fwd_f32": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p,
+                                      c_void_p, c_longlong, c_void_p, c_void_p]),
+    "csn_masked_ce_bwd_f32": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p,
+                                      c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p]),
     "csn_outproj_ln_fwd_f32": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p,
                                        c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float,
                                        c_ulonglong, c_void_p, c_void_p, c_longlong, c_void_p]),

@@ -602,6 +602,43 @@ int csn_varlen_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_e
                            max_queries, ld_kv, nullptr, 0, stream, n_queries, n_keys);
 }
 
+long long csn_masked_ce_workspace_bytes(int n_shapes, int n_points) {
+  if (n_shapes <= 0 || n_points <= 0) return 0;
+  return csn_masked_ce_blocks(n_shapes, n_points) * 3 * (long long)sizeof(double);
+}
+
+int csn_masked_ce_fwd_f32(const float* logits, long long shape_stride, int ld, const long long* labels, long long label_shape_stride,
+                          int n_shapes, int n_classes, int n_points, int mask, float* lse, void* ws, long long ws_bytes,
+                          float* stats, void* stream) {
+  if (!logits || !labels || !lse || !ws || !stats || n_shapes <= 0 || n_classes <= 0 || n_points <= 0 || n_points > ld) return CSN_E_ARG;
+  if (n_shapes > 65535 || n_classes > 65535) return CSN_E_DIM;
+  if (reinterpret_cast<unsigned long long>(ws) & 7) return CSN_E_PTR;
+  if (ws_bytes < csn_masked_ce_workspace_bytes(n_shapes, n_points)) return CSN_E_WORKSPACE;
+  CsnMaskedCeArgs a{};
+  a.logits = logits; a.shape_stride = shape_stride; a.ld = ld; a.labels = labels; a.label_shape_stride = label_shape_stride;
+  a.n_shapes = n_shapes; a.n_classes = n_classes; a.n_points = n_points; a.mask = mask;
+  a.lse = lse; a.partials = static_cast<double*>(ws); a.stats = stats;
+  return csn_launch_masked_ce_fwd(a, (hipStream_t)stream);
+}
+
+int csn_masked_ce_bwd_f32(const float* logits, long long shape_stride, int ld, const long long* labels, long long label_shape_stride,
+                          int n_shapes, int n_classes, int n_points, int mask, const float* lse, const float* stats,
+                          const float* grad_out, float* dlogits, long long dshape_stride, int dld, void* stream) {
+  if (!logits || !labels || !lse || !stats || !grad_out || !dlogits || n_shapes <= 0 || n_classes <= 0 || n_points <= 0 || n_points > ld ||
+      n_points > dld)
+    return CSN_E_ARG;
+  if (n_shapes > 65535 || n_classes > 65535) return CSN_E_DIM;
+  if ((ld & 3) || (dld & 3) || (n_points & 3)) return CSN_E_ALIGN;
+  if ((shape_stride & 3) || (dshape_stride & 3)) return CSN_E_STRIDE;
+  if (mis16(logits) || mis16(dlogits) || mis16(lse)) return CSN_E_PTR;
+  CsnMaskedCeArgs a{};
+  a.logits = logits; a.shape_stride = shape_stride; a.ld = ld; a.labels = labels; a.label_shape_stride = label_shape_stride;
+  a.n_shapes = n_shapes; a.n_classes = n_classes; a.n_points = n_points; a.mask = mask;
+  a.lse = const_cast<float*>(lse); a.stats = const_cast<float*>(stats); a.grad_out = grad_out;
+  a.dlogits = dlogits; a.dshape_stride = dshape_stride; a.dld = dld;
+  return csn_launch_masked_ce_bwd(a, (hipStream_t)stream);
+}
+
 long long csn_outproj_ln_workspace_floats(int n_evals, int d_model, int d_inner, int n_points) {
   if (n_evals <= 0 || d_model <= 0 || d_inner <= 0 || n_points <= 0) return 0;
   const long long tiled = (long long)n_evals * ((n_points + 255) / 256) * d_model;

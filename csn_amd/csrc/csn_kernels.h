@@ -158,6 +158,20 @@ int csn_launch_partial_sums_f32(const float* ws, float* out, long long rows_oute
 int csn_launch_outproj_ln_fwd_f32(const CsnOutProjArgs& a, int mode, hipStream_t st);   // mode 0: fp32, 1..3: 16-bit matrix-core contraction
 int csn_launch_outproj_ln_big(const CsnOutProjArgs& a, int mode, hipStream_t st);       // gemm_bf16x3.hip: C = 256, 256 x 256 tiles
 
+// masked cross-entropy on class-major logits (loss.hip; csa_training.py:94-108)
+struct CsnMaskedCeArgs {
+  const float* logits;  long long shape_stride;  int ld;          // [shape][class][ld]
+  const long long* labels;  long long label_shape_stride;         // [shape][n_points] int64
+  int n_shapes, n_classes, n_points, mask;                        // counted: mask < label < n_classes
+  float* lse;                                                     // [shape][n_points]
+  double* partials;                                               // forward: 3 per block (csn_masked_ce_blocks)
+  float* stats;                                                   // [3]: mean loss, accuracy, counted points
+  const float* grad_out;  float* dlogits;  long long dshape_stride;  int dld;      // backward
+};
+long long csn_masked_ce_blocks(int n_shapes, int n_points);
+int csn_launch_masked_ce_fwd(const CsnMaskedCeArgs& a, hipStream_t st);
+int csn_launch_masked_ce_bwd(const CsnMaskedCeArgs& a, hipStream_t st);
+
 struct CsnLnBwdArgs {
   const float* dxhat; const float* xhat; const float* rstd;   // [e][C][ld], [e][C][ld], [e][n_points]
   const float* dxhat_rows;                                     // optional [e][C]: added to every point of row (e, c)

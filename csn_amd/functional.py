@@ -919,3 +919,54 @@ def compat_head(pooled: torch.Tensor, wq: torch.Tensor, bq: torch.Tensor, wk: to
     """The compatibility weights comp (B, K+1) of csa_models.py:222-230 from the pooled descriptors (B, K+1, C) and the two
     nn.Linear heads, with the reference's key-row bookkeeping for B > 1 (``reference_layout``) or per shape."""
     return _CompatHead.apply(pooled, wq, bq, wk, bk, bool(reference_layout))
+
+
+# ------------------------------------------------------------------------------------------------------
+# the loss the layers are trained with (csa_training.py:94-108)
+# ------------------------------------------------------------------------------------------------------
+class _MaskedCE(torch.autograd.Function):
+    """logits (S, n_classes, N) class-major (any shape / class stride, points contiguous), labels (S, N) int64 ->
+    stats (3,): mean cross-entropy over the points with mask < label < n_classes, their accuracy, their number."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, mask):
+        _need_cuda(logits)
+        if labels.dtype != torch.int64 or not labels.is_cuda:
+            raise _lib.CsnError(f"masked_cross_entropy takes int64 labels on the device (got {labels.dtype}, {labels.device})")
+        S, n_cls, N = logits.shape
+        if logits.stride(2) != 1 or tuple(labels.shape) != (S, N) or labels.stride(1) != 1:
+            raise _lib.CsnError("masked_cross_entropy: logits (S, classes, N) with contiguous points, labels (S, N)")
+        L = _lib.lib()
+        dev = logits.device
+        lse = torch.empty((S, N), device=dev, dtype=torch.float32)
+        stats = torch.empty((3,), device=dev, dtype=torch.float32)
+        ws_bytes = int(L.csn_masked_ce_workspace_bytes(S, N))
+        ws = torch.empty((ws_bytes // 8,), device=dev, dtype=torch.float64)
+        _lib.check(L.csn_masked_ce_fwd_f32(_ptr(logits), logits.stride(0), logits.stride(1), _ptr(labels), labels.stride(0), S, n_cls, N,
+                                           int(mask), _ptr(lse), _ptr(ws), ws_bytes, _ptr(stats), _stream()), "csn_masked_ce_fwd_f32")
+        ctx.save_for_backward(logits, labels, lse, stats)
+        ctx.mask = int(mask)
+        ctx.mark_non_differentiable(labels)
+        return stats
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, lse, stats = ctx.saved_tensors
+        S, n_cls, N = logits.shape
+        # only the loss (stats[0]) carries a gradient; accuracy and count are piecewise constant
+        g0 = g[0:1].contiguous().float()
+        dlogits = torch.empty((S, n_cls, N), device=logits.device, dtype=torch.float32)
+        _lib.check(_lib.lib().csn_masked_ce_bwd_f32(_ptr(logits), logits.stride(0), logits.stride(1), _ptr(labels), labels.stride(0), S,
+                                                    n_cls, N, ctx.mask, _ptr(lse), _ptr(stats), _ptr(g0), _ptr(dlogits), n_cls * N, N,
+                                                    _stream()), "csn_masked_ce_bwd_f32")
+        return dlogits, None, None
+
+
+def masked_cross_entropy(logits: torch.Tensor, labels: torch.Tensor, mask: int = 0):
+    """csa_training.py:94-108 on the device: (mean cross-entropy, accuracy, number of counted points) over the points whose label
+    is above ``mask``; logits (S, n_classes, N[, 1]) class-major as the logit layer writes them, labels (S, N) int64.  One pass
+    over the logits forward and one backward, instead of transpose + gather + log_softmax + nll of the reference's form."""
+    if logits.dim() == 4:
+        logits = logits.squeeze(-1)
+    st = _MaskedCE.apply(logits, labels, mask)
+    return st[0], st[1], st[2]

@@ -27,7 +27,13 @@ def _flatten(logit: torch.Tensor, label: torch.Tensor) -> Tuple[torch.Tensor, to
 
 def loss_functions_seg(logit: torch.Tensor, label_gt: torch.Tensor, num_class: int, weight_decay: float = 0.0,
                        mask: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Mean cross-entropy and accuracy over the points whose label is > mask (csa_training.py:94-108)."""
+    """Mean cross-entropy and accuracy over the points whose label is > mask (csa_training.py:94-108).  Device logits in fp32
+    go through the fused HIP pair (csn_amd.functional.masked_cross_entropy: the class-major logits are read where they lie);
+    host tensors — the CPU tests of this module's bookkeeping — take the reference's own sequence of torch calls."""
+    if logit.is_cuda and logit.dtype == torch.float32 and label_gt.shape[1:] == logit.shape[2:3]:
+        from .functional import masked_cross_entropy
+        loss, accu, _ = masked_cross_entropy(logit, label_gt.long(), mask)
+        return loss, accu
     flat, lab = _flatten(logit, label_gt)
     keep = torch.where(lab > mask)[0]
     sel, tgt = flat[keep], lab[keep].long()

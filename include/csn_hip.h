@@ -389,6 +389,26 @@ int csn_compat_bwd_f32(const float* dcomp, const float* comp, const double* save
                        const float* wq, const float* wk, double* ws, long long ws_doubles, float* dpooled, float* dwq, float* dbq,
                        float* dwk, float* dbk, int n_shapes, int k1, int channels, int reference_layout, void* stream);
 
+/* ---- (10) the loss the layers are trained with (csa_training.py:94-108) -----------------------------------------------
+ * The reference transposes the logits to [point][class], gathers the points with label > mask and calls F.cross_entropy and
+ * an argmax accuracy on the selection.  Here the class-major logits [shape][class][ld] (the layout the logit layer writes,
+ * csa_models.py:151) are read where they lie:
+ *   forward   stats[0] = mean over the counted points (mask < label < n_classes) of lse - z[label], stats[1] = the fraction of
+ *             them whose first arg-max class is the label, stats[2] = their number (0 counted points: 0 / 0 = nan, as the
+ *             reference's empty selection gives); lse [n_shapes][n_points] is kept for the backward.  ws: scratch of
+ *             csn_masked_ce_workspace_bytes(n_shapes, n_points) bytes, 8-byte aligned (per-block fp64 partial sums, added in a
+ *             fixed order: bitwise reproducible).
+ *   backward  dlogits[s][c][n] = counted ? (exp(z - lse) - [c == label]) * grad_out[0] / stats[2] : 0, every class row of
+ *             every shape written (n_points, ld, dld % 4 == 0).
+ * labels are int64 (torch.long), label_shape_stride elements apart per shape. */
+long long csn_masked_ce_workspace_bytes(int n_shapes, int n_points);
+int csn_masked_ce_fwd_f32(const float* logits, long long shape_stride, int ld, const long long* labels, long long label_shape_stride,
+                          int n_shapes, int n_classes, int n_points, int mask, float* lse, void* ws, long long ws_bytes,
+                          float* stats, void* stream);
+int csn_masked_ce_bwd_f32(const float* logits, long long shape_stride, int ld, const long long* labels, long long label_shape_stride,
+                          int n_shapes, int n_classes, int n_points, int mask, const float* lse, const float* stats,
+                          const float* grad_out, float* dlogits, long long dshape_stride, int dld, void* stream);
+
 /* ---- DEVELOPMENT SECTION -------------------------------------------------------------------------------------------------
  * Kernel-selection switches for A/B timing and for the equality tests between two kernel forms of one product.  They are
  * PROCESS-wide, not thread-safe, change no result beyond fp32 rounding and are not part of the drop-in surface: a product
