@@ -126,12 +126,13 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
   // LDS images: A x 2 stages, B x 2 (RC && EARLY: x 3 — the key-contiguous K image is then committed in segment 1 too, which
   // needs a third stage), RC: + C x 2 (the K tile in tileA's form)
   constexpr int NB_ST = (RC && EARLY) ? 3 : 2;
-  constexpr int TILE_EL = (2 + NB_ST + (RC ? 2 : 0)) * NPL * PLANE, STAGE_EL = D * 128 * 2;
+  constexpr bool C_ALIASED = CSN_RC_ALIAS && RC && NPL == 2 && DT > 4;        // timing experiment: image C laid over image B
+  constexpr int TILE_EL = (2 + NB_ST + (RC && !C_ALIASED ? 2 : 0)) * NPL * PLANE, STAGE_EL = D * 128 * 2;
   static_assert(2 * (TILE_EL > STAGE_EL ? TILE_EL : STAGE_EL) <= 160 * 1024, "LDS budget of one CU");
   __shared__ __attribute__((aligned(16))) short tiles[TILE_EL > STAGE_EL ? TILE_EL : STAGE_EL];
   auto tileA = [&](int st, int pl) -> short* { return tiles + (st * NPL + pl) * PLANE; };
   auto tileB = [&](int st, int pl) -> short* { return tiles + ((2 + st) * NPL + pl) * PLANE; };
-  auto tileC = [&](int st, int pl) -> short* { return tiles + ((2 + NB_ST + st) * NPL + pl) * PLANE; };
+  auto tileC = [&](int st, int pl) -> short* { return tiles + ((2 + (C_ALIASED ? 0 : NB_ST) + st) * NPL + pl) * PLANE; };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, kq = lane >> 4;

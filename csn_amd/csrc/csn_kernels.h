@@ -105,7 +105,12 @@ struct CsnAttnArgs {
   int sc_layout = 0;
 };
 // score recomputation needs three LDS tile images per stage: one plane at every width, two planes up to d = 128
-constexpr bool csn_attn_recompute_fits(int planes, int dt) { return planes == 1 || dt <= 4; }
+// (-DCSN_RC_ALIAS=1, TIMING EXPERIMENT ONLY — results are wrong: the two-plane d = 256 instance is built with its third image
+//  laid over the second, to price a one-K-image recomputing kernel before writing it; profiles/r4r_recompute_d256_experiment.txt)
+#ifndef CSN_RC_ALIAS
+#define CSN_RC_ALIAS 0
+#endif
+constexpr bool csn_attn_recompute_fits(int planes, int dt) { return planes == 1 || dt <= 4 || CSN_RC_ALIAS; }
 // ---- key-stationary dK / dV with recomputed scores (attn_dkv.hip; 16-bit modes, block mode, d <= 128) ----------------
 struct CsnAttnDkvArgs {
   const float* q;     long long q_shape_stride;  const int* q_index;     // pre-scaled queries Qs^T [slot][H*d][ld], evaluation -> slot
