@@ -103,6 +103,7 @@ struct CsnAttnArgs {
   // [key tile kt][query][32 keys] (the 128 bytes of a query's tile, fp32 scores or [hi 32 | lo 32] planes): what a wave stores
   // or loads per instruction is then one contiguous run instead of sixteen 64-byte pieces 2 KB apart
   int sc_layout = 0;
+  int dev_ablate = 0;                                    // development, attn_fwd_x8.hip: timing-only ablations (results wrong)
 };
 // score recomputation needs three LDS tile images per stage: one plane at every width, two planes up to d = 128
 // (-DCSN_RC_ALIAS=1, TIMING EXPERIMENT ONLY — results are wrong: the two-plane d = 256 instance is built with its third image
@@ -134,6 +135,7 @@ constexpr bool csn_attn_dkv_flash_fits(int dt) { return dt <= 4; }         // K^
 // forward at d = 256 in bf16x3 on four 32-query waves (attn_fwd_x4.hip)
 extern int csn_dev_attn_x4;
 bool csn_attn_fwd_x4_takes(const CsnAttnArgs& a, int d, int mode);
+int csn_launch_attn_fwd_x8(const CsnAttnArgs& a, hipStream_t st);     // attn_fwd_x8.hip
 int csn_launch_attn_fwd_x4(const CsnAttnArgs& a, hipStream_t st);
 
 int csn_launch_attn_fwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);

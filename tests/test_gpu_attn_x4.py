@@ -35,7 +35,8 @@ def _planes(kv, T, nb):
 @pytest.mark.parametrize("S,E,H,T,nb,NP,drop,keep", [(3, 5, 1, 500, 2, 1000, 0.1, True), (2, 3, 2, 500, 2, 1000, 0.0, True),
                                                      (2, 4, 1, 500, 3, 1300, 0.1, True), (2, 2, 1, 100, 3, 300, 0.2, False),
                                                      (1, 1, 1, 36, 2, 72, 0.0, True)])
-def test_four_wave_forward_equals_the_eight_wave_forward(L, S, E, H, T, nb, NP, drop, keep):
+@pytest.mark.parametrize("form", [1, 2])          # 1: four waves x 32 queries (attn_fwd_x4.hip); 2: 4 query groups x 2 channel halves (attn_fwd_x8.hip)
+def test_four_wave_forward_equals_the_eight_wave_forward(L, S, E, H, T, nb, NP, drop, keep, form):
     lib = L.lib()
     d, D, Tp = 256, 256 * H, (T + 31) // 32 * 32
     rng = np.random.default_rng(S * 100 + T)
@@ -47,7 +48,7 @@ def test_four_wave_forward_equals_the_eight_wave_forward(L, S, E, H, T, nb, NP, 
     ks = torch.from_numpy(rng.integers(0, S, size=E).astype(np.int32)).cuda()
     st = torch.cuda.current_stream().cuda_stream
     outs = []
-    for x4 in (0, 1):
+    for x4 in (0, form):
         lib.csn_dev_set(L.DEV_ATTN_X4, x4)
         try:
             ctx = torch.full((E, D, NP), float("nan"), device="cuda")
