@@ -163,6 +163,8 @@ _SIGNATURES = {
                                         c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_longlong, c_longlong, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
                                         c_float, c_ulonglong, c_void_p]),
+    "csn_project_qkv_f32": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_int, c_int, c_void_p, c_longlong, c_int, c_void_p,
+                                    c_longlong, c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "csn_outproj_ln_workspace_floats": (c_longlong, [c_int, c_int, c_int, c_int]),
     "csn_masked_ce_workspace_bytes": (c_longlong, [c_int, c_int]),
     "csn_masked_ce_fwd_f32": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p,

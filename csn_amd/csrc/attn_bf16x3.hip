@@ -111,6 +111,12 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
 #ifndef CSN_LDS_V
 #define CSN_LDS_V 1
 #endif
+// (1: the forward asks for the first K / V tile before it stages its operand block, 2: the backward too.  Measured: forward
+//  5.17 / 5.16 ms against 5.17 / 5.14 without, backward 7.41 / 7.33 against 7.14 / 7.06 — 53 spilled registers instead of 19;
+//  profiles/r4u_attention_prologue_and_priority.txt.  Off.)
+#ifndef CSN_PREFETCH_TILE0
+#define CSN_PREFETCH_TILE0 0
+#endif
   constexpr int PLANE = D * KT + (CSN_LDS_V ? 32 : 64);
   // [A | B][stage][plane hi/lo][row][32 keys] — one array, so that the prologue / epilogue can use all of it as a
   // [D rows][128 queries] fp32 staging block for 16-byte global accesses (which sets the size in the one-plane modes)
@@ -210,6 +216,50 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
   // per-lane byte offsets (scalar offsets handed to the buffer instructions must be wave-uniform, so
   // everything that depends on the lane lives here); lanes of query rows beyond the block are switched off
 
+  // ---- streamed tiles: global -> registers -> LDS (swizzled) ---------------------------------------
+  // piece idx = tid + 512 i  ->  row tid / UPR + RPP i.  fp32 input: keys 4 c .. 4 c + 3, c = tid % 8.  Tile planes: 16-byte
+  // unit tid % UPR of the row's 64 NPL bytes (units 0..3: hi plane keys 8 u .. 8 u + 7, units 4..7: lo plane).  Everything that
+  // depends on i is wave-uniform (scalar offset of the load, immediate offset of the LDS store): rows 64 apart share the swizzles.
+  const int t_c = tid & (UPR - 1), t_row = tid / UPR;
+  constexpr int SWB = (KVP && NPL == 1) ? 1 : 0;        // one plane: a 16-lane store group covers rows r .. r + 3 — swap on bit 1
+  // tileA chunk swap: rows r and r + 8 are read together by the transposing read, and the 8-byte stores of a 16-lane group
+  // cover rows r, r + 1 of both planes — so the swap bit is (r >> 3) ^ r: both pairs then sit on complementary banks
+  const int t_sw = (CSN_LDS_V ? ((t_row >> 3) ^ (t_row >> SWB)) : (t_row >> 3)) & 1, t_swz = (-((t_row >> 2) & 3)) & 3;
+  const unsigned t_off = KVP ? (unsigned)(t_row * kld * 2 + t_c * 16) : (unsigned)(t_row * ldk + 4 * t_c) * 4u;
+  // only the last piece can fall beyond the tile — and not even that one when the pieces fill the passes (compile-time: the
+  // guards around the last piece's stores fold away)
+  const bool t_last_ok = (PIECES % 512 == 0) || (tid + 512 * (NP_T - 1) < PIECES);
+  // fp32: 8-byte chunk c -> tileA chunk c ^ sw;  tileB unit (c >> 1) ^ swz, half c & 1
+  // planes: unit u = c & 3 of plane c >> 2 -> tileA chunks (2 u) ^ sw and (2 u + 1) ^ sw;  tileB unit u ^ swz
+  const int t_u = t_c & 3, t_pl = t_c >> 2;
+  const int a_dst = KVP ? t_pl * PLANE + t_row * KT + 8 * t_u : t_row * KT + 4 * (t_c ^ t_sw);
+  const int b_dst = KVP ? t_pl * PLANE + t_row * KT + 8 * (t_u ^ t_swz) : t_row * KT + 8 * ((t_c >> 1) ^ t_swz) + 4 * (t_c & 1);
+  f32x4 g[NP_T];
+  f32x4 g2[(RC || EARLY) ? NP_T : 1];                   // RC: the K tile's pieces (committed to two images) beside the V tile's; EARLY: tileB's
+  auto fetch_to = [&](const csn_rsrc_t& rs, int kt, f32x4* g) {
+    if (KVP) {
+      // keys beyond the block end are zero in the planes; units that lie entirely beyond it are not fetched at all
+      const unsigned off = (kt * KT + 8 * t_u) < T ? t_off : CSN_OOB;
+#pragma unroll
+      for (int i = 0; i < NP_T; ++i)
+        g[i] = csn_bload4(rs, (i == NP_T - 1 && !t_last_ok) ? CSN_OOB : off, (unsigned)(kt * (64 * NPL) + RPP * i * kld * 2));
+    } else {
+      const int k0 = kt * KT;
+      // T % 4 == 0: a 16-byte piece is all in or all out; pieces past the block end are switched off
+      const unsigned off = (k0 + 4 * t_c) < T ? t_off : CSN_OOB;
+#pragma unroll
+      for (int i = 0; i < NP_T; ++i)
+        g[i] = csn_bload4(rs, (i == NP_T - 1 && !t_last_ok) ? CSN_OOB : off, (unsigned)(k0 + 64 * i * ldk) * 4u);
+    }
+  };
+  // The first tile's pieces are asked for BEFORE the operand block is staged (the stamps of the d = 256 forward: 21 k of a
+  // work-group's 135 k cycles were this prologue, most of it three memory round trips in a row — operand block, K tile, V
+  // tile — with nothing else in flight; profiles/r4u_attention_forward_stamps.txt): they travel beside the operand block and
+  // wait in registers until the staging block has been read
+  constexpr bool PRE0 = CSN_PREFETCH_TILE0 && !RC && !EARLY && (!BWD || CSN_PREFETCH_TILE0 > 1);      // (backward: 19 -> 53 spilled registers)
+  f32x4 gp[PRE0 ? NP_T : 1];
+  if constexpr (PRE0) { fetch_to(Ar, 0, g); fetch_to(Br, 0, gp); }
+
   // ---- register-resident operand R[d][q]: lane (q, kq) keeps rows d = 32 s + 8 kq + j as bf16 hi / lo ------
   // A wave-level memory instruction costs ~100 cycles of issue whatever its width, and the register layout would need
   // 64 four-byte loads per lane (128 in the backward, which also reads O for delta).  So the work-group fetches its
@@ -303,42 +353,6 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
   const unsigned s_base = tile_major ? (unsigned)(qrow * KT + 8 * kq) * 4u : (unsigned)(qrow * Tp + 8 * kq) * 4u;
   const unsigned s_tile = tile_major ? (unsigned)Tq * (KT * 4u) : KT * 4u;      // bytes from one key tile to the next
 
-  // ---- streamed tiles: global -> registers -> LDS (swizzled) ---------------------------------------
-  // piece idx = tid + 512 i  ->  row tid / UPR + RPP i.  fp32 input: keys 4 c .. 4 c + 3, c = tid % 8.  Tile planes: 16-byte
-  // unit tid % UPR of the row's 64 NPL bytes (units 0..3: hi plane keys 8 u .. 8 u + 7, units 4..7: lo plane).  Everything that
-  // depends on i is wave-uniform (scalar offset of the load, immediate offset of the LDS store): rows 64 apart share the swizzles.
-  const int t_c = tid & (UPR - 1), t_row = tid / UPR;
-  constexpr int SWB = (KVP && NPL == 1) ? 1 : 0;        // one plane: a 16-lane store group covers rows r .. r + 3 — swap on bit 1
-  // tileA chunk swap: rows r and r + 8 are read together by the transposing read, and the 8-byte stores of a 16-lane group
-  // cover rows r, r + 1 of both planes — so the swap bit is (r >> 3) ^ r: both pairs then sit on complementary banks
-  const int t_sw = (CSN_LDS_V ? ((t_row >> 3) ^ (t_row >> SWB)) : (t_row >> 3)) & 1, t_swz = (-((t_row >> 2) & 3)) & 3;
-  const unsigned t_off = KVP ? (unsigned)(t_row * kld * 2 + t_c * 16) : (unsigned)(t_row * ldk + 4 * t_c) * 4u;
-  // only the last piece can fall beyond the tile — and not even that one when the pieces fill the passes (compile-time: the
-  // guards around the last piece's stores fold away)
-  const bool t_last_ok = (PIECES % 512 == 0) || (tid + 512 * (NP_T - 1) < PIECES);
-  // fp32: 8-byte chunk c -> tileA chunk c ^ sw;  tileB unit (c >> 1) ^ swz, half c & 1
-  // planes: unit u = c & 3 of plane c >> 2 -> tileA chunks (2 u) ^ sw and (2 u + 1) ^ sw;  tileB unit u ^ swz
-  const int t_u = t_c & 3, t_pl = t_c >> 2;
-  const int a_dst = KVP ? t_pl * PLANE + t_row * KT + 8 * t_u : t_row * KT + 4 * (t_c ^ t_sw);
-  const int b_dst = KVP ? t_pl * PLANE + t_row * KT + 8 * (t_u ^ t_swz) : t_row * KT + 8 * ((t_c >> 1) ^ t_swz) + 4 * (t_c & 1);
-  f32x4 g[NP_T];
-  f32x4 g2[(RC || EARLY) ? NP_T : 1];                   // RC: the K tile's pieces (committed to two images) beside the V tile's; EARLY: tileB's
-  auto fetch_to = [&](const csn_rsrc_t& rs, int kt, f32x4* g) {
-    if (KVP) {
-      // keys beyond the block end are zero in the planes; units that lie entirely beyond it are not fetched at all
-      const unsigned off = (kt * KT + 8 * t_u) < T ? t_off : CSN_OOB;
-#pragma unroll
-      for (int i = 0; i < NP_T; ++i)
-        g[i] = csn_bload4(rs, (i == NP_T - 1 && !t_last_ok) ? CSN_OOB : off, (unsigned)(kt * (64 * NPL) + RPP * i * kld * 2));
-    } else {
-      const int k0 = kt * KT;
-      // T % 4 == 0: a 16-byte piece is all in or all out; pieces past the block end are switched off
-      const unsigned off = (k0 + 4 * t_c) < T ? t_off : CSN_OOB;
-#pragma unroll
-      for (int i = 0; i < NP_T; ++i)
-        g[i] = csn_bload4(rs, (i == NP_T - 1 && !t_last_ok) ? CSN_OOB : off, (unsigned)(k0 + 64 * i * ldk) * 4u);
-    }
-  };
   // backward of an fp16 forward (math mode 3): the K / V tile planes hold fp16 bits and the backward's products are bf16 —
   // every piece is converted once, in registers, on its way into LDS (instead of projecting K and V a second time)
   constexpr bool CAN_CVT = BWD && KVP && PR::NPL == 1 && !PR::HALF;
@@ -627,8 +641,12 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
     fetch_to(Br, 0, g2); commitB_from(0, g2);
     if (nkt > 1) fetch_to(Ar, 1, g);
   } else {
-    fetch(Ar, 0); commitA(0);
-    fetch(Br, 0); commitB(0);
+    if constexpr (PRE0) {
+      commitA(0); commitB_from(0, gp);
+    } else {
+      fetch(Ar, 0); commitA(0);
+      fetch(Br, 0); commitB(0);
+    }
     if (nkt > 1) fetch(Ar, 1);
   }
   __syncthreads();
@@ -649,7 +667,18 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
   // shift is hazard-free: a K stage is rewritten in segments 2kt / 2kt+1 (early / late half), last read in 2kt-1 and
   // next read in 2kt+2; a V stage is rewritten in 2kt+1 / 2kt+2, last read in 2kt and next read in 2kt+3.
   WGSTAMP(1);
-  if (late) __syncthreads();
+  // Static priority for the late half.  The stamps of the d = 256 forward (profiles/r4u_attention_forward_stamps.txt): waves 4..7
+  // — dispatched second, the losers of the SIMD's age-ordered issue arbitration — spend 5.65 k cycles of a tile working and
+  // 0.5 k at barriers, waves 0..3 4.4 k and 2.1 k: the older half waits for the younger at both barriers of every tile.
+  // Measured with s_setprio 1 on the late half: forward 5.26 / 5.20 ms against 5.25 / 5.17, backward 7.32 / 7.16 against 7.05 /
+  // 7.32 — nothing (profiles/r4u_attention_prologue_and_priority.txt).  Off.
+#ifndef CSN_LATE_PRIO
+#define CSN_LATE_PRIO 0
+#endif
+  if (late) {
+    if (CSN_LATE_PRIO) __builtin_amdgcn_s_setprio(CSN_LATE_PRIO);
+    __syncthreads();
+  }
   // (a two-tiles-per-trip form of this loop, with the LDS stage a compile-time constant, was built and dropped: at d = 256 it
   //  spilled 28 registers in the forward and 82 in the backward kernel)
   for (int kt = 0; kt < nkt; ++kt) {
@@ -709,6 +738,7 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
   }
 
   if (!late) __syncthreads();                           // pairs with the last barrier of the late half: tiles are idle now
+  else if (CSN_LATE_PRIO) __builtin_amdgcn_s_setprio(0);
   }                                                     // next item of the group (its prologue reuses the tiles as staging)
 
   // ---- epilogue -----------------------------------------------------------------------------------

@@ -221,6 +221,41 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
   return launch_gemm(g, /*b_is_nk=*/0, n_shapes, (hipStream_t)stream);
 }
 
+int csn_project_qkv_f32(const float* x, long long x_shape_stride, int ld_x, const float* w_qkv, int d_inner, int channels,
+                        float* q_out, long long q_shape_stride, int ld_q, void* kv_out, long long kv_shape_stride, int ld_kv,
+                        int n_shapes, int n_points, float temperature, int block, void* stream) {
+  if (!q_out || !kv_out || d_inner <= 0) return CSN_E_ARG;
+  if (mode() == 0) return CSN_E_ARG;                                  // tile planes: the 16-bit modes
+  // one pass over x where the streaming kernel takes the product (bf16x3, 256 channels, 256 rows each of Q, K, V) ...
+  if (mode() == 1 && d_inner == 256 && csn_wx_takes(3 * d_inner, channels)) {
+    if (!x || !w_qkv || channels <= 0 || n_shapes <= 0 || n_points <= 0) return CSN_E_ARG;
+    const int bp = 512 * planes_of(mode());
+    if (block <= 0 || block > 512 || (block & 3) || (ld_kv % bp)) return CSN_E_ARG;
+    if (((long long)n_points + block - 1) / block * bp > ld_kv) return CSN_E_ARG;
+    if (n_points > ld_x || n_points > ld_q) return CSN_E_ARG;
+    if ((ld_x & 3) || (ld_q & 3) || (n_points & 3)) return CSN_E_ALIGN;
+    if (mis16(x) || mis16(w_qkv) || mis16(q_out) || mis16(kv_out)) return CSN_E_PTR;
+    if ((x_shape_stride & 3) || (q_shape_stride & 3) || (kv_shape_stride & 7)) return CSN_E_STRIDE;
+    CsnWxArgs a;
+    a.w = w_qkv; a.x = x; a.x_item_stride = x_shape_stride; a.ldx = ld_x;
+    a.out = kv_out; a.out_item_stride = kv_shape_stride; a.ldo = ld_kv;
+    a.out_f32 = q_out; a.out_f32_item_stride = q_shape_stride; a.ldo_f32 = ld_q; a.n_f32 = 1;
+    a.n_items = n_shapes; a.n_points = n_points; a.n_sets = 3;
+    a.div_rows = d_inner; a.div_val = temperature; a.div_rcp = 1.f / temperature;
+    int ex = 0;
+    a.div_exact = (std::frexp(temperature, &ex) == 0.5f && temperature > 0.f) ? 1 : 0;
+    a.tb = block;
+    const int rc = csn_launch_wx(a, 4, (hipStream_t)stream);
+    if (rc != -1) return rc;
+  }
+  // ... two projections elsewhere (the same results: an output element is one dot product in one order on either route)
+  const int rc = csn_project_f32(x, x_shape_stride, ld_x, w_qkv, d_inner, channels, q_out, q_shape_stride, ld_q, n_shapes, n_points,
+                                 d_inner, temperature, 0, 0, stream);
+  if (rc) return rc;
+  return csn_project_f32(x, x_shape_stride, ld_x, w_qkv + (long long)d_inner * channels, 2 * d_inner, channels,
+                         static_cast<float*>(kv_out), kv_shape_stride, ld_kv, n_shapes, n_points, 0, 1.f, 2, block, stream);
+}
+
 static int attn_fwd_impl(const float* q, const float* k, const float* v, long long q_shape_stride,
                          long long kv_shape_stride, const int* q_index, const int* kv_index, int ld, float* ctx,
                          long long ctx_eval_stride, float* scores, float* lse, int n_evals, int n_heads,

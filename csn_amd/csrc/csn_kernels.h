@@ -50,10 +50,12 @@ struct CsnWxArgs {
   float* rstd = nullptr;                                  // [item][n_points]
   float eps = 0.f, dropout_p = 0.f;  unsigned long long seed = 0;
   float* sum_ws = nullptr;  int sum_slots = 0;            // optional [item][sum_slots][256]: per-stream sums over points of xhat
+  // out_mode 4 — Q | K | V in one pass over x: the first n_f32 row sets leave as fp32 maps, the others as tile planes through `out`
+  float* out_f32 = nullptr;  long long out_f32_item_stride = 0;  int ldo_f32 = 0;  int n_f32 = 0;
 };
 extern int csn_gemm_big_tiles, csn_gemm_wide, csn_gemm_wide_set, csn_dev_wx;   // development switches (csn_dev_set)
 bool csn_wx_takes(int rows, int k);                       // this product shape runs on the streaming kernel
-int csn_launch_wx(const CsnWxArgs& a, int out_mode /* 0 fp32, 2 tile planes, 3 LayerNorm */, hipStream_t st);
+int csn_launch_wx(const CsnWxArgs& a, int out_mode /* 0 fp32, 2 tile planes, 3 LayerNorm, 4 fp32 + tile planes */, hipStream_t st);
 int csn_wx_ln_sum_slots(int n_items, int n_points);      // out_mode 3: sum_slots the launch will use (sum_ws = n_items * slots * 256 floats)
 int csn_launch_wx_ln_sums(const float* ws, float* out, int n_items, int n_points, hipStream_t st);   // out[item][256] from sum_ws
 

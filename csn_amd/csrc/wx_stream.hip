@@ -111,7 +111,8 @@ __global__ __launch_bounds__(512, 2) void csn_wx_kernel(CsnWxArgs p) {
   // chunk map.  fp32 output: chunk = 32 consecutive points of an item.  Tile planes: chunk = one 32-key tile of an attention
   // block (blocks of tb points start anywhere mod 32): a chunk then writes whole [hi 32 | lo 32] lines — chunks that straddle
   // two tiles left every 128-byte line to two work-groups, each with a partial write (K/V projection 1.98 ms against 1.63 tiled)
-  const unsigned blen = OUT == 2 ? (unsigned)p.tb : (unsigned)p.n_points;          // points per chunked block
+  constexpr bool PLANES = OUT == 2 || OUT == 4;                                  // chunk = one 32-key tile of an attention block
+  const unsigned blen = PLANES ? (unsigned)p.tb : (unsigned)p.n_points;            // points per chunked block
   const unsigned cpb = (blen + WX_CH - 1) / WX_CH;                                 // chunks per block
   const unsigned cpi = cpb * ((unsigned)(p.n_points + (int)blen - 1) / blen);        // chunks per item
   const int n_chunks = p.n_items * (int)cpi;                  // (the launcher keeps it below 2^31)
@@ -252,21 +253,26 @@ __global__ __launch_bounds__(512, 2) void csn_wx_kernel(CsnWxArgs p) {
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) eb[csn_acc_row(r, h) * 32 + l31] = acc[r] * dscale;
-    if constexpr (OUT == 0) {
+    // OUT 4: the first n_f32 row sets leave as fp32 maps (out_f32), the others as tile planes (out), from the same chunks of x
+    const bool f32_set = OUT == 0 || (OUT == 4 && set < p.n_f32);
+    const int pset = OUT == 4 ? set - p.n_f32 : set;
+    if (f32_set) {
       f32x4 vals[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) vals[t] = *reinterpret_cast<const f32x4*>(&eb[(erow + 8 * t) * 32 + 4 * c8]);
-      const csn_rsrc_t Or = csn_make_rsrc(reinterpret_cast<float*>(p.out) + (long long)item * p.out_item_stride + (long long)(256 * set) * p.ldo,
-                                          (long long)256 * p.ldo * 4);
-      const unsigned off = n_ok ? (unsigned)((32 * wave + erow) * p.ldo + n) * 4u : CSN_OOB;
+      float* const ob = OUT == 4 ? p.out_f32 : reinterpret_cast<float*>(p.out);
+      const long long ois = OUT == 4 ? p.out_f32_item_stride : p.out_item_stride;
+      const int ol = OUT == 4 ? p.ldo_f32 : p.ldo;
+      const csn_rsrc_t Or = csn_make_rsrc(ob + (long long)item * ois + (long long)(256 * set) * ol, (long long)256 * ol * 4);
+      const unsigned off = n_ok ? (unsigned)((32 * wave + erow) * ol + n) * 4u : CSN_OOB;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) csn_bstore4(vals[t], Or, off, (unsigned)(8 * t * p.ldo) * 4u);
+      for (int t = 0; t < 4; ++t) csn_bstore4(vals[t], Or, off, (unsigned)(8 * t * ol) * 4u);
     } else {
       // the tile's 32 keys leave whole, 8 keys = 16 bytes per lane and plane (lane -> row lane / 4 + 16 t, keys 8 (lane % 4) ..):
       // points beyond the block's (or the row's) end were never loaded, their sums are zeros — exactly the padding the
       // attention kernels expect behind a block's last key
       const int prow = lane >> 2, c4k = lane & 3;
-      const csn_rsrc_t Or = csn_make_rsrc(reinterpret_cast<short*>(p.out) + (long long)item * p.out_item_stride + (long long)(256 * set) * p.ldo,
+      const csn_rsrc_t Or = csn_make_rsrc(reinterpret_cast<short*>(p.out) + (long long)item * p.out_item_stride + (long long)(256 * pset) * p.ldo,
                                           (long long)256 * p.ldo * 2);
       const unsigned tcol = blk * 1024u + tile * 64u + 8u * (unsigned)c4k;
       const unsigned off = valid > 0 ? ((unsigned)((32 * wave + prow) * p.ldo) + tcol) * 2u : CSN_OOB;
@@ -535,7 +541,8 @@ int csn_launch_wx_ln_sums(const float* ws, float* out, int n_items, int n_points
 int csn_launch_wx(const CsnWxArgs& a, int out_mode, hipStream_t st) {
   if (a.n_items <= 0 || a.n_points <= 0) return 0;
   if ((a.ldx & 3) || (a.ldo & 3) || (a.n_points & 3)) return -2;
-  if (out_mode == 2 && (a.tb <= 0 || (a.tb & 3))) return -2;
+  if ((out_mode == 2 || out_mode == 4) && (a.tb <= 0 || (a.tb & 3))) return -2;
+  if (out_mode == 4 && (a.n_f32 <= 0 || a.n_f32 >= a.n_sets || !a.out_f32 || (a.ldo_f32 & 3))) return -2;
   if ((a.div_rows & 31) || ((long long)a.n_items * ((a.n_points + WX_CH - 1) / WX_CH + 16) + 4ll * wx_grid()) * 2 >= (1ll << 31)) return -1;
   const int grid = wx_grid();
   if ((grid >> 3) < a.n_sets) return -1;
@@ -550,6 +557,7 @@ int csn_launch_wx(const CsnWxArgs& a, int out_mode, hipStream_t st) {
     else hipLaunchKernelGGL((csn_wx_kernel<3, false>), dim3(grid), dim3(512), 0, st, b);
   } else if (out_mode == 0) hipLaunchKernelGGL((csn_wx_kernel<0>), dim3(grid), dim3(512), 0, st, b);
   else if (out_mode == 2) hipLaunchKernelGGL((csn_wx_kernel<2>), dim3(grid), dim3(512), 0, st, b);
+  else if (out_mode == 4) hipLaunchKernelGGL((csn_wx_kernel<4>), dim3(grid), dim3(512), 0, st, b);
   else return -1;
   return (int)hipGetLastError();
 }

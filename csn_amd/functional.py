@@ -407,11 +407,16 @@ class _MHAEvals(torch.autograd.Function):
             kv_dtype = torch.float16 if ctx.mode == 3 else torch.bfloat16
             # (the projection writes the zero padding of every block's last 32-key tile itself)
             kv = torch.empty((S, 2 * D, ldp), device=dev, dtype=kv_dtype)
-            for first, step, count in (plan.q_ranges or [(0, 1, S)]):
+            one_pass = plan.q_ranges is None and plan.kv_ranges is None and not a16 and tuning.current().qkv_one_pass
+            if one_pass:
+                # Q, K and V of every slot from ONE pass over x (csn_project_qkv_f32; the same bits as the two calls below)
+                _lib.check(L.csn_project_qkv_f32(_ptr(x_all), C * NP, NP, _ptr(w_qkv), D, C, _ptr(qkv), D * NP, NP, _ptr(kv),
+                                                 2 * D * ldp, ldp, S, NP, temperature, T, _stream()), "csn_project_qkv_f32")
+            for first, step, count in ([] if one_pass else (plan.q_ranges or [(0, 1, S)])):
                 _lib.check(L.csn_project_f32(x_all.data_ptr() + 4 * first * C * NP, step * C * NP, NP, _ptr(w_qkv), D, C,
                                              qkv.data_ptr() + qkv.element_size() * first * D * NP, step * D * NP, NP, count, NP, D,
                                              temperature, 3 if a16 else 0, 0, _stream()), "csn_project_f32")
-            for first, step, count in (plan.kv_ranges or [(0, 1, S)]):
+            for first, step, count in ([] if one_pass else (plan.kv_ranges or [(0, 1, S)])):
                 _lib.check(L.csn_project_f32(x_all.data_ptr() + 4 * first * C * NP, step * C * NP, NP, _ptr(w_qkv[D:]), 2 * D, C,
                                              kv.data_ptr() + 2 * first * 2 * D * ldp, step * 2 * D * ldp, ldp, count, NP, 0, 1.0, 2,
                                              T, _stream()), "csn_project_f32")

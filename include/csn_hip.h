@@ -130,6 +130,15 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
                     float* out, long long out_shape_stride, int ld_out, int n_shapes, int n_points, int div_rows,
                     float temperature, int out_split, long long out_plane_stride, void* stream);
 
+/* Q, K and V of the same slots in one call (csa_models.py:103-105 on one input): w_qkv = [W_q ; W_k ; W_v] (3 d_inner rows),
+ * Qs = W_q x / temperature as an fp32 map q_out [slot][d_inner][ld_q], K | V as tile planes kv_out [slot][2 d_inner][ld_kv] —
+ * exactly what csn_project_f32(.., div_rows = d_inner, out_split = 0) and csn_project_f32(.., out_split = 2,
+ * out_plane_stride = block) write, bit for bit; 16-bit math modes only (tile planes).  In the bf16x3 mode with 256 channels and
+ * d_inner = 256 the three row sets share ONE pass over x (the streaming kernel); elsewhere it is the two calls. */
+int csn_project_qkv_f32(const float* x, long long x_shape_stride, int ld_x, const float* w_qkv, int d_inner, int channels,
+                        float* q_out, long long q_shape_stride, int ld_q, void* kv_out, long long kv_shape_stride, int ld_kv,
+                        int n_shapes, int n_points, float temperature, int block, void* stream);
+
 /* ---- (2) block-diagonal scaled-dot-product attention, forward ----------------------------------------
  * For evaluation e, head h, block b:  P = softmax(Qs K^T) over the block's keys, ctx = P V
  * (ScaledDotProductAttention.forward, csa_models.py:138-144, eval mode; Qs is already divided by the

@@ -4,10 +4,11 @@ import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("CSN_LIB_PATH", "build/v9.so")
+os.environ.setdefault("CSN_LIB_PATH", "csn_amd/libcsn_stf.so")      # scripts/dev/build_variant.sh stf -DCSN_STAMPS=0
 from csn_amd import _lib, functional as CF
 from bench_attn import to_tiles
 L = _lib.lib()
+RAW = L._handle          # the stamp readers are not part of the declared interface
 H, d, T, nb = 1, 256, 500, 20
 D, NP, Tp, S, E = 256, 10000, 512, 16, 64
 qkv = torch.randn((S, 3 * D, NP), device="cuda"); qkv[:, :D] *= 0.25
@@ -45,8 +46,8 @@ if os.environ.get("CSN_STAMP_BWD") == "1":       # library built with -DCSN_STAM
 torch.cuda.synchronize()
 n = 2048 * 8 * 4 * 8
 buf = np.zeros(n, dtype=np.uint64)
-L.csn_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
-rc = L.csn_debug_read(buf.ctypes.data, n * 8)
+RAW.csn_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+rc = RAW.csn_debug_read(buf.ctypes.data, n * 8)
 st = buf.reshape(2048, 8, 4, 8).astype(np.int64)
 d_ = np.diff(st, axis=-1)                     # [wg][wave][iter][6 segments]
 names = ["P1", "commitA+fetchB", "barrierX", "pointwise", "P2", "commitB+fetchA", "barrierY"]
@@ -63,8 +64,8 @@ print("start skew wave4 - wave0:", (st[ok][:, 4, :, 0] - st[ok][:, 0, :, 0]).mea
 # whole-kernel stamps (work-groups 4096..6143, i.e. well inside the launch): entry, loop start, loop end, exit
 m = 2048 * 8 * 4
 wb = np.zeros(m, dtype=np.uint64)
-L.csn_debug_read_wg.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
-L.csn_debug_read_wg(wb.ctypes.data, m * 8)
+RAW.csn_debug_read_wg.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+RAW.csn_debug_read_wg(wb.ctypes.data, m * 8)
 w = wb.reshape(2048, 8, 4).astype(np.int64)
 okw = (w[..., 0] > 0).all(axis=1)
 w = w[okw]
@@ -74,8 +75,8 @@ print("whole kernel, work-groups:", okw.sum(), " (s_memtime ticks = 100 MHz x ? 
 print("  per wave mean: prologue=%.0f loop=%.0f epilogue=%.0f total=%.0f" % (dw[..., 0].mean(), dw[..., 1].mean(), dw[..., 2].mean(), (w[..., 3] - w[..., 0]).mean()))
 print("  per work-group (first entry -> last exit): %.0f" % (w[:, :, 3].max(axis=1) - w[:, :, 0].min(axis=1)).mean())
 rb = np.zeros(2048 * 8 * 2, dtype=np.uint64)
-L.csn_debug_read_rt.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
-L.csn_debug_read_rt(rb.ctypes.data, rb.nbytes)
+RAW.csn_debug_read_rt.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+RAW.csn_debug_read_rt(rb.ctypes.data, rb.nbytes)
 r = rb.reshape(2048, 8, 2).astype(np.int64)[okw]
 clk = (w[..., 3] - w[..., 0]) / np.maximum(r[..., 1] - r[..., 0], 1) * 100.0
 print("  in-kernel clock (d s_memtime / d s_memrealtime x 100 MHz): median %.0f MHz  (p10 %.0f, p90 %.0f);  work-group wall %.1f us" %

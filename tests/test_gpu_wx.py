@@ -202,3 +202,34 @@ def test_out_projection_layer_norm_on_the_stream(L, E, S, NP, ld, p, indexed):
         ref = (z - z.mean(dim=1, keepdim=True)) / torch.sqrt(z.var(dim=1, unbiased=False, keepdim=True) + 1e-6)
         assert _rel(xh, ref) < 5e-6
         assert ((rs.double() - 1 / torch.sqrt(z.var(dim=1, unbiased=False) + 1e-6)).abs() * torch.sqrt(z.var(dim=1, unbiased=False))).max() < 1e-5
+
+
+@pytest.mark.parametrize("S,N,T,nb,temp", [(3, 1000, 500, 2, 16.0), (2, 1300, 500, 3, math.sqrt(200.0)), (5, 72, 36, 2, 16.0),
+                                           (130, 500, 500, 1, 16.0)])
+def test_q_k_v_in_one_pass_equal_the_two_projections_bit_for_bit(L, S, N, T, nb, temp):
+    """csn_project_qkv_f32 (csa_models.py:103-105 on one input): one launch, three row sets walking the same chunks of x, against
+    csn_project_f32 twice — every bit of Qs and of the K | V tile planes, padding included, nothing written beyond."""
+    lib = L.lib()
+    rng = np.random.default_rng(31)
+    C = D = 256
+    x = _rand(rng, S, C, N).cuda()
+    w = (_rand(rng, 3 * D, C) / 16).cuda()
+    ldp = nb * 1024
+    res = []
+    for one in (True, False):
+        qpool = torch.full((S * D * N + 1024,), float("nan"), device="cuda")
+        kvpool = torch.full((S * 2 * D * ldp + 2048,), 7.0, device="cuda", dtype=torch.bfloat16)
+        q, kv = qpool[:S * D * N].view(S, D, N), kvpool[:S * 2 * D * ldp].view(S, 2 * D, ldp)
+        if one:
+            L.check(lib.csn_project_qkv_f32(x.data_ptr(), C * N, N, w.data_ptr(), D, C, q.data_ptr(), D * N, N, kv.data_ptr(), 2 * D * ldp, ldp,
+                                            S, N, temp, T, _stream()))
+        else:
+            L.check(lib.csn_project_f32(x.data_ptr(), C * N, N, w.data_ptr(), D, C, q.data_ptr(), D * N, N, S, N, D, temp, 0, 0, _stream()))
+            L.check(lib.csn_project_f32(x.data_ptr(), C * N, N, w[D:].data_ptr(), 2 * D, C, kv.data_ptr(), 2 * D * ldp, ldp, S, N, 0, 1.0, 2, T,
+                                        _stream()))
+        torch.cuda.synchronize()
+        assert torch.isnan(qpool[S * D * N:]).all() and (kvpool[S * 2 * D * ldp:] == 7.0).all()
+        res.append((q.cpu(), kv.cpu().view(torch.int16)))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    ref = torch.einsum("rc,scn->srn", w[:D].double().cpu(), x.double().cpu()) / temp
+    assert _rel(res[0][0], ref) < 2e-5
