@@ -217,13 +217,19 @@ def main():
         if os.environ["CSN_BENCH_HOST_NB"] == "1":
             x_nb_host = x_nb_host.pin_memory()
 
-    # HIP events around every launching C-ABI call of the timed steps: entry point -> [(start, end), ...]
+    # HIP events around the launching C-ABI calls: entry point -> [(start, end), ...].  An event record is a barrier packet in the
+    # queue — around every one of a step's ~45 calls they cost the config-3 step 0.5 ms — so EVERY call is bracketed only in the
+    # warm-up steps (which is where `launches` and the choice of the longest launch come from), and the timed steps bracket the
+    # attention launches and that longest launch alone (`roofline.launch_ms` is live, from the timed region)
     call_events = {}
+    watch = [None]                                                       # None: every call; a set: those entry points
     ATTN_CALLS = {"csn_block_attn_fwd_f32": "fwd", "csn_block_attn_bwd_dq_f32": "bwd", "csn_block_attn_bwd_dq_recompute_f32": "bwd",
                   "csn_block_attn_bwd_dkv_flash_f32": "dkv"}  # dkv: the key-stationary dK / dV launch of the score-recomputing flow
     _open = {}
 
     def call_hook(name, phase):
+        if watch[0] is not None and name not in watch[0]:
+            return
         ev = torch.cuda.Event(enable_timing=True)
         ev.record()
         if phase == "begin":
@@ -303,10 +309,18 @@ def main():
         model.train(train_mode)                                          # train: dropout p = 0.1 live (csa_training.py:192)
         torch.manual_seed(1)
         call_events.clear()
+        watch[0] = None
         group = grouped and not local
-        for _ in range(args.warmup):
-            step(local=local)
+        for w in range(args.warmup):
+            if w == 1:
+                call_events.clear()                                      # (the first warm-up step pays for allocations)
+            step(record=True, local=local)
         torch.cuda.synchronize()
+        n_warm = max(1, args.warmup - 1) if args.warmup else 0
+        warm_calls = {k: float(np.sum([a.elapsed_time(b) for a, b in v])) / n_warm for k, v in call_events.items()} if n_warm else {}
+        if warm_calls:
+            watch[0] = set(ATTN_CALLS) | {max(warm_calls, key=warm_calls.get)}
+        call_events.clear()
         if group:
             dist.barrier()
         torch.cuda.synchronize()
@@ -331,7 +345,10 @@ def main():
         # per STEP: the attention launches of one step summed (N = 1: one forward and one backward launch; the overlapped
         # multi-GPU path: two of each — own shapes first, the evaluations that need neighbour data after the exchange)
         per_call = {k: float(np.sum([a.elapsed_time(b) for a, b in v])) / args.steps for k, v in call_events.items()}
-        ms = {"fwd": float("nan"), "bwd": float("nan"), "dkv": float("nan"), "calls": per_call}
+        watch[0] = None
+        # every call of the step from the warm-up steps, the watched ones overwritten with their timed-region means
+        ms = {"fwd": float("nan"), "bwd": float("nan"), "dkv": float("nan"), "calls": {**warm_calls, **per_call},
+              "calls_live": sorted(per_call)}
         for name, which in ATTN_CALLS.items():
             if name in per_call:
                 ms[which] = per_call[name] if np.isnan(ms[which]) else ms[which] + per_call[name]
@@ -458,8 +475,10 @@ def main():
                        "step_tflops_algorithmic": 3 * algorithmic_flops_fwd(S, K, N, C, D, T) / (med_ms * 1e-3) / 1e12},
             "roofline": dominant, "roofline_other": second,
             # every launching entry point of the step, mean ms per step (HIP events around the C-ABI calls; a call may be several
-            # kernels: csn_outproj_ln_bwd_f32 = LayerNorm backward + dCtx + W_fc gradient, csn_block_attn_bwd_dkv_f32 = dV + dK)
+            # kernels: csn_outproj_ln_bwd_f32 = LayerNorm backward + dCtx + W_fc gradient, csn_block_attn_bwd_dkv_f32 = dV + dK).
+            # launches_live: the entry points bracketed inside the timed steps; the others were bracketed in the warm-up steps
             "launches": {k: round(v, 4) for k, v in sorted(attn_ms.get("calls", {}).items(), key=lambda kv: -kv[1])},
+            "launches_live": attn_ms.get("calls_live", []),
         }
         if grouped:
             sent, recvd = getattr(shard, "payload_bytes", (None, None))

@@ -33,8 +33,11 @@ class Tuning:
     # the 16-byte pieces 2 KB apart were not what the dQ kernel or the dV / dK products wait for.  Off; kept as the measured
     # form (tests/test_gpu_score_layout.py holds it to the row-major step bit for bit)
     tile_major_scores: bool = False
-    # Q, K and V of all slots from one pass over x (csn_project_qkv_f32) where every slot needs all three; False: two calls
-    qkv_one_pass: bool = True
+    # Q, K and V of all slots from ONE pass over x (csn_project_qkv_f32: three row sets of the streaming kernel walking the same
+    # chunks) where every slot needs all three.  The same bits, 1.15 GB less HBM traffic per step (FETCH / WRITE passes), and not
+    # faster: the launch alone 1.96 ms against 0.54 + 1.06 + launch gap = 1.78 for the two calls, the config-3 step 26.95 against
+    # 26.99 ms (profiles/r4t_qkv_one_pass.txt).  Off; kept as the measured form (tests/test_gpu_wx.py holds it bit for bit)
+    qkv_one_pass: bool = False
     # attention backward data flow by (math mode of the backward: 1 bf16x3, 2 bf16 — fp16 forwards run their backward in 2;
     # head width), or by mode alone; taken where the kernels have an instance for it (csn_attn_bwd_grouping bits 2 / 3),
     # KEEP_SCORES otherwise.  Measured per mode and width, DESIGN.md §4 "data flow A/B": at d = 256 the extra matrix products
