@@ -195,7 +195,7 @@ _SIGNATURES = {
 
 EXPORTS = tuple(_SIGNATURES)
 # keys of csn_dev_set / csn_dev_get (include/csn_hip.h, development section)
-DEV_BIG_TILES, DEV_WIDE_GEMM, DEV_WIDE_FORMS, DEV_WX, DEV_ATTN_X4 = 0, 1, 2, 3, 4
+DEV_BIG_TILES, DEV_WIDE_GEMM, DEV_WIDE_FORMS, DEV_WX, DEV_ATTN_X4, DEV_LNB_GROUP = 0, 1, 2, 3, 4, 5
 
 
 def lib() -> ctypes.CDLL:

@@ -123,6 +123,7 @@ int csn_dev_get(int key) {
     case CSN_DEV_WIDE_FORMS: return csn_gemm_wide_set;
     case CSN_DEV_WX: return csn_dev_wx;
     case CSN_DEV_ATTN_X4: return csn_dev_attn_x4;
+    case CSN_DEV_LNB_GROUP: return csn_dev_lnb_group;
     default: return CSN_E_ARG;
   }
 }
@@ -134,6 +135,7 @@ int csn_dev_set(int key, int value) {
     case CSN_DEV_WIDE_FORMS: csn_gemm_wide_set = value; break;
     case CSN_DEV_WX: csn_dev_wx = value; break;
     case CSN_DEV_ATTN_X4: csn_dev_attn_x4 = value; break;
+    case CSN_DEV_LNB_GROUP: csn_dev_lnb_group = value < 0 ? 0 : value; break;
     default: return CSN_E_ARG;
   }
   return prev;
@@ -734,15 +736,26 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
   const int a16 = act16();
   if (a16 && (!act16_bwd_ok() || dctx_split)) return CSN_E_ARG;
   l.act16 = a16;
-  int rc = csn_launch_ln_bwd_f32(l, st);
-  if (rc) return rc;
+  int rc = 0;
   // dctx[e][D][n] = wfc_t[D][c] dz[e][c][n]
   if (mode() == 1 && !a16 && !dctx_split && csn_wx_takes(d_inner, d_model)) {
-    rc = launch_wx(wfc_t, dz, eval_stride, ld, dctx, ctx_eval_stride, ld, d_inner, n_evals, n_points, 0, 1.f, 0, 0, st);
+    // (development switch CSN_DEV_LNB_GROUP = G > 0: LayerNorm backward and dCtx alternate over groups of G evaluations, so that a
+    //  group's dz is read back while it may still sit in the 256 MB Infinity Cache)
+    const int G = csn_dev_lnb_group > 0 ? csn_dev_lnb_group : n_evals;
+    for (int e0 = 0; e0 < n_evals && !rc; e0 += G) {
+      const int ng = n_evals - e0 < G ? n_evals - e0 : G;
+      l.e_base = e0; l.E = ng;
+      rc = csn_launch_ln_bwd_f32(l, st);
+      if (rc) return rc;
+      rc = launch_wx(wfc_t, dz + (long long)e0 * eval_stride, eval_stride, ld, dctx + (long long)e0 * ctx_eval_stride, ctx_eval_stride, ld,
+                     d_inner, ng, n_points, 0, 1.f, 0, 0, st);
+    }
     if (rc) return rc;
     return wgrad(dz, eval_stride, ld, ctx, ctx_eval_stride, ld, dwfc, d_model, d_inner, n_evals, n_points, 1.f, accumulate, ws,
                  ws_floats, st, 0, 0);
   }
+  rc = csn_launch_ln_bwd_f32(l, st);
+  if (rc) return rc;
   CsnGemmArgs g;
   g.A = operand(wfc_t, 0, 0, 0, nullptr, d_model);
   g.B = operand(dz, 0, 0, eval_stride, nullptr, ld);

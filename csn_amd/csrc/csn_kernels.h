@@ -53,7 +53,7 @@ struct CsnWxArgs {
   // out_mode 4 — Q | K | V in one pass over x: the first n_f32 row sets leave as fp32 maps, the others as tile planes through `out`
   float* out_f32 = nullptr;  long long out_f32_item_stride = 0;  int ldo_f32 = 0;  int n_f32 = 0;
 };
-extern int csn_gemm_big_tiles, csn_gemm_wide, csn_gemm_wide_set, csn_dev_wx;   // development switches (csn_dev_set)
+extern int csn_gemm_big_tiles, csn_gemm_wide, csn_gemm_wide_set, csn_dev_wx, csn_dev_lnb_group;   // development switches (csn_dev_set)
 bool csn_wx_takes(int rows, int k);                       // this product shape runs on the streaming kernel
 int csn_launch_wx(const CsnWxArgs& a, int out_mode /* 0 fp32, 2 tile planes, 3 LayerNorm, 4 fp32 + tile planes */, hipStream_t st);
 int csn_wx_ln_sum_slots(int n_items, int n_points);      // out_mode 3: sum_slots the launch will use (sum_ws = n_items * slots * 256 floats)
@@ -196,6 +196,7 @@ struct CsnLnBwdArgs {
   float dropout_p;
   unsigned long long seed;
   int act16 = 0;                                               // xhat is an fp16 map, dz leaves as a bf16 map (dxhat, dz_res stay fp32)
+  int e_base = 0;                                              // the launch covers evaluations e_base .. e_base + E - 1 of the maps
 };
 int csn_launch_ln_bwd_f32(const CsnLnBwdArgs& a, hipStream_t st);
 

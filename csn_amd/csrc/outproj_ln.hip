@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void csn_ln_bwd_kernel(CsnLnBwdArgs p) {
   __shared__ float red[2][4][64];
   const int lane = threadIdx.x & 63, g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n = blockIdx.x * 64 + lane;
-  const int e = blockIdx.y;
+  const int e = blockIdx.y + p.e_base;
   const bool ok = n < p.n_points;
   constexpr int C = 4 * CPT;
   const long long win = ((long long)(C - 1) * p.ld + p.n_points) * 4;

@@ -519,6 +519,10 @@ void wx_ln_geometry(int n_items, int n_points, int& cpi, int& run, int& slots) {
 
 }  // namespace
 
+// LayerNorm backward + dCtx alternate over groups of this many evaluations (0: one launch each).  Measured over the config-3
+// step, 256 evaluations (profiles/r4aa_ln_backward_groups.txt): groups of 8 +0.68 ms, 16 +0.25, 32 -0.08, 64 -0.10..-0.18,
+// 128 -0.14 — not cache residency (a group of 128 is 1.3 GB of dz), the same bits either way
+int csn_dev_lnb_group = 128;
 int csn_dev_wx = 1;      // development switch (csn_dev_set): 0 = these products on the tiled kernels of gemm_bf16x3.hip
 
 bool csn_wx_takes(int rows, int k) { return (csn_dev_wx & 1) != 0 && k == WX_K && rows > 0 && rows % 256 == 0 && rows / 256 <= 32; }

@@ -434,6 +434,8 @@ int csn_masked_ce_bwd_f32(const float* logits, long long shape_stride, int ld, c
 #define CSN_DEV_WX 3
 #define CSN_DEV_ATTN_X4 4   /* default 0; 1: the attention forward at d = 256 in bf16x3 on four 32-query waves
                                (v_mfma_f32_32x32x16_bf16, one wave per SIMD) — built, measured 25 % slower, kept as the measured form */
+#define CSN_DEV_LNB_GROUP 5 /* default 128; G > 0: csn_outproj_ln_bwd_f32 alternates its LayerNorm backward and its dCtx product
+                               over groups of G evaluations (bf16x3, streaming dCtx; the same results; 0: one launch each) */
 int csn_dev_set(int key, int value);
 int csn_dev_get(int key);
 

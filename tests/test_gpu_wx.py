@@ -233,3 +233,35 @@ def test_q_k_v_in_one_pass_equal_the_two_projections_bit_for_bit(L, S, N, T, nb,
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     ref = torch.einsum("rc,scn->srn", w[:D].double().cpu(), x.double().cpu()) / temp
     assert _rel(res[0][0], ref) < 2e-5
+
+
+def test_layer_norm_backward_in_groups_of_evaluations_is_the_same_call(L):
+    """csn_outproj_ln_bwd_f32 alternates LayerNorm backward and dCtx over groups of evaluations (CSN_DEV_LNB_GROUP): every output
+    of a call in groups of 2 (5 evaluations: 2 + 2 + 1) equals the one-launch call bit for bit — the dropout masks, the scale
+    rows and the shared gradient maps are indexed by the evaluation's own number, not by its place in the group."""
+    lib = L.lib()
+    rng = np.random.default_rng(12)
+    E, C, D, NP, grp = 5, 256, 256, 260, 2
+    dfeats = _rand(rng, (E + grp - 1) // grp, C, NP).cuda()
+    scale, rows = _rand(rng, E, C).cuda(), (_rand(rng, E, C) / NP).cuda()
+    xhat, rstd, ctx = _rand(rng, E, C, NP).cuda(), (torch.rand(E, NP) + 0.5).cuda(), _rand(rng, E, D, NP).cuda()
+    wfc_t = (_rand(rng, D, C) / 16).cuda()
+    res = []
+    for G in (0, 2):
+        prev = lib.csn_dev_set(L.DEV_LNB_GROUP, G)
+        try:
+            dz, dzr = torch.full((E, C, NP), float("nan"), device="cuda"), torch.full((E, C, NP), float("nan"), device="cuda")
+            dctx, dw = torch.full((E, D, NP), float("nan"), device="cuda"), torch.empty((C, D), device="cuda")
+            ws_n = lib.csn_wgrad_workspace_floats(C, D, E, NP)
+            ws = torch.empty((ws_n,), device="cuda")
+            L.check(lib.csn_outproj_ln_bwd_f32(dfeats.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), C * NP, ctx.data_ptr(), D * NP,
+                                               wfc_t.data_ptr(), dz.data_ptr(), dzr.data_ptr(), dctx.data_ptr(), dw.data_ptr(), ws.data_ptr(), ws_n,
+                                               E, C, D, NP, NP, 0, 0.2, 0x5eed, 0, 0, rows.data_ptr(), E - 1, scale.data_ptr(), grp, _stream()))
+            torch.cuda.synchronize()
+            res.append([t.cpu() for t in (dz, dzr, dctx, dw)])
+        finally:
+            lib.csn_dev_set(L.DEV_LNB_GROUP, prev)
+    for a, b in zip(*res):
+        assert not torch.isnan(a).any() and torch.equal(a, b)
+    assert (res[0][0] == 0).float().mean() > 0.1                      # the fc dropout mask is live in dz, and absent from dz_res
+    assert (res[0][1] == 0).float().mean() < 0.01
