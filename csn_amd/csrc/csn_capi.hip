@@ -742,8 +742,18 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
     // (development switch CSN_DEV_LNB_GROUP = G > 0: LayerNorm backward and dCtx alternate over groups of G evaluations, so that a
     //  group's dz is read back while it may still sit in the 256 MB Infinity Cache)
     const int G = csn_dev_lnb_group > 0 ? csn_dev_lnb_group : n_evals;
+    const bool fused = csn_wx_lnb_takes(l, d_inner) && eval_stride == ctx_eval_stride;
     for (int e0 = 0; e0 < n_evals && !rc; e0 += G) {
       const int ng = n_evals - e0 < G ? n_evals - e0 : G;
+      if (fused) {                                       // one pass: xhat in, dz (and dz_res) and dCtx out (wx_lnb.hip)
+        CsnWxLnbArgs f{};
+        f.w = wfc_t; f.xhat = xhat; f.rstd = rstd; f.eval_stride = eval_stride; f.ld = ld;
+        f.dxhat = dxhat; f.dxhat_group = l.dxhat_group; f.n_dense = n_dense_evals; f.dxhat_scale = dxhat_scale; f.dxhat_rows = dxhat_rows;
+        f.dz = dz; f.dz_res = dz_res; f.dctx = dctx; f.dctx_eval_stride = ctx_eval_stride;
+        f.n_items = ng; f.n_points = n_points; f.e_base = e0; f.dropout_p = dropout_p; f.seed = seed;
+        rc = csn_launch_wx_lnb(f, st);
+        if (rc != -1) continue;
+      }
       l.e_base = e0; l.E = ng;
       rc = csn_launch_ln_bwd_f32(l, st);
       if (rc) return rc;

@@ -199,6 +199,19 @@ struct CsnLnBwdArgs {
   int e_base = 0;                                              // the launch covers evaluations e_base .. e_base + E - 1 of the maps
 };
 int csn_launch_ln_bwd_f32(const CsnLnBwdArgs& a, hipStream_t st);
+// LayerNorm backward fused into the dCtx stream (wx_lnb.hip; bf16x3, d_model = d_inner = 256, fp32 maps)
+struct CsnWxLnbArgs {
+  const float* w;                                              // W_fc^T [d_inner][d_model] row-major
+  const float* xhat; const float* rstd; long long eval_stride; int ld;
+  const float* dxhat; int dxhat_group; int n_dense; const float* dxhat_scale; const float* dxhat_rows;     // as CsnLnBwdArgs
+  float* dz; float* dz_res;                                    // [e][256][ld]; dz_res optional
+  float* dctx; long long dctx_eval_stride;                     // [e][256][ld]
+  int n_items, n_points, e_base;                               // evaluations e_base .. e_base + n_items - 1
+  float dropout_p; unsigned long long seed;
+  int ablate = 0;
+};
+bool csn_wx_lnb_takes(const CsnLnBwdArgs& a, int d_inner);
+int csn_launch_wx_lnb(const CsnWxLnbArgs& a, hipStream_t st);
 
 // delta[e][h][n] = sum_{c in head h} a[e][c][n] * b[e][c][n]
 int csn_launch_rowdot_f32(const float* a, const float* b, float* out, const int* eval_ids, int E, int H, int d, int ld,

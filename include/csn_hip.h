@@ -425,17 +425,18 @@ int csn_masked_ce_bwd_f32(const float* logits, long long shape_stride, int ld, c
  *   CSN_DEV_BIG_TILES   1   256 x 256 GEMM tiles where the output fills them (0: 128 x 128 tiles everywhere)
  *   CSN_DEV_WIDE_GEMM   1   sixteen-wave form of the 256 x 256 tiles in the bf16x3 mode (0 off, 2: the one-plane modes too)
  *   CSN_DEV_WIDE_FORMS  7   bit set of the product forms that take it: 1 plain, 2 tile-plane B (dV / dK), 4 weight gradients
- *   CSN_DEV_WX          1   K = 256 weight products (projections, dCtx, out-projection + LayerNorm) of the bf16x3 mode on the
- *                           weight-stationary streaming kernel (0: on the tiled GEMM kernels; 3: streaming with the two
- *                           wave halves staggered; bits 4..6: timing-only ablations, results wrong) */
+ *   CSN_DEV_WX          9   bit set for the K = 256 weight products of the bf16x3 mode: 1 projections, dCtx and out-projection +
+ *                           LayerNorm on the weight-stationary streaming kernel (0: the tiled GEMM kernels); 2 its wave halves
+ *                           staggered; 4 out-projection + LayerNorm back on the tiled kernel; 8 LayerNorm backward fused into
+ *                           the dCtx stream; bits 4..7: timing-only ablations, results wrong */
 #define CSN_DEV_BIG_TILES 0
 #define CSN_DEV_WIDE_GEMM 1
 #define CSN_DEV_WIDE_FORMS 2
 #define CSN_DEV_WX 3
 #define CSN_DEV_ATTN_X4 4   /* default 0; 1: the attention forward at d = 256 in bf16x3 on four 32-query waves
                                (v_mfma_f32_32x32x16_bf16, one wave per SIMD) — built, measured 25 % slower, kept as the measured form */
-#define CSN_DEV_LNB_GROUP 5 /* default 128; G > 0: csn_outproj_ln_bwd_f32 alternates its LayerNorm backward and its dCtx product
-                               over groups of G evaluations (bf16x3, streaming dCtx; the same results; 0: one launch each) */
+#define CSN_DEV_LNB_GROUP 5 /* default 0; G > 0: csn_outproj_ln_bwd_f32 runs its LayerNorm backward and its dCtx product over groups
+                               of G evaluations (bf16x3, streaming dCtx; the same results) */
 int csn_dev_set(int key, int value);
 int csn_dev_get(int key);
 

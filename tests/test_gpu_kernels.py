@@ -712,7 +712,7 @@ def test_sixteen_wave_gemm_equals_the_eight_wave_one(L, mode, S, C, N, R, div_ro
         assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1])
     finally:
         lib.csn_dev_set(L.DEV_WIDE_GEMM, 1)
-        lib.csn_dev_set(L.DEV_WX, 1)
+        lib.csn_dev_set(L.DEV_WX, L.DEV_WX_DEFAULT)
         lib.csn_set_math_mode(1)
 
 
@@ -743,6 +743,6 @@ def test_sixteen_wave_forms_leave_the_step_bit_for_bit(L):
             outs.append((logits.detach().clone(), [p.grad.clone() for p in model.parameters() if p.grad is not None]))
     finally:
         lib.csn_dev_set(L.DEV_WIDE_FORMS, 7)
-        lib.csn_dev_set(L.DEV_WX, 1)
+        lib.csn_dev_set(L.DEV_WX, L.DEV_WX_DEFAULT)
     assert torch.equal(outs[0][0], outs[1][0]) and len(outs[0][1]) == 11
     assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))

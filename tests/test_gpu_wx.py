@@ -17,7 +17,7 @@ def L():
     _lib.build()
     lib = _lib.lib()
     _lib.check(lib.csn_set_math_mode(1))
-    assert lib.csn_dev_get(_lib.DEV_WX) == 1
+    assert lib.csn_dev_get(_lib.DEV_WX) == _lib.DEV_WX_DEFAULT
     return _lib
 
 
@@ -60,7 +60,7 @@ def test_projection_against_float64_and_the_tiled_kernel(L, S, N, ld, R, div_row
                                         temp, 0, 0, _stream()))
             outs.append(out.cpu())
         finally:
-            lib.csn_dev_set(L.DEV_WX, 1)
+            lib.csn_dev_set(L.DEV_WX, L.DEV_WX_DEFAULT)
     for out in outs:
         assert _rel(out[:, :, :N], ref) < 2e-5
         assert torch.isnan(out[:, :, N:]).all()                       # nothing beyond the points of a row is written
@@ -88,7 +88,7 @@ def test_tile_planes_against_float64_and_the_tiled_kernel(L, S, T, nb, N, R):
                                         _stream()))
             outs.append(kv.view(S, R, nb, 16, 2, 32).float().cpu())
         finally:
-            lib.csn_dev_set(L.DEV_WX, 1)
+            lib.csn_dev_set(L.DEV_WX, L.DEV_WX_DEFAULT)
     assert torch.equal(torch.isnan(outs[0]), torch.isnan(outs[1]))     # the same elements are written by both kernels
     assert torch.equal(torch.nan_to_num(outs[0]), torch.nan_to_num(outs[1]))   # ... with the same bits
     for t in outs:
@@ -141,7 +141,7 @@ def test_dctx_product_inside_the_layer_norm_backward(L):
                                                E, C, D, NP, NP, 0, 0.0, 0, 0, 0, None, E, None, 1, _stream()))
             res.append((dz.cpu(), dctx.cpu(), dw.cpu()))
         finally:
-            lib.csn_dev_set(L.DEV_WX, 1)
+            lib.csn_dev_set(L.DEV_WX, L.DEV_WX_DEFAULT)
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][2], res[1][2])
     ref = torch.einsum("dc,ecn->edn", wfc_t.double().cpu(), res[0][0].double())
     assert _rel(res[0][1], ref) < 2e-5 and torch.equal(res[0][1], res[1][1])
@@ -190,7 +190,7 @@ def test_out_projection_layer_norm_on_the_stream(L, E, S, NP, ld, p, indexed):
                 assert torch.isnan(xhat[:, :, NP:]).all()
             res.append((xhat[:, :, :NP].cpu(), rstd[:E * NP].view(E, NP).cpu(), sums.cpu()))
         finally:
-            lib.csn_dev_set(L.DEV_WX, 1)
+            lib.csn_dev_set(L.DEV_WX, L.DEV_WX_DEFAULT)
     (xh, rs, sm), (xh_t, rs_t, sm_t), (xh_n, rs_n, sm_n) = res
     assert torch.equal(xh, xh_n) and torch.equal(rs, rs_n)         # with or without the fused sums: the same maps
     assert (xh - xh_t).abs().max() < 2e-5 and ((rs - rs_t).abs() / rs_t).max() < 2e-5
@@ -247,8 +247,8 @@ def test_layer_norm_backward_in_groups_of_evaluations_is_the_same_call(L):
     xhat, rstd, ctx = _rand(rng, E, C, NP).cuda(), (torch.rand(E, NP) + 0.5).cuda(), _rand(rng, E, D, NP).cuda()
     wfc_t = (_rand(rng, D, C) / 16).cuda()
     res = []
-    for G in (0, 2):
-        prev = lib.csn_dev_set(L.DEV_LNB_GROUP, G)
+    for wx, G in ((wx, G) for wx in (1, 9) for G in (0, 2)):         # the two launches, then the fused kernel (wx_lnb.hip)
+        prev, prev_wx = lib.csn_dev_set(L.DEV_LNB_GROUP, G), lib.csn_dev_set(L.DEV_WX, wx)
         try:
             dz, dzr = torch.full((E, C, NP), float("nan"), device="cuda"), torch.full((E, C, NP), float("nan"), device="cuda")
             dctx, dw = torch.full((E, D, NP), float("nan"), device="cuda"), torch.empty((C, D), device="cuda")
@@ -261,7 +261,65 @@ def test_layer_norm_backward_in_groups_of_evaluations_is_the_same_call(L):
             res.append([t.cpu() for t in (dz, dzr, dctx, dw)])
         finally:
             lib.csn_dev_set(L.DEV_LNB_GROUP, prev)
-    for a, b in zip(*res):
-        assert not torch.isnan(a).any() and torch.equal(a, b)
+            lib.csn_dev_set(L.DEV_WX, prev_wx)
+    for one, grouped in ((res[0], res[1]), (res[2], res[3])):
+        for a, b in zip(one, grouped):
+            assert not torch.isnan(a).any() and torch.equal(a, b)
     assert (res[0][0] == 0).float().mean() > 0.1                      # the fc dropout mask is live in dz, and absent from dz_res
     assert (res[0][1] == 0).float().mean() < 0.01
+
+
+@pytest.mark.parametrize("E,NP,p,with_res,grp", [(5, 260, 0.2, True, 2), (3, 1000, 0.0, False, 1), (40, 96, 0.1, True, 8), (2, 10000, 0.1, False, 2)])
+def test_layer_norm_backward_fused_into_the_dctx_stream(L, E, NP, p, with_res, grp):
+    """csn_outproj_ln_bwd_f32 with the LayerNorm backward computed on the chunks' way into the dCtx product (wx_lnb.hip, CSN_DEV_WX
+    bit 3) against the two launches it replaces: dz (the same dropout mask: the same zeros), dz_res, dCtx and the weight gradient to
+    fp32 rounding (the row sums are formed in another order), against float64, twice the same bits, nothing outside the maps."""
+    lib = L.lib()
+    rng = np.random.default_rng(21)
+    C = D = 256
+    n_src = (E + grp - 1) // grp
+    dfeats = _rand(rng, n_src, C, NP).cuda()
+    scale, rows = _rand(rng, E, C).cuda(), (_rand(rng, E, C) / 8).cuda()
+    xh = _rand(rng, E, C, NP)
+    xh = (xh - xh.mean(dim=1, keepdim=True)) / xh.std(dim=1, unbiased=False, keepdim=True)       # what a LayerNorm leaves
+    xhat, rstd, ctx = xh.cuda(), (torch.rand(E, NP) + 0.5).cuda(), _rand(rng, E, D, NP).cuda()
+    wfc_t = (_rand(rng, D, C) / 16).cuda()
+    n_dense = E - 1
+    res = []
+    for wx in (9, 9, 1):
+        prev = lib.csn_dev_set(L.DEV_WX, wx)
+        try:
+            pool = torch.full((3 * E * C * NP + 4096,), float("nan"), device="cuda")
+            dz, dzr, dctx = (pool[i * E * C * NP:(i + 1) * E * C * NP].view(E, C, NP) for i in range(3))
+            dw = torch.empty((C, D), device="cuda")
+            ws_n = lib.csn_wgrad_workspace_floats(C, D, E, NP)
+            ws = torch.empty((ws_n,), device="cuda")
+            L.check(lib.csn_outproj_ln_bwd_f32(dfeats.data_ptr(), xhat.data_ptr(), rstd.data_ptr(), C * NP, ctx.data_ptr(), D * NP,
+                                               wfc_t.data_ptr(), dz.data_ptr(), dzr.data_ptr() if with_res else None, dctx.data_ptr(), dw.data_ptr(),
+                                               ws.data_ptr(), ws_n, E, C, D, NP, NP, 0, p, 0xabcdef, 0, 0, rows.data_ptr(), n_dense, scale.data_ptr(),
+                                               grp, _stream()))
+            torch.cuda.synchronize()
+            assert torch.isnan(pool[3 * E * C * NP:]).all()
+            if not with_res:
+                assert torch.isnan(dzr).all()
+            res.append([t.cpu().clone() for t in (dz, dzr, dctx, dw)])
+        finally:
+            lib.csn_dev_set(L.DEV_WX, prev)
+    a, a2, b = res
+    for t, u in zip(a, a2):
+        assert torch.equal(torch.nan_to_num(t, nan=7.0), torch.nan_to_num(u, nan=7.0))
+    assert not torch.isnan(a[0]).any() and not torch.isnan(a[2]).any()
+    assert torch.equal(a[0] == 0, b[0] == 0)                                    # the mask
+    for i in ((0, 1, 2, 3) if with_res else (0, 2, 3)):
+        assert (a[i] - b[i]).abs().max() <= 2e-5 * b[i].abs().max(), i
+    # float64: the LayerNorm backward itself (dz_res is dz without the mask)
+    dx = torch.zeros((E, C, NP), dtype=torch.float64)
+    src = torch.arange(E) // grp
+    dx[:n_dense] = dfeats.cpu().double()[src[:n_dense]] * scale.cpu().double()[:n_dense, :, None]
+    dx += rows.cpu().double()[:, :, None]
+    x64 = xh.double()
+    ref = rstd.cpu().double()[:, None, :] * (dx - dx.mean(dim=1, keepdim=True) - x64 * (dx * x64).mean(dim=1, keepdim=True))
+    got = a[1] if with_res else a[0]
+    keep = torch.ones_like(ref, dtype=torch.bool) if with_res else (a[0] != 0)
+    sc = 1.0 if with_res else 1.0 / (1.0 - p)
+    assert ((got.double() - ref * sc).abs()[keep]).max() <= 2e-5 * ref.abs().max() * sc
