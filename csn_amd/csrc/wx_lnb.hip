@@ -38,10 +38,10 @@ CSN_DEVINL float lnb_sum_row_groups(float v) {
   // (asm, not __builtin_amdgcn_permlane16_swap / 32_swap: hipcc 7.2 maps BOTH elements of the builtin's result to the first
   //  register — `v_permlane16_swap v5, v4 ; v_add_f32 v2, v5, v5` — and the sum comes out as twice one half)
   float c = v;
-  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v), "+v"(c));
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v), "+v"(c));
   v += c;
   c = v;
-  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v), "+v"(c));
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v), "+v"(c));
   return v + c;
 }
 
