@@ -5,6 +5,7 @@ import argparse, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import csn_amd
+import csn_amd.functional
 from csn_amd import tuning
 from csn_amd.csa_models import get_model
 
@@ -29,7 +30,7 @@ lab = torch.from_numpy(rng.integers(0, 39, size=(B, N))).cuda()
 def step():
     for p in model.parameters():
         p.grad = None
-    loss = torch.nn.functional.cross_entropy(model(x, "train", nbf).squeeze(-1), lab, ignore_index=0)
+    loss = csn_amd.functional.masked_cross_entropy(model(x, "train", nbf), lab, 0)[0]
     loss.backward()
 
 bits = csn_amd.lib().csn_attn_bwd_grouping(C, 500) if mode != 3 else 0

@@ -5,6 +5,7 @@ import argparse, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import csn_amd
+import csn_amd.functional
 from csn_amd.csa_models import get_model
 
 ap = argparse.ArgumentParser()
@@ -26,7 +27,7 @@ for math in ("fp32", "bf16x3", "bf16", "fp16"):
     for it in range(a.steps):
         torch.manual_seed(100 + it)
         opt.zero_grad()
-        loss = torch.nn.functional.cross_entropy(model(nbf[:, 0], "train", nbf).squeeze(-1), lab, ignore_index=0)
+        loss = csn_amd.functional.masked_cross_entropy(model(nbf[:, 0], "train", nbf), lab, 0)[0]
         loss.backward()
         opt.step()
         losses.append(loss.item())

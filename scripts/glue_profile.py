@@ -9,7 +9,8 @@ import torch
 from torch.profiler import ProfilerActivity, profile
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import csn_amd  # noqa: E402
+import csn_amd
+import csn_amd.functional  # noqa: E402
 from csn_amd.csa_models import get_model  # noqa: E402
 
 B, K, N, C, nb = 32, 3, 10000, 256, 20
@@ -31,7 +32,7 @@ def step():
         from csn_amd.training import masked_ce
         loss = masked_ce(logits, lab)
     else:
-        loss = torch.nn.functional.cross_entropy(logits.squeeze(-1), lab, ignore_index=0)
+        loss = csn_amd.functional.masked_cross_entropy(logits, lab, 0)[0]
     loss.backward()
 
 
