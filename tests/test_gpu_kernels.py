@@ -657,6 +657,52 @@ def test_abi_argument_validation_table(L):
         lib.csn_set_math_mode(1)
 
 
+def test_abi_argument_validation_table_round4_entries(L):
+    """The entry points added in round 4 — csn_project_qkv_f32, csn_masked_ce_fwd_f32 / _bwd_f32 — refuse what they cannot take
+    with the documented status, like the rest of the table above."""
+    lib = L.lib()
+    ARG, ALIGN, PTR, STRIDE, DIM, WS = -1, -2, -3, -4, -5, -6
+    dev = "cuda"
+    L.check(lib.csn_set_math_mode(1))
+    S, C, D, N, T, nb = 2, 256, 256, 72, 36, 2
+    ldp = nb * 1024
+    x = torch.randn(S, C, N, device=dev); w = torch.randn(3 * D, C, device=dev)
+    q = torch.empty(S, D, N, device=dev); kv = torch.empty(S, 2 * D, ldp, device=dev, dtype=torch.bfloat16)
+    names = ["x", "xs", "ldx", "w", "D", "C", "q", "qs", "ldq", "kv", "kvs", "ldkv", "S", "np", "temp", "T", "st"]
+    valid = dict(x=x.data_ptr(), xs=C * N, ldx=N, w=w.data_ptr(), D=D, C=C, q=q.data_ptr(), qs=D * N, ldq=N, kv=kv.data_ptr(), kvs=2 * D * ldp,
+                 ldkv=ldp, S=S, np=N, temp=16.0, T=T, st=_stream())
+    _mutations(lib.csn_project_qkv_f32, names, valid, [
+        ("x", None, ARG), ("w", None, ARG), ("q", None, ARG), ("kv", None, ARG), ("D", 0, ARG), ("S", 0, ARG), ("np", 0, ARG), ("T", 0, ARG),
+        ("T", 516, ARG), ("T", 34, ARG), ("ldkv", ldp - 8, ARG), ("ldkv", 1024, ARG), ("ldx", N - 4, ARG), ("ldq", N - 4, ARG), ("np", N - 2, ALIGN),
+        ("ldx", N + 2, ALIGN), ("x", x.data_ptr() + 4, PTR), ("q", q.data_ptr() + 8, PTR), ("xs", C * N + 2, STRIDE), ("kvs", 2 * D * ldp + 4, STRIDE)])
+    L.check(lib.csn_set_math_mode(0))
+    try:
+        assert lib.csn_project_qkv_f32(*[valid[n] for n in names]) == ARG           # tile planes: the 16-bit modes only
+    finally:
+        L.check(lib.csn_set_math_mode(1))
+
+    n_cls, NP = 39, 200
+    z = torch.randn(S, n_cls + 1, NP, device=dev); lab = torch.randint(0, n_cls, (S, NP), device=dev)
+    lse = torch.empty(S, NP, device=dev); stats = torch.empty(3, device=dev)
+    wsb = lib.csn_masked_ce_workspace_bytes(S, NP)
+    ws = torch.empty(wsb // 8 + 1, device=dev, dtype=torch.float64)
+    names = ["z", "zs", "ld", "lab", "ls", "S", "ncls", "np", "mask", "lse", "ws", "wsb", "stats", "st"]
+    valid = dict(z=z.data_ptr(), zs=(n_cls + 1) * NP, ld=NP, lab=lab.data_ptr(), ls=NP, S=S, ncls=n_cls, np=NP, mask=0, lse=lse.data_ptr(),
+                 ws=ws.data_ptr(), wsb=wsb, stats=stats.data_ptr(), st=_stream())
+    _mutations(lib.csn_masked_ce_fwd_f32, names, valid, [
+        ("z", None, ARG), ("lab", None, ARG), ("lse", None, ARG), ("ws", None, ARG), ("stats", None, ARG), ("S", 0, ARG), ("ncls", 0, ARG),
+        ("np", 0, ARG), ("ld", NP - 4, ARG), ("wsb", wsb - 8, WS), ("ws", ws.data_ptr() + 4, PTR), ("S", 70000, DIM)])
+    g = torch.ones(1, device=dev); dz = torch.empty(S, n_cls, NP, device=dev)
+    names = ["z", "zs", "ld", "lab", "ls", "S", "ncls", "np", "mask", "lse", "stats", "g", "dz", "dzs", "dld", "st"]
+    valid = dict(z=z.data_ptr(), zs=(n_cls + 1) * NP, ld=NP, lab=lab.data_ptr(), ls=NP, S=S, ncls=n_cls, np=NP, mask=0, lse=lse.data_ptr(),
+                 stats=stats.data_ptr(), g=g.data_ptr(), dz=dz.data_ptr(), dzs=n_cls * NP, dld=NP, st=_stream())
+    _mutations(lib.csn_masked_ce_bwd_f32, names, valid, [
+        ("z", None, ARG), ("lab", None, ARG), ("lse", None, ARG), ("stats", None, ARG), ("g", None, ARG), ("dz", None, ARG), ("S", 0, ARG),
+        ("np", 0, ARG), ("np", NP - 2, ALIGN), ("ld", NP + 2, ALIGN), ("dld", NP - 4, ARG), ("zs", (n_cls + 1) * NP + 2, STRIDE),
+        ("dzs", n_cls * NP + 1, STRIDE), ("z", z.data_ptr() + 4, PTR), ("dz", dz.data_ptr() + 8, PTR)])
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("B,K1,C,ref_layout", [(1, 3, 256, True), (2, 4, 256, True), (32, 4, 256, True), (5, 5, 96, True),
                                                (3, 3, 128, False), (4, 8, 64, True)])
 def test_compat_head(L, math_mode, B, K1, C, ref_layout):
