@@ -35,8 +35,13 @@ __device__ unsigned long long csn_dbg_rt[2048 * 8 * 2];     // s_memrealtime (10
 extern "C" int csn_debug_read_wg(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_dbg_wg), bytes); }
 extern "C" int csn_debug_read_rt(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_dbg_rt), bytes); }
 #define WGSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if ((BWD == (CSN_STAMPS != 0)) && DT == 8 && blockIdx.x >= 4096 && blockIdx.x < 6144 && (threadIdx.x & 63) == 0) { csn_dbg_wg[((blockIdx.x - 4096) * 8 + (threadIdx.x >> 6)) * 4 + i] = __builtin_amdgcn_s_memtime(); if (i == 0 || i == 3) csn_dbg_rt[((blockIdx.x - 4096) * 8 + (threadIdx.x >> 6)) * 2 + (i == 3)] = __builtin_amdgcn_s_memrealtime(); } __builtin_amdgcn_sched_barrier(0); } while (0)
+// prologue stamps of the same work-groups: entry, operand block requested, landed (barrier), picked, tiles fetched and committed
+__device__ unsigned long long csn_dbg_pro[2048 * 8 * 8];
+extern "C" int csn_debug_read_pro(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_dbg_pro), bytes); }
+#define PSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if ((BWD == (CSN_STAMPS != 0)) && DT == 8 && blockIdx.x >= 4096 && blockIdx.x < 6144 && (threadIdx.x & 63) == 0) csn_dbg_pro[((blockIdx.x - 4096) * 8 + (threadIdx.x >> 6)) * 8 + i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define WGSTAMP(i)
+#define PSTAMP(i)
 #endif
 
 namespace {
@@ -287,8 +292,11 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
     }
   };
   auto pick = [&](int row) { return xbuf[row * 128 + ((((col >> 2) ^ (4 * ((row >> 3) & 1))) << 2) | (col & 3))]; };
+  PSTAMP(0);
   stage_in(Rr, p.r_fmt);
+  PSTAMP(1);
   __syncthreads();
+  PSTAMP(2);
   float rv[D / 4];
 #pragma unroll
   for (int s = 0; s < D / 32; ++s)
@@ -299,6 +307,7 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
       Rh[s][j] = to16<PR::HALF>(v);
       Rl[s][j] = PR::NT == 3 ? to16<PR::HALF>(v - from16<PR::HALF>(Rh[s][j])) : Rh[s][j];
     }
+  PSTAMP(3);
   float delta_q = 0.f;
   if (BWD) {
     const csn_rsrc_t Xr = map_rsrc(p.ctx, qs * p.q_shape_stride + head_off, p.ctx_fmt);
@@ -641,15 +650,19 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
     fetch_to(Br, 0, g2); commitB_from(0, g2);
     if (nkt > 1) fetch_to(Ar, 1, g);
   } else {
+    PSTAMP(4);
     if constexpr (PRE0) {
       commitA(0); commitB_from(0, gp);
     } else {
       fetch(Ar, 0); commitA(0);
+      PSTAMP(5);
       fetch(Br, 0); commitB(0);
     }
+    PSTAMP(6);
     if (nkt > 1) fetch(Ar, 1);
   }
   __syncthreads();
+  PSTAMP(7);
 
   // -DCSN_STAMPS: development build that records s_memtime at the phase boundaries of tiles 4..7 (scripts/attn_stamps.py)
 #ifdef CSN_STAMPS

@@ -81,3 +81,13 @@ r = rb.reshape(2048, 8, 2).astype(np.int64)[okw]
 clk = (w[..., 3] - w[..., 0]) / np.maximum(r[..., 1] - r[..., 0], 1) * 100.0
 print("  in-kernel clock (d s_memtime / d s_memrealtime x 100 MHz): median %.0f MHz  (p10 %.0f, p90 %.0f);  work-group wall %.1f us" %
       (np.median(clk), np.percentile(clk, 10), np.percentile(clk, 90), np.median(r[..., 1] - r[..., 0]) / 100.0))
+
+# prologue stamps (forward, or backward with CSN_STAMP_BWD=1): entry of the item loop body, operand block requested, landed
+# (barrier), picked (forward: before the tile fetches), first tile A fetched + committed, B likewise, loop start
+pb = np.zeros(2048 * 8 * 8, dtype=np.uint64)
+RAW.csn_debug_read_pro.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
+RAW.csn_debug_read_pro(pb.ctypes.data, pb.nbytes)
+pr = pb.reshape(2048, 8, 8).astype(np.int64)[okw]
+dp = np.diff(pr, axis=-1)
+names = ["request operand block", "wait + barrier", "pick + split", "(backward: delta round) ", "tile A fetch + commit", "tile B fetch + commit", "request tile 1 + barrier"]
+print("prologue, mean cycles per wave: " + "  ".join(f"{n}={dp[..., i].mean():.0f}" for i, n in enumerate(names)), " sum=%.0f" % (pr[..., 7] - pr[..., 0]).mean())
