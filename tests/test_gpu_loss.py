@@ -88,3 +88,35 @@ def test_wrong_types_are_refused():
         masked_cross_entropy(buf.cuda()[:, :39].half(), lab.cuda(), 0)
     with pytest.raises(_lib.CsnError):
         masked_cross_entropy(buf.cuda()[:, :39], lab.cuda().int(), 0)
+
+
+def test_the_reference_s_own_loss_and_gradients_through_the_fused_pair(golden_dir):
+    """Golden set G7 holds the loss value and the 11 gradients the REFERENCE produced (its loss_functions_seg on its logits,
+    tests/golden/make_golden.py).  The module's logits through the fused pair give that loss to 1e-5 and — the loss' gradient is
+    where the backward starts — the reference's gradients to 1e-4, like the oracle's loss does in tests/test_gpu_module.py."""
+    import os
+    from csn_amd.csa_models import get_model
+    from csn_amd.functional import masked_cross_entropy
+    g = np.load(os.path.join(golden_dir, "g7_csa_conditioned.npz"))
+    for i in (0, 1):
+        B, K, H, n_cls, seed = (int(v) for v in g[f"g7_{i}_cfg"])
+        fc_s, q_s, off = (float(v) for v in g[f"g7_{i}_scales"])
+        p, x, nb, lab = orc.conditioned_csa_case(np.random.default_rng(seed), B, K, H, n_cls, fc_s, q_s, off)
+        model = get_model("csa", n_cls, H, K)
+        model.load_state_dict(p, strict=False)
+        model = model.cuda().eval()
+        logits = model(x.cuda(), "test", nb)
+        loss, accu, count = masked_cross_entropy(logits, lab.cuda().long(), 0)
+        loss.backward()
+        assert abs(loss.item() - g[f"g7_{i}_loss"][0]) < 1e-5
+        assert count.item() == (lab > 0).sum().item()
+        seen = 0
+        for name, prm in model.named_parameters():
+            if name.startswith("fc_1"):
+                continue
+            ref = g[f"g7_{i}_grad_{name}"]
+            gr = prm.grad.detach().cpu()
+            got = gr.numpy() if gr.numel() <= 10000 else gr.reshape(gr.shape[0], -1)[::17, ::13].contiguous().numpy()
+            assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), name
+            seen += 1
+        assert seen == 11
