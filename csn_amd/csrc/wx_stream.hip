@@ -214,21 +214,45 @@ __global__ __launch_bounds__(512, 2) void csn_wx_kernel(CsnWxArgs p) {
       // the tile's 32 keys leave whole, 8 keys = 16 bytes per lane and plane (lane -> row lane / 4 + 16 t, keys 8 (lane % 4) ..):
       // points beyond the block's (or the row's) end were never loaded, their sums are zeros — exactly the padding the
       // attention kernels expect behind a block's last key
-      const int prow = lane >> 2, c4k = lane & 3;
+// (-DCSN_WX_PLANE_LINES=1: every store instruction writes 8 whole 128-byte lines instead of 16 half lines, at twice the
+//  conversion work — measured 1.10 ms against 1.06 for the K / V projection, same bits; off)
+#ifndef CSN_WX_PLANE_LINES
+#define CSN_WX_PLANE_LINES 0
+#endif
       const csn_rsrc_t Or = csn_make_rsrc(reinterpret_cast<short*>(p.out) + (long long)item * p.out_item_stride + (long long)(256 * pset) * p.ldo,
                                           (long long)256 * p.ldo * 2);
-      const unsigned tcol = blk * 1024u + tile * 64u + 8u * (unsigned)c4k;
-      const unsigned off = valid > 0 ? ((unsigned)((32 * wave + prow) * p.ldo) + tcol) * 2u : CSN_OOB;
+      if constexpr (CSN_WX_PLANE_LINES != 0) {
+        // whole 128-byte lines per store instruction: lane -> row lane / 8 + 8 t, 16-byte unit lane % 8 of the row's [hi 32 | lo 32]
+        // (units 0..3: keys 8 u .. + 7 of the hi plane, 4..7: of the lo plane).  A lane splits its 8 keys and keeps one plane —
+        // twice the conversion work of the form below, where a store instruction wrote 16 half lines (rows 40 KB apart)
+        const int prow = lane >> 3, u = lane & 7, ku = u & 3;
+        const unsigned tcol = blk * 1024u + tile * 64u + 8u * (unsigned)u;
+        const unsigned off = valid > 0 ? ((unsigned)((32 * wave + prow) * p.ldo) + tcol) * 2u : CSN_OOB;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(&eb[(prow + 16 * t) * 32 + 8 * c4k]);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(&eb[(prow + 16 * t) * 32 + 8 * c4k + 4]);
-        s16x4 h0, l0, h1, l1;
-        split4<Bf16x3>(v0, h0, l0);
-        split4<Bf16x3>(v1, h1, l1);
-        const unsigned so = (unsigned)(16 * t * p.ldo) * 2u;
-        csn_bstore4(__builtin_bit_cast(f32x4, join8(h0, h1)), Or, off, so);
-        csn_bstore4(__builtin_bit_cast(f32x4, join8(l0, l1)), Or, off, so + 64u);
+        for (int t = 0; t < 4; ++t) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(&eb[(prow + 8 * t) * 32 + 8 * ku]);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(&eb[(prow + 8 * t) * 32 + 8 * ku + 4]);
+          s16x4 h0, l0, h1, l1;
+          split4<Bf16x3>(v0, h0, l0);
+          split4<Bf16x3>(v1, h1, l1);
+          const s16x8 keep = u < 4 ? join8(h0, h1) : join8(l0, l1);
+          csn_bstore4(__builtin_bit_cast(f32x4, keep), Or, off, (unsigned)(8 * t * p.ldo) * 2u);
+        }
+      } else {
+        const int prow = lane >> 2, c4k = lane & 3;
+        const unsigned tcol = blk * 1024u + tile * 64u + 8u * (unsigned)c4k;
+        const unsigned off = valid > 0 ? ((unsigned)((32 * wave + prow) * p.ldo) + tcol) * 2u : CSN_OOB;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(&eb[(prow + 16 * t) * 32 + 8 * c4k]);
+          const f32x4 v1 = *reinterpret_cast<const f32x4*>(&eb[(prow + 16 * t) * 32 + 8 * c4k + 4]);
+          s16x4 h0, l0, h1, l1;
+          split4<Bf16x3>(v0, h0, l0);
+          split4<Bf16x3>(v1, h1, l1);
+          const unsigned so = (unsigned)(16 * t * p.ldo) * 2u;
+          csn_bstore4(__builtin_bit_cast(f32x4, join8(h0, h1)), Or, off, so);
+          csn_bstore4(__builtin_bit_cast(f32x4, join8(l0, l1)), Or, off, so + 64u);
+        }
       }
     }
   };
