@@ -4,8 +4,10 @@
     python bench.py --gpus 1 --steps 20 --warmup 5                      # BASELINE.json configs[2] (the metric's config)
     python bench.py --same-work                                         # N = 1 with the per-GPU work of the N > 1 path (K+2 evaluations)
     python bench.py --config 2 | --config 5                             # configs[1] / configs[4] as workloads of their own
+    python bench.py --gpus N --steps K --warmup W                      # N > 1 without a launcher: starts its own N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --heads 8 --K 4 --shapes 8                          # the reference's published geometry (get_csa_pred.py:35-36)
 
 A "step" = one pass of the hot path over one batch of synthetic shapes, exactly what
 MID-FC/csa_training.py:202-211 does per batch: model(x, neighbours) -> masked cross-entropy -> backward
@@ -47,7 +49,7 @@ MATH_MODES = {"fp32": 0, "bf16x3": 1, "bf16": 2, "fp16": 3}
 DTYPE_TEXT = {"fp32": "f32", "bf16x3": "bf16x3 (fp32 operands split into 2 bf16, 3 bf16 MFMA per product, fp32 accumulate)",
               "bf16": "bf16 (one bf16 MFMA per product, fp32 accumulate; outside the 1e-4 contract)",
               "fp16": "fp16 forward / bf16 backward (one MFMA per product, fp32 accumulate; outside the 1e-4 contract)"}
-H, N_CLS = 1, 39
+N_CLS = 39
 CONFIGS = {
     2: dict(B=4, K=2, N=10000, C=256, d=256, T=500, nb=20, name="BASELINE configs[1]"),
     3: dict(B=32, K=3, N=10000, C=256, d=256, T=500, nb=20, name="BASELINE configs[2]"),
@@ -82,7 +84,7 @@ def cpu_model_name():
     return "unknown"
 
 
-def cpu_baseline(cfg, sample_shapes, threads, dropout=True):
+def cpu_baseline(cfg, sample_shapes, threads, dropout=True, H=1):
     """The oracle's port of the reference on the host, fwd + bwd, in the same mode as the headline run (train mode: both
     dropouts live, csa_training.py:192).  Reference geometry (20 x 500, d = 256): the faithful op sequence (chunk loop, index
     gather, growing cat, 2K+2 MHA calls); other geometries: the closed form of the same arithmetic."""
@@ -122,6 +124,54 @@ def cpu_baseline(cfg, sample_shapes, threads, dropout=True):
                       f"steps after 1 warm-up, {t:.2f} s/step; {what}"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: this process — BEFORE anything of it touches a GPU —
+    starts N fresh copies of itself, one rank per GPU, with the environment `torch.distributed.run` would give them
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT on 127.0.0.1), relays rank 0's JSON line (every rank's stderr
+    passes through) and exits non-zero if any rank does.  The launcher form of the docstring keeps working: with WORLD_SIZE
+    already in the environment nothing is spawned."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if port is None:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, CSN_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench: ranks failed (rank, exit code): {bad}", file=sys.stderr, flush=True)
+        sys.exit(1)
+    sys.exit(0)
+
+
+def launch_check():
+    """CSN_BENCH_LAUNCH_CHECK=1 (tests/test_bench_launch.py, no GPU): the ranks of a self-launched run only prove that they
+    exist — process group over gloo on the CPU, one all-reduce, rank 0 prints what it saw — and leave."""
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    if os.environ.get("CSN_BENCH_LAUNCH_CHECK") == "fail" and rank == world - 1:
+        sys.exit(3)                                                      # (the parent must notice a rank that dies)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_ranks_seen": dist.get_world_size(), "rank_sum": t.item(),
+                          "local_rank": int(os.environ["LOCAL_RANK"]), "argv": sys.argv[1:]}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,6 +181,9 @@ def main():
                     help="workload: 3 = the metric's configuration (default), 2 / 5 = BASELINE configs[1] / configs[4]")
     ap.add_argument("--shapes", type=int, default=None, help="query shapes per GPU (default: the configuration's)")
     ap.add_argument("--K", type=int, default=None)
+    ap.add_argument("--heads", type=int, default=1,
+                    help="n_heads (d_k = d_v = d per head): 1 = csa_training.py:37's default and the metric's configuration; 8 with "
+                         "--K 4 = the reference's published checkpoint (get_csa_pred.py:35-36)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--math", choices=sorted(MATH_MODES), default="bf16x3",
                     help="arithmetic of the contractions: exact fp32 matrix cores; three bf16 products per fp32 product "
@@ -142,6 +195,12 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the secondary runs (other math mode, eval-mode arithmetic): what the profiles are taken with")
     args = ap.parse_args()
+    H = args.heads
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                                                # (never returns; nothing has touched a GPU yet)
+    if os.environ.get("CSN_BENCH_LAUNCH_CHECK"):
+        return launch_check()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -167,7 +226,7 @@ def main():
         else:
             dist.init_process_group(backend=backend)
         n_ranks_seen = dist.get_world_size()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -239,7 +298,7 @@ def main():
     exchange_mode = os.environ.get("CSN_EXCHANGE", "alltoall")           # "allgather": the whole collection to every rank
     # --math bf16 / fp16: the neighbour features cross xGMI as bf16 (the consumers round them to 16 bits anyway): config 4 as
     # SURVEY.md §8(e) sizes it; the parity modes exchange the fp32 maps
-    payload_dtype = torch.bfloat16 if args.math in ("bf16", "fp16") else None
+    payload_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(args.math)      # (fp16 consumers keep 11 bits: an fp16 payload)
     overlap = os.environ.get("CSN_OVERLAP", "1") != "0"                  # exchange in flight under the self-attention evaluations
 
     # CSN_BENCH_SPLIT=1 (N = 1, development aid): run the two-phase evaluation order of the multi-GPU path with the stack
@@ -365,6 +424,15 @@ def main():
         same_work_ms = float(np.median(sw))
     elapsed, loss_val, attn_ms, gnorm, step_ms = timed(True)
     if not args.headline_only:
+        if not grouped and x_nb_host is None and not same_work_n1:
+            # the module's DEFAULT path beside the headline: without `trust_neighbor_slot0` CrossShapeAt re-assembles the neighbour
+            # stack with the query features in slot 0 (csa_models.py:344-356 of this package; 1.3 GB at config 3) — what a caller
+            # gets whose stack does not come from CSADatasetK
+            model.trust_neighbor_slot0 = False
+            _, loss_default, _, _, step_ms_default = timed(True)
+            model.trust_neighbor_slot0 = True
+        else:
+            step_ms_default = None
         elapsed_eval, loss_eval, _, _, step_ms_eval = timed(False)      # eval-mode arithmetic (dropout off), gradients on
         set_math(other)
         elapsed_other, loss_other, attn_ms_other, gnorm_other, step_ms_other = timed(True)
@@ -402,7 +470,7 @@ def main():
                  "traffic_source": (entry["source"] + " (rocprofv3 --pmc passes of this command, not measured in this run)") if entry else None,
                  "launch_ms": ms, "launch_ms_is": f"mean over {args.steps} timed steps of the step's launches of this kernel (HIP events on the launch stream)",
                  "flops_per_launch": launch_flops,
-                 "note": f"algorithmic FLOPs: 4*T*d = {4 * T * d // 1000} kFLOP per query point per evaluation x {N} points x "
+                 "note": f"algorithmic FLOPs: 4*T*D = {4 * T * D // 1000} kFLOP per query point per evaluation ({H} head(s) of d = {d}) x {N} points x "
                          f"{n_evals} evaluations in the launch"
                          + (" (dV = P^T dO and dK = dS^T Qs; the S and dP products this kernel recomputes are not credited)" if which == "dkv" else "")
                          + (" (dP and dQ; the recomputed S product is not credited)" if which == "bwd" and flash else "")}
@@ -497,6 +565,12 @@ def main():
                                              "as the collection, no exchange) — the like-for-like N = 1 point of the scaling curve; "
                                              "NOT the metric's headline (that is the default run: the reference's 2K+2)")
         if not args.headline_only:
+            if step_ms_default is not None:
+                out["config"]["default_path"] = {"ms_per_step": float(np.median(step_ms_default)),
+                                                 "points_per_s": S * N / (float(np.median(step_ms_default)) * 1e-3), "loss": loss_default,
+                                                 "note": "the same step with model.trust_neighbor_slot0 = False (the module's default): the "
+                                                         "neighbour stack is re-assembled with the query features in slot 0 first; the "
+                                                         "headline sets the flag because its stack has the CSADatasetK form (slot 0 = self)"}
             out["config"]["dropout_off"] = {"points_per_s": S * N / (float(np.median(step_ms_eval)) * 1e-3),
                                             "ms_per_step": float(np.median(step_ms_eval)), "loss": loss_eval,
                                             "note": "same step with eval-mode arithmetic (2K+1 evaluations/shape), gradients on"}
@@ -516,7 +590,8 @@ def main():
                       f"loss {loss_val} vs {loss_other}, |grad| {gnorm} vs {gnorm_other}", file=sys.stderr, flush=True)
         if not grouped and not args.no_cpu_baseline:
             cores = min(len(os.sched_getaffinity(0)), 16)          # the GPU box gives one GPU a 16-core share
-            out["cpu_baseline"] = cpu_baseline(cfg, 4 if args.config == 3 else (2 if args.config == 2 else 1), cores)
+            sample = 1 if H > 1 else (4 if args.config == 3 else (2 if args.config == 2 else 1))
+            out["cpu_baseline"] = cpu_baseline(cfg, min(sample, B), cores, H=H)
         print(json.dumps(out), flush=True)
     if grouped:
         dist.destroy_process_group()

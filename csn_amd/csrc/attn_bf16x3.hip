@@ -28,16 +28,16 @@
 
 #ifdef CSN_STAMPS
 __device__ unsigned long long csn_dbg[2048 * 8 * 4 * 8];
-extern "C" int csn_debug_read(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_dbg), bytes); }
+extern "C" __attribute__((visibility("default"))) int csn_debug_read(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_dbg), bytes); }
 // whole-kernel stamps per wave: entry, tile loop start, tile loop end, exit
 __device__ unsigned long long csn_dbg_wg[2048 * 8 * 4];
 __device__ unsigned long long csn_dbg_rt[2048 * 8 * 2];     // s_memrealtime (100 MHz) at entry and exit: in-kernel clock
-extern "C" int csn_debug_read_wg(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_dbg_wg), bytes); }
-extern "C" int csn_debug_read_rt(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_dbg_rt), bytes); }
+extern "C" __attribute__((visibility("default"))) int csn_debug_read_wg(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_dbg_wg), bytes); }
+extern "C" __attribute__((visibility("default"))) int csn_debug_read_rt(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_dbg_rt), bytes); }
 #define WGSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if ((BWD == (CSN_STAMPS != 0)) && DT == 8 && blockIdx.x >= 4096 && blockIdx.x < 6144 && (threadIdx.x & 63) == 0) { csn_dbg_wg[((blockIdx.x - 4096) * 8 + (threadIdx.x >> 6)) * 4 + i] = __builtin_amdgcn_s_memtime(); if (i == 0 || i == 3) csn_dbg_rt[((blockIdx.x - 4096) * 8 + (threadIdx.x >> 6)) * 2 + (i == 3)] = __builtin_amdgcn_s_memrealtime(); } __builtin_amdgcn_sched_barrier(0); } while (0)
 // prologue stamps of the same work-groups: entry, operand block requested, landed (barrier), picked, tiles fetched and committed
 __device__ unsigned long long csn_dbg_pro[2048 * 8 * 8];
-extern "C" int csn_debug_read_pro(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_dbg_pro), bytes); }
+extern "C" __attribute__((visibility("default"))) int csn_debug_read_pro(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_dbg_pro), bytes); }
 #define PSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if ((BWD == (CSN_STAMPS != 0)) && DT == 8 && blockIdx.x >= 4096 && blockIdx.x < 6144 && (threadIdx.x & 63) == 0) csn_dbg_pro[((blockIdx.x - 4096) * 8 + (threadIdx.x >> 6)) * 8 + i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define WGSTAMP(i)
@@ -861,7 +861,6 @@ int launch_mode(const CsnAttnArgs& a, int d, int mode, bool bwd, hipStream_t st)
 }  // namespace
 
 int csn_launch_attn_fwd_bf16x3(const CsnAttnArgs& a, int d, int mode, hipStream_t st) {
-  if (csn_attn_fwd_x4_takes(a, d, mode)) return csn_launch_attn_fwd_x4(a, st);      // d = 256, bf16x3: four 32-query waves
   return launch_mode(a, d, mode, false, st);
 }
 int csn_launch_attn_bwd_bf16x3(const CsnAttnArgs& a, int d, int mode, hipStream_t st) { return launch_mode(a, d, mode, true, st); }

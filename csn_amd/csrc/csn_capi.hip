@@ -101,7 +101,7 @@ int wgrad(const float* a, long long a_stride, int lda, const float* b, long long
       w.ws = ws; w.n_items = n_maps; w.n_points = n_points; w.n_sets = rows / 256;
       const int rc = csn_launch_wx_wgrad(w, st);
       if (rc == 0) return csn_launch_slab_reduce(ws, dw, slabs, (long long)rows * cols, scale, accumulate, st);
-      if (rc != -1) return rc;
+      if (rc != CSN_NOT_TAKEN) return rc;
     }
   }
   const int chunk = wgrad_chunk(n_maps, n_points);
@@ -133,7 +133,6 @@ int csn_dev_get(int key) {
     case CSN_DEV_WIDE_GEMM: return csn_gemm_wide;
     case CSN_DEV_WIDE_FORMS: return csn_gemm_wide_set;
     case CSN_DEV_WX: return csn_dev_wx;
-    case CSN_DEV_ATTN_X4: return csn_dev_attn_x4;
     case CSN_DEV_LNB_GROUP: return csn_dev_lnb_group;
     default: return CSN_E_ARG;
   }
@@ -145,7 +144,6 @@ int csn_dev_set(int key, int value) {
     case CSN_DEV_WIDE_GEMM: csn_gemm_wide = value; break;
     case CSN_DEV_WIDE_FORMS: csn_gemm_wide_set = value; break;
     case CSN_DEV_WX: csn_dev_wx = value; break;
-    case CSN_DEV_ATTN_X4: csn_dev_attn_x4 = value; break;
     case CSN_DEV_LNB_GROUP: csn_dev_lnb_group = value < 0 ? 0 : value; break;
     default: return CSN_E_ARG;
   }
@@ -219,9 +217,11 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
   if ((ld_x & 3) || (ld_out & 3) || (n_points & 3) || (channels & 3)) return CSN_E_ALIGN;
   if (mis16(x) || mis16(w) || mis16(out)) return CSN_E_PTR;
   if ((x_shape_stride & 3) || (out_shape_stride & 3)) return CSN_E_STRIDE;
-  if (mode() == 1 && !x16 && (out_split == 0 || out_split == 2) && !(div_rows & 31) && csn_wx_takes(rows, channels))
-    return launch_wx(w, x, x_shape_stride, ld_x, out, out_shape_stride, ld_out, rows, n_shapes, n_points, div_rows, temperature,
-                     out_split, (int)out_plane_stride, (hipStream_t)stream);
+  if (mode() == 1 && !x16 && (out_split == 0 || out_split == 2) && !(div_rows & 31) && csn_wx_takes(rows, channels)) {
+    const int rc = launch_wx(w, x, x_shape_stride, ld_x, out, out_shape_stride, ld_out, rows, n_shapes, n_points, div_rows, temperature,
+                             out_split, (int)out_plane_stride, (hipStream_t)stream);
+    if (rc != CSN_NOT_TAKEN) return rc;                               // (a geometry the stream does not take: the tiled kernel below)
+  }
   CsnGemmArgs g;
   g.A = operand(w, 0, 0, 0, nullptr, channels);
   g.B = operand(x, 0, 0, x_shape_stride, nullptr, ld_x);
@@ -259,7 +259,7 @@ int csn_project_qkv_f32(const float* x, long long x_shape_stride, int ld_x, cons
     a.div_exact = (std::frexp(temperature, &ex) == 0.5f && temperature > 0.f) ? 1 : 0;
     a.tb = block;
     const int rc = csn_launch_wx(a, 4, (hipStream_t)stream);
-    if (rc != -1) return rc;
+    if (rc != CSN_NOT_TAKEN) return rc;
   }
   // ... two projections elsewhere (the same results: an output element is one dot product in one order on either route)
   const int rc = csn_project_f32(x, x_shape_stride, ld_x, w_qkv, d_inner, channels, q_out, q_shape_stride, ld_q, n_shapes, n_points,
@@ -676,9 +676,7 @@ int csn_masked_ce_bwd_f32(const float* logits, long long shape_stride, int ld, c
       n_points > dld)
     return CSN_E_ARG;
   if (n_shapes > 65535 || n_classes > 65535) return CSN_E_DIM;
-  if ((ld & 3) || (dld & 3) || (n_points & 3)) return CSN_E_ALIGN;
-  if ((shape_stride & 3) || (dshape_stride & 3)) return CSN_E_STRIDE;
-  if (mis16(logits) || mis16(dlogits) || mis16(lse)) return CSN_E_PTR;
+  // (any point count, pitch and alignment, like the forward: the launcher takes the 16-byte form where the geometry allows it)
   CsnMaskedCeArgs a{};
   a.logits = logits; a.shape_stride = shape_stride; a.ld = ld; a.labels = labels; a.label_shape_stride = label_shape_stride;
   a.n_shapes = n_shapes; a.n_classes = n_classes; a.n_points = n_points; a.mask = mask;
@@ -749,7 +747,8 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
   l.act16 = a16;
   int rc = 0;
   // dctx[e][D][n] = wfc_t[D][c] dz[e][c][n]
-  if (mode() == 1 && !a16 && !dctx_split && csn_wx_takes(d_inner, d_model)) {
+  if (mode() == 1 && !a16 && !dctx_split && csn_wx_takes(d_inner, d_model) &&
+      csn_wx_geometry_takes(csn_dev_lnb_group > 0 && csn_dev_lnb_group < n_evals ? csn_dev_lnb_group : n_evals, n_points, d_inner / 256)) {
     // (development switch CSN_DEV_LNB_GROUP = G > 0: LayerNorm backward and dCtx alternate over groups of G evaluations, so that a
     //  group's dz is read back while it may still sit in the 256 MB Infinity Cache)
     const int G = csn_dev_lnb_group > 0 ? csn_dev_lnb_group : n_evals;
@@ -763,7 +762,7 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
         f.dz = dz; f.dz_res = dz_res; f.dctx = dctx; f.dctx_eval_stride = ctx_eval_stride;
         f.n_items = ng; f.n_points = n_points; f.e_base = e0; f.dropout_p = dropout_p; f.seed = seed;
         rc = csn_launch_wx_lnb(f, st);
-        if (rc != -1) continue;
+        if (rc != CSN_NOT_TAKEN) continue;
       }
       l.e_base = e0; l.E = ng;
       rc = csn_launch_ln_bwd_f32(l, st);

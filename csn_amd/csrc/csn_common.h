@@ -50,8 +50,17 @@ CSN_DEVINL f32x4 csn_bload4(csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
 CSN_DEVINL void csn_bstore(float v, csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
 }
+// Store-data hazard (DESIGN, "platform findings"): on gfx950 a 12 / 16-byte buffer store needs TWO wait states before a vector
+// instruction rewrites its data registers.  hipcc pads them when the store's soffset is an immediate and not when it is a
+// register (the rule it inherits says the hazard exists only in the first case; measured on MI355X: ~600 of 400 000 elements
+// of a LayerNorm epilogue stored the NEXT value).  Every 16-byte store of this library whose soffset is not a compile-time
+// constant is therefore followed by a guard: an `s_nop 1` that names the data registers as an input, so no instruction that
+// rewrites them can be scheduled between the store and the end of the two wait states.  tests/test_cpu_store_hazard.py scans the
+// gfx950 assembly of every shipped source for a site the guard does not cover.
+CSN_DEVINL void csn_store_guard(f32x4 v) { asm volatile("s_nop 1" :: "v"(v)); }
 CSN_DEVINL void csn_bstore4(f32x4 v, csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, 0);
+  if (!__builtin_constant_p(soff)) csn_store_guard(v);
 }
 // streaming forms for bytes that are written once and read once much later (the saved scores, the P / dS planes).
 // -DCSN_NT=1 gives them the nt cache policy (aux bit 1) so that they do not push the K / V tiles out of the XCD's L2:
@@ -65,6 +74,7 @@ CSN_DEVINL f32x4 csn_bload4_stream(csn_rsrc_t r, unsigned voff, unsigned soff = 
 }
 CSN_DEVINL void csn_bstore4_stream(f32x4 v, csn_rsrc_t r, unsigned voff, unsigned soff = 0) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, voff, soff, CSN_NT ? 2 : 0);
+  if (!__builtin_constant_p(soff)) csn_store_guard(v);
 }
 // 8-byte (4 x bf16) and 2-byte (1 x bf16) accesses for split-bf16 planes
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));

@@ -53,7 +53,11 @@ struct CsnWxArgs {
   // out_mode 4 — Q | K | V in one pass over x: the first n_f32 row sets leave as fp32 maps, the others as tile planes through `out`
   float* out_f32 = nullptr;  long long out_f32_item_stride = 0;  int ldo_f32 = 0;  int n_f32 = 0;
 };
+// "this geometry is not taken by the streaming kernel": an INTERNAL return value of the csn_launch_wx* launchers, distinct from
+// every CSN_E_* status of the C ABI — the caller falls through to the tiled kernels and never hands it to the user
+constexpr int CSN_NOT_TAKEN = -1000;
 extern int csn_gemm_big_tiles, csn_gemm_wide, csn_gemm_wide_set, csn_dev_wx, csn_dev_lnb_group;   // development switches (csn_dev_set)
+bool csn_wx_geometry_takes(int n_items, int n_points, int n_sets);   // ... and this launch geometry (else CSN_NOT_TAKEN)
 bool csn_wx_takes(int rows, int k);                       // this product shape runs on the streaming kernel
 int csn_launch_wx(const CsnWxArgs& a, int out_mode /* 0 fp32, 2 tile planes, 3 LayerNorm, 4 fp32 + tile planes */, hipStream_t st);
 int csn_wx_ln_sum_slots(int n_items, int n_points);      // out_mode 3: sum_slots the launch will use (sum_ws = n_items * slots * 256 floats)
@@ -105,7 +109,6 @@ struct CsnAttnArgs {
   // [key tile kt][query][32 keys] (the 128 bytes of a query's tile, fp32 scores or [hi 32 | lo 32] planes): what a wave stores
   // or loads per instruction is then one contiguous run instead of sixteen 64-byte pieces 2 KB apart
   int sc_layout = 0;
-  int dev_ablate = 0;                                    // development, attn_fwd_x8.hip: timing-only ablations (results wrong)
 };
 // score recomputation needs three LDS tile images per stage: one plane at every width, two planes up to d = 128
 // (-DCSN_RC_ALIAS=1, TIMING EXPERIMENT ONLY — results are wrong: the two-plane d = 256 instance is built with its third image
@@ -133,12 +136,6 @@ struct CsnAttnDkvArgs {
 };
 int csn_launch_attn_dkv_flash(const CsnAttnDkvArgs& a, int d, int mode, hipStream_t st);
 constexpr bool csn_attn_dkv_flash_fits(int dt) { return dt <= 4; }         // K^T, V^T, dK^T, dV^T of 16 keys in one wave's registers
-
-// forward at d = 256 in bf16x3 on four 32-query waves (attn_fwd_x4.hip)
-extern int csn_dev_attn_x4;
-bool csn_attn_fwd_x4_takes(const CsnAttnArgs& a, int d, int mode);
-int csn_launch_attn_fwd_x8(const CsnAttnArgs& a, hipStream_t st);     // attn_fwd_x8.hip
-int csn_launch_attn_fwd_x4(const CsnAttnArgs& a, hipStream_t st);
 
 int csn_launch_attn_fwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
 int csn_launch_attn_bwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);

@@ -31,7 +31,7 @@
 // work-group (scripts/gemm_stamps.py)
 #ifdef CSN_STAMPS
 __device__ unsigned long long csn_gdbg[65536 * 8];
-extern "C" int csn_gemm_debug_read(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_gdbg), bytes); }
+extern "C" __attribute__((visibility("default"))) int csn_gemm_debug_read(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_gdbg), bytes); }
 #define GSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); gst[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 // 256 x 256 kernel: entry, tile loop start, tile loop end, [LN: after the residual pass, after the variance pass], exit
 #define BSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0 && blockIdx.x < 8192) csn_gdbg[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -1110,7 +1110,7 @@ int csn_launch_outproj_ln_big(const CsnOutProjArgs& a, int mode, hipStream_t st)
     const bool fused = a.xhat_sum && a.sum_ws && a.sum_ws_floats >= (long long)a.E * slots * 256;
     if (fused) { w.sum_ws = a.sum_ws; w.sum_slots = slots; }
     const int rc = csn_launch_wx(w, 3, st);
-    if (rc != -1) {                                      // (-1: a geometry the streaming kernel does not take)
+    if (rc != CSN_NOT_TAKEN) {                           // (a geometry the streaming kernel does not take: the tiled kernel below)
       if (rc || !a.xhat_sum) return rc;
       if (fused) return csn_launch_wx_ln_sums(a.sum_ws, a.xhat_sum, a.E, a.n_points, st);
       return csn_launch_rowsum_f32(a.xhat, a.xhat_sum, (long long)a.E * a.C, a.n_points, a.ld, st, 0);

@@ -29,7 +29,7 @@ __global__ __launch_bounds__(CE_BLOCK) void csn_masked_ce_fwd_kernel(CsnMaskedCe
         m = v;
         arg = c;
       } else {
-        sum += __expf(v - m);
+        sum += v == m ? 1.f : __expf(v - m);           // (v == m covers a logit of -inf while the maximum still is: -inf - -inf)
       }
       if (c == lab) zl = v;
     }
@@ -78,24 +78,35 @@ __global__ __launch_bounds__(256) void csn_masked_ce_finish_kernel(const double*
   }
 }
 
-// thread = 4 points of one class row (16-byte accesses); grid (point groups, classes, shapes)
+// thread = 4 points of one class row (16-byte accesses), or — VEC = false — one point (any point count, pitch and alignment:
+// the reference's loss takes any N, csa_training.py:94-108); grid (point groups, classes, shapes)
+template <bool VEC>
 __global__ __launch_bounds__(CE_BLOCK) void csn_masked_ce_bwd_kernel(CsnMaskedCeArgs p) {
-  const int n = (blockIdx.x * CE_BLOCK + threadIdx.x) * 4, c = blockIdx.y, s = blockIdx.z;
+  constexpr int W = VEC ? 4 : 1;
+  const int n = (blockIdx.x * CE_BLOCK + threadIdx.x) * W, c = blockIdx.y, s = blockIdx.z;
   if (n >= p.n_points) return;
   const float scale = p.grad_out[0] / p.stats[2];
   const long long row = (long long)s * p.shape_stride + (long long)c * p.ld + n;
   const long long dro = (long long)s * p.dshape_stride + (long long)c * p.dld + n;
-  const f32x4 z = *reinterpret_cast<const f32x4*>(p.logits + row);
-  const f32x4 lse = *reinterpret_cast<const f32x4*>(p.lse + (long long)s * p.n_points + n);
   const long long* lp = p.labels + (long long)s * p.label_shape_stride + n;
-  f32x4 d;
+  float z[W], lse[W], d[W];
+  if constexpr (VEC) {
+    const f32x4 zv = *reinterpret_cast<const f32x4*>(p.logits + row);
+    const f32x4 lv = *reinterpret_cast<const f32x4*>(p.lse + (long long)s * p.n_points + n);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i) { z[i] = zv[i]; lse[i] = lv[i]; }
+  } else {
+    z[0] = p.logits[row];
+    lse[0] = p.lse[(long long)s * p.n_points + n];
+  }
+#pragma unroll
+  for (int i = 0; i < W; ++i) {
     const long long lab = lp[i];
     const bool counted = lab > p.mask && lab < p.n_classes;
     d[i] = counted ? (__expf(z[i] - lse[i]) - (lab == c ? 1.f : 0.f)) * scale : 0.f;
   }
-  *reinterpret_cast<f32x4*>(p.dlogits + dro) = d;
+  if constexpr (VEC) *reinterpret_cast<f32x4*>(p.dlogits + dro) = f32x4{d[0], d[1], d[2], d[3]};
+  else p.dlogits[dro] = d[0];
 }
 
 }  // namespace
@@ -110,7 +121,16 @@ int csn_launch_masked_ce_fwd(const CsnMaskedCeArgs& a, hipStream_t st) {
 }
 
 int csn_launch_masked_ce_bwd(const CsnMaskedCeArgs& a, hipStream_t st) {
-  const int bx = (a.n_points / 4 + CE_BLOCK - 1) / CE_BLOCK;
-  hipLaunchKernelGGL(csn_masked_ce_bwd_kernel, dim3(bx, a.n_classes, a.n_shapes), dim3(CE_BLOCK), 0, st, a);
+  // 16-byte accesses where every row of logits, lse and dlogits starts 16-byte aligned and holds whole groups of 4 points
+  const bool vec = !(a.n_points & 3) && !(a.ld & 3) && !(a.dld & 3) && !(a.shape_stride & 3) && !(a.dshape_stride & 3) &&
+                   !(reinterpret_cast<uintptr_t>(a.logits) & 15) && !(reinterpret_cast<uintptr_t>(a.dlogits) & 15) &&
+                   !(reinterpret_cast<uintptr_t>(a.lse) & 15);
+  if (vec) {
+    const int bx = (a.n_points / 4 + CE_BLOCK - 1) / CE_BLOCK;
+    hipLaunchKernelGGL(csn_masked_ce_bwd_kernel<true>, dim3(bx, a.n_classes, a.n_shapes), dim3(CE_BLOCK), 0, st, a);
+  } else {
+    const int bx = (a.n_points + CE_BLOCK - 1) / CE_BLOCK;
+    hipLaunchKernelGGL(csn_masked_ce_bwd_kernel<false>, dim3(bx, a.n_classes, a.n_shapes), dim3(CE_BLOCK), 0, st, a);
+  }
   return (int)hipGetLastError();
 }

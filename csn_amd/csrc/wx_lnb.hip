@@ -316,7 +316,7 @@ bool csn_wx_lnb_takes(const CsnLnBwdArgs& a, int d_inner) {
 
 int csn_launch_wx_lnb(const CsnWxLnbArgs& a, hipStream_t st) {
   if (a.n_items <= 0 || a.n_points <= 0) return 0;
-  if ((long long)a.n_items * ((a.n_points + WX_CH - 1) / WX_CH + 16) * 2 >= (1ll << 31)) return -1;
+  if ((long long)a.n_items * ((a.n_points + WX_CH - 1) / WX_CH + 16) * 2 >= (1ll << 31)) return CSN_NOT_TAKEN;
   CsnWxLnbArgs b = a;
   b.ablate = (csn_dev_wx >> 4) & 15;
   const int grid = wx_grid();

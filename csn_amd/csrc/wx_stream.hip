@@ -489,6 +489,11 @@ int csn_dev_wx = 9;
 bool csn_wx_takes(int rows, int k) { return (csn_dev_wx & 1) != 0 && k == WX_K && rows > 0 && rows % 256 == 0 && rows / 256 <= 32; }
 
 
+// the launch geometry the persistent grid and its 32-bit chunk cursors cover (otherwise: CSN_NOT_TAKEN, the tiled kernels)
+bool csn_wx_geometry_takes(int n_items, int n_points, int n_sets) {
+  return ((long long)n_items * ((n_points + WX_CH - 1) / WX_CH + 16) + 4ll * wx_grid()) * 2 < (1ll << 31) && (wx_grid() >> 3) >= n_sets;
+}
+
 int csn_wx_ln_sum_slots(int n_items, int n_points) {
   int cpi, run, slots;
   wx_ln_geometry(n_items, n_points, cpi, run, slots);
@@ -508,9 +513,8 @@ int csn_launch_wx(const CsnWxArgs& a, int out_mode, hipStream_t st) {
   if ((a.ldx & 3) || (a.ldo & 3) || (a.n_points & 3)) return -2;
   if ((out_mode == 2 || out_mode == 4) && (a.tb <= 0 || (a.tb & 3))) return -2;
   if (out_mode == 4 && (a.n_f32 <= 0 || a.n_f32 >= a.n_sets || !a.out_f32 || (a.ldo_f32 & 3))) return -2;
-  if ((a.div_rows & 31) || ((long long)a.n_items * ((a.n_points + WX_CH - 1) / WX_CH + 16) + 4ll * wx_grid()) * 2 >= (1ll << 31)) return -1;
+  if ((a.div_rows & 31) || !csn_wx_geometry_takes(a.n_items, a.n_points, a.n_sets)) return CSN_NOT_TAKEN;
   const int grid = wx_grid();
-  if ((grid >> 3) < a.n_sets) return -1;
   CsnWxArgs b = a;
   b.stagger = (csn_dev_wx & 2) ? 1 : 0;
   b.ablate = (csn_dev_wx >> 4) & 15;
@@ -523,6 +527,6 @@ int csn_launch_wx(const CsnWxArgs& a, int out_mode, hipStream_t st) {
   } else if (out_mode == 0) hipLaunchKernelGGL((csn_wx_kernel<0>), dim3(grid), dim3(512), 0, st, b);
   else if (out_mode == 2) hipLaunchKernelGGL((csn_wx_kernel<2>), dim3(grid), dim3(512), 0, st, b);
   else if (out_mode == 4) hipLaunchKernelGGL((csn_wx_kernel<4>), dim3(grid), dim3(512), 0, st, b);
-  else return -1;
+  else return CSN_NOT_TAKEN;
   return (int)hipGetLastError();
 }

@@ -154,7 +154,7 @@ int csn_wx_wgrad_slabs(int rows, int cols) {
 int csn_launch_wx_wgrad(const CsnWxWgradArgs& a, hipStream_t st) {
   if (a.n_items <= 0 || a.n_points <= 0) return -1;
   if ((a.lda & 3) || (a.ldb & 3) || (a.n_points & 3)) return -2;
-  if ((long long)a.n_items * ((a.n_points + WX_CH - 1) / WX_CH + 16) * 2 + 8ll * wx_grid() >= (1ll << 31)) return -1;
+  if ((long long)a.n_items * ((a.n_points + WX_CH - 1) / WX_CH + 16) * 2 + 8ll * wx_grid() >= (1ll << 31)) return CSN_NOT_TAKEN;
   CsnWxWgradArgs b = a;
   b.ablate = (csn_dev_wx >> 4) & 15;
   hipLaunchKernelGGL(csn_wx_wgrad_kernel, dim3(wx_grid()), dim3(512), 0, st, b);

@@ -161,20 +161,32 @@ class ShapeGraphShard:
         """Sum (or average) the weight gradients over ranks in ONE bucket (≈0.4 M parameters: latency-bound)."""
         if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
             return
-        # (every parameter handed in, a missing gradient as zeros: the bucket has the same size on every rank by construction)
-        plist: List[torch.nn.Parameter] = list(params)
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in plist])
-        dist.all_reduce(flat)
-        if average:
-            flat /= self.world
-        off = 0
-        for p in plist:
-            piece = flat[off:off + p.numel()].view_as(p)
-            if p.grad is None:
-                p.grad = piece.clone()
-            else:
-                p.grad.copy_(piece)
-            off += p.numel()
+        _allreduce_bucket(list(params), self.world, None, average)
+
+
+def _allreduce_bucket(plist: List[torch.nn.Parameter], world: int, group, average: bool) -> None:
+    """Sum (or average) the gradients of `plist` over the ranks in ONE bucket.  The bucket covers EVERY parameter handed in, a
+    missing gradient as zeros, so its size is the same on every rank by construction (a bucket of "whoever has a grad" hangs or
+    corrupts the collective the day the sets differ).  A parameter that had no gradient on ANY rank keeps ``grad = None``
+    afterwards — as in a single process, where optimizers skip such parameters (no weight decay, no moment update): the bucket
+    carries one presence count per parameter for that, read only on a rank that has a missing gradient itself."""
+    dev = plist[0].device
+    missing = [p.grad is None for p in plist]
+    present = torch.tensor([0.0 if m else 1.0 for m in missing], device=dev, dtype=plist[0].dtype)
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in plist] + [present])
+    dist.all_reduce(flat, group=group)
+    n_par = len(plist)
+    counts = flat[-n_par:].tolist() if any(missing) else None          # (a host sync only where a gradient is missing locally)
+    if average:
+        flat[:-n_par] /= world
+    off = 0
+    for i, p in enumerate(plist):
+        piece = flat[off:off + p.numel()].view_as(p)
+        if p.grad is not None:
+            p.grad.copy_(piece)
+        elif counts[i] > 0:
+            p.grad = piece.clone()                                   # another rank used this parameter: its gradient counts here too
+        off += p.numel()
 
 
 class _GatherDescriptors(torch.autograd.Function):
@@ -408,21 +420,7 @@ class ResidentCollection:
         """The weight gradients summed (or averaged) over the ranks in one bucket, as ShapeGraphShard.allreduce_grads."""
         if self.world == 1:
             return
-        # the bucket covers EVERY parameter handed in, a missing gradient as zeros: its size is then the same on every rank by
-        # construction (a bucket of "whoever has a grad" hangs or corrupts the collective the day the sets differ)
-        plist = list(params)
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in plist])
-        dist.all_reduce(flat, group=self.group)
-        if average:
-            flat /= self.world
-        off = 0
-        for p in plist:
-            piece = flat[off:off + p.numel()].view_as(p)
-            if p.grad is None:
-                p.grad = piece.clone()
-            else:
-                p.grad.copy_(piece)
-            off += p.numel()
+        _allreduce_bucket(list(params), self.world, self.group, average)
 
 
 # -- kNN shape graph, rows of the retrieval matrix sharded by query shape (SURVEY.md §8e, collective 4) --------------------

@@ -28,6 +28,8 @@ extern "C" {
 #endif
 
 #define CSN_ABI_VERSION 16
+/* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exported symbols. */
+#define CSN_API __attribute__((visibility("default")))
 
 /* math modes (csn_set_math_mode / csn_set_thread_math_mode) */
 #define CSN_MATH_FP32 0
@@ -43,7 +45,7 @@ extern "C" {
 #define CSN_E_WORKSPACE (-6) /* workspace too small                        */
 
 /* ABI version of the loaded library (== CSN_ABI_VERSION). */
-int csn_version(void);
+CSN_API int csn_version(void);
 /* Arithmetic of the contractions (projections, attention products, out-projection, every gradient product):
  *   0 CSN_MATH_FP32    exact fp32 on the matrix cores (v_mfma_f32_32x32x2_f32 / 16x16x4: bit-identical to an fmaf chain);
  *   1 CSN_MATH_BF16X3  every fp32 operand is split into two bf16 terms and a product is three bf16 MFMAs
@@ -100,8 +102,8 @@ int csn_version(void);
  * type; backward entry points take either fmt in mode 2.  fmt + 4 (5 or 6) also makes the gradient maps dQ / dK / dV bf16:
  * they are then written once per slot (grouped calls; accumulate != 0 returns CSN_E_ARG), and what contracts them rounds them to
  * bf16 anyway — the weight gradients are the same bits. */
-int csn_set_thread_act16(int fmt);
-int csn_get_thread_act16(void);
+CSN_API int csn_set_thread_act16(int fmt);
+CSN_API int csn_get_thread_act16(void);
 /* SCORE STORAGE of the block-attention entry points (3), (3c), per calling thread.  0 (default): the scores of a block are
  * [query][key] rows of pitch score_pitch — what a caller that reads probabilities expects.  1: TILE-MAJOR — per block
  * [key tile of 32][query][32 keys]: the forward's scores, and the P / dS tile planes the backward hands from its dQ call to its
@@ -109,15 +111,15 @@ int csn_get_thread_act16(void);
  * 64-byte pieces 2 KB apart).  Same arithmetic, same buffer sizes; only meaningful when the three calls of one evaluation batch
  * agree.  Taken where csn_attn_bwd_grouping reports bit 4 (bf16x3 mode, block mode, tile-plane K / V, probs_tiles = 1, the dK / dV
  * products on the 256 x 256 tiles); CSN_E_ARG otherwise.  csn_amd sets it around the training step's three calls. */
-int csn_set_thread_score_layout(int layout);
-int csn_get_thread_score_layout(void);
-int csn_set_math_mode(int mode);
-int csn_set_thread_math_mode(int mode);
-int csn_get_math_mode(void);
+CSN_API int csn_set_thread_score_layout(int layout);
+CSN_API int csn_get_thread_score_layout(void);
+CSN_API int csn_set_math_mode(int mode);
+CSN_API int csn_set_thread_math_mode(int mode);
+CSN_API int csn_get_math_mode(void);
 /* The calling thread's own override as set by csn_set_thread_math_mode (-1 = none): what a scoped override saves and restores. */
-int csn_get_thread_math_mode(void);
+CSN_API int csn_get_thread_math_mode(void);
 /* Human-readable text for a status code returned by any function below. Host pointer, static storage. */
-const char* csn_status_string(int status);
+CSN_API const char* csn_status_string(int status);
 
 /* ---- (1) pre-attention projections ------------------------------------------------------------------
  * out[s][r][n] = sum_c w[r][c] * x[s][c][n],  r < rows, n < n_points; rows r < div_rows are then divided
@@ -126,7 +128,7 @@ const char* csn_status_string(int status);
  * project a shape once for all of its evaluations).  out_split: 0 fp32 maps, 1 / 2 split tensors / tile planes (above), 3 (math
  * modes 2 / 3): ONE 16-bit map per shape in the mode's type — out_shape_stride and ld_out count 16-bit elements.  out_split + 16
  * (math mode 2): x itself is a bf16 map (x_shape_stride, ld_x in elements) — the input gradient W^T dqkv from bf16 gradient maps. */
-int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const float* w, int rows, int channels,
+CSN_API int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const float* w, int rows, int channels,
                     float* out, long long out_shape_stride, int ld_out, int n_shapes, int n_points, int div_rows,
                     float temperature, int out_split, long long out_plane_stride, void* stream);
 
@@ -135,7 +137,7 @@ int csn_project_f32(const float* x, long long x_shape_stride, int ld_x, const fl
  * exactly what csn_project_f32(.., div_rows = d_inner, out_split = 0) and csn_project_f32(.., out_split = 2,
  * out_plane_stride = block) write, bit for bit; 16-bit math modes only (tile planes).  In the bf16x3 mode with 256 channels and
  * d_inner = 256 the three row sets share ONE pass over x (the streaming kernel); elsewhere it is the two calls. */
-int csn_project_qkv_f32(const float* x, long long x_shape_stride, int ld_x, const float* w_qkv, int d_inner, int channels,
+CSN_API int csn_project_qkv_f32(const float* x, long long x_shape_stride, int ld_x, const float* w_qkv, int d_inner, int channels,
                         float* q_out, long long q_shape_stride, int ld_q, void* kv_out, long long kv_shape_stride, int ld_kv,
                         int n_shapes, int n_points, float temperature, int block, void* stream);
 
@@ -156,7 +158,7 @@ int csn_project_qkv_f32(const float* x, long long x_shape_stride, int ld_x, cons
  * dropout_p / seed: train-mode dropout on the probabilities (nn.Dropout(0.1), csa_models.py:133-141):
  * P_drop = mask * P / (1 - p) with a counter-based mask, a pure function of (seed, position in `scores`), so
  * the backward call regenerates it from the same (dropout_p, seed).  0 = eval mode. */
-int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
+CSN_API int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
                            long long kv_shape_stride, const int* q_index, const int* kv_index, int ld, float* ctx,
                            long long ctx_eval_stride, float* scores, float* lse, int n_evals, int n_heads,
                            int d_head, int block, int n_blocks, int score_pitch, float rescale_threshold,
@@ -204,8 +206,8 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
  * kv_f16 != 0 (math mode 2 only; also csn_block_attn_bwd_dkv_flash_f32, and kv_split = 2 of csn_block_attn_bwd_dq_f32): k and
  * v are the tile planes of a forward that ran in math mode 3 — fp16 bits.  The kernels convert every piece to bf16 in
  * registers on its way into LDS, so the "fp16 forward / bf16 backward" pairing needs no second projection of K and V. */
-int csn_attn_bwd_grouping(int d_head, int block);
-int csn_block_attn_bwd_dq_recompute_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* q,
+CSN_API int csn_attn_bwd_grouping(int d_head, int block);
+CSN_API int csn_block_attn_bwd_dq_recompute_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* q,
                                         long long q_shape_stride, const int* q_index, const float* k, const float* v,
                                         long long kv_shape_stride, const int* kv_index, int ld, float* probs,
                                         float* dscores, const float* lse, float* delta, float* dq,
@@ -214,7 +216,7 @@ int csn_block_attn_bwd_dq_recompute_f32(const float* dctx, const float* ctx, lon
                                         int score_pitch, float dropout_p, unsigned long long seed,
                                         long long kv_plane_stride, int kv_f16, int probs_tiles, const int* group_offsets,
                                         int n_groups, void* stream);
-int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* k,
+CSN_API int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* k,
                               const float* v, long long kv_shape_stride, const int* kv_index, int ld, float* scores,
                               float* dscores, const float* lse, float* delta, float* dq, long long dq_slot_stride,
                               const int* dq_index, int accumulate, const int* eval_ids, int n_launch_evals, int n_heads,
@@ -222,7 +224,7 @@ int csn_block_attn_bwd_dq_f32(const float* dctx, const float* ctx, long long ctx
                               unsigned long long seed, int dctx_split, long long dctx_plane_stride, int kv_split,
                               long long kv_plane_stride, int probs_tiles, const int* group_offsets, int n_groups,
                               void* stream);
-int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
+CSN_API int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
                                const int* q_index, int ld, const float* probs, const float* dscores, float* dk,
                                float* dv, long long dkv_slot_stride, const int* dk_index, const int* dv_index,
                                int accumulate, const int* eval_ids, int n_launch_evals, int n_heads, int d_head,
@@ -239,7 +241,7 @@ int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_stride, con
  * forward; a group's evaluations must share their key and their value slot (they do when grouped by output slot).  Run after
  * csn_block_attn_bwd_dq_recompute_f32 (probs_tiles = 0), which computes delta.  eval_ids / group_offsets / accumulate as in
  * the grouped csn_block_attn_bwd_dkv_f32 call; without group_offsets every listed evaluation is its own group. */
-int csn_block_attn_bwd_dkv_flash_f32(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
+CSN_API int csn_block_attn_bwd_dkv_flash_f32(const float* dctx, long long ctx_eval_stride, const float* q, long long q_shape_stride,
                                      const int* q_index, const float* k, const float* v, long long kv_shape_stride,
                                      const int* kv_index, long long kv_plane_stride, int kv_f16, int ld, const float* lse,
                                      const float* delta, float* dk, float* dv, long long dkv_slot_stride,
@@ -259,11 +261,11 @@ int csn_block_attn_bwd_dkv_flash_f32(const float* dctx, long long ctx_eval_strid
  *   lse, delta       : [n_evals][n_heads][n_queries]
  * n_keys is arbitrary; n_queries must be a multiple of 4 (pad with zero points: their rows cost little and contribute
  * nothing to any gradient).  Evaluation e reads maps e (no slot indices, no accumulation). */
-int csn_cross_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
+CSN_API int csn_cross_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
                            long long kv_shape_stride, int ld_q, int ld_kv, float* ctx, long long ctx_eval_stride,
                            float* scores, float* lse, int n_evals, int n_heads, int d_head, int n_queries, int n_keys,
                            int score_pitch, float rescale_threshold, float dropout_p, unsigned long long seed, void* stream);
-int csn_cross_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* q, const float* k,
+CSN_API int csn_cross_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* q, const float* k,
                            const float* v, long long q_shape_stride, long long kv_shape_stride, int ld_q, int ld_kv,
                            float* scores, float* dscores, const float* lse, float* delta, float* dq, float* dk, float* dv,
                            long long dq_eval_stride, long long dkv_eval_stride, int n_evals, int n_heads, int d_head,
@@ -282,12 +284,12 @@ int csn_cross_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_ev
  * visited, so a short evaluation costs its own size.  Rows / columns beyond an evaluation's own counts are neither read as
  * data nor written: the caller zero-fills ctx, dq, dk, dv where it goes on to use the padding (csn_amd does), and the padding
  * points of the input maps must be finite (zeros).  Dropout masks are indexed with the launch's max_queries / score_pitch. */
-int csn_varlen_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
+CSN_API int csn_varlen_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
                             long long kv_shape_stride, int ld_q, int ld_kv, float* ctx, long long ctx_eval_stride,
                             float* scores, float* lse, int n_evals, int n_heads, int d_head, int max_queries, int max_keys,
                             const int* n_queries, const int* n_keys, int score_pitch, float rescale_threshold,
                             float dropout_p, unsigned long long seed, void* stream);
-int csn_varlen_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* q, const float* k,
+CSN_API int csn_varlen_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_eval_stride, const float* q, const float* k,
                             const float* v, long long q_shape_stride, long long kv_shape_stride, int ld_q, int ld_kv,
                             float* scores, float* dscores, const float* lse, float* delta, float* dq, float* dk, float* dv,
                             long long dq_eval_stride, long long dkv_eval_stride, int n_evals, int n_heads, int d_head,
@@ -310,8 +312,8 @@ int csn_varlen_attn_bwd_f32(const float* dctx, const float* ctx, long long ctx_e
  * csn_outproj_ln_workspace_floats: the sum_ws size with which the fused sums are taken on every kernel that has them (the
  * streaming kernel of the bf16x3 mode keeps one partial per work-group and evaluation it touches; a smaller workspace is
  * never an error — the streaming pass runs instead). */
-long long csn_outproj_ln_workspace_floats(int n_evals, int d_model, int d_inner, int n_points);
-int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const float* wfc, const float* xres,
+CSN_API long long csn_outproj_ln_workspace_floats(int n_evals, int d_model, int d_inner, int n_points);
+CSN_API int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const float* wfc, const float* xres,
                            long long xres_shape_stride, const int* res_index, float* xhat,
                            long long xhat_eval_stride, float* rstd, int n_evals, int d_model, int d_inner, int ld,
                            int n_points, float eps, float dropout_p, unsigned long long seed, float* xhat_sum,
@@ -332,7 +334,7 @@ int csn_outproj_ln_fwd_f32(const float* ctx, long long ctx_eval_stride, const fl
  * — with dxhat = the gradient of the mixed features (dfeats of csn_mix_bwd_f32, one map per query shape), dxhat_group = the
  * evaluations mixed per shape and dxhat_scale = comp * gamma, the per-evaluation gradient maps of the mix (:233, :238) are
  * rebuilt on the fly and never travel through HBM. */
-int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* rstd, long long eval_stride,
+CSN_API int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* rstd, long long eval_stride,
                            const float* ctx, long long ctx_eval_stride, const float* wfc_t, float* dz, float* dz_res,
                            float* dctx, float* dwfc, float* ws, long long ws_floats, int n_evals, int d_model,
                            int d_inner, int ld, int n_points, int accumulate, float dropout_p,
@@ -342,13 +344,13 @@ int csn_outproj_ln_bwd_f32(const float* dxhat, const float* xhat, const float* r
 
 /* ---- (6) projection weight gradient ----------------------------------------------------------------------
  * dw[r][c] (+)= scale * sum_{s,n} dout[s][r][n] * x[s][c][n]        (autograd of csa_models.py:103-105) */
-int csn_project_wgrad_f32(const float* dout, long long dout_shape_stride, int ld_dout, const float* x,
+CSN_API int csn_project_wgrad_f32(const float* dout, long long dout_shape_stride, int ld_dout, const float* x,
                           long long x_shape_stride, int ld_x, float* dw, int rows, int channels, int n_shapes,
                           int n_points, float scale, int accumulate, float* ws, long long ws_floats,
                           void* stream);
 
 /* Scratch floats needed by (5)/(6) for a [rows][cols] gradient reduced over n_maps maps of n_points points. */
-long long csn_wgrad_workspace_floats(int rows, int cols, int n_maps, int n_points);
+CSN_API long long csn_wgrad_workspace_floats(int rows, int cols, int n_maps, int n_points);
 
 /* ---- (7) retrieval measure for the shape kNN graph (csa_models.py:244-267) ------------------------------
  * r[i][j] = mean_n max_m cos(f1[i][n][:], f2[j][m][:]) over L2-normalised rows (eps 1e-12), for
@@ -356,7 +358,7 @@ long long csn_wgrad_workspace_floats(int rows, int cols, int n_maps, int n_point
  * (csa_models.py:299).  ws: at least (s1*n1 + s2*n2) floats (inverse row norms) + s1*s2*n1 floats (per-point maxima): O(s1*s2),
  * so a caller with many shapes scores the query shapes in row chunks (csn_amd.functional.retrieval_measure does).  Any pair
  * count is accepted up to ceil(n1/128)*s1*s2 < 2^31 work-groups (CSN_E_ARG beyond). */
-int csn_retrieval_measure_f32(const float* f1, const float* f2, float* out, int s1, int n1, int s2, int n2,
+CSN_API int csn_retrieval_measure_f32(const float* f1, const float* f2, float* out, int s1, int n1, int s2, int n2,
                               int channels, float* ws, long long ws_floats, void* stream);
 
 /* ---- (8) pooled descriptors and the cross-shape mix (csa_models.py:211-212, 218-219, 232-240) --------------
@@ -373,10 +375,10 @@ int csn_retrieval_measure_f32(const float* f1, const float* f2, float* out, int 
  * xhat / dxhat hold the k1 - 1 others, [b*(k1-1) + k-1] — the form the overlapped multi-GPU path produces (own shapes are
  * evaluated while the neighbour exchange is in flight), so that no concatenation of the two is ever built.
  * All maps dense channel-major [..][channels][n_points], n_points % 4 == 0, k1 <= 8. */
-int csn_rowsum_f32(const float* x, float* out, long long rows, int n_points, long long ld, void* stream);
-int csn_mix_fwd_f32(const float* xhat, const float* comp, const float* gamma, const float* beta, float* feats,
+CSN_API int csn_rowsum_f32(const float* x, float* out, long long rows, int n_points, long long ld, void* stream);
+CSN_API int csn_mix_fwd_f32(const float* xhat, const float* comp, const float* gamma, const float* beta, float* feats,
                     int n_shapes, int k1, int channels, int n_points, const float* xhat_self, void* stream);
-int csn_mix_bwd_f32(const float* dfeats, const float* xhat, const float* comp, const float* gamma, float* dxhat,
+CSN_API int csn_mix_bwd_f32(const float* dfeats, const float* xhat, const float* comp, const float* gamma, float* dxhat,
                     float* rowdot, float* rowsum, int n_shapes, int k1, int channels, int n_points, const float* xhat_self,
                     float* dxhat_self, void* stream);
 
@@ -392,9 +394,9 @@ int csn_mix_bwd_f32(const float* dfeats, const float* xhat, const float* comp, c
  * Backward: wq / wk as stored ([out][in]); ws >= 2 n_shapes (k1 + 1) channels DOUBLES of scratch; writes the gradients
  * dpooled (n_shapes, k1, channels), dwq / dwk (channels, channels) and dbq / dbk (channels) — overwritten, not accumulated;
  * sums over the shapes run in a fixed order (bitwise reproducible). */
-int csn_compat_fwd_f32(const float* pooled, const float* wq_t, const float* bq, const float* wk_t, const float* bk, float* comp,
+CSN_API int csn_compat_fwd_f32(const float* pooled, const float* wq_t, const float* bq, const float* wk_t, const float* bk, float* comp,
                        double* save_u, double* save_norm, int n_shapes, int k1, int channels, int reference_layout, void* stream);
-int csn_compat_bwd_f32(const float* dcomp, const float* comp, const double* save_u, const double* save_norm, const float* pooled,
+CSN_API int csn_compat_bwd_f32(const float* dcomp, const float* comp, const double* save_u, const double* save_norm, const float* pooled,
                        const float* wq, const float* wk, double* ws, long long ws_doubles, float* dpooled, float* dwq, float* dbq,
                        float* dwk, float* dbk, int n_shapes, int k1, int channels, int reference_layout, void* stream);
 
@@ -408,13 +410,15 @@ int csn_compat_bwd_f32(const float* dcomp, const float* comp, const double* save
  *             csn_masked_ce_workspace_bytes(n_shapes, n_points) bytes, 8-byte aligned (per-block fp64 partial sums, added in a
  *             fixed order: bitwise reproducible).
  *   backward  dlogits[s][c][n] = counted ? (exp(z - lse) - [c == label]) * grad_out[0] / stats[2] : 0, every class row of
- *             every shape written (n_points, ld, dld % 4 == 0).
+ *             every shape written; any point count, pitch and alignment (16-byte accesses where n_points, ld, dld and the shape
+ *             strides are % 4 == 0 and logits, lse, dlogits 16-byte aligned; one point per thread otherwise).  A logit of -inf
+ *             is a probability of zero (also as a point's first class).
  * labels are int64 (torch.long), label_shape_stride elements apart per shape. */
-long long csn_masked_ce_workspace_bytes(int n_shapes, int n_points);
-int csn_masked_ce_fwd_f32(const float* logits, long long shape_stride, int ld, const long long* labels, long long label_shape_stride,
+CSN_API long long csn_masked_ce_workspace_bytes(int n_shapes, int n_points);
+CSN_API int csn_masked_ce_fwd_f32(const float* logits, long long shape_stride, int ld, const long long* labels, long long label_shape_stride,
                           int n_shapes, int n_classes, int n_points, int mask, float* lse, void* ws, long long ws_bytes,
                           float* stats, void* stream);
-int csn_masked_ce_bwd_f32(const float* logits, long long shape_stride, int ld, const long long* labels, long long label_shape_stride,
+CSN_API int csn_masked_ce_bwd_f32(const float* logits, long long shape_stride, int ld, const long long* labels, long long label_shape_stride,
                           int n_shapes, int n_classes, int n_points, int mask, const float* lse, const float* stats,
                           const float* grad_out, float* dlogits, long long dshape_stride, int dld, void* stream);
 
@@ -434,12 +438,11 @@ int csn_masked_ce_bwd_f32(const float* logits, long long shape_stride, int ld, c
 #define CSN_DEV_WIDE_GEMM 1
 #define CSN_DEV_WIDE_FORMS 2
 #define CSN_DEV_WX 3
-#define CSN_DEV_ATTN_X4 4   /* default 0; 1: the attention forward at d = 256 in bf16x3 on four 32-query waves
-                               (v_mfma_f32_32x32x16_bf16, one wave per SIMD) — built, measured 25 % slower, kept as the measured form */
+/* (key 4 was the 32-queries-per-wave attention forward of round 4: measured 25 % slower, removed; profiles/README.md) */
 #define CSN_DEV_LNB_GROUP 5 /* default 0; G > 0: csn_outproj_ln_bwd_f32 runs its LayerNorm backward and its dCtx product over groups
                                of G evaluations (bf16x3, streaming dCtx; the same results) */
-int csn_dev_set(int key, int value);
-int csn_dev_get(int key);
+CSN_API int csn_dev_set(int key, int value);
+CSN_API int csn_dev_get(int key);
 
 #ifdef __cplusplus
 }

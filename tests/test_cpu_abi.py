@@ -32,6 +32,10 @@ def test_header_symbols_are_exported(L):
     missing = [n for n in names if n not in exported]
     assert not missing, missing
     assert sorted(L.EXPORTS) == names            # the ctypes binding covers exactly the header
+    # ... and the header covers exactly what the library exports (-fvisibility=hidden + CSN_API): no internal launcher, no
+    # mangled C++ symbol; the `__hip_*` data words are the HIP toolchain's own registration markers
+    others = [l.split()[-1] for l in out.splitlines() if l.strip() and l.split()[-1] not in names and not l.split()[-1].startswith("__hip_")]
+    assert not others, others
 
 
 def test_library_loads_and_reports_version(L):

@@ -18,7 +18,8 @@ def _case(S, n_cls, N, pad_rows, seed, p_ignored=0.15, scale=3.0):
     return buf, lab
 
 
-@pytest.mark.parametrize("S,n_cls,N,pad_rows", [(3, 39, 1000, 1), (32, 39, 10000, 1), (1, 5, 4, 0), (2, 50, 260, 2), (4, 2, 516, 0)])
+@pytest.mark.parametrize("S,n_cls,N,pad_rows", [(3, 39, 1000, 1), (32, 39, 10000, 1), (1, 5, 4, 0), (2, 50, 260, 2), (4, 2, 516, 0),
+                                                (2, 39, 1001, 1), (3, 7, 3, 0), (1, 11, 10007, 0)])        # N % 4 != 0: the reference's loss takes any N
 def test_loss_accuracy_and_gradient_against_the_oracle(S, n_cls, N, pad_rows):
     from csn_amd.functional import masked_cross_entropy
     buf, lab = _case(S, n_cls, N, pad_rows, seed=S + n_cls)
@@ -120,3 +121,48 @@ def test_the_reference_s_own_loss_and_gradients_through_the_fused_pair(golden_di
             assert np.abs(got - ref).max() <= 1e-4 * np.abs(ref).max(), name
             seen += 1
         assert seen == 11
+
+
+def test_any_point_count_and_a_view_that_is_not_16_byte_aligned():
+    """csa_training.py:94-108 takes any N and any view; the backward's 16-byte form needs N, pitches % 4 == 0 and aligned rows, so
+    other geometries run its one-point-per-thread form instead of failing inside autograd (round-4 advisor finding)."""
+    from csn_amd.functional import masked_cross_entropy
+    rng = np.random.default_rng(5)
+    S, n_cls, N = 2, 39, 1001
+    wide = torch.from_numpy((2.0 * rng.standard_normal((S, n_cls, N + 3))).astype(np.float32))
+    lab = torch.from_numpy(np.where(rng.random((S, N)) < 0.2, 0, rng.integers(0, n_cls, size=(S, N))).astype(np.int64))
+    wd = wide.cuda().requires_grad_(True)
+    view = wd[:, :, 1:1 + N]                                  # rows start 4 bytes into a 16-byte unit, N % 4 == 1
+    assert view.data_ptr() % 16 != 0
+    loss, accu, count = masked_cross_entropy(view, lab.cuda(), 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    ref_in = wide[:, :, 1:1 + N].double().requires_grad_(True)
+    ref = orc.masked_ce_loss(ref_in.unsqueeze(-1), lab)
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 2e-6 * abs(ref.item()) and count.item() == (lab > 0).sum().item()
+    g = wd.grad.cpu()
+    assert torch.all(g[:, :, 0] == 0) and torch.all(g[:, :, 1 + N:] == 0)
+    assert (g[:, :, 1:1 + N].double() - ref_in.grad).abs().max().item() < 2e-6 * ref_in.grad.abs().max().item()
+
+
+def test_a_logit_of_minus_infinity_is_a_probability_of_zero_not_a_nan():
+    """torch's log_softmax handles -inf logits (a masked class); the online log-sum-exp must too, also when -inf comes FIRST."""
+    from csn_amd.functional import masked_cross_entropy
+    buf, lab = _case(2, 6, 64, 0, seed=9)
+    buf[:, 0, :] = -float("inf")                              # first class of every point
+    buf[0, 3, ::2] = -float("inf")
+    lab[lab == 0] = 1
+    lab[(buf.gather(1, lab.unsqueeze(1)).squeeze(1) == -float("inf"))] = 2      # never the label itself (that loss IS inf)
+    lab[(buf.gather(1, lab.unsqueeze(1)).squeeze(1) == -float("inf"))] = 4
+    bd = buf.cuda().requires_grad_(True)
+    loss, accu, count = masked_cross_entropy(bd, lab.cuda(), 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    ref_in = buf.double().requires_grad_(True)
+    ref = orc.masked_ce_loss(ref_in.unsqueeze(-1), lab)
+    ref.backward()
+    assert np.isfinite(loss.item()) and abs(loss.item() - ref.item()) < 2e-6 * abs(ref.item())
+    g = bd.grad.cpu()
+    assert torch.isfinite(g).all() and torch.all(g[:, 0] == 0)
+    assert (g.double() - ref_in.grad).abs().max().item() < 2e-6 * ref_in.grad.abs().max().item()

@@ -145,8 +145,10 @@ def _a2a_worker(rank, world, port):
     pa.grad = torch.full((2,), float(rank + 1))
     if rank == 0:
         pb.grad = torch.ones(3)                                                # only rank 0 has a gradient for pb
-    shard.allreduce_grads([pa, pb], average=False)
+    pc = torch.nn.Parameter(torch.zeros(4))                                    # no gradient on ANY rank: stays None, as at N = 1
+    shard.allreduce_grads([pa, pb, pc], average=False)
     assert torch.equal(pa.grad, torch.full((2,), float(sum(range(1, world + 1))))) and torch.equal(pb.grad, torch.ones(3))
+    assert pc.grad is None
     dist.barrier()
     dist.destroy_process_group()
 
