@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--d", type=int, default=256)
     ap.add_argument("--nb", type=int, default=20)
     ap.add_argument("--dev", default="", help="development switches for the timed runs, key=value,... (csn_dev_set; 4=0: forward on the 8-wave kernel)")
+    ap.add_argument("--digest", action="store_true", help="print sha256 digests of every output of one fwd + dq (+ dkv) pass: two builds "
+                    "(CSN_LIB_PATH) give the same lines iff they give the same bits")
     ap.add_argument("--recompute", type=int, default=0, help="1: dq rebuilds the scores, P / dS planes still written; 2: nothing written")
     a = ap.parse_args()
     L = _lib.lib()
@@ -143,6 +145,15 @@ def main():
         if a.check:
             print("   dk err", (dqkv[:, D:2 * D] - ref["dk"]).abs().max().item(), "scale", ref["dk"].abs().max().item(),
                   "dv err", (dqkv[:, 2 * D:] - ref["dv"]).abs().max().item(), "scale", ref["dv"].abs().max().item())
+    if a.digest:
+        import hashlib
+        dig = lambda t: hashlib.sha256(t.detach().contiguous().cpu().numpy().tobytes()).hexdigest()[:16]
+        fwd(); torch.cuda.synchronize()
+        print("digest fwd: att", dig(att), "lse", dig(lse), "scores", dig(scores), flush=True)
+        dqkv.zero_(); dq(); torch.cuda.synchronize()
+        print("digest dq: dq", dig(dqkv[:, :D]), "delta", dig(delta), "P", dig(scores), "dS", dig(dscores), flush=True)
+        dkv(); torch.cuda.synchronize()
+        print("digest dkv: dk", dig(dqkv[:, D:2 * D]), "dv", dig(dqkv[:, 2 * D:]), flush=True)
     if hasattr(L, "csn_gemm_debug_read") or os.environ.get("CSN_GEMM_STAMPS"):
         import ctypes
         L.csn_gemm_debug_read.argtypes = [ctypes.c_void_p, ctypes.c_longlong]
