@@ -134,6 +134,7 @@ int csn_dev_get(int key) {
     case CSN_DEV_WIDE_FORMS: return csn_gemm_wide_set;
     case CSN_DEV_WX: return csn_dev_wx;
     case CSN_DEV_LNB_GROUP: return csn_dev_lnb_group;
+    case CSN_DEV_DKV_STREAM: return csn_dev_dkv_stream;
     default: return CSN_E_ARG;
   }
 }
@@ -145,6 +146,7 @@ int csn_dev_set(int key, int value) {
     case CSN_DEV_WIDE_FORMS: csn_gemm_wide_set = value; break;
     case CSN_DEV_WX: csn_dev_wx = value; break;
     case CSN_DEV_LNB_GROUP: csn_dev_lnb_group = value < 0 ? 0 : value; break;
+    case CSN_DEV_DKV_STREAM: csn_dev_dkv_stream = value; break;
     default: return CSN_E_ARG;
   }
   return prev;
@@ -496,6 +498,7 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   g.n_arr = t_arr; g.k_arr = tq_arr;            // ragged batch: keys (rounded up to 4 by the kernel) / queries of every evaluation
   g.n_last = g.k_last = t_last;                 // the row ends inside the last block
   const int n_batch = group_offsets ? n_groups : n_launch_evals;
+  int rc = 0;
   if (act16() && (!act16_bwd_ok() || !probs_tiles || block_q != 0)) return CSN_E_ARG;
   g.A = operand(dctx, bq, (long long)d_head * ld, dctx_split ? 2 * ctx_eval_stride : ctx_eval_stride, nullptr, ld);
   g.A.planes = dctx_split; g.A.plane_stride = dctx_plane_stride;
@@ -516,9 +519,24 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   g.B.planes = probs_tiles ? (tile_major ? 3 : 2) : 0;
   const bool g16 = act16() && grad16();
   if (g16 && accumulate) return CSN_E_ARG;                            // a 16-bit gradient map is written once (grouped calls)
+  // bf16x3 at d_head = 256 on row-major planes: both products as output-stationary streams (dkv_stream.hip) — the GEMM route's bits
+  if (mode() == 1 && probs_tiles && !tile_major && !act16() && block_q == 0 && !tq_arr && !t_arr && csn_dkv_stream_takes(d_head, block, score_pitch)) {
+    CsnDkvStreamArgs s{};
+    s.ld = ld; s.H = n_heads; s.T = block; s.Tp = score_pitch; s.n_blocks = n_blocks; s.T_last = t_last; s.accumulate = accumulate;
+    s.items = eval_ids; s.grp_off = group_offsets; s.n_groups = n_batch;
+    s.a = dctx; s.a_stride = ctx_eval_stride; s.a_index = nullptr; s.planes = reinterpret_cast<const short*>(probs);
+    s.out = dv; s.out_stride = dkv_slot_stride; s.out_index = dv_index;
+    rc = csn_launch_dkv_stream(s, st);
+    if (rc == 0) {
+      s.a = q; s.a_stride = q_shape_stride; s.a_index = q_index; s.planes = reinterpret_cast<const short*>(dscores);
+      s.out = dk; s.out_index = dk_index;
+      return csn_launch_dkv_stream(s, st);
+    }
+    if (rc != CSN_NOT_TAKEN) return rc;
+  }
   g.C = operand(dv, block, (long long)d_head * lk, dkv_slot_stride, dv_index, lk);
   if (g16) g.C.planes = 1;
-  int rc = launch_gemm(g, 0, n_blocks * n_heads * n_batch, st);
+  rc = launch_gemm(g, 0, n_blocks * n_heads * n_batch, st);
   if (rc) return rc;
   g.A = operand(q, bq, (long long)d_head * ld, q_shape_stride, q_index, ld);
   g.A.planes = q_split; g.A.plane_stride = q_plane_stride;
