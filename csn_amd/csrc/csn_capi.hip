@@ -134,7 +134,6 @@ int csn_dev_get(int key) {
     case CSN_DEV_WIDE_FORMS: return csn_gemm_wide_set;
     case CSN_DEV_WX: return csn_dev_wx;
     case CSN_DEV_LNB_GROUP: return csn_dev_lnb_group;
-    case CSN_DEV_DKV_STREAM: return csn_dev_dkv_stream;
     default: return CSN_E_ARG;
   }
 }
@@ -146,7 +145,6 @@ int csn_dev_set(int key, int value) {
     case CSN_DEV_WIDE_FORMS: csn_gemm_wide_set = value; break;
     case CSN_DEV_WX: csn_dev_wx = value; break;
     case CSN_DEV_LNB_GROUP: csn_dev_lnb_group = value < 0 ? 0 : value; break;
-    case CSN_DEV_DKV_STREAM: csn_dev_dkv_stream = value; break;
     default: return CSN_E_ARG;
   }
   return prev;
@@ -519,21 +517,6 @@ static int attn_bwd_dkv_impl(const float* dctx, long long ctx_eval_stride, const
   g.B.planes = probs_tiles ? (tile_major ? 3 : 2) : 0;
   const bool g16 = act16() && grad16();
   if (g16 && accumulate) return CSN_E_ARG;                            // a 16-bit gradient map is written once (grouped calls)
-  // bf16x3 at d_head = 256 on row-major planes: both products as output-stationary streams (dkv_stream.hip) — the GEMM route's bits
-  if (mode() == 1 && probs_tiles && !tile_major && !act16() && block_q == 0 && !tq_arr && !t_arr && csn_dkv_stream_takes(d_head, block, score_pitch)) {
-    CsnDkvStreamArgs s{};
-    s.ld = ld; s.H = n_heads; s.T = block; s.Tp = score_pitch; s.n_blocks = n_blocks; s.T_last = t_last; s.accumulate = accumulate;
-    s.items = eval_ids; s.grp_off = group_offsets; s.n_groups = n_batch;
-    s.a = dctx; s.a_stride = ctx_eval_stride; s.a_index = nullptr; s.planes = reinterpret_cast<const short*>(probs);
-    s.out = dv; s.out_stride = dkv_slot_stride; s.out_index = dv_index;
-    rc = csn_launch_dkv_stream(s, st);
-    if (rc == 0) {
-      s.a = q; s.a_stride = q_shape_stride; s.a_index = q_index; s.planes = reinterpret_cast<const short*>(dscores);
-      s.out = dk; s.out_index = dk_index;
-      return csn_launch_dkv_stream(s, st);
-    }
-    if (rc != CSN_NOT_TAKEN) return rc;
-  }
   g.C = operand(dv, block, (long long)d_head * lk, dkv_slot_stride, dv_index, lk);
   if (g16) g.C.planes = 1;
   rc = launch_gemm(g, 0, n_blocks * n_heads * n_batch, st);

@@ -137,19 +137,6 @@ struct CsnAttnDkvArgs {
 int csn_launch_attn_dkv_flash(const CsnAttnDkvArgs& a, int d, int mode, hipStream_t st);
 constexpr bool csn_attn_dkv_flash_fits(int dt) { return dt <= 4; }         // K^T, V^T, dK^T, dV^T of 16 keys in one wave's registers
 
-// dV / dK on the P / dS tile planes as an output-stationary stream (dkv_stream.hip; bf16x3, d_head = 256, row-major planes)
-struct CsnDkvStreamArgs {
-  const float* a;  long long a_stride;  const int* a_index;  int ld;     // operand maps [map][H * 256][ld] fp32 (dO: per evaluation; Qs: per slot); evaluation -> map
-  const short* planes;                                                   // [evaluation][H][n_blocks][T query rows][2 Tp 16-bit elements]: tiles of [hi 32 | lo 32]
-  float* out;  long long out_stride;  const int* out_index;              // [slot][H * 256][ld]; the group's first evaluation -> slot
-  const int* items;  const int* grp_off;  int n_groups;                  // group g = items[grp_off[g] .. grp_off[g+1]) (no offsets: one item each; no items: identity)
-  int H, T, Tp, n_blocks, T_last, accumulate;
-  int ablate = 0;                                                        // development: 1 no A requests, 2 no plane pieces, 4 no matrix instructions, 8 no stores
-};
-extern int csn_dev_dkv_stream;
-bool csn_dkv_stream_takes(int d_head, int block, int score_pitch);
-int csn_launch_dkv_stream(const CsnDkvStreamArgs& a, hipStream_t st);
-
 int csn_launch_attn_fwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
 int csn_launch_attn_bwd_f32(const CsnAttnArgs& a, int d, hipStream_t st);
 int csn_launch_attn_fwd_bf16x3(const CsnAttnArgs& a, int d, int mode, hipStream_t st);     // attn_bf16x3.hip; mode 1..3 (2, 3: tile-plane K/V only)

@@ -441,8 +441,7 @@ CSN_API int csn_masked_ce_bwd_f32(const float* logits, long long shape_stride, i
 /* (key 4 was the 32-queries-per-wave attention forward of round 4: measured 25 % slower, removed; profiles/README.md) */
 #define CSN_DEV_LNB_GROUP 5 /* default 0; G > 0: csn_outproj_ln_bwd_f32 runs its LayerNorm backward and its dCtx product over groups
                                of G evaluations (bf16x3, streaming dCtx; the same results) */
-#define CSN_DEV_DKV_STREAM 6 /* default 1: dV / dK of the bf16x3 mode at d_head = 256 on the P / dS tile planes as output-stationary
-                               streams (dkv_stream.hip); 0: the grouped 256 x 256-tile GEMMs (the same bits) */
+/* (key 6 was the output-stationary dV / dK stream of round 5: the GEMM route is as fast over the step; profiles/r5_dkv_stream.txt) */
 CSN_API int csn_dev_set(int key, int value);
 CSN_API int csn_dev_get(int key);
 
