@@ -16,7 +16,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libcsn_hip.so")
-SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "wx_stream.hip", "wx_lnb.hip", "wx_wgrad.hip", "loss.hip", "attn_f32.hip", "attn_bf16x3.hip", "attn_dkv.hip", "outproj_ln.hip", "retrieval.hip", "combine.hip", "compat.hip", "csn_capi.hip"]
+SOURCES = ["gemm_f32.hip", "gemm_bf16x3.hip", "wx_stream.hip", "wx_lnb.hip", "loss.hip", "attn_f32.hip", "attn_bf16x3.hip", "attn_dkv.hip", "outproj_ln.hip", "retrieval.hip", "combine.hip", "compat.hip", "csn_capi.hip"]
 HEADERS = ["csn_common.h", "csn_kernels.h", "csn_window.h", "wx_common.h", os.path.join("..", "..", "include", "csn_hip.h")]
 ARCH = "gfx950"
 BUILD_FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-shared"]

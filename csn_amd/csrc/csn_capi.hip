@@ -93,17 +93,6 @@ int wgrad_chunk(int n_maps, int n_points) {
 int wgrad(const float* a, long long a_stride, int lda, const float* b, long long b_stride, int ldb, float* dw, int rows,
           int cols, int n_maps, int n_points, float scale, int accumulate, float* ws, long long ws_floats,
           hipStream_t st, int a_fmt = 0, int b_fmt = 0) {
-  if (mode() == 1 && !a_fmt && !b_fmt) {                  // bf16x3, fp32 maps, 256 columns: the output-stationary stream (wx_wgrad.hip)
-    const int slabs = csn_wx_wgrad_slabs(rows, cols);
-    if (slabs > 0 && ws_floats >= (long long)slabs * rows * cols) {
-      CsnWxWgradArgs w;
-      w.a = a; w.a_stride = a_stride; w.lda = lda; w.b = b; w.b_stride = b_stride; w.ldb = ldb;
-      w.ws = ws; w.n_items = n_maps; w.n_points = n_points; w.n_sets = rows / 256;
-      const int rc = csn_launch_wx_wgrad(w, st);
-      if (rc == 0) return csn_launch_slab_reduce(ws, dw, slabs, (long long)rows * cols, scale, accumulate, st);
-      if (rc != CSN_NOT_TAKEN) return rc;
-    }
-  }
   const int chunk = wgrad_chunk(n_maps, n_points);
   const int n_chunks = (n_points + chunk - 1) / chunk;
   const long long slabs = (long long)n_maps * n_chunks;

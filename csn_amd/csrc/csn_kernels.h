@@ -207,16 +207,6 @@ struct CsnWxLnbArgs {
   float dropout_p; unsigned long long seed;
   int ablate = 0;
 };
-// weight gradients as a stream over the points (wx_wgrad.hip; bf16x3, fp32 maps, 256 columns, rows a multiple of 256)
-struct CsnWxWgradArgs {
-  const float* a; long long a_stride; int lda;                 // [item][256 n_sets][lda]
-  const float* b; long long b_stride; int ldb;                 // [item][256][ldb]
-  float* ws;                                                   // [slab][256 n_sets][256]
-  int n_items, n_points, n_sets;
-  int ablate = 0;
-};
-int csn_wx_wgrad_slabs(int rows, int cols);
-int csn_launch_wx_wgrad(const CsnWxWgradArgs& a, hipStream_t st);
 bool csn_wx_lnb_takes(const CsnLnBwdArgs& a, int d_inner);
 int csn_launch_wx_lnb(const CsnWxLnbArgs& a, hipStream_t st);
 

@@ -432,8 +432,7 @@ CSN_API int csn_masked_ce_bwd_f32(const float* logits, long long shape_stride, i
  *   CSN_DEV_WX          9   bit set for the K = 256 weight products of the bf16x3 mode: 1 projections, dCtx and out-projection +
  *                           LayerNorm on the weight-stationary streaming kernel (0: the tiled GEMM kernels); 2 its wave halves
  *                           staggered; 4 out-projection + LayerNorm back on the tiled kernel; 8 LayerNorm backward fused into
- *                           the dCtx stream; bits 4..7: timing-only ablations, results wrong; 256 / 512 weight gradients of one /
- *                           up to four 256-row sets on the output-stationary stream (measured, not faster over the step) */
+ *                           the dCtx stream; bits 4..7: timing-only ablations, results wrong */
 #define CSN_DEV_BIG_TILES 0
 #define CSN_DEV_WIDE_GEMM 1
 #define CSN_DEV_WIDE_FORMS 2

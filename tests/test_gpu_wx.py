@@ -323,35 +323,3 @@ def test_layer_norm_backward_fused_into_the_dctx_stream(L, E, NP, p, with_res, g
     keep = torch.ones_like(ref, dtype=torch.bool) if with_res else (a[0] != 0)
     sc = 1.0 if with_res else 1.0 / (1.0 - p)
     assert ((got.double() - ref * sc).abs()[keep]).max() <= 2e-5 * ref.abs().max() * sc
-
-
-@pytest.mark.parametrize("S,N,ld,R", [(3, 1000, 1000, 256), (2, 520, 528, 768), (130, 64, 64, 256), (1, 10000, 10000, 768), (5, 36, 40, 512),
-                                      (1, 4, 4, 256)])
-def test_weight_gradient_as_a_stream_over_the_points(L, S, N, ld, R):
-    """csn_project_wgrad_f32 on the output-stationary streaming kernel (wx_wgrad.hip) against float64 and against the tiled kernel
-    with its slab reduction (the stream is a measured form, off by default: CSN_DEV_WX bit 9 switches it on): one, two and three 256-row sets, ragged last chunks, row
-    pitch above the point count, more items than streams, accumulate and scale; twice the same bits."""
-    lib = L.lib()
-    rng = np.random.default_rng(41)
-    C = 256
-    dout, x = torch.zeros((S, R, ld)), torch.zeros((S, C, ld))
-    dout[:, :, :N], x[:, :, :N] = _rand(rng, S, R, N), _rand(rng, S, C, N)
-    dd, xd = dout.cuda(), x.cuda()
-    ref = torch.einsum("srn,scn->rc", dout.double(), x.double()) * 0.5 + 1.0
-    ws_n = lib.csn_wgrad_workspace_floats(R, C, S, N)
-    outs = []
-    for wx in (L.DEV_WX_DEFAULT | 512, L.DEV_WX_DEFAULT | 512, L.DEV_WX_DEFAULT):
-        prev = lib.csn_dev_set(L.DEV_WX, wx)
-        try:
-            ws = torch.full((ws_n + 1024,), float("nan"), device="cuda")
-            dw = torch.ones((R, C), device="cuda")
-            L.check(lib.csn_project_wgrad_f32(dd.data_ptr(), R * ld, ld, xd.data_ptr(), C * ld, ld, dw.data_ptr(), R, C, S, N, 0.5, 1, ws.data_ptr(),
-                                              ws_n, _stream()))
-            torch.cuda.synchronize()
-            assert torch.isnan(ws[ws_n:]).all()
-            outs.append(dw.cpu())
-        finally:
-            lib.csn_dev_set(L.DEV_WX, prev)
-    assert torch.equal(outs[0], outs[1])
-    scale = ref.abs().max().item()
-    assert (outs[0].double() - ref).abs().max().item() < 2e-5 * scale and (outs[2].double() - ref).abs().max().item() < 2e-5 * scale
