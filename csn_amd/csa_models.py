@@ -298,14 +298,25 @@ class CrossShapeAt(nn.Module):
             w = F.pad(w, (0, 0, 0, pad))
         return CF.linear_cm(feats_cm.contiguous(), w)[:, :n_cls].unsqueeze(-1)
 
+    def _logits_of_input(self, x) -> torch.Tensor:
+        """``after_fc=False`` (csa_models.py:191-202): the attention is skipped and the logit layer is applied to the input as it
+        stands — to every point of it (the 20 x 500 chunking belongs to the attention).  The HIP GEMM wants point counts in
+        multiples of 4: other counts run with up to three zero points appended, which are cut off again."""
+        n = x.shape[2]
+        xc = _channel_major(x, n)
+        pad = (-n) % 4
+        if pad:
+            xc = F.pad(xc, (0, pad))
+        return self._logits(xc)[:, :, :n]
+
     def forward_ssa(self, x, mode=None):
         if not self.after_fc:
-            raise NotImplementedError("only the after_fc=True models that get_model builds are supported")
+            return self._logits_of_input(x)
         return self._logits(self._ssa_cm(x))
 
     def forward_csa(self, x, x_neighbors, mode=None):
         if not self.after_fc:
-            raise NotImplementedError("only the after_fc=True models that get_model builds are supported")
+            return self._logits_of_input(x)
         return self._logits(self._csa_cm(x, x_neighbors))
 
     def _ssa_cm(self, x) -> torch.Tensor:

@@ -265,6 +265,12 @@ def forward_ssa(x: torch.Tensor, p: Params, n_head: int, **kw) -> torch.Tensor:
     return F.conv2d(ssa_feats(x, p, n_head, **kw), p["logit.weight"])            # :193-194
 
 
+def forward_logit_only(x: torch.Tensor, p: Params) -> torch.Tensor:
+    """``after_fc=False`` (csa_models.py:147, 191-202): forward_ssa / forward_csa skip the attention and apply the logit layer to
+    the input as it stands — every point of it."""
+    return F.conv2d(x, p["logit.weight"])                                          # :194 / :201
+
+
 def forward_csa(x: torch.Tensor, x_neighbors: torch.Tensor, p: Params, n_head: int, **kw) -> torch.Tensor:
     return F.conv2d(csa_feats(x, x_neighbors, p, n_head, **kw), p["logit.weight"])  # :199-201
 

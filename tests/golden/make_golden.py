@@ -276,13 +276,37 @@ def g9_data_path(out):
         os.listdir = listdir
 
 
+def g10_after_fc_false(out):
+    """`CrossShapeAt(..., after_fc=False)` (csa_models.py:147, 191-202): the attention layer is skipped, the model is the logit
+    layer alone — on EVERY point of the input (the 20 x 500 chunking lives in the attention, csa_models.py:83-90)."""
+    n_cls = 39
+    for i, (kind, B, N, H, K) in enumerate([("ssa", 2, 10000, 1, None), ("csa", 1, 7001, 8, 2), ("ssa", 1, 12000, 1, None)]):
+        seed = 1000 + i
+        rng = np.random.default_rng(seed)
+        p = orc.make_params(rng, H, n_cls=n_cls, csa=kind == "csa")
+        x = orc.synth_points(rng, (B, 256, N, 1))
+        lab = labels_for(rng, B, N, n_cls)
+        model = load_into(ref.CrossShapeAt(n_cls, 256, H, K, attention_type=kind, after_fc=False), p).eval()
+        nb = orc.synth_points(rng, (B, K + 1, 256, N, 1)) if kind == "csa" else None
+        logits = model(x, "train", nb)
+        assert tuple(logits.shape) == (B, n_cls, N, 1)
+        loss = orc.masked_ce_loss(logits, lab)
+        loss.backward()
+        out[f"g10_{i}_cfg"] = np.array([0 if kind == "ssa" else 1, B, N, H, K or 0, n_cls, seed])
+        out[f"g10_{i}_logit_rows"] = logits.detach().squeeze(-1).permute(0, 2, 1)[:, ::ROW_STRIDE].contiguous().numpy()
+        out[f"g10_{i}_loss"] = np.array([loss.item()], dtype=np.float64)
+        grads = {n: prm.grad for n, prm in model.named_parameters() if prm.grad is not None}
+        assert sorted(grads) == ["logit.weight"], sorted(grads)           # nothing else is on the path
+        out[f"g10_{i}_grad_logit.weight"] = grads["logit.weight"].detach().numpy().astype(np.float32)
+
+
 def main():
     only = set(sys.argv[1:])
     for name, fn in [("g1_sdpa", g1_sdpa), ("g2_self_attention", g2_self_attention),
                      ("g3_mha_forward", g3_mha_forward), ("g4_csa", g4_csa), ("g5_ssa", g5_ssa),
                      ("g6_retrieval", g6_retrieval),
                      ("g7_csa_conditioned", g7_csa_conditioned), ("g8_mha_unequal_head_widths", g8_mha_unequal_head_widths),
-                     ("g9_data_path", g9_data_path)]:
+                     ("g9_data_path", g9_data_path), ("g10_after_fc_false", g10_after_fc_false)]:
         if only and name not in only:
             continue
         out = {}

@@ -446,6 +446,35 @@ def test_g5_ssa_forward_backward_against_reference_goldens(golden_dir):
         _grad_check(model, g, f"g5_{i}", 7)
 
 
+def test_g10_after_fc_false_against_reference_goldens(golden_dir):
+    """CrossShapeAt(..., after_fc=False) — the reference skips the attention and applies the logit layer to every point of the
+    input (csa_models.py:191-202) — against the reference's own outputs: 'ssa' and 'csa', 10000 / 7001 / 12000 points."""
+    from csn_amd.csa_models import CrossShapeAt
+    g = _load(golden_dir, "g10_after_fc_false")
+    for i in range(3):
+        kind, B, N, H, K, n_cls, seed = (int(v) for v in g[f"g10_{i}_cfg"])
+        rng = np.random.default_rng(seed)
+        p = orc.make_params(rng, H, n_cls=n_cls, csa=kind == 1)
+        x = orc.synth_points(rng, (B, 256, N, 1))
+        lab = orc.synth_labels(rng, B, N, n_cls)
+        nb = orc.synth_points(rng, (B, K + 1, 256, N, 1)) if kind == 1 else None
+        model = CrossShapeAt(n_cls, 256, H, K or None, attention_type="csa" if kind == 1 else "ssa", after_fc=False)
+        missing, unexpected = model.load_state_dict(p, strict=False)
+        assert not unexpected and all(k.startswith("fc_1.") for k in missing)
+        model = model.cuda().eval()
+        logits = model(x.cuda(), "train", nb)
+        assert tuple(logits.shape) == (B, n_cls, N, 1)
+        loss = orc.masked_ce_loss(logits, lab.cuda())
+        loss.backward()
+        rows = logits.detach().cpu().squeeze(-1).permute(0, 2, 1)[:, ::ROW_STRIDE].numpy()
+        assert np.abs(rows - g[f"g10_{i}_logit_rows"]).max() < ATOL
+        assert abs(loss.item() - g[f"g10_{i}_loss"][0]) < 1e-5
+        grads = {n: q.grad for n, q in model.named_parameters() if q.grad is not None}
+        assert sorted(grads) == ["logit.weight"]
+        ref = g[f"g10_{i}_grad_logit.weight"]
+        assert np.abs(grads["logit.weight"].cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
+
+
 def test_g6_knn_graph_indices_bit_exact(golden_dir):
     g = _load(golden_dir, "g6_retrieval")
     from csn_amd.csa_models import get_model

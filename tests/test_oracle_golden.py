@@ -170,6 +170,27 @@ def test_g5_ssa(golden_dir):
         assert _check_grads(g, f"g5_{i}", grads) == 7
 
 
+def test_g10_after_fc_false_is_the_logit_layer_on_every_point(golden_dir):
+    """golden set G10: the reference's CrossShapeAt(..., after_fc=False) (csa_models.py:191-202), 'ssa' and 'csa', point counts
+    10000 / 7001 / 12000 — the oracle's restatement (forward_logit_only) against logits, loss and the one gradient."""
+    g = _load(golden_dir, "g10_after_fc_false")
+    for i in range(3):
+        kind, B, N, H, K, n_cls, seed = (int(v) for v in g[f"g10_{i}_cfg"])
+        rng = np.random.default_rng(seed)
+        p = orc.make_params(rng, H, n_cls=n_cls, csa=kind == 1)
+        x = orc.synth_points(rng, (B, 256, N, 1))
+        lab = orc.synth_labels(rng, B, N, n_cls)
+        w = p["logit.weight"].clone().requires_grad_(True)
+        logits = orc.forward_logit_only(x, {"logit.weight": w})
+        assert tuple(logits.shape) == (B, n_cls, N, 1)
+        loss = orc.masked_ce_loss(logits, lab)
+        loss.backward()
+        _close(logits.detach().squeeze(-1).permute(0, 2, 1)[:, ::ROW_STRIDE].numpy(), g[f"g10_{i}_logit_rows"])
+        assert abs(loss.item() - g[f"g10_{i}_loss"][0]) < 1e-5
+        ref = g[f"g10_{i}_grad_logit.weight"]
+        assert np.abs(w.grad.numpy() - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
 def test_g6_retrieval_and_knn_indices_bit_exact(golden_dir):
     g = _load(golden_dir, "g6_retrieval")
     for i in range(2):
