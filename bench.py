@@ -146,8 +146,8 @@ def self_launch(args):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     out, _ = procs[0].communicate()
     codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
-    sys.stdout.flush()
+    for line in out.splitlines():                     # stdout carries the JSON line only; anything else a library printed goes to stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
         print(f"bench: ranks failed (rank, exit code): {bad}", file=sys.stderr, flush=True)
