@@ -282,7 +282,7 @@ def main():
     # attention launches and that longest launch alone (`roofline.launch_ms` is live, from the timed region)
     call_events = {}
     watch = [None]                                                       # None: every call; a set: those entry points
-    ATTN_CALLS = {"csn_block_attn_fwd_f32": "fwd", "csn_block_attn_bwd_dq_f32": "bwd", "csn_block_attn_bwd_dq_recompute_f32": "bwd",
+    ATTN_CALLS = {"csn_block_attn_fwd_f32": "fwd", "csn_block_attn_fwd_grouped_f32": "fwd", "csn_block_attn_bwd_dq_f32": "bwd", "csn_block_attn_bwd_dq_recompute_f32": "bwd",
                   "csn_block_attn_bwd_dkv_flash_f32": "dkv"}  # dkv: the key-stationary dK / dV launch of the score-recomputing flow
     _open = {}
 

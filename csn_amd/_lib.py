@@ -131,6 +131,10 @@ _SIGNATURES = {
     "csn_block_attn_fwd_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_void_p, c_void_p, c_int,
                                        c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                        c_int, c_float, c_float, c_ulonglong, c_int, c_longlong, c_void_p]),
+    "csn_block_attn_fwd_grouped_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_longlong, c_void_p, c_void_p, c_int,
+                                               c_void_p, c_longlong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                               c_int, c_float, c_float, c_ulonglong, c_int, c_longlong, c_void_p, c_void_p, c_int,
+                                               c_void_p]),
     "csn_block_attn_bwd_dq_f32": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_int,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_int,
                                           c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_ulonglong,
@@ -212,7 +216,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        if handle.csn_version() != 16:
+        if handle.csn_version() != 17:
             raise CsnError("libcsn_hip.so ABI version mismatch")
         _lib = _Hooked(handle)
     return _lib

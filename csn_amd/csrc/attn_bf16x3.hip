@@ -163,8 +163,11 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
   // the group's evaluations eval_ids[grp_off[g] .. grp_off[g+1]) run one after the other into the same OUT accumulators,
   // which leave once — no read-modify-write passes over the gradient maps
   const int zz = u / Y;
-  const int it0 = (BWD && p.grp_off) ? p.grp_off[zz] : zz;
-  const int it1 = (BWD && p.grp_off) ? p.grp_off[zz + 1] : it0 + 1;     // (forward: always one item — the loop folds away)
+  // Grouped forward (round 5, csn_block_attn_fwd_grouped_f32): the group's evaluations share the QUERY slot — the register operand
+  // Qs is staged once and stays in registers while the group's evaluations run one after the other (own K / V, own scores,
+  // own output: the epilogue is inside the loop)
+  const int it0 = p.grp_off ? p.grp_off[zz] : zz;
+  const int it1 = p.grp_off ? p.grp_off[zz + 1] : it0 + 1;
   const int e0 = p.eval_ids ? p.eval_ids[it0] : it0;
   const int hd = (u % Y) % p.H, blk = (u % Y) / p.H;
   // ragged batches: this evaluation's own query / key counts (Tq, p.T stay the maxima that lay out the buffers)
@@ -177,13 +180,13 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
   const bool q_ok = qrow < Tq_e;
   const long long head_off = (long long)hd * D * ld + (long long)blk * Tq;
   const long long win = ((long long)(D - 1) * ld + Tq) * 4;    // bytes spanned by a [D][Tq] fp32 window of pitch ld
-  const long long os = p.out_index ? p.out_index[e0] : e0;
+  long long os = p.out_index ? p.out_index[e0] : e0;
   // 16-bit activation maps (single-product modes; r_fmt / ctx_fmt / q2_fmt / out_fmt: 0 fp32, 1 bf16, 2 fp16): a [D][Tq] window
   // of a map in format f starts `el` elements into it
   auto map_rsrc = [&](const void* base, long long el, int f) {
     return f ? csn_make_rsrc(reinterpret_cast<const short*>(base) + el, win / 2) : csn_make_rsrc(reinterpret_cast<const float*>(base) + el, win);
   };
-  const long long stat_off0 = ((long long)e0 * p.H + hd) * ((long long)p.n_blocks * Tq) + (long long)blk * Tq;
+  long long stat_off0 = ((long long)e0 * p.H + hd) * ((long long)p.n_blocks * Tq) + (long long)blk * Tq;
   float* xbuf = reinterpret_cast<float*>(tiles);
   constexpr int CH_T = D / 16;                                     // 16-byte chunks per thread: D rows x 32 chunks / 512
   const int cc = tid & 31, crow = tid >> 5;                        // chunk column, first row of this thread (rows + 16 t)
@@ -193,7 +196,56 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
   f32x4v O[D / 16];
 #pragma unroll
   for (int c = 0; c < D / 16; ++c) O[c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+  s16x8 Rh[D / 32], Rl[D / 32];                          // the register operand (forward groups: staged by the first item)
   float m_run = -INFINITY, m2_run = -INFINITY, l_run = 0.f;   // forward: running max / partial sum of this lane's key quarter
+
+  // ---- epilogue (backward: once, behind the group's last item; forward: behind every item) ----------------------------
+  auto write_out = [&]() __attribute__((always_inline)) {
+    float inv = 1.f;
+    if (!BWD) {
+      float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+      l_tot += __shfl_xor(l_tot, 32, 64);
+      inv = 1.f / l_tot;
+      if (q_ok && kq == 0 && p.lse) p.lse[stat_off0 + qrow] = m2_run * LN2 + logf(l_tot);
+    }
+    // OUT leaves through the same [D][128] LDS block as 16-byte rows (chunk c of row r at c ^ 4 ((r >> 2) & 1): the lane
+    // quarters write rows 4 apart); when several evaluations share the output slot, the previous partial sums are fetched
+    // first — one batch of 16-byte loads in flight — then added and stored
+  #pragma unroll
+    for (int c = 0; c < D / 16; ++c)
+  #pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * c + 4 * kq + r;
+        xbuf[row * 128 + ((((col >> 2) ^ (4 * ((row >> 2) & 1))) << 2) | (col & 3))] = O[c][r] * inv;
+      }
+    __syncthreads();
+    {
+      f32x4 ch[CH_T];
+  #pragma unroll
+      for (int t = 0; t < CH_T; ++t) {
+        const int row = crow + 16 * t;
+        ch[t] = *reinterpret_cast<const f32x4*>(&xbuf[row * 128 + ((cc ^ (4 * ((row >> 2) & 1))) << 2)]);
+      }
+      const csn_rsrc_t Or = map_rsrc(p.out, os * p.out_eval_stride + head_off, p.out_fmt);
+      if (NPL == 1 && p.out_fmt) {                                   // a 16-bit map (written once: the launcher refuses accumulate)
+  #pragma unroll
+        for (int t = 0; t < CH_T; ++t) {
+          const s16x4 v = p.out_fmt == 2 ? to16x4<true>(ch[t]) : to16x4<false>(ch[t]);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), Or, c_off == CSN_OOB ? CSN_OOB : c_off >> 1, (unsigned)(16 * t * ld) * 2u, 0);
+        }
+      } else {
+        if (p.accumulate) {
+          f32x4 prev[CH_T];
+  #pragma unroll
+          for (int t = 0; t < CH_T; ++t) prev[t] = csn_bload4(Or, c_off, (unsigned)(16 * t * ld) * 4u);
+  #pragma unroll
+          for (int t = 0; t < CH_T; ++t) ch[t] += prev[t];
+        }
+  #pragma unroll
+        for (int t = 0; t < CH_T; ++t) csn_bstore4(ch[t], Or, c_off, (unsigned)(16 * t * ld) * 4u);
+      }
+    }
+  };
 
   for (int it = it0; it < it1; ++it) {
   const int e = p.eval_ids ? p.eval_ids[it] : it;
@@ -272,7 +324,6 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
   // lane picks its values from there.  Chunk c of row r sits at c ^ 4 ((r >> 3) & 1): rows 8 apart (lane quarters kq, kq+1)
   // use different banks.  Backward: delta_q = sum_d dO[d][q] O[d][q] (the softmax-backward row constant) from a second
   // round with O.
-  s16x8 Rh[D / 32], Rl[D / 32];
   auto stage_in = [&](const csn_rsrc_t& rs, int fmt) {
     f32x4 ch[CH_T];
     if (NPL == 1 && fmt) {                                         // a 16-bit map: half the bytes, widened on the way into LDS
@@ -293,20 +344,29 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
   };
   auto pick = [&](int row) { return xbuf[row * 128 + ((((col >> 2) ^ (4 * ((row >> 3) & 1))) << 2) | (col & 3))]; };
   PSTAMP(0);
-  stage_in(Rr, p.r_fmt);
-  PSTAMP(1);
-  __syncthreads();
-  PSTAMP(2);
   float rv[D / 4];
+  if (BWD || it == it0) {                                          // (forward group: the operand of the first item serves them all)
+    stage_in(Rr, p.r_fmt);
+    PSTAMP(1);
+    __syncthreads();
+    PSTAMP(2);
 #pragma unroll
-  for (int s = 0; s < D / 32; ++s)
+    for (int s = 0; s < D / 32; ++s)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float v = pick(32 * s + 8 * kq + j);
-      rv[8 * s + j] = v;
-      Rh[s][j] = to16<PR::HALF>(v);
-      Rl[s][j] = PR::NT == 3 ? to16<PR::HALF>(v - from16<PR::HALF>(Rh[s][j])) : Rh[s][j];
-    }
+      for (int j = 0; j < 8; ++j) {
+        const float v = pick(32 * s + 8 * kq + j);
+        rv[8 * s + j] = v;
+        Rh[s][j] = to16<PR::HALF>(v);
+        Rl[s][j] = PR::NT == 3 ? to16<PR::HALF>(v - from16<PR::HALF>(Rh[s][j])) : Rh[s][j];
+      }
+  }
+  if (!BWD) {                                                      // forward: every item has its own output and statistics
+    os = p.out_index ? p.out_index[e] : e;
+    stat_off0 = stat_off;
+#pragma unroll
+    for (int c = 0; c < D / 16; ++c) O[c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    m_run = -INFINITY; m2_run = -INFINITY; l_run = 0.f;
+  }
   PSTAMP(3);
   float delta_q = 0.f;
   if (BWD) {
@@ -752,54 +812,11 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
 
   if (!late) __syncthreads();                           // pairs with the last barrier of the late half: tiles are idle now
   else if (CSN_LATE_PRIO) __builtin_amdgcn_s_setprio(0);
+  if constexpr (!BWD) write_out();                      // (the barrier that ends the next item's prologue separates its tile commits from this)
   }                                                     // next item of the group (its prologue reuses the tiles as staging)
 
-  // ---- epilogue -----------------------------------------------------------------------------------
   WGSTAMP(2);
-  float inv = 1.f;
-  if (!BWD) {
-    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-    l_tot += __shfl_xor(l_tot, 32, 64);
-    inv = 1.f / l_tot;
-    if (q_ok && kq == 0 && p.lse) p.lse[stat_off0 + qrow] = m2_run * LN2 + logf(l_tot);
-  }
-  // OUT leaves through the same [D][128] LDS block as 16-byte rows (chunk c of row r at c ^ 4 ((r >> 2) & 1): the lane
-  // quarters write rows 4 apart); when several evaluations share the output slot, the previous partial sums are fetched
-  // first — one batch of 16-byte loads in flight — then added and stored
-#pragma unroll
-  for (int c = 0; c < D / 16; ++c)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 16 * c + 4 * kq + r;
-      xbuf[row * 128 + ((((col >> 2) ^ (4 * ((row >> 2) & 1))) << 2) | (col & 3))] = O[c][r] * inv;
-    }
-  __syncthreads();
-  {
-    f32x4 ch[CH_T];
-#pragma unroll
-    for (int t = 0; t < CH_T; ++t) {
-      const int row = crow + 16 * t;
-      ch[t] = *reinterpret_cast<const f32x4*>(&xbuf[row * 128 + ((cc ^ (4 * ((row >> 2) & 1))) << 2)]);
-    }
-    const csn_rsrc_t Or = map_rsrc(p.out, os * p.out_eval_stride + head_off, p.out_fmt);
-    if (NPL == 1 && p.out_fmt) {                                   // a 16-bit map (written once: the launcher refuses accumulate)
-#pragma unroll
-      for (int t = 0; t < CH_T; ++t) {
-        const s16x4 v = p.out_fmt == 2 ? to16x4<true>(ch[t]) : to16x4<false>(ch[t]);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), Or, c_off == CSN_OOB ? CSN_OOB : c_off >> 1, (unsigned)(16 * t * ld) * 2u, 0);
-      }
-    } else {
-      if (p.accumulate) {
-        f32x4 prev[CH_T];
-#pragma unroll
-        for (int t = 0; t < CH_T; ++t) prev[t] = csn_bload4(Or, c_off, (unsigned)(16 * t * ld) * 4u);
-#pragma unroll
-        for (int t = 0; t < CH_T; ++t) ch[t] += prev[t];
-      }
-#pragma unroll
-      for (int t = 0; t < CH_T; ++t) csn_bstore4(ch[t], Or, c_off, (unsigned)(16 * t * ld) * 4u);
-    }
-  }
+  if constexpr (BWD) write_out();
   WGSTAMP(3);
 }
 

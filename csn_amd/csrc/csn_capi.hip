@@ -263,7 +263,8 @@ static int attn_fwd_impl(const float* q, const float* k, const float* v, long lo
                          long long ctx_eval_stride, float* scores, float* lse, int n_evals, int n_heads,
                          int d_head, int block, int n_blocks, int score_pitch, float rescale_threshold,
                          float dropout_p, unsigned long long seed, int qkv_split, long long qkv_plane_stride,
-                         int block_q, int ld_kv, void* stream, const int* tq_arr = nullptr, const int* t_arr = nullptr) {
+                         int block_q, int ld_kv, void* stream, const int* tq_arr = nullptr, const int* t_arr = nullptr,
+                         const int* eval_ids = nullptr, const int* group_offsets = nullptr, int n_groups = 0) {
   // block_q / ld_kv != 0: the queries of a block are counted separately from its keys (block = keys) and K/V maps have
   // their own leading dimension; key counts need not be multiples of 4 then (fp32 K/V maps only).  tq_arr / t_arr: the
   // per-evaluation counts of a ragged batch (block_q / block are then the maxima)
@@ -298,7 +299,11 @@ static int attn_fwd_impl(const float* q, const float* k, const float* v, long lo
   a.scores = scores; a.dscores = nullptr; a.lse = lse; a.delta = nullptr; a.ctx = nullptr;
   a.E = n_evals; a.H = n_heads; a.T = block; a.Tp = score_pitch; a.n_blocks = n_blocks;
   a.rescale_threshold = rescale_threshold;
-  a.eval_ids = nullptr; a.grp_off = nullptr; a.out_index = nullptr; a.accumulate = 0;
+  a.eval_ids = eval_ids; a.grp_off = nullptr; a.out_index = nullptr; a.accumulate = 0;
+  if (group_offsets) {                                               // grouped by query slot (16-bit modes; fp32: the listed evaluations, ungrouped)
+    if (!eval_ids || n_groups <= 0 || n_groups > n_evals || block_q != 0 || tq_arr || t_arr) return CSN_E_ARG;
+    if (mode() != 0) { a.grp_off = group_offsets; a.E = n_groups; }
+  }
   a.dropout_p = dropout_p; a.seed = seed;
   a.r_planes = 0; a.kv_planes = qkv_split; a.r_plane_stride = 0; a.kv_plane_stride = 0; a.sc_tiles = 0;
   a.tq_arr = tq_arr; a.t_arr = t_arr;
@@ -323,6 +328,18 @@ int csn_block_attn_fwd_f32(const float* q, const float* k, const float* v, long 
   return attn_fwd_impl(q, k, v, q_shape_stride, kv_shape_stride, q_index, kv_index, ld, ctx, ctx_eval_stride, scores, lse,
                        n_evals, n_heads, d_head, block, n_blocks, score_pitch, rescale_threshold, dropout_p, seed, qkv_split,
                        qkv_plane_stride, 0, 0, stream);
+}
+
+int csn_block_attn_fwd_grouped_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
+                                   long long kv_shape_stride, const int* q_index, const int* kv_index, int ld, float* ctx,
+                                   long long ctx_eval_stride, float* scores, float* lse, int n_evals, int n_heads,
+                                   int d_head, int block, int n_blocks, int score_pitch, float rescale_threshold,
+                                   float dropout_p, unsigned long long seed, int qkv_split, long long qkv_plane_stride,
+                                   const int* eval_ids, const int* group_offsets, int n_groups, void* stream) {
+  if (!eval_ids || !group_offsets) return CSN_E_ARG;
+  return attn_fwd_impl(q, k, v, q_shape_stride, kv_shape_stride, q_index, kv_index, ld, ctx, ctx_eval_stride, scores, lse,
+                       n_evals, n_heads, d_head, block, n_blocks, score_pitch, rescale_threshold, dropout_p, seed, qkv_split,
+                       qkv_plane_stride, 0, 0, stream, nullptr, nullptr, eval_ids, group_offsets, n_groups);
 }
 
 int csn_cross_attn_fwd_f32(const float* q, const float* k, const float* v, long long q_shape_stride,

@@ -449,11 +449,20 @@ class _MHAEvals(torch.autograd.Function):
         ctx.sc_layout = 1 if (scores is not None and tiles and ctx.mode == 1 and tune.tile_major_scores and tune.grouped_dq and
                               tune.grouped_dkv and Tp >= (T + 31) // 32 * 32 and (L.csn_attn_bwd_grouping(d, T) & 19) == 19) else 0
         with score_layout(ctx.sc_layout):
-            _lib.check(L.csn_block_attn_fwd_f32(q_ptr, k_ptr, v_ptr, q_stride, kv_stride,
-                                                _ptr(q_slots), _ptr(kv_slots), NP, _ptr(att), D * NP, _ptr(scores),
-                                                _ptr(lse), E, H, d, T, nb, Tp, RESCALE_THRESHOLD, p_attn, seed_attn,
-                                                kv_flag, kv_pitch, _stream()),
-                       "csn_block_attn_fwd_f32")
+            if tune.grouped_fwd and fast_math() and plan.n_q_groups < E:
+                # evaluations that share their query slot (the query shape's K+2) run in one work-group, Qs staged once
+                _lib.check(L.csn_block_attn_fwd_grouped_f32(q_ptr, k_ptr, v_ptr, q_stride, kv_stride,
+                                                            _ptr(q_slots), _ptr(kv_slots), NP, _ptr(att), D * NP, _ptr(scores),
+                                                            _ptr(lse), E, H, d, T, nb, Tp, RESCALE_THRESHOLD, p_attn, seed_attn,
+                                                            kv_flag, kv_pitch, _ptr(plan.q_group_items), _ptr(plan.q_group_off),
+                                                            plan.n_q_groups, _stream()),
+                           "csn_block_attn_fwd_grouped_f32")
+            else:
+                _lib.check(L.csn_block_attn_fwd_f32(q_ptr, k_ptr, v_ptr, q_stride, kv_stride,
+                                                    _ptr(q_slots), _ptr(kv_slots), NP, _ptr(att), D * NP, _ptr(scores),
+                                                    _ptr(lse), E, H, d, T, nb, Tp, RESCALE_THRESHOLD, p_attn, seed_attn,
+                                                    kv_flag, kv_pitch, _stream()),
+                           "csn_block_attn_fwd_f32")
         xhat = torch.empty((E, C, NP), device=dev, dtype=torch.float16 if a16 else torch.float32)
         rstd = torch.empty((E, NP), device=dev, dtype=torch.float32)
         w_fc = w_fc.contiguous()

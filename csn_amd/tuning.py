@@ -26,6 +26,7 @@ class Tuning:
     link_mix: bool = True            # False: the mix backward writes per-evaluation gradient maps
     grouped_dkv: bool = True         # False: dK / dV by one read-modify-write launch per colour
     grouped_dq: bool = True          # False: dQ likewise
+    grouped_fwd: bool = True         # 16-bit modes: the forward's evaluations grouped by query slot (the query operand staged once per group)
     fused_compat_head: bool = True   # False: the compatibility head as torch ops (two nn.Linear, normalize, einsum, softmax)
     act16: bool = True               # bf16 / fp16 modes, linked mix: Qs, Ctx, xhat, dZ, dCtx between the launches as 16-bit maps
     # bf16x3, kept scores: S and the P / dS planes stored [key tile][query][32 keys], so that every wave instruction that touches

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CSN_ABI_VERSION 16
+#define CSN_ABI_VERSION 17
 /* The library is built with -fvisibility=hidden: the entry points declared here are its ONLY exported symbols. */
 #define CSN_API __attribute__((visibility("default")))
 
@@ -164,6 +164,20 @@ CSN_API int csn_block_attn_fwd_f32(const float* q, const float* k, const float* 
                            int d_head, int block, int n_blocks, int score_pitch, float rescale_threshold,
                            float dropout_p, unsigned long long seed, int qkv_split, long long qkv_plane_stride,
                            void* stream);
+
+/* The same forward with the evaluations GROUPED BY QUERY SLOT: group g = eval_ids[group_offsets[g] .. group_offsets[g+1])
+ * (device int32 arrays; every evaluation of [0, n_evals) listed exactly once; all evaluations of a group have the same
+ * q_index — CSN_E_ARG semantics are the caller's: the library does not read the arrays on the host).  In the 16-bit math modes a
+ * work-group stages the pre-scaled queries of its 128-query tile ONCE and runs the group's evaluations one after the other
+ * with the operand in registers (the query shape of a CSA step serves K+2 evaluations: csa_models.py:210, 232-237 — half of
+ * the step's operand blocks are never fetched); in the fp32 mode the evaluations run ungrouped.  Every output is the
+ * ungrouped call's, bit for bit. */
+CSN_API int csn_block_attn_fwd_grouped_f32(const float* q, const float* k, const float* v, long long q_shape_stride,
+                           long long kv_shape_stride, const int* q_index, const int* kv_index, int ld, float* ctx,
+                           long long ctx_eval_stride, float* scores, float* lse, int n_evals, int n_heads,
+                           int d_head, int block, int n_blocks, int score_pitch, float rescale_threshold,
+                           float dropout_p, unsigned long long seed, int qkv_split, long long qkv_plane_stride,
+                           const int* eval_ids, const int* group_offsets, int n_groups, void* stream);
 
 /* ---- (3) block attention, backward (autograd of csa_models.py:139-142) -------------------------------
  * Two calls, because their outputs are shared differently between evaluations (the query shape's Q serves

@@ -40,7 +40,7 @@ def test_header_symbols_are_exported(L):
 
 def test_library_loads_and_reports_version(L):
     lib = L.lib()
-    assert lib.csn_version() == 16
+    assert lib.csn_version() == 17
     assert lib.csn_status_string(0) == b"ok"
     assert b"workspace" in lib.csn_status_string(-6)
 
