@@ -537,6 +537,11 @@ def test_abi_argument_validation_table(L):
             ("Tp", 30, ALIGN), ("Tp", 16, ALIGN), ("q", q.data_ptr() + 4, PTR), ("sc", sc.data_ptr() + 4, PTR),
             ("qs", H * d * N + 2, STRIDE), ("cs", H * d * N + 1, STRIDE), ("E", 0, ARG), ("H", 0, ARG), ("T", 0, ARG), ("nb", 0, ARG),
             ("p", 1.0, ARG), ("p", -0.1, ARG), ("nb", 3, ARG)])          # 3 blocks of 20 > 40 points: the last block would be empty
+        # the same forward grouped by query slot (round 5): the lists are device arrays, checked for presence and count only
+        ids = torch.zeros(1, device=dev, dtype=torch.int32); off = torch.tensor([0, 1], device=dev, dtype=torch.int32)
+        _mutations(lib.csn_block_attn_fwd_grouped_f32, names[:-1] + ["ids", "off", "ng", "st"],
+                   {**valid, "ids": ids.data_ptr(), "off": off.data_ptr(), "ng": 1}, [
+            ("ids", None, ARG), ("off", None, ARG), ("ng", 0, ARG), ("ng", 2, ARG), ("q", None, ARG), ("d", 48, DIM), ("ld", N - 1, ALIGN)])
 
         # cross-length and ragged-batch forward
         lq, lk = 24, 37
