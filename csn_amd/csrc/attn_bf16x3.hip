@@ -133,7 +133,13 @@ __global__ __launch_bounds__(512, csn_attn_waves(PR::NPL, DT, BWD)) void csn_att
 #ifndef CSN_EARLY_ALL
 #define CSN_EARLY_ALL 0
 #endif
-  constexpr bool EARLY = CSN_EARLY && (NPL == 1 || DT <= 4 || CSN_EARLY_ALL);
+  // Round 5: the two-plane d = 256 FORWARD too — its second register set costs no spills there (255 registers) — forward alone
+  // 5.29 -> 5.22 ms, config-3 step 25.94 -> 25.76 ms over four alternations (profiles/r5q_forward_early_requests.txt); the
+  // backward at this width does not gain (-DCSN_EARLY_ALL=1: 7.00 -> 7.10 ms)
+#ifndef CSN_EARLY_FWD8
+#define CSN_EARLY_FWD8 1
+#endif
+  constexpr bool EARLY = CSN_EARLY && (NPL == 1 || DT <= 4 || CSN_EARLY_ALL || (CSN_EARLY_FWD8 && !BWD && !RC));
   // LDS images: A x 2 stages, B x 2 (RC && EARLY: x 3 — the key-contiguous K image is then committed in segment 1 too, which
   // needs a third stage), RC: + C x 2 (the K tile in tileA's form)
   constexpr int NB_ST = (RC && EARLY) ? 3 : 2;
