@@ -29,6 +29,7 @@ WHATEVER it is — today a fused block-attention launch (forward: S = Q K^T, sof
 `cpu_baseline` is the oracle's faithful op-for-op port of the reference timed on the host cores over a bounded sample.
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -50,6 +51,8 @@ DTYPE_TEXT = {"fp32": "f32", "bf16x3": "bf16x3 (fp32 operands split into 2 bf16,
               "bf16": "bf16 (one bf16 MFMA per product, fp32 accumulate; outside the 1e-4 contract)",
               "fp16": "fp16 forward / bf16 backward (one MFMA per product, fp32 accumulate; outside the 1e-4 contract)"}
 N_CLS = 39
+INIT_TIMEOUT_S = 180                 # process-group timeout: rendezvous and every collective of the run (a step is milliseconds)
+LAUNCH_GRACE_S = 5.0                 # self-launch: seconds a rank gets between SIGTERM and SIGKILL when another rank has failed
 CONFIGS = {
     2: dict(B=4, K=2, N=10000, C=256, d=256, T=500, nb=20, name="BASELINE configs[1]"),
     3: dict(B=32, K=3, N=10000, C=256, d=256, T=500, nb=20, name="BASELINE configs[2]"),
@@ -129,26 +132,79 @@ def self_launch(args):
     starts N fresh copies of itself, one rank per GPU, with the environment `torch.distributed.run` would give them
     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT on 127.0.0.1), relays rank 0's JSON line (every rank's stderr
     passes through) and exits non-zero if any rank does.  The launcher form of the docstring keeps working: with WORLD_SIZE
-    already in the environment nothing is spawned."""
+    already in the environment nothing is spawned.
+
+    Failure path (a rank that dies while the others sit inside an RCCL collective would otherwise hold the run until the
+    collective's own timeout): the parent POLLS all ranks; on the first non-zero exit — or when the parent itself is told to
+    stop (SIGTERM / SIGINT, e.g. from `timeout`), or raises — the remaining ranks get SIGTERM, then SIGKILL after
+    `LAUNCH_GRACE_S`, each in its own session so that the signal reaches whatever the rank started; the parent then exits
+    non-zero within seconds.  Ranks are only ever fresh children: nothing that touched a GPU is re-executed.  (The rendezvous
+    port is picked by bind-and-close: another process can take it in between; the run then fails at rendezvous — loudly, through
+    this same path — and is simply started again.)"""
+    import signal
     import socket
     import subprocess
+    import threading
     port = os.environ.get("MASTER_PORT")
     if port is None:
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = str(sk.getsockname()[1])
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, CSN_BENCH_CHILD="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    for line in out.splitlines():                     # stdout carries the JSON line only; anything else a library printed goes to stderr
-        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    procs, out_lines = [], []
+
+    def stop_ranks(why):
+        alive = [(r, p) for r, p in enumerate(procs) if p.poll() is None]
+        if not alive:
+            return
+        print(f"bench: {why}: stopping ranks {[r for r, _ in alive]} (pids {[p.pid for _, p in alive]})", file=sys.stderr, flush=True)
+        for sig, grace in ((signal.SIGTERM, LAUNCH_GRACE_S), (signal.SIGKILL, LAUNCH_GRACE_S)):
+            for _, p in alive:
+                if p.poll() is None:
+                    try:
+                        os.killpg(p.pid, sig)                  # start_new_session: the rank leads its own process group
+                    except (ProcessLookupError, PermissionError):
+                        pass
+            t_end = time.monotonic() + grace
+            while time.monotonic() < t_end and any(p.poll() is None for _, p in alive):
+                time.sleep(0.05)
+
+    def on_signal(signum, _frame):
+        stop_ranks(f"parent received signal {signum}")
+        sys.exit(128 + signum)
+
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+    deadline = float(os.environ.get("CSN_BENCH_LAUNCH_TIMEOUT_S", "0")) or None
+    t0 = time.monotonic()
+    try:
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=port, CSN_BENCH_CHILD="1")
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True,
+                                          start_new_session=True))
+        reader = threading.Thread(target=lambda: out_lines.extend(procs[0].stdout), daemon=True)   # rank 0's pipe never fills
+        reader.start()
+        bad = []
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad or all(c == 0 for c in codes):
+                break
+            if deadline is not None and time.monotonic() - t0 > deadline:
+                bad = [("launcher", f"no result after CSN_BENCH_LAUNCH_TIMEOUT_S={deadline:g} s")]
+                break
+            time.sleep(0.1)
+        if bad:
+            stop_ranks(f"ranks failed (rank, exit code): {bad}")
+        reader.join(timeout=5)
+    finally:
+        stop_ranks("launcher leaving")
+        for sg, h in old.items():
+            signal.signal(sg, h)
+    for line in out_lines:                            # stdout carries the JSON line only; anything else a library printed goes to stderr
+        line = line.rstrip("\n")
+        print(line, file=sys.stdout if line.startswith("{") and not bad else sys.stderr, flush=True)
     if bad:
         print(f"bench: ranks failed (rank, exit code): {bad}", file=sys.stderr, flush=True)
         sys.exit(1)
@@ -157,13 +213,30 @@ def self_launch(args):
 
 def launch_check():
     """CSN_BENCH_LAUNCH_CHECK=1 (tests/test_bench_launch.py, no GPU): the ranks of a self-launched run only prove that they
-    exist — process group over gloo on the CPU, one all-reduce, rank 0 prints what it saw — and leave."""
+    exist — process group over gloo on the CPU, one all-reduce, rank 0 prints what it saw — and leave.  Failure modes the test
+    drives: `fail` (the last rank exits 3 AFTER the collective), `die_before_collective` (the last rank exits 3 BEFORE it while
+    the others behave like ranks stuck inside an RCCL collective: whatever gloo tells them, they do not return), `sleep` (every
+    rank stays in the step until it is stopped: the parent-is-signalled case)."""
+    import datetime
     import torch.distributed as dist
+    mode = os.environ.get("CSN_BENCH_LAUNCH_CHECK")
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    print(f"bench-rank-pid {rank} {os.getpid()}", file=sys.stderr, flush=True)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=INIT_TIMEOUT_S))
     t = torch.tensor([float(rank + 1)])
+    if mode == "die_before_collective":
+        if rank == world - 1:
+            os._exit(3)
+        try:
+            dist.all_reduce(t)
+        except Exception:
+            pass
+        time.sleep(600)                                                  # (an RCCL rank would still be inside the collective)
     dist.all_reduce(t)
-    if os.environ.get("CSN_BENCH_LAUNCH_CHECK") == "fail" and rank == world - 1:
+    if mode == "sleep":
+        print(f"bench-rank-ready {rank}", file=sys.stderr, flush=True)
+        time.sleep(600)
+    if mode == "fail" and rank == world - 1:
         sys.exit(3)                                                      # (the parent must notice a rank that dies)
     if rank == 0:
         print(json.dumps({"launch_check": True, "n_ranks_seen": dist.get_world_size(), "rank_sum": t.item(),
@@ -192,6 +265,8 @@ def main():
                     help="N = 1 only: run the per-GPU work of the N > 1 path (K+2 evaluations per shape: every pooled descriptor "
                          "computed once, by its owner; the 32 shapes are their own collection, no exchange) instead of the "
                          "reference's 2K+2 — the like-for-like N = 1 point of the scaling curve")
+    ap.add_argument("--no-named-modes", action="store_true",
+                    help="skip config.named_modes (BASELINE configs[1] in bf16 and configs[4] in fp16 after the default headline)")
     ap.add_argument("--headline-only", action="store_true",
                     help="skip the secondary runs (other math mode, eval-mode arithmetic): what the profiles are taken with")
     args = ap.parse_args()
@@ -222,14 +297,61 @@ def main():
             local_rank = 0
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=INIT_TIMEOUT_S))
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=INIT_TIMEOUT_S))
         n_ranks_seen = dist.get_world_size()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    import types
+    ctx = types.SimpleNamespace(world=world, rank=rank, local_rank=local_rank, n_ranks_seen=n_ranks_seen, grouped=grouped, dev=dev)
+    out = run(args, ctx)
+    if out is not None:
+        if named_modes_wanted(args, grouped):
+            out["config"]["named_modes"] = named_modes(args, ctx)
+        print(json.dumps(out), flush=True)
+    if grouped:
+        dist.destroy_process_group()
+
+
+# BASELINE.json names a precision for configs[1] ("bf16") and configs[4] ("fp16 MFMA"): after the headline the default run times
+# those two workloads in those modes (a few steps each), so that the driver's line carries them too (config.named_modes)
+NAMED_MODES = [(2, "bf16"), (5, "fp16")]
+NAMED_STEPS, NAMED_WARMUP = 5, 2
+
+
+def named_modes_wanted(args, grouped):
+    return (not grouped and not args.no_named_modes and not args.headline_only and not args.same_work and args.config == 3
+            and args.math == "bf16x3" and args.shapes is None and args.K is None and args.heads == 1
+            and not any(os.environ.get(k) for k in ("CSN_BENCH_HOST_NB", "CSN_BENCH_SPLIT")))
+
+
+def named_modes(args, ctx):
+    import copy
+    res = []
+    for config, math in NAMED_MODES:
+        a = copy.copy(args)
+        a.config, a.math, a.steps, a.warmup, a.headline_only, a.no_cpu_baseline = config, math, NAMED_STEPS, NAMED_WARMUP, True, True
+        o = run(a, ctx)
+        r = o["roofline"]
+        res.append({"baseline_config": CONFIGS[config]["name"], "workload": o["config"]["workload"], "math": math, "dtype": o["dtype"],
+                    "steps": NAMED_STEPS, "warmup": NAMED_WARMUP, "ms_per_step": o["ms_per_step"], "points_per_s": o["value"],
+                    "loss": o["config"]["loss"], "step_tflops_algorithmic": o["config"]["step_tflops_algorithmic"],
+                    "dominant_launch": {k: r.get(k) for k in ("kernel", "launch_ms", "achieved", "peak", "unit", "frac", "traffic",
+                                                              "traffic_source", "hbm", "profile")},
+                    "launches": o["launches"]})
+    return res
+
+
+def run(args, ctx):
+    """One workload (args.config / args.math / args.steps ...) timed on this rank; rank 0 returns the JSON object of the line."""
+    world, rank, local_rank, n_ranks_seen, grouped, dev = ctx.world, ctx.rank, ctx.local_rank, ctx.n_ranks_seen, ctx.grouped, ctx.dev
+    H = args.heads
+    if grouped:
+        import torch.distributed as dist
     import csn_amd
     from csn_amd import functional as CF, tuning
     from csn_amd.csa_models import get_model
@@ -299,6 +421,16 @@ def main():
     # --math bf16 / fp16: the neighbour features cross xGMI as bf16 (the consumers round them to 16 bits anyway): config 4 as
     # SURVEY.md §8(e) sizes it; the parity modes exchange the fp32 maps
     payload_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}.get(args.math)      # (fp16 consumers keep 11 bits: an fp16 payload)
+    # an fp16 payload has fp16's RANGE too: checked once, outside the timed region, on what is sent — features beyond half of
+    # fp16's largest number travel as bf16 instead (no silent inf on real feature files); `config.exchange` says what was done
+    payload_range = None
+    if payload_dtype is torch.float16 and grouped:
+        amax = float(feats.abs().max())
+        tiny = float((feats.abs() < 6.0e-8).logical_and(feats != 0).float().mean())
+        if amax > 32752.0:
+            payload_dtype = torch.bfloat16
+        payload_range = {"send_amax": amax, "fraction_below_fp16_subnormal": tiny, "fp16_max": 65504.0,
+                         "payload_kept_fp16": payload_dtype is torch.float16}
     overlap = os.environ.get("CSN_OVERLAP", "1") != "0"                  # exchange in flight under the self-attention evaluations
 
     # CSN_BENCH_SPLIT=1 (N = 1, development aid): run the two-phase evaluation order of the multi-GPU path with the stack
@@ -551,6 +683,7 @@ def main():
         if grouped:
             sent, recvd = getattr(shard, "payload_bytes", (None, None))
             out["config"]["exchange"] = {"mode": exchange_mode, "payload_dtype": str(payload_dtype or torch.float32).replace("torch.", ""),
+                                         "payload_range_check": payload_range,
                                          "bytes_sent_per_rank": sent, "bytes_received_per_rank": recvd,
                                          "note": "rank 0's neighbour-only all-to-all of one step (None: the all-gather fallback moves the whole collection)"}
             out["config"]["n1_same_work_ms_per_step"] = same_work_ms
@@ -592,9 +725,8 @@ def main():
             cores = min(len(os.sched_getaffinity(0)), 16)          # the GPU box gives one GPU a 16-core share
             sample = 1 if H > 1 else (4 if args.config == 3 else (2 if args.config == 2 else 1))
             out["cpu_baseline"] = cpu_baseline(cfg, min(sample, B), cores, H=H)
-        print(json.dumps(out), flush=True)
-    if grouped:
-        dist.destroy_process_group()
+        return out
+    return None
 
 
 if __name__ == "__main__":

@@ -28,7 +28,7 @@ from . import functional as CF, tuning
 from ._lib import CsnError
 
 __all__ = ["ScaledDotProductAttention", "MultiHeadAttention", "CrossShapeAt", "get_model",
-           "backbone_fc_ssa_logit", "backbone_fc_csa_logit", "device"]
+           "backbone_fc_ssa_logit", "backbone_fc_csa_logit", "backbone_ssa_fc_logit", "backbone_csa_fc_logit", "device"]
 
 device = torch.device("cuda" if torch.cuda.is_available() else "cpu")       # csa_models.py:8
 
@@ -246,15 +246,20 @@ class CrossShapeAt(nn.Module):
     """csa_models.py:146-404."""
 
     def __init__(self, num_classes, d_model, n_heads, K=None, d_k=256, d_v=256, attention_type='ssa',
-                 after_fc=False, device=None, block=CF.REF_BLOCK, n_blocks=CF.REF_NBLOCKS, math=None):
+                 after_fc=False, device=None, block=CF.REF_BLOCK, n_blocks=CF.REF_NBLOCKS, math=None, feature_width=None):
         """Arguments as the reference's (csa_models.py:147).  The reference hard-codes 256 for the widths of ``fc_1``,
         ``logit`` and the compatibility head (:150-151, :160-161) and 20 x 500 for the chunking (:83-84): here they follow
         ``d_model`` / ``block`` / ``n_blocks`` (identical for the defaults), so that the other BASELINE configurations —
-        e.g. 8 x 50000 points x 96 channels in 100 blocks — run through the same module."""
+        e.g. 8 x 50000 points x 96 channels in 100 blocks — run through the same module.  ``feature_width`` (the width of
+        the feature map ``fc_1`` produces and ``logit`` / the compatibility head consume) defaults to ``d_model`` up to the
+        widest map this library runs (256) and to the reference's constant 256 beyond it — the reference's only other
+        ``d_model`` is the backbone's 928 of ``backbone_{ssa,csa}_fc_logit`` (:406-409, :416-419), whose state dict this
+        reproduces key by key."""
         super().__init__()
         self.d_model = d_model
-        self.fc_1 = self._conv1x1_bn_relu(928, d_model)        # never executed when after_fc=True; kept for checkpoints
-        self.logit = self._conv1x1(d_model, num_classes)
+        self.feature_width = fw = feature_width if feature_width is not None else (d_model if d_model <= 256 else 256)
+        self.fc_1 = self._conv1x1_bn_relu(928, fw)             # never executed by any forward (csa_models.py:191-202); kept for checkpoints
+        self.logit = self._conv1x1(fw, num_classes)
         self.attention = MultiHeadAttention(n_heads, d_model, d_k, d_v, block=block, n_blocks=n_blocks, math=math)
         self.attention_type = attention_type
         self.after_fc = after_fc
@@ -267,8 +272,8 @@ class CrossShapeAt(nn.Module):
         self._side_streams = {}               # device -> the stream host-resident neighbour stacks are copied on (made on first use)
         if 'csa' in self.attention_type:
             self.K = K
-            self.compatibility_q = nn.Linear(d_model, d_model)
-            self.compatibility_k = nn.Linear(d_model, d_model)
+            self.compatibility_q = nn.Linear(fw, fw)
+            self.compatibility_k = nn.Linear(fw, fw)
 
     @staticmethod
     def _conv1x1(nin, nout, use_bias=False):
@@ -506,6 +511,17 @@ class CrossShapeAt(nn.Module):
         measure = self.get_retrieval_measure_big(query_loader, candidate_loader, candidate_shape_indices)
         scores, knn_graph = measure.topk(K + 1, -1)
         return knn_graph
+
+
+def backbone_ssa_fc_logit(num_classes, n_heads):
+    """csa_models.py:406-409: attention width 928 (the backbone's concatenated map), ``after_fc=False`` — the forward is the
+    logit layer on a 256-channel map (:191-195); the 928-wide attention only contributes its state-dict keys."""
+    return CrossShapeAt(num_classes, 928, n_heads, attention_type='ssa', after_fc=False)
+
+
+def backbone_csa_fc_logit(num_classes, n_heads, K):
+    """csa_models.py:416-419 (see backbone_ssa_fc_logit)."""
+    return CrossShapeAt(num_classes, 928, n_heads, K, attention_type='csa', after_fc=False)
 
 
 def backbone_fc_ssa_logit(num_classes, n_heads, **geometry):

@@ -137,8 +137,10 @@ class EvalPlan:
         # early), group g = kv_group_items[kv_group_off[g] : kv_group_off[g+1]] — one grouped dK / dV call accumulates a
         # group's products in registers and writes its slot once (csn_block_attn_bwd_dkv_f32, group_offsets)
         items, off = self._groups(kv)
+        self._check_groups(items, off, kv)
         self.kv_group_items, self.kv_group_off, self.n_kv_groups = as_dev(items), as_dev(off), int(off.size - 1)
         items, off = self._groups(q)
+        self._check_groups(items, off, q)
         self.q_group_items, self.q_group_off, self.n_q_groups = as_dev(items), as_dev(off), int(off.size - 1)
         # the first colour of a pass holds the first evaluation of EVERY slot the pass writes, so it may overwrite; only the
         # gradient maps of slots a pass never writes need a zero fill (the weight gradients read all of them)
@@ -156,6 +158,18 @@ class EvalPlan:
         items = np.concatenate([order[start[g]:start[g] + count[g]] for g in by_size])
         off = np.concatenate(([0], np.cumsum(count[by_size])))
         return items, off
+
+    @staticmethod
+    def _check_groups(items, off, slots):
+        """The grouped kernels trust these arrays (include/csn_hip.h: a group that mixed slots would silently run every item on
+        the first item's operand, items beyond the last offset would never be written): hold the invariants where the arrays
+        are made — every evaluation in exactly one group, the offsets cover all of them, one slot per group."""
+        import numpy as np
+        E = slots.size
+        assert items.shape == (E,) and np.array_equal(np.sort(items), np.arange(E)), "group items must be a permutation of the evaluations"
+        assert off[0] == 0 and off[-1] == E and (np.diff(off) > 0).all(), "group offsets must cover every evaluation"
+        first = np.repeat(slots[items[off[:-1]]], np.diff(off))
+        assert np.array_equal(slots[items], first), "a group must hold the evaluations of ONE slot"
 
     @staticmethod
     def _colors(slots):

@@ -169,10 +169,16 @@ def _allreduce_bucket(plist: List[torch.nn.Parameter], world: int, group, averag
     missing gradient as zeros, so its size is the same on every rank by construction (a bucket of "whoever has a grad" hangs or
     corrupts the collective the day the sets differ).  A parameter that had no gradient on ANY rank keeps ``grad = None``
     afterwards — as in a single process, where optimizers skip such parameters (no weight decay, no moment update): the bucket
-    carries one presence count per parameter for that, read only on a rank that has a missing gradient itself."""
-    dev = plist[0].device
+    carries one presence count per parameter for that, read only on a rank that has a missing gradient itself — a host sync
+    (``.tolist()``) that only such a rank pays: correct, but it shows as per-rank skew in a max-over-ranks step time.
+    One bucket = one tensor: all parameters must share dtype and device (asserted; true of this model, fp32 on one GPU).
+    An empty list is a no-op — on EVERY rank or on none: the collective is skipped, so the lists must agree in length."""
+    if not plist:
+        return
+    dev, dt = plist[0].device, plist[0].dtype
+    assert all(p.device == dev and p.dtype == dt for p in plist), "gradient bucket: parameters of one dtype on one device"
     missing = [p.grad is None for p in plist]
-    present = torch.tensor([0.0 if m else 1.0 for m in missing], device=dev, dtype=plist[0].dtype)
+    present = torch.tensor([0.0 if m else 1.0 for m in missing], device=dev, dtype=dt)
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in plist] + [present])
     dist.all_reduce(flat, group=group)
     n_par = len(plist)

@@ -55,6 +55,20 @@ def test_state_dict_keys_match_reference_contract():
     assert set(ssa.state_dict()) == {k for k in want if not k.startswith("compatibility")}
     with pytest.raises(AttributeError):
         get_model("nope", 4, 1)
+    # the two d_model = 928 factories (csa_models.py:406-409, 416-419): a 928-wide attention beside the 256-wide fc_1 / logit /
+    # compatibility head — shapes as the reference builds them (probed by importing it; restated here as numbers)
+    import csn_amd.csa_models as M
+    assert {"backbone_ssa_fc_logit", "backbone_csa_fc_logit", "backbone_fc_ssa_logit", "backbone_fc_csa_logit"} <= set(M.__all__)
+    want928 = dict(want)
+    want928.update({"logit.weight": (39, 256, 1, 1), "attention.w_qs.weight": (2048, 928), "attention.w_ks.weight": (2048, 928),
+                    "attention.w_vs.weight": (2048, 928), "attention.fc.weight": (928, 2048), "attention.norm.weight": (928,),
+                    "attention.norm.bias": (928,)})
+    m = M.backbone_csa_fc_logit(39, 8, 3)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == want928
+    assert m.after_fc is False and m.attention_type == "csa" and m.K == 3
+    m = M.backbone_ssa_fc_logit(39, 8)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: v for k, v in want928.items() if not k.startswith("compat")}
+    assert m.after_fc is False and m.attention_type == "ssa"
 
 
 def test_g2_self_attention_config1_shapes(golden_dir):
@@ -458,9 +472,14 @@ def test_g10_after_fc_false_against_reference_goldens(golden_dir):
         x = orc.synth_points(rng, (B, 256, N, 1))
         lab = orc.synth_labels(rng, B, N, n_cls)
         nb = orc.synth_points(rng, (B, K + 1, 256, N, 1)) if kind == 1 else None
-        model = CrossShapeAt(n_cls, 256, H, K or None, attention_type="csa" if kind == 1 else "ssa", after_fc=False)
-        missing, unexpected = model.load_state_dict(p, strict=False)
-        assert not unexpected and all(k.startswith("fc_1.") for k in missing)
+        if i == 1:          # through the factory: the 928-wide attention is never on the path (csa_models.py:197-202)
+            from csn_amd.csa_models import backbone_csa_fc_logit
+            model = backbone_csa_fc_logit(n_cls, H, K)
+            model.load_state_dict({k: v for k, v in p.items() if not k.startswith("attention.")}, strict=False)
+        else:
+            model = CrossShapeAt(n_cls, 256, H, K or None, attention_type="csa" if kind == 1 else "ssa", after_fc=False)
+            missing, unexpected = model.load_state_dict(p, strict=False)
+            assert not unexpected and all(k.startswith("fc_1.") for k in missing)
         model = model.cuda().eval()
         logits = model(x.cuda(), "train", nb)
         assert tuple(logits.shape) == (B, n_cls, N, 1)

@@ -79,19 +79,23 @@ def test_big_category_graph_maps_candidate_ids_back():
     assert set(tr.reshape(-1).tolist()) <= centres and set(te.reshape(-1).tolist()) <= centres
 
 
-def test_save_knn_graph_cli_writes_the_files_csa_training_reads(tmp_path):
+@pytest.mark.parametrize("testing", [False, True])
+def test_save_knn_graph_cli_writes_the_files_csa_training_reads(tmp_path, monkeypatch, testing):
     """``python -m csn_amd.save_knn_graph`` — the script MID-FC/run_save_knn.py:50 launches and the reference does not ship — run
-    through its main(): feature files on disk in the O-CNN layout (fc_1/*.npy (1, 256, n, 1), point_labels/*.npy), a saved SSA
-    checkpoint, and out come train.npy / test.npy as int64 (S, K+1) tables (csa_training.py:286-290 reads them) that equal what
-    update_knn_graphs builds from the same loaders."""
+    through its main() with EXACTLY the argv the launcher builds (run_save_knn.py:60-72, with and without --testing; the data
+    root comes from CSN_DATAROOT in the reference's <root>/<split>_data_features/<Part> layout, csa_training.py:269-272):
+    feature files on disk in the O-CNN layout (fc_1/*.npy (1, 256, n, 1), point_labels/*.npy), a saved SSA checkpoint, and out
+    come train.npy / test.npy as int64 (S, K+1) tables (csa_training.py:286-290 reads them) that equal what update_knn_graphs
+    builds from the same loaders."""
     from csn_amd import save_knn_graph
     from csn_amd.csa_models import get_model
+    from tests.test_training_host import launcher_argv
     rng = np.random.default_rng(9)
-    n_cls, K, part = 4, 2, "Bottle"
+    n_cls, part = 4, "Bottle"
     root = tmp_path / "data"
     sizes = {"train": [10000, 7000, 10000, 5100, 10000], "test": [10000, 6000]}          # short shapes are wrap-around padded
     for split, ns in sizes.items():
-        d = root / f"{part}_{split}_feats"
+        d = root / f"{split}_data_features" / part
         (d / "fc_1").mkdir(parents=True)
         (d / "point_labels").mkdir()
         for i, n in enumerate(ns):
@@ -99,16 +103,22 @@ def test_save_knn_graph_cli_writes_the_files_csa_training_reads(tmp_path):
             np.save(d / "point_labels" / f"shape_{i:02d}.npy", rng.integers(0, n_cls, size=n))
     torch.manual_seed(1)
     ssa = get_model("ssa", n_cls, 1).cuda().eval()
-    logs = tmp_path / "ssa_logs"
-    logs.mkdir()
-    torch.save(ssa.state_dict(), logs / "trained_layers.pth")                            # csa_training.py:324-326
-    graphs = tmp_path / "graphs"
-    save_knn_graph.main(["--ssa_logs_dir", str(logs), "--graphs_dir", str(graphs), "--partname", part, "--dataroot", str(root),
-                         "--num_classes", str(n_cls), "--K", str(K)])
+    logs = tmp_path / "logs" / "ssa_n_heads_1"
+    (logs / part).mkdir(parents=True)
+    torch.save(ssa.state_dict(), logs / part / "trained_layers.pth")                     # csa_training.py:324-326
+    monkeypatch.setenv(save_knn_graph.DATAROOT_ENV, str(root))
+    monkeypatch.setattr(save_knn_graph, "TESTING_SHAPES", 3)
+    save_knn_graph.main(launcher_argv(str(logs), part, num_workers=0, num_classes=n_cls, testing=testing))
+    graphs = logs / "knn_graphs" / part
     tr, te = np.load(graphs / "train.npy"), np.load(graphs / "test.npy")
-    assert tr.dtype == np.int64 and te.dtype == np.int64 and tr.shape == (5, K + 1) and te.shape == (2, K + 1)
-    assert (tr[:, 0] == np.arange(5)).all() and tr.min() >= 0 and tr.max() < 5 and te.max() < 5
-    train_ld = DataLoader(D.FeaturesDataset(str(root / f"{part}_train_feats")), 1, shuffle=False)
-    test_ld = DataLoader(D.FeaturesDataset(str(root / f"{part}_test_feats")), 1, shuffle=False)
+    n_tr = 3 if testing else 5
+    K = n_tr - 1                                                                          # the launcher's K = 10, cut to the candidates
+    assert tr.dtype == np.int64 and te.dtype == np.int64 and tr.shape == (n_tr, K + 1) and te.shape == (2, K + 1)
+    assert (tr[:, 0] == np.arange(n_tr)).all() and tr.min() >= 0 and tr.max() < n_tr and te.max() < n_tr
+    train_set = D.FeaturesDataset(str(root / "train_data_features" / part))
+    if testing:
+        train_set = torch.utils.data.Subset(train_set, range(3))
+    train_ld = DataLoader(train_set, 1, shuffle=False)
+    test_ld = DataLoader(D.FeaturesDataset(str(root / "test_data_features" / part)), 1, shuffle=False)
     tr2, te2 = T.update_knn_graphs(ssa, train_ld, test_ld, K, torch.device("cuda"))
     assert np.array_equal(tr, tr2) and np.array_equal(te, te2)

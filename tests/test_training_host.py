@@ -250,3 +250,44 @@ def test_head_width_generalisation_host_side():
     geo = MultiHeadAttention(3, 96, 48, 80, block=100, n_blocks=4).geometry()
     assert geo.d_head == 96 and abs(geo.temperature - 48 ** 0.5) < 1e-12
     assert MultiHeadAttention(1, 256, 256, 256).geometry().temperature == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------
+# save_knn_graph CLI: the argv of its only caller (MID-FC/run_save_knn.py:60-72)
+# ---------------------------------------------------------------------------------------------------------
+def launcher_argv(ssa_logs_dir, name, n_heads=1, num_workers=3, batch_size=1, num_classes=9, testing=False):
+    """The command words run_save_knn.py:60-72 builds for one category (its defaults: :31-38), after the script name."""
+    words = [f"--ssa_logs_dir={ssa_logs_dir}/{name}", f"--graphs_dir={ssa_logs_dir}/knn_graphs/{name}", f"--partname={name}",
+             f"--n_heads={n_heads}", f"--num_workers={num_workers}", f"--batch_size={batch_size}", f"--num_classes={num_classes}"]
+    return words + (["--testing"] if testing else [])
+
+
+@pytest.mark.parametrize("testing", [False, True])
+def test_save_knn_graph_cli_takes_the_launchers_argv(testing, monkeypatch, tmp_path):
+    from csn_amd import save_knn_graph as S
+    monkeypatch.delenv(S.DATAROOT_ENV, raising=False)
+    args = S.parse_args(launcher_argv("logs/ssa_n_heads_1", "Bottle", testing=testing))
+    assert args.ssa_logs_dir == "logs/ssa_n_heads_1/Bottle" and args.graphs_dir == "logs/ssa_n_heads_1/knn_graphs/Bottle"
+    assert (args.partname, args.n_heads, args.num_workers, args.batch_size, args.num_classes) == ("Bottle", 1, 3, 1, 9)
+    assert args.testing is testing and args.K == 10 and args.dataroot is None
+    with pytest.raises(SystemExit, match="CSN_DATAROOT"):               # no root anywhere: a clear message, not a traceback
+        S.main(launcher_argv("logs/ssa_n_heads_1", "Bottle", testing=testing))
+    monkeypatch.setenv(S.DATAROOT_ENV, str(tmp_path))
+    assert S.parse_args(launcher_argv("l", "Bed")).dataroot == str(tmp_path)
+    assert S.parse_args(launcher_argv("l", "Bed") + ["--dataroot=/x"]).dataroot == "/x"
+
+
+def test_save_knn_graph_cli_finds_the_reference_data_layout(tmp_path):
+    """csa_training.py:269-272: <root>/{train,test}_data_features/<Part>; the earlier <Part>_<split>_feats as a fallback."""
+    from csn_amd import save_knn_graph as S
+    ref = tmp_path / "train_data_features" / "Bed" / "fc_1"
+    ref.mkdir(parents=True)
+    old = tmp_path / "Bed_test_feats" / "fc_1"
+    old.mkdir(parents=True)
+    assert S.split_root(str(tmp_path), "train", "Bed") == str(ref.parent)
+    assert S.split_root(str(tmp_path), "test", "Bed") == str(old.parent)
+    with pytest.raises(FileNotFoundError, match="Vase"):
+        S.split_root(str(tmp_path), "train", "Vase")
+    assert S.checkpoint_path(str(tmp_path)) == str(tmp_path / "trained_layers.pth")      # utils.py:29-31
+    (tmp_path / "w.pth").write_bytes(b"")
+    assert S.checkpoint_path(str(tmp_path / "w.pth")) == str(tmp_path / "w.pth")
