@@ -19,6 +19,16 @@
 #include "csn_common.h"
 #include "csn_kernels.h"
 
+#ifdef CSN_DKV_STAMPS
+// -DCSN_DKV_STAMPS: development build that records s_memtime at the phase boundaries of tiles 4..7 of 1024 work-groups of the
+// d = 96 one-plane instances (scripts/dkv_stamps.py)
+__device__ unsigned long long csn_dkv_dbg[1024 * 8 * 4 * 8];
+extern "C" __attribute__((visibility("default"))) int csn_dkv_debug_read(void* dst, long long bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(csn_dkv_dbg), bytes); }
+#define DSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (dbg_on) dstamps[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DSTAMP(i)
+#endif
+
 namespace {
 
 constexpr int QT = 32;               // queries per streamed tile
@@ -74,8 +84,14 @@ CSN_DEVINL f32x4v mma16(s16x8 ah, s16x8 al, s16x8 bh, s16x8 bl, f32x4v c) {
 #define CSN_DKV_NARROW 1
 #endif
 constexpr int csn_dkv_waves(int npl, int dt) { return (npl == 1 && dt <= 3) ? CSN_DKV_NW : 8; }
-constexpr bool csn_dkv_narrow(int npl, int dt) { return CSN_DKV_NARROW && npl == 1 && dt <= 2; }
-template <typename PR, int DT, int QF = 0, int NW = 8>
+#ifndef CSN_DKV_NARROW_MAXDT
+#define CSN_DKV_NARROW_MAXDT 2
+#endif
+constexpr bool csn_dkv_narrow(int npl, int dt) { return CSN_DKV_NARROW && npl == 1 && dt <= CSN_DKV_NARROW_MAXDT; }
+// DR: dropout live (a compile-time property since round 6: as a run-time flag every element of the pointwise segment carried its
+// own wave-uniform branch around the keep decision — sixteen branch instructions per tile in a loop that is bound by the
+// number of instructions a wave issues)
+template <typename PR, int DT, int QF = 0, int NW = 8, bool DR = true>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT) ? 4 : 2)) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) {
   constexpr bool NARROW = csn_dkv_narrow(PR::NPL, DT);
   static_assert(QF == 0 || PR::NPL == 1, "16-bit activation maps: the one-plane mode");
@@ -86,12 +102,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
   constexpr int D = 32 * DT;
   constexpr int PLANE = D * QT + 32;                    // hi and lo planes 64 bytes out of phase (store banks, attn_bf16x3.hip)
   constexpr int NP_T = (D * 8 + NT - 1) / NT;           // 16-byte pieces of a [D][32] fp32 tile per thread
-  constexpr int IMG_EL = 4 * 2 * NPL * PLANE;           // [image: QA, OA, QB, OB][stage][plane]
+  constexpr int NST = 2;                                // image stages
+  constexpr int IMG_EL = 4 * NST * NPL * PLANE;         // [image: QA, OA, QB, OB][stage][plane]
   constexpr int STAGE_EL = D * KW * 2;                  // prologue / epilogue: a [D][KW keys] fp32 block
   constexpr int BUF_EL = IMG_EL > STAGE_EL ? IMG_EL : STAGE_EL;
   static_assert(2 * BUF_EL + 3 * 64 * 4 <= 160 * 1024, "LDS budget of one CU");
   __shared__ __attribute__((aligned(16))) short tiles[BUF_EL + 3 * 64 * 2];
-  auto image = [&](int img, int st, int pl) -> short* { return tiles + ((img * 2 + st) * NPL + pl) * PLANE; };
+  auto image = [&](int img, int st, int pl) -> short* { return tiles + ((img * NST + st) * NPL + pl) * PLANE; };
   float* rowc = reinterpret_cast<float*>(tiles + BUF_EL);          // [stage of 3][lse2: 32 | delta: 32]
   float* xbuf = reinterpret_cast<float*>(tiles);
 
@@ -194,7 +211,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
 #pragma unroll
   for (int c = 0; c < D / 16; ++c) { dK[c] = f32x4v{0.f, 0.f, 0.f, 0.f}; dV[c] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
 
-  const bool drop = p.dropout_p > 0.f;
+  constexpr bool drop = DR;
   const unsigned thr16 = csn_drop_threshold16(p.dropout_p);
   const float keep_scale = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
   const int mp = p.T > Tp ? p.T : Tp;                               // mask pitch of the forward (queries per block vs score pitch)
@@ -225,37 +242,38 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
   // (q_fmt == 2: fp16 bits of a math-mode-3 forward, converted to bf16 at the commit)
   constexpr int q_fmt = QF, o_fmt = QF ? 1 : 0;
   constexpr int q_es = q_fmt ? 2 : 4, o_es = o_fmt ? 2 : 4;
-  const char* f_q = nullptr; const char* f_o = nullptr; const float* f_lse = nullptr; const float* f_dl = nullptr;
+  // Everything that depends on the item — the four buffer descriptors (windows: the whole block of this item's maps) — is
+  // built when the item changes; a tile adds one scalar offset (round 6: the per-tile descriptors were ~40 scalar instructions
+  // of a loop whose pace is the instruction count).  The hardware range check does not see scalar offsets, so queries beyond
+  // the block end are switched off in the lane offset; the row constants need no predicate (their lane offset carries the tile).
+  csn_rsrc_t Qr_it, Or_it, Lr_it, Dr_it;
   auto fetch_item = [&]() {
     const int e = p.eval_ids ? p.eval_ids[f_it] : f_it;
     const long long qs = p.q_index ? p.q_index[e] : e;
     const long long head_off = (long long)hd * D * ld + (long long)blk * p.T;
     const long long stat = ((long long)e * p.H + hd) * ((long long)p.n_blocks * p.T) + (long long)blk * p.T;
-    f_q = reinterpret_cast<const char*>(p.q) + (qs * p.q_shape_stride + head_off) * q_es;
-    f_o = reinterpret_cast<const char*>(p.dctx) + ((long long)e * p.ctx_eval_stride + head_off) * o_es;
-    f_lse = p.lse + stat;
-    f_dl = p.delta + stat;
+    const long long win = (long long)(D - 1) * ld + T;                                // elements of a [D][T] window of pitch ld
+    Qr_it = csn_make_rsrc(reinterpret_cast<const char*>(p.q) + (qs * p.q_shape_stride + head_off) * q_es, win * q_es);
+    Or_it = csn_make_rsrc(reinterpret_cast<const char*>(p.dctx) + ((long long)e * p.ctx_eval_stride + head_off) * o_es, win * o_es);
+    Lr_it = csn_make_rsrc(p.lse + stat, (long long)T * 4);
+    Dr_it = csn_make_rsrc(p.delta + stat, (long long)T * 4);
   };
   fetch_item();
+  const unsigned t_off = (unsigned)(t_row * ld + 4 * t_c);                             // (elements) this thread's piece inside a tile
   auto fetch = [&]() {
-    const int nq = T - f_qt * QT;                                   // queries left in the block from this tile on
-    const long long win = (long long)(D - 1) * ld + (nq < QT ? nq : QT);          // elements
-    const csn_rsrc_t Qr = csn_make_rsrc(f_q + (long long)f_qt * QT * q_es, win * q_es);
-    const csn_rsrc_t Or = csn_make_rsrc(f_o + (long long)f_qt * QT * o_es, win * o_es);
-    const unsigned off = (4 * t_c) < nq ? (unsigned)(t_row * ld + 4 * t_c) : CSN_OOB;      // (elements) T % 4 == 0: a piece is all in or all out
+    const int q_first = f_qt * QT;                                                     // first query of the tile inside the block
+    const unsigned off = (q_first + 4 * t_c) < T ? t_off : CSN_OOB;                   // T % 4 == 0: a piece is all in or all out
 #pragma unroll
     for (int i = 0; i < NP_T; ++i) {
       const unsigned o = ((CSN_DKV_ABL & 1) || (i == NP_T - 1 && !t_last_ok)) ? CSN_OOB : off;
-      if constexpr (q_fmt != 0) hQ[i] = csn_bload2(Qr, o == CSN_OOB ? o : o * 2u, (unsigned)(RPT * i * ld) * 2u);
-      else gQ[i] = csn_bload4(Qr, o == CSN_OOB ? o : o * 4u, (unsigned)(RPT * i * ld) * 4u);
-      if constexpr (o_fmt != 0) hO[i] = csn_bload2(Or, o == CSN_OOB ? o : o * 2u, (unsigned)(RPT * i * ld) * 2u);
-      else gO[i] = csn_bload4(Or, o == CSN_OOB ? o : o * 4u, (unsigned)(RPT * i * ld) * 4u);
+      if constexpr (q_fmt != 0) hQ[i] = csn_bload2(Qr_it, o == CSN_OOB ? o : o * 2u, (unsigned)(q_first + RPT * i * ld) * 2u);
+      else gQ[i] = csn_bload4(Qr_it, o == CSN_OOB ? o : o * 4u, (unsigned)(q_first + RPT * i * ld) * 4u);
+      if constexpr (o_fmt != 0) hO[i] = csn_bload2(Or_it, o == CSN_OOB ? o : o * 2u, (unsigned)(q_first + RPT * i * ld) * 2u);
+      else gO[i] = csn_bload4(Or_it, o == CSN_OOB ? o : o * 4u, (unsigned)(q_first + RPT * i * ld) * 4u);
     }
-    if (wave0) {
-      const long long rwin = (nq < QT ? nq : QT) * 4;
-      const csn_rsrc_t Lr = csn_make_rsrc(f_lse + f_qt * QT, rwin), Dr = csn_make_rsrc(f_dl + f_qt * QT, rwin);
-      gca = csn_bload(Lr, lane < 32 ? (unsigned)lane * 4u : CSN_OOB);                  // (queries beyond the block: 0)
-      gcb = csn_bload(Dr, lane >= 32 ? (unsigned)(lane - 32) * 4u : CSN_OOB);
+    if (wave0) {                                                                       // (queries beyond the block: 0, by the range check)
+      gca = csn_bload(Lr_it, lane < 32 ? (unsigned)(q_first + lane) * 4u : CSN_OOB);
+      gcb = csn_bload(Dr_it, lane >= 32 ? (unsigned)(q_first + lane - 32) * 4u : CSN_OOB);
     }
     if (++f_qt == nqt) {                                            // next tile: the first of the next item (if any)
       f_qt = 0;
@@ -307,10 +325,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
   const int b_pos = lq * QT + 8 * (kq ^ ((-((lq >> 2) & 3)) & 3));
 
   // Both products of a phase run in ONE loop (the S and dP accumulators, the dV and dK accumulators are independent): the LDS
-  // fragment reads of the two images run PD steps ahead of the matrix instructions in one register ring each, and a phase
+  // fragment reads of the two images run PD1 / PD2 steps ahead of the matrix instructions in one register ring each, and a phase
   // pays the LDS latency once.  At the narrow head widths a phase is only 2 x D/16 matrix instructions, so what a tile costs
   // is the number of such exposed latencies, not the matrix work.
-  constexpr int PD = NARROW ? 1 : 2;
+  // Ring depths.  Round 6 measured deeper rings on the one-plane instances (-DCSN_DKV_PD1=4 -DCSN_DKV_PD2=6: ALL of phase 2's
+  // fragments requested before the pointwise segment, 203 registers at d = 96): phase 2 655 -> 584 cycles by the stamps, the
+  // pointwise segment behind the twelve reads 436 -> 655, the config-5 step +-0 (profiles/r6_dkv_kernel.txt) — the phases are
+  // not waiting for LDS, the SIMD's two waves are waiting for each other's vector and matrix issue.  Two deep stays.
+#ifndef CSN_DKV_PD1
+#define CSN_DKV_PD1 2
+#endif
+#ifndef CSN_DKV_PD2
+#define CSN_DKV_PD2 2
+#endif
+  constexpr int PD1 = NARROW ? 1 : (NPL == 1 ? CSN_DKV_PD1 : 2);
+  constexpr int PD2 = NARROW ? 1 : (NPL == 1 ? CSN_DKV_PD2 : 2);
   // phase 1: S[q][key] = sum_d Qs^T[d][q] K^T[d][key]  and  dP[q][key] = sum_d dO^T[d][q] V^T[d][key]   (images 0 and 1)
   auto phase1 = [&](int st, f32x4v& S0, f32x4v& S1, f32x4v& P0, f32x4v& P1) {
     S0 = f32x4v{0.f, 0.f, 0.f, 0.f}; S1 = S0; P0 = S0; P1 = S0;
@@ -319,7 +348,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
     const short* __restrict__ oh_ = image(1, st, 0);
     const short* __restrict__ ol_ = image(1, st, NPL - 1);
     constexpr int NH = 2 * DT;
-    s16x8 aqh[PD], aql[PD], aoh[PD], aol[PD];
+    s16x8 aqh[PD1], aql[PD1], aoh[PD1], aol[PD1];
     auto rd = [&](const short* th, const short* tl, int h, s16x8& fh, s16x8& fl) {
       const int o = 32 * (h >> 1) * QT + ((h & 1) ? a_pos1 : a_pos0);
       fh = join8(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(th + o)),
@@ -331,14 +360,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
     };
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int h = 0; h < PD && h < NH; ++h) { rd(qh_, ql_, h, aqh[h], aql[h]); rd(oh_, ol_, h, aoh[h], aol[h]); }
-    __builtin_amdgcn_sched_group_barrier(0x100, 4 * NPL * (PD < NH ? PD : NH), 0);
+    for (int h = 0; h < PD1 && h < NH; ++h) { rd(qh_, ql_, h, aqh[h], aql[h]); rd(oh_, ol_, h, aoh[h], aol[h]); }
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 * NPL * (PD1 < NH ? PD1 : NH), 0);
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
-      const int r = h % PD, sidx = h >> 1;
+      const int r = h % PD1, sidx = h >> 1;
       if (h & 1) { S1 = mma16<PR>(aqh[r], aql[r], Kh[sidx], Kl[sidx], S1); P1 = mma16<PR>(aoh[r], aol[r], Vh[sidx], Vl[sidx], P1); }
       else { S0 = mma16<PR>(aqh[r], aql[r], Kh[sidx], Kl[sidx], S0); P0 = mma16<PR>(aoh[r], aol[r], Vh[sidx], Vl[sidx], P0); }
-      if (h + PD < NH) { rd(qh_, ql_, h + PD, aqh[r], aql[r]); rd(oh_, ol_, h + PD, aoh[r], aol[r]); }
+      if (h + PD1 < NH) { rd(qh_, ql_, h + PD1, aqh[r], aql[r]); rd(oh_, ol_, h + PD1, aoh[r], aol[r]); }
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * PR::NT, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 4 * NPL, 0);
     }
@@ -347,13 +376,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
   // phase 2: dV^T[c][key] += sum_q dO^T[c][q] P_drop[q][key]  and  dK^T[c][key] += sum_q Qs^T[c][q] dS[q][key]   (images 3 and 2).
   // Its first fragment reads do not depend on the pointwise segment: they are issued before it (phase2_ahead) and land under it.
   constexpr int NC = D / 16;
-  s16x8 voh[PD], vol[PD], vqh[PD], vql[PD];
+  s16x8 voh[PD2], vol[PD2], vqh[PD2], vql[PD2];
   const lds_s16* tOh = nullptr; const lds_s16* tQh = nullptr;
   auto phase2_ahead = [&](int st) {
     tOh = opaque_lds(image(3, st, 0) + b_pos);
     tQh = opaque_lds(image(2, st, 0) + b_pos);
 #pragma unroll
-    for (int c = 0; c < PD && c < NC; ++c) {
+    for (int c = 0; c < PD2 && c < NC; ++c) {
       voh[c] = *reinterpret_cast<const lds_s16x8*>(tOh + c * 16 * QT);
       vol[c] = *reinterpret_cast<const lds_s16x8*>(tOh + (NPL - 1) * PLANE + c * 16 * QT);
       vqh[c] = *reinterpret_cast<const lds_s16x8*>(tQh + c * 16 * QT);
@@ -364,14 +393,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const int r = c % PD;
+      const int r = c % PD2;
       dV[c] = mma16<PR>(voh[r], vol[r], ph, pl, dV[c]);
       dK[c] = mma16<PR>(vqh[r], vql[r], dh, dl, dK[c]);
-      if (c + PD < NC) {
-        voh[r] = *reinterpret_cast<const lds_s16x8*>(tOh + (c + PD) * 16 * QT);
-        vol[r] = *reinterpret_cast<const lds_s16x8*>(tOh + (NPL - 1) * PLANE + (c + PD) * 16 * QT);
-        vqh[r] = *reinterpret_cast<const lds_s16x8*>(tQh + (c + PD) * 16 * QT);
-        vql[r] = *reinterpret_cast<const lds_s16x8*>(tQh + (NPL - 1) * PLANE + (c + PD) * 16 * QT);
+      if (c + PD2 < NC) {
+        voh[r] = *reinterpret_cast<const lds_s16x8*>(tOh + (c + PD2) * 16 * QT);
+        vol[r] = *reinterpret_cast<const lds_s16x8*>(tOh + (NPL - 1) * PLANE + (c + PD2) * 16 * QT);
+        vqh[r] = *reinterpret_cast<const lds_s16x8*>(tQh + (c + PD2) * 16 * QT);
+        vql[r] = *reinterpret_cast<const lds_s16x8*>(tQh + (NPL - 1) * PLANE + (c + PD2) * 16 * QT);
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 2 * PR::NT, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * NPL, 0);
@@ -379,39 +408,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  // images: 0 = Qs k-major, 1 = dO k-major, 2 = Qs query-contiguous, 3 = dO query-contiguous
-  fetch();
-  commit_kmajor(0); commit_contig(0); commit_rowc(0);
-  if (n_steps > 1) fetch();
-  __syncthreads();
-  if (late) __syncthreads();
-
-  // Two barrier segments per tile; waves 4..7 run one segment behind.  The k-major images are read in segment 1 and rewritten
-  // in segment 1 of the tile before; the query-contiguous images are read in segment 2 and rewritten in
-  // segment 2 of the tile before (the hazard analysis of attn_bf16x3.hip with its A / B stages).  Tile t + 2 is requested in
-  // segment 1 of tile t, right after the pieces of tile t + 1 have been split and committed — a whole tile of cover for the
-  // HBM latency, which the short matrix phases of the narrow head widths cannot give.
-  f32x4v S0, S1, P0, P1;
-  int c_it = it0, c_qt = 0;                                         // (item, query tile) of the products
-  int rc_cur = 0;
-  unsigned salt = 0;
-  for (int step = 0; step < n_steps; ++step) {
-    const int cur = step & 1, nxt = cur ^ 1;
-    const int rc_nxt = rc_cur == 2 ? 0 : rc_cur + 1;                // stage of the row constants of this tile / the next
-    const bool more = step + 1 < n_steps;
-    if (c_qt == 0) {                                                // a new item: its mask salt (scalar unit)
-      const int e = p.eval_ids ? p.eval_ids[c_it] : c_it;
-      salt = csn_block_salt((unsigned long long)(((long long)e * p.H + hd) * p.n_blocks + blk), p.seed);
-    }
-    if (!(CSN_DKV_ABL & 8)) phase1(cur, S0, S1, P0, P1);                                    // S = Qs K^T (the forward's product, roles transposed), dP = dO V^T
-    if (more) {
-      commit_kmajor(nxt);                                           // (splits the pieces: the fp32 registers are free again)
-      commit_rowc(rc_nxt);
-      if (step + 2 < n_steps) fetch();                              // a whole tile ahead of its first use
-    }
-    if (!CSN_DKV_LOCKSTEP) __syncthreads();
-    if constexpr (!NARROW) phase2_ahead(cur);
-    // ---- pointwise: this lane's key against queries qt * 32 + 8 kq .. + 7 --------------------------------------------
+  // ---- pointwise: this lane's key against queries qt * 32 + 8 kq .. + 7 of tile c_qt (row constants in ring stage rc_cur) ----
+  s16x8 ph, pl, dh, dl;                                             // P_drop and dS of the tile as phase-2 B fragments
+  f32x4v S0, S1, P0, P1;                                            // phase 1's accumulators: S and dP of the tile
+  auto pointwise = [&](int c_qt, unsigned salt, int rc_cur) __attribute__((always_inline)) {
     const f32x4 l0 = *reinterpret_cast<const f32x4*>(&rowc[rc_cur * 64 + 8 * kq]), l1 = *reinterpret_cast<const f32x4*>(&rowc[rc_cur * 64 + 8 * kq + 4]);
     const f32x4 d0 = *reinterpret_cast<const f32x4*>(&rowc[rc_cur * 64 + 32 + 8 * kq]), d1 = *reinterpret_cast<const f32x4*>(&rowc[rc_cur * 64 + 32 + 8 * kq + 4]);
     const float lse2[8] = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
@@ -419,8 +419,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
     const float sv[8] = {S0[0], S0[1], S0[2], S0[3], S1[0], S1[1], S1[2], S1[3]};
     const float dp[8] = {P0[0], P0[1], P0[2], P0[3], P1[0], P1[1], P1[2], P1[3]};
     const int q0 = c_qt * QT + 8 * kq;                              // first of this lane's 8 queries (inside the block)
-    const int nv = T - q0;                                          // valid queries among them (only the last tile has fewer than 8)
-    const bool last_tile = c_qt == nqt - 1;
+    // Queries beyond the block end (the last tile) need no masking: their rows of Qs and dO are zeros in the images (switched
+    // off in the request) and so are their row constants, hence S = dP = delta = 0, P = exp2(0 - 0) = 1 is finite, dS =
+    // P (0 - 0) = 0 adds nothing to dK, and P_drop meets a zero row of dO in dV.  (Round 6: the masks were 24 vector
+    // instructions in every tile.)
     float pd[8], ds[8];
     // One mixer round decides the two keys of a pair (low / high 16 bits), and the two keys of a pair sit on NEIGHBOURING lanes
     // here: the even lane hashes queries 0..3, the odd lane 4..7, and a quad swap hands each the other's four — half the
@@ -438,15 +440,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       if (CSN_DKV_ABL & 2) { pd[r] = sv[r]; ds[r] = dp[r]; continue; }
-      float pv = __builtin_amdgcn_exp2f(fmaf(sv[r], LOG2E, -lse2[r]));       // softmax probability (csa_models.py:141)
-      if (last_tile) pv = r < nv ? pv : 0.f;                                 // queries beyond the block end (wave-uniform branch)
+      const float pv = __builtin_amdgcn_exp2f(fmaf(sv[r], LOG2E, -lse2[r]));  // softmax probability (csa_models.py:141)
       bool keep = true;
       if (drop) keep = (key_odd ? (hsh[r] >> 16) : (hsh[r] & 0xffffu)) >= thr16;
       const float md = keep ? keep_scale : 0.f;                              // d P_drop / d P
       pd[r] = pv * md;                                                       // what dV contracts: the dropped probabilities
-      ds[r] = pv * (dp[r] * md - dlt[r]);                                    // d softmax
+      ds[r] = pv * fmaf(dp[r], md, -dlt[r]);                                 // d softmax (the fused form, written out: no contraction choice left to the compiler)
     }
-    s16x8 ph, pl, dh, dl;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       ph[r] = to16<PR::HALF>(pd[r]);
@@ -454,13 +454,63 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
       dh[r] = to16<PR::HALF>(ds[r]);
       dl[r] = PR::NT == 3 ? to16<PR::HALF>(ds[r] - from16<PR::HALF>(dh[r])) : dh[r];
     }
+  };
+
+  // images: 0 = Qs k-major, 1 = dO k-major, 2 = Qs query-contiguous, 3 = dO query-contiguous
+  fetch();
+  commit_kmajor(0); commit_contig(0); commit_rowc(0);
+  if (n_steps > 1) fetch();
+  __syncthreads();
+  if (late) __syncthreads();
+
+  // Two barrier segments per tile; waves 4..7 run one segment behind.  The k-major images are read in segment 1 and rewritten
+  // in segment 1 of the tile before; the query-contiguous images are read in segment 2 and rewritten in
+  // segment 2 of the tile before (the hazard analysis of attn_bf16x3.hip with its A / B stages).  Tile t + 2 is requested in
+  // segment 1 of tile t, right after the pieces of tile t + 1 have been split and committed — a whole tile of cover for the
+  // HBM latency, which the short matrix phases of the narrow head widths cannot give.
+  int c_it = it0, c_qt = 0;                                         // (item, query tile) of the products
+  int rc_cur = 0;
+  unsigned salt = 0;
+  for (int step = 0; step < n_steps; ++step) {
+    const int cur = step & 1, nxt = cur ^ 1;
+    const int rc_nxt = rc_cur == 2 ? 0 : rc_cur + 1;                // stage of the row constants of this tile / the next
+    const bool more = step + 1 < n_steps;
+    if (c_qt == 0) {                                                // a new item: its mask salt (scalar unit)
+      const int e = p.eval_ids ? p.eval_ids[c_it] : c_it;
+      salt = csn_block_salt((unsigned long long)(((long long)e * p.H + hd) * p.n_blocks + blk), p.seed);
+    }
+#ifdef CSN_DKV_STAMPS
+    unsigned long long dstamps[8];
+    const bool dbg_on = DT == 3 && PR::NPL == 1 && blockIdx.x >= 2048 && blockIdx.x < 3072 && step >= 4 && step < 8;
+#endif
+    DSTAMP(0);
+    if (!(CSN_DKV_ABL & 8)) phase1(cur, S0, S1, P0, P1);                                    // S = Qs K^T (the forward's product, roles transposed), dP = dO V^T
+    DSTAMP(1);
+    if (more) {
+      commit_kmajor(nxt);                                           // (splits the pieces: the fp32 registers are free again)
+      commit_rowc(rc_nxt);
+      if (step + 2 < n_steps) fetch();                              // a whole tile ahead of its first use
+    }
+    DSTAMP(2);
+    if (!CSN_DKV_LOCKSTEP) __syncthreads();
+    DSTAMP(3);
+    if constexpr (!NARROW) phase2_ahead(cur);
+    pointwise(c_qt, salt, rc_cur);
+    DSTAMP(4);
     if constexpr (NARROW) phase2_ahead(cur);                         // (register diet: nothing of phase 2 lives across the pointwise segment)
     if (!(CSN_DKV_ABL & 4)) phase2(ph, pl, dh, dl);                                         // dV^T += dO^T P_drop,  dK^T += Qs^T dS
     else { dV[0][0] += from16<PR::HALF>(ph[0]) + from16<PR::HALF>(ph[7]); dK[0][0] += from16<PR::HALF>(dh[0]) + from16<PR::HALF>(dh[7]); }
+    DSTAMP(5);
     if (more) commit_contig(nxt);
     if (++c_qt == nqt) { c_qt = 0; ++c_it; }
     rc_cur = rc_nxt;
+    DSTAMP(6);
     __syncthreads();
+    DSTAMP(7);
+#ifdef CSN_DKV_STAMPS
+    if (dbg_on && lane == 0)
+      for (int i = 0; i < 8; ++i) csn_dkv_dbg[(((blockIdx.x - 2048) * 8 + wave) * 4 + (step - 4)) * 8 + i] = dstamps[i];
+#endif
   }
   if (!late) __syncthreads();                                       // pairs with the last barrier of the late half
 
@@ -511,7 +561,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
   store_out(dV, p.dv, ovslot);
 }
 
-template <typename PR, int DT>
+template <typename PR, int DT, bool DR>
 int launch_dt(const CsnAttnDkvArgs& a, hipStream_t st) {
   constexpr int NW = csn_dkv_waves(PR::NPL, DT);
   const long long units = (long long)a.n_blocks * a.H * a.n_groups;
@@ -520,12 +570,17 @@ int launch_dt(const CsnAttnDkvArgs& a, hipStream_t st) {
   if (a.q_fmt || a.dctx_fmt) {
     if constexpr (PR::NPL == 1) {
       if (a.dctx_fmt != 1) return -1;
-      if (a.q_fmt == 1) hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 1, NW>), grid, dim3(64 * NW), 0, st, a);
-      else if (a.q_fmt == 2) hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 2, NW>), grid, dim3(64 * NW), 0, st, a);
+      if (a.q_fmt == 1) hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 1, NW, DR>), grid, dim3(64 * NW), 0, st, a);
+      else if (a.q_fmt == 2) hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 2, NW, DR>), grid, dim3(64 * NW), 0, st, a);
       else return -1;
     } else return -1;
-  } else hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 0, NW>), grid, dim3(64 * NW), 0, st, a);
+  } else hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 0, NW, DR>), grid, dim3(64 * NW), 0, st, a);
   return (int)hipGetLastError();
+}
+
+template <typename PR, int DT>
+int launch_dt(const CsnAttnDkvArgs& a, hipStream_t st) {
+  return a.dropout_p > 0.f ? launch_dt<PR, DT, true>(a, st) : launch_dt<PR, DT, false>(a, st);
 }
 
 template <typename PR>
