@@ -592,11 +592,22 @@ def run(args, ctx):
             # (descriptor reuse / the two-phase order of the N > 1 path, --shapes, --K) have no measured traffic
             same_launch = (B, K) == (CONFIGS[args.config]["B"], CONFIGS[args.config]["K"]) and not reuse and not split_probe
             entry = traffic_tab.get(f"{args.config}/{math}/{which}") if same_launch else None
+            base = "csn_attn_dkv_kernel" if which == "dkv" else "csn_attn_bf16x3_kernel" if fast else "csn_attn_f32_kernel"
+            what = {"bwd": " (fused block attention backward: dP, dS, dQ" + ("; scores recomputed)" if flash else ")"),
+                    "fwd": " (fused block attention forward)",
+                    "dkv": " (key-stationary attention backward: dV, dK from recomputed P, dS)"}[which]
+            # the kernel's NAME comes from the committed kernel-trace statistics of this command where there are any (the name
+            # rocprofv3 prints); the template arguments this run derives from its geometry must be among that name's, in order
+            prof = None
+            if entry and entry.get("kernel"):
+                pn = entry["kernel"]
+                p_args = [t.strip() for t in pn[pn.index("<") + 1:pn.index(">")].split(",")] if "<" in pn else []
+                want, it_ = [t for t in tmpl.strip("<>").split(",")], iter(p_args)
+                prof = {"kernel_stats_avg_ms": entry.get("kernel_stats_avg_ms"), "source": entry.get("kernel_stats_source"),
+                        "name_matches_this_run": pn.startswith(base + "<") and all(t in it_ for t in want)}
             r = {"bound": "mfma",
-                 "kernel": ("csn_attn_dkv_kernel" if which == "dkv" else "csn_attn_bf16x3_kernel" if fast else "csn_attn_f32_kernel") + tmpl
-                           + {"bwd": " (fused block attention backward: dP, dS, dQ" + ("; scores recomputed)" if flash else ")"),
-                              "fwd": " (fused block attention forward)",
-                              "dkv": " (key-stationary attention backward: dV, dK from recomputed P, dS)"}[which],
+                 "kernel": (entry["kernel"] if prof and prof["name_matches_this_run"] else base + tmpl) + what,
+                 "profile": prof,
                  "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                  "traffic": entry["bytes_per_launch"] if entry else None,
                  "traffic_source": (entry["source"] + " (rocprofv3 --pmc passes of this command, not measured in this run)") if entry else None,

@@ -10,6 +10,7 @@ for d in gpurun_out/${tag}_c*/; do
   cp $d/hbm.txt profiles/${tag}_pmc_hbm_traffic_${name}.txt
   cp $d/bench.json profiles/${tag}_bench_under_profiler_${name}.json
   cfg=${name%%_*}; math=${name#*_}
-  python3 scripts/traffic_json.py profiles/${tag}_pmc_hbm_traffic_${name}.txt ${cfg#c} $math > /dev/null
+  python3 scripts/traffic_json.py profiles/${tag}_pmc_hbm_traffic_${name}.txt ${cfg#c} $math profiles/${tag}_pmc_hbm_traffic_${name}.txt \
+      profiles/${tag}_kernel_stats_${name}.csv profiles/${tag}_kernel_stats_${name}.csv > /dev/null
 done
 ls profiles | grep "^${tag}_" | wc -l

@@ -1,8 +1,9 @@
 """Every BASELINE.json configuration as a workload THROUGH the drop-in module (SURVEY.md §8d numbering):
    config 2  CSA K = 2, 4 shapes x 10000 points x 256 channels           — against the CPU oracle at full size
-   config 3  CSA K = 3, 32 x 10000 x 256 (the benched step)               — full size, cross-checked between the math modes
-   config 5  CSA K = 4, 8 x 50000 x 96 in 100 blocks of 500               — against the oracle at a size the CPU affords
-                                                                            (2 x 5000 x 96, K = 4) and at full size through
+   config 3  CSA K = 3, 32 x 10000 x 256 (the benched step)               — full size against the CPU oracle (eval-mode arithmetic)
+                                                                            and cross-checked between the math modes (train mode)
+   config 5  CSA K = 4, 8 x 50000 x 96 in 100 blocks of 500               — against the float64 oracle at 2 x 5000 x 96, at full
+                                                                            size against the fp32 oracle, and through
                                                                             size-independent properties
 (config 1 is the CPU plumbing case of tests/test_gpu_module.py::test_g2..., config 4 the 8-GPU run of the driver).  Inputs carry
 per-shape channel offsets (oracle.conditioned_csa_case) so that all 11 gradients are well-conditioned and held to 1e-4."""
@@ -87,6 +88,34 @@ def test_config5_geometry_against_the_oracle(mode):
     got = _step(model, x.cuda(), nb.cuda(), lab.cuda())
     ref = _oracle_step(p, x, nb, lab, torch.float64, d_k=C, d_v=C, block=500, n_blocks=N // 500)
     _check_against_oracle(got, ref)
+
+
+def test_config3_full_size_against_the_oracle():
+    """BASELINE configs[2] at its FULL size — 32 shapes x 10000 points x 256 channels, K = 3, one batch (the reference's B > 1
+    compatibility-row bookkeeping couples the shapes of a batch, csa_models.py:220,227, so a smaller batch is another function)
+    — in the default math mode against the CPU oracle (fp32 closed form, pinned to the reference by G4 / G7; ~30 GB and under a
+    minute of host time): logits 1e-4, loss 1e-5, all 11 gradients 1e-4 relative.  Eval-mode arithmetic (the masks of train mode
+    have no CPU counterpart at this size; test_config3_full_size_benched_step_is_checked holds train mode to the fp32 mode)."""
+    _set_mode(1)
+    B, K, n_cls = 32, 3, 39
+    p, x, nb, lab = orc.conditioned_csa_case(np.random.default_rng(3003), B, K, 1, n_cls, 4.0, 2.0, 1.0)
+    model = _module(p, n_cls, K).eval()
+    got = _step(model, x.cuda(), nb.cuda(), lab.cuda())
+    torch.cuda.empty_cache()
+    _check_against_oracle(got, _oracle_step(p, x, nb, lab, torch.float32))
+
+
+def test_config5_full_size_against_the_oracle():
+    """BASELINE configs[4] at its FULL size — 8 shapes x 50000 points x 96 channels, K = 4, 100 blocks of 500 — in the default math
+    mode against the CPU oracle (fp32 closed form): logits, loss, all 11 gradients."""
+    _set_mode(1)
+    B, K, n_cls, C, N = 8, 4, 39, 96, 50000
+    geo = dict(d_model=C, d_k=C, d_v=C, block=500, n_blocks=N // 500)
+    p, x, nb, lab = orc.conditioned_csa_case(np.random.default_rng(5055), B, K, 1, n_cls, 4.0, 2.0, 1.0, n_points=N, d_model=C, d_k=C)
+    model = _module(p, n_cls, K, **geo).eval()
+    got = _step(model, x.cuda(), nb.cuda(), lab.cuda())
+    torch.cuda.empty_cache()
+    _check_against_oracle(got, _oracle_step(p, x, nb, lab, torch.float32, d_k=C, d_v=C, block=500, n_blocks=N // 500))
 
 
 def _full_size_properties(B, K, N, C, T, seed, tol_loss=1e-5, tol_grad=1e-4):
