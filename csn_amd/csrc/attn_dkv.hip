@@ -5,6 +5,7 @@
 // owns 128 keys of one (key/value slot, head, block): wave w keeps K^T and V^T of its 16 keys as register operands and the
 // dK^T / dV^T accumulators [d][16 keys] of those keys, and the work-group streams 32-query tiles of Qs^T and dO^T through LDS,
 // for every evaluation that reads this slot, one after the other (the group loop of the grouped dK / dV product it replaces).
+// (One plane at d = 96 — BASELINE configs[4]: a wave owns TWO such 16-key groups, the work-group 256 keys; template parameter G.)
 // Per tile and wave, with the key on the matrix instruction's lane:
 //   phase 1   S [q][key] = sum_d Qs^T[d][q] K^T[d][key]        dP[q][key] = sum_d dO^T[d][q] V^T[d][key]
 //   pointwise P = exp2(S log2e - lse2[q]),  mask regenerated from (seed, position),  dS = P (dP mask/(1-p) - delta[q])
@@ -91,13 +92,18 @@ constexpr bool csn_dkv_narrow(int npl, int dt) { return CSN_DKV_NARROW && npl ==
 // DR: dropout live (a compile-time property since round 6: as a run-time flag every element of the pointwise segment carried its
 // own wave-uniform branch around the keep decision — sixteen branch instructions per tile in a loop that is bound by the
 // number of instructions a wave issues)
-template <typename PR, int DT, int QF = 0, int NW = 8, bool DR = true>
+// G: 16-key groups per wave (round 6).  With one group the loop is bound by the instructions a wave issues per tile — requests,
+// commits, barriers, scalar bookkeeping, fragment reads — of which only the pointwise segment and the matrix instructions grow
+// with the keys.  A wave that owns TWO groups (32 keys; the work-group 256) reuses every fragment it reads for both, and the
+// work-group stages each tile for twice the keys: per key half the LDS reads, commits, requests, barriers and scalar work.
+// Costs 88 registers (operands, accumulators, S / dP of the second group): the one-plane d = 96 instance has them.
+template <typename PR, int DT, int QF = 0, int NW = 8, bool DR = true, int G = 1>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT) ? 4 : 2)) void csn_attn_dkv_kernel(CsnAttnDkvArgs p) {
   constexpr bool NARROW = csn_dkv_narrow(PR::NPL, DT);
   static_assert(QF == 0 || PR::NPL == 1, "16-bit activation maps: the one-plane mode");
   static_assert(NW == 8 || NW == 4, "work-groups of 8 or 4 waves");
   constexpr int NT = 64 * NW;                           // threads
-  constexpr int KW = 16 * NW;                           // keys per work-group
+  constexpr int KW = 16 * NW * G;                       // keys per work-group
   constexpr int NPL = PR::NPL;
   constexpr int D = 32 * DT;
   constexpr int PLANE = D * QT + 32;                    // hi and lo planes 64 bytes out of phase (store banks, attn_bf16x3.hip)
@@ -138,15 +144,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
 #endif
   // (-DCSN_DKV_LOCKSTEP=1, measured: all waves in step, ONE barrier per tile instead of two and no stagger)
   const bool late = !CSN_DKV_LOCKSTEP && __builtin_amdgcn_readfirstlane(wave) >= NW / 2;
-  const int col = 16 * wave + lq;                                   // this lane's key inside the chunk of 128
-  const int key = kc * KW + col;                                    // ... inside the block
+  const int col0 = 16 * G * wave + lq;                              // this lane's (first) key inside the chunk; group g: + 16 g
+  const int key0 = kc * KW + col0;                                  // ... inside the block
 
   // ---- register operands K^T, V^T [d][16 keys] from the tile planes -----------------------------------------------
   // The chunk's 128 keys are 4 tiles of [hi 32 | lo 32] (one plane: [32]) per row: 256 NPL bytes.  The work-group fetches the
   // [D][4 tiles] block with 16-byte loads into LDS (the tile buffers are idle) and every lane picks its 16-bit values.
   constexpr int RPC = (KW / 8) * NPL;                               // 16-byte pieces per row of the block
   constexpr int CH_K = (D * RPC + NT - 1) / NT;
-  s16x8 Kh[DT], Kl[DT], Vh[DT], Vl[DT];
+  s16x8 Kh[G][DT], Kl[G][DT], Vh[G][DT], Vl[G][DT];
   {
     const int kld = p.kv_ld;
     const int cc = tid % RPC, crow = tid / RPC;                     // piece column, first row (rows + NT / RPC per pass)
@@ -170,53 +176,61 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
       }
     };
     // element (row, local key kl): tile kl >> 5, position kl & 31 -> piece (kl >> 5) * 4 NPL + plane * 4 + ((kl & 31) >> 3)
-    auto pick = [&](int row, int plane) {
+    auto pick = [&](int row, int plane, int col) {
       const int piece = (col >> 5) * (4 * NPL) + plane * 4 + ((col & 31) >> 3);
       return sbuf[row * (KW * NPL) + (((piece ^ (2 * ((row >> 3) & 3))) << 3) | (col & 7))];
     };
     stage_planes(reinterpret_cast<const short*>(p.k));
     __syncthreads();
 #pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
     for (int s = 0; s < DT; ++s)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        Kh[s][j] = pick(32 * s + 8 * kq + j, 0);
-        Kl[s][j] = pick(32 * s + 8 * kq + j, NPL - 1);
+        Kh[g][s][j] = pick(32 * s + 8 * kq + j, 0, col0 + 16 * g);
+        Kl[g][s][j] = pick(32 * s + 8 * kq + j, NPL - 1, col0 + 16 * g);
       }
     __syncthreads();
     stage_planes(reinterpret_cast<const short*>(p.v));
     __syncthreads();
 #pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
     for (int s = 0; s < DT; ++s)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        Vh[s][j] = pick(32 * s + 8 * kq + j, 0);
-        Vl[s][j] = pick(32 * s + 8 * kq + j, NPL - 1);
+        Vh[g][s][j] = pick(32 * s + 8 * kq + j, 0, col0 + 16 * g);
+        Vl[g][s][j] = pick(32 * s + 8 * kq + j, NPL - 1, col0 + 16 * g);
       }
     __syncthreads();                                                // the staging block becomes the tile images
     if constexpr (NPL == 1 && !PR::HALF) {
       if (p.kv_f16) {                                               // planes of an fp16 forward: this kernel's products are bf16
 #pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
         for (int s = 0; s < DT; ++s)
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            Kh[s][j] = Kl[s][j] = to16<false>(from16<true>(Kh[s][j]));
-            Vh[s][j] = Vl[s][j] = to16<false>(from16<true>(Vh[s][j]));
+            Kh[g][s][j] = Kl[g][s][j] = to16<false>(from16<true>(Kh[g][s][j]));
+            Vh[g][s][j] = Vl[g][s][j] = to16<false>(from16<true>(Vh[g][s][j]));
           }
       }
     }
   }
 
-  f32x4v dK[D / 16], dV[D / 16];
+  f32x4v dK[G][D / 16], dV[G][D / 16];
 #pragma unroll
-  for (int c = 0; c < D / 16; ++c) { dK[c] = f32x4v{0.f, 0.f, 0.f, 0.f}; dV[c] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+  for (int c = 0; c < D / 16; ++c) { dK[g][c] = f32x4v{0.f, 0.f, 0.f, 0.f}; dV[g][c] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
 
   constexpr bool drop = DR;
   const unsigned thr16 = csn_drop_threshold16(p.dropout_p);
   const float keep_scale = drop ? 1.f / (1.f - p.dropout_p) : 1.f;
   const int mp = p.T > Tp ? p.T : Tp;                               // mask pitch of the forward (queries per block vs score pitch)
-  const unsigned pw_key = (unsigned)((key >> 1) * mp);              // pair index of this lane's key: (key / 2) * mp + query
-  const bool key_odd = key & 1;
+  const unsigned pw_key = (unsigned)((key0 >> 1) * mp);             // pair index of this lane's key: (key / 2) * mp + query (group g: + 8 g mp)
+  const bool key_odd = key0 & 1;                                    // (the same in every group: groups are 16 keys apart)
 
   // ---- streamed tiles: fp32 [d][32 queries] -> bf16 hi / lo -> LDS, in both forms (the fp32 staging of attn_bf16x3.hip) ----
   const int t_c = tid & 7, t_row = tid >> 3;                        // 16-byte piece of the row (queries 4 c ..), first row (+ RPT i)
@@ -341,8 +355,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
   constexpr int PD1 = NARROW ? 1 : (NPL == 1 ? CSN_DKV_PD1 : 2);
   constexpr int PD2 = NARROW ? 1 : (NPL == 1 ? CSN_DKV_PD2 : 2);
   // phase 1: S[q][key] = sum_d Qs^T[d][q] K^T[d][key]  and  dP[q][key] = sum_d dO^T[d][q] V^T[d][key]   (images 0 and 1)
-  auto phase1 = [&](int st, f32x4v& S0, f32x4v& S1, f32x4v& P0, f32x4v& P1) {
-    S0 = f32x4v{0.f, 0.f, 0.f, 0.f}; S1 = S0; P0 = S0; P1 = S0;
+  f32x4v S0[G], S1[G], P0[G], P1[G];                                // phase 1's accumulators: S and dP of the tile, per key group
+  auto phase1 = [&](int st) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) { S0[g] = f32x4v{0.f, 0.f, 0.f, 0.f}; S1[g] = S0[g]; P0[g] = S0[g]; P1[g] = S0[g]; }
     const short* __restrict__ qh_ = image(0, st, 0);
     const short* __restrict__ ql_ = image(0, st, NPL - 1);
     const short* __restrict__ oh_ = image(1, st, 0);
@@ -365,10 +381,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int r = h % PD1, sidx = h >> 1;
-      if (h & 1) { S1 = mma16<PR>(aqh[r], aql[r], Kh[sidx], Kl[sidx], S1); P1 = mma16<PR>(aoh[r], aol[r], Vh[sidx], Vl[sidx], P1); }
-      else { S0 = mma16<PR>(aqh[r], aql[r], Kh[sidx], Kl[sidx], S0); P0 = mma16<PR>(aoh[r], aol[r], Vh[sidx], Vl[sidx], P0); }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {                                 // (a fragment serves every key group of the wave)
+        if (h & 1) { S1[g] = mma16<PR>(aqh[r], aql[r], Kh[g][sidx], Kl[g][sidx], S1[g]); P1[g] = mma16<PR>(aoh[r], aol[r], Vh[g][sidx], Vl[g][sidx], P1[g]); }
+        else { S0[g] = mma16<PR>(aqh[r], aql[r], Kh[g][sidx], Kl[g][sidx], S0[g]); P0[g] = mma16<PR>(aoh[r], aol[r], Vh[g][sidx], Vl[g][sidx], P0[g]); }
+      }
       if (h + PD1 < NH) { rd(qh_, ql_, h + PD1, aqh[r], aql[r]); rd(oh_, ol_, h + PD1, aoh[r], aol[r]); }
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * PR::NT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * PR::NT * G, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 4 * NPL, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -389,36 +408,40 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
       vql[c] = *reinterpret_cast<const lds_s16x8*>(tQh + (NPL - 1) * PLANE + c * 16 * QT);
     }
   };
-  auto phase2 = [&](const s16x8& ph, const s16x8& pl, const s16x8& dh, const s16x8& dl) {
+  s16x8 ph[G], pl[G], dh[G], dl[G];                                 // P_drop and dS of the tile as phase-2 B fragments, per key group
+  auto phase2 = [&]() {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       const int r = c % PD2;
-      dV[c] = mma16<PR>(voh[r], vol[r], ph, pl, dV[c]);
-      dK[c] = mma16<PR>(vqh[r], vql[r], dh, dl, dK[c]);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        dV[g][c] = mma16<PR>(voh[r], vol[r], ph[g], pl[g], dV[g][c]);
+        dK[g][c] = mma16<PR>(vqh[r], vql[r], dh[g], dl[g], dK[g][c]);
+      }
       if (c + PD2 < NC) {
         voh[r] = *reinterpret_cast<const lds_s16x8*>(tOh + (c + PD2) * 16 * QT);
         vol[r] = *reinterpret_cast<const lds_s16x8*>(tOh + (NPL - 1) * PLANE + (c + PD2) * 16 * QT);
         vqh[r] = *reinterpret_cast<const lds_s16x8*>(tQh + (c + PD2) * 16 * QT);
         vql[r] = *reinterpret_cast<const lds_s16x8*>(tQh + (NPL - 1) * PLANE + (c + PD2) * 16 * QT);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, 2 * PR::NT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * PR::NT * G, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * NPL, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
 
   // ---- pointwise: this lane's key against queries qt * 32 + 8 kq .. + 7 of tile c_qt (row constants in ring stage rc_cur) ----
-  s16x8 ph, pl, dh, dl;                                             // P_drop and dS of the tile as phase-2 B fragments
-  f32x4v S0, S1, P0, P1;                                            // phase 1's accumulators: S and dP of the tile
   auto pointwise = [&](int c_qt, unsigned salt, int rc_cur) __attribute__((always_inline)) {
     const f32x4 l0 = *reinterpret_cast<const f32x4*>(&rowc[rc_cur * 64 + 8 * kq]), l1 = *reinterpret_cast<const f32x4*>(&rowc[rc_cur * 64 + 8 * kq + 4]);
     const f32x4 d0 = *reinterpret_cast<const f32x4*>(&rowc[rc_cur * 64 + 32 + 8 * kq]), d1 = *reinterpret_cast<const f32x4*>(&rowc[rc_cur * 64 + 32 + 8 * kq + 4]);
     const float lse2[8] = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
     const float dlt[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
-    const float sv[8] = {S0[0], S0[1], S0[2], S0[3], S1[0], S1[1], S1[2], S1[3]};
-    const float dp[8] = {P0[0], P0[1], P0[2], P0[3], P1[0], P1[1], P1[2], P1[3]};
     const int q0 = c_qt * QT + 8 * kq;                              // first of this lane's 8 queries (inside the block)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {                                   // (the row constants serve every key group)
+    const float sv[8] = {S0[g][0], S0[g][1], S0[g][2], S0[g][3], S1[g][0], S1[g][1], S1[g][2], S1[g][3]};
+    const float dp[8] = {P0[g][0], P0[g][1], P0[g][2], P0[g][3], P1[g][0], P1[g][1], P1[g][2], P1[g][3]};
     // Queries beyond the block end (the last tile) need no masking: their rows of Qs and dO are zeros in the images (switched
     // off in the request) and so are their row constants, hence S = dP = delta = 0, P = exp2(0 - 0) = 1 is finite, dS =
     // P (0 - 0) = 0 adds nothing to dK, and P_drop meets a zero row of dO in dV.  (Round 6: the masks were 24 vector
@@ -431,7 +454,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
     if (drop && !(CSN_DKV_ABL & 2)) {
       unsigned mine[4], theirs[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mine[j] = csn_pair_hash(pw_key + (unsigned)(q0 + (key_odd ? 4 : 0) + j), salt);
+      for (int j = 0; j < 4; ++j) mine[j] = csn_pair_hash(pw_key + (unsigned)(8 * g * mp) + (unsigned)(q0 + (key_odd ? 4 : 0) + j), salt);
 #pragma unroll
       for (int j = 0; j < 4; ++j) theirs[j] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine[j], 0xB1, 0xf, 0xf, false);   // lane ^ 1
 #pragma unroll
@@ -449,10 +472,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      ph[r] = to16<PR::HALF>(pd[r]);
-      pl[r] = PR::NT == 3 ? to16<PR::HALF>(pd[r] - from16<PR::HALF>(ph[r])) : ph[r];
-      dh[r] = to16<PR::HALF>(ds[r]);
-      dl[r] = PR::NT == 3 ? to16<PR::HALF>(ds[r] - from16<PR::HALF>(dh[r])) : dh[r];
+      ph[g][r] = to16<PR::HALF>(pd[r]);
+      pl[g][r] = PR::NT == 3 ? to16<PR::HALF>(pd[r] - from16<PR::HALF>(ph[g][r])) : ph[g][r];
+      dh[g][r] = to16<PR::HALF>(ds[r]);
+      dl[g][r] = PR::NT == 3 ? to16<PR::HALF>(ds[r] - from16<PR::HALF>(dh[g][r])) : dh[g][r];
+    }
     }
   };
 
@@ -484,7 +508,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
     const bool dbg_on = DT == 3 && PR::NPL == 1 && blockIdx.x >= 2048 && blockIdx.x < 3072 && step >= 4 && step < 8;
 #endif
     DSTAMP(0);
-    if (!(CSN_DKV_ABL & 8)) phase1(cur, S0, S1, P0, P1);                                    // S = Qs K^T (the forward's product, roles transposed), dP = dO V^T
+    if (!(CSN_DKV_ABL & 8)) phase1(cur);                                    // S = Qs K^T (the forward's product, roles transposed), dP = dO V^T
     DSTAMP(1);
     if (more) {
       commit_kmajor(nxt);                                           // (splits the pieces: the fp32 registers are free again)
@@ -498,8 +522,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
     pointwise(c_qt, salt, rc_cur);
     DSTAMP(4);
     if constexpr (NARROW) phase2_ahead(cur);                         // (register diet: nothing of phase 2 lives across the pointwise segment)
-    if (!(CSN_DKV_ABL & 4)) phase2(ph, pl, dh, dl);                                         // dV^T += dO^T P_drop,  dK^T += Qs^T dS
-    else { dV[0][0] += from16<PR::HALF>(ph[0]) + from16<PR::HALF>(ph[7]); dK[0][0] += from16<PR::HALF>(dh[0]) + from16<PR::HALF>(dh[7]); }
+    if (!(CSN_DKV_ABL & 4)) phase2();                                                       // dV^T += dO^T P_drop,  dK^T += Qs^T dS
+    else { dV[0][0][0] += from16<PR::HALF>(ph[0][0]) + from16<PR::HALF>(ph[0][7]); dK[0][0][0] += from16<PR::HALF>(dh[0][0]) + from16<PR::HALF>(dh[0][7]); }
     DSTAMP(5);
     if (more) commit_contig(nxt);
     if (++c_qt == nqt) { c_qt = 0; ++c_it; }
@@ -514,27 +538,32 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
   }
   if (!late) __syncthreads();                                       // pairs with the last barrier of the late half
 
-  // ---- epilogue: dK^T, dV^T [d][128 keys] leave as 16-byte rows through an LDS transpose ---------------------------------
-  const int cc = tid & (KW / 4 - 1), crow = tid / (KW / 4);       // 4-key chunk of the row, first row (+ 16 t: NT / (KW / 4) = 16)
-  constexpr int CH_T = D / 16;
+  // ---- epilogue: dK^T, dV^T [d][KW keys] leave as 16-byte rows through an LDS transpose ---------------------------------
+  constexpr int RPE = NT / (KW / 4);                                // rows per pass of the work-group's threads (16; two groups: 8)
+  const int cc = tid & (KW / 4 - 1), crow = tid / (KW / 4);       // 4-key chunk of the row, first row (+ RPE t)
+  constexpr int CH_T = D / RPE;
   const long long okslot = p.dk_index ? p.dk_index[e_first] : e_first, ovslot = p.dv_index ? p.dv_index[e_first] : e_first;
   const long long out_off = (long long)hd * D * ld + (long long)blk * p.T + kc * KW;
   const int nk = T - kc * KW;                                       // keys of this chunk that exist
   const long long owin = ((long long)(D - 1) * ld + (nk < KW ? nk : KW)) * 4;
   const unsigned c_off = (4 * cc) < nk ? (unsigned)(crow * ld + 4 * cc) * 4u : CSN_OOB;
-  auto store_out = [&](const f32x4v* OUT, float* base, long long slot) {
+  auto store_out = [&](const f32x4v (*OUT)[D / 16], float* base, long long slot) {
 #pragma unroll
-    for (int c = 0; c < D / 16; ++c)
+    for (int g = 0; g < G; ++g) {
+      const int col = col0 + 16 * g;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * c + 4 * kq + r;
-        xbuf[row * KW + ((((col >> 2) ^ (4 * ((row >> 2) & 1))) << 2) | (col & 3))] = OUT[c][r];
-      }
+      for (int c = 0; c < D / 16; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * c + 4 * kq + r;
+          xbuf[row * KW + ((((col >> 2) ^ (4 * ((row >> 2) & 1))) << 2) | (col & 3))] = OUT[g][c][r];
+        }
+    }
     __syncthreads();
     f32x4 ch[CH_T];
 #pragma unroll
     for (int t = 0; t < CH_T; ++t) {
-      const int row = crow + 16 * t;
+      const int row = crow + RPE * t;
       ch[t] = *reinterpret_cast<const f32x4*>(&xbuf[row * KW + ((cc ^ (4 * ((row >> 2) & 1))) << 2)]);
     }
     if (NPL == 1 && p.out_fmt) {                                    // bf16 gradient maps (16-bit activation maps; written once)
@@ -542,39 +571,47 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : (csn_dkv_narrow(PR::NPL, DT)
 #pragma unroll
       for (int t = 0; t < CH_T; ++t)
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, to16x4<false>(ch[t])), r16, c_off == CSN_OOB ? CSN_OOB : c_off >> 1,
-                                              (unsigned)(16 * t * ld) * 2u, 0);
+                                              (unsigned)(RPE * t * ld) * 2u, 0);
       return;
     }
     const csn_rsrc_t rs = csn_make_rsrc(base + slot * p.dkv_slot_stride + out_off, owin);
     if (p.accumulate) {
       f32x4 prev[CH_T];
 #pragma unroll
-      for (int t = 0; t < CH_T; ++t) prev[t] = csn_bload4(rs, c_off, (unsigned)(16 * t * ld) * 4u);
+      for (int t = 0; t < CH_T; ++t) prev[t] = csn_bload4(rs, c_off, (unsigned)(RPE * t * ld) * 4u);
 #pragma unroll
       for (int t = 0; t < CH_T; ++t) ch[t] += prev[t];
     }
 #pragma unroll
-    for (int t = 0; t < CH_T; ++t) csn_bstore4(ch[t], rs, c_off, (unsigned)(16 * t * ld) * 4u);
+    for (int t = 0; t < CH_T; ++t) csn_bstore4(ch[t], rs, c_off, (unsigned)(RPE * t * ld) * 4u);
   };
   store_out(dK, p.dk, okslot);
   __syncthreads();
   store_out(dV, p.dv, ovslot);
 }
 
+#ifndef CSN_DKV_G2
+#define CSN_DKV_G2 1
+#endif
+// two 16-key groups per wave where the registers allow: one plane, d = 96 (the instances below it run two work-groups per CU
+// under the four-wave bound instead, the ones above it and the two-plane ones have no room)
+constexpr int csn_dkv_groups(int npl, int dt, int nw) { return (CSN_DKV_G2 && npl == 1 && dt == 3 && nw == 8) ? 2 : 1; }
+
 template <typename PR, int DT, bool DR>
 int launch_dt(const CsnAttnDkvArgs& a, hipStream_t st) {
   constexpr int NW = csn_dkv_waves(PR::NPL, DT);
+  constexpr int G = csn_dkv_groups(PR::NPL, DT, NW);
   const long long units = (long long)a.n_blocks * a.H * a.n_groups;
-  const int KC = (a.T + 16 * NW - 1) / (16 * NW);
+  const int KC = (a.T + 16 * NW * G - 1) / (16 * NW * G);
   dim3 grid((unsigned)(((units + 7) / 8) * 8 * KC));
   if (a.q_fmt || a.dctx_fmt) {
     if constexpr (PR::NPL == 1) {
       if (a.dctx_fmt != 1) return -1;
-      if (a.q_fmt == 1) hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 1, NW, DR>), grid, dim3(64 * NW), 0, st, a);
-      else if (a.q_fmt == 2) hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 2, NW, DR>), grid, dim3(64 * NW), 0, st, a);
+      if (a.q_fmt == 1) hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 1, NW, DR, G>), grid, dim3(64 * NW), 0, st, a);
+      else if (a.q_fmt == 2) hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 2, NW, DR, G>), grid, dim3(64 * NW), 0, st, a);
       else return -1;
     } else return -1;
-  } else hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 0, NW, DR>), grid, dim3(64 * NW), 0, st, a);
+  } else hipLaunchKernelGGL((csn_attn_dkv_kernel<PR, DT, 0, NW, DR, G>), grid, dim3(64 * NW), 0, st, a);
   return (int)hipGetLastError();
 }
 

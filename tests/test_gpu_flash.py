@@ -79,6 +79,10 @@ CASES = [
     (2, 2, 3, 1, 256, 500, 2, 0.1),
     (2, 3, 5, 2, 64, 100, 3, 0.0),
     (2, 2, 4, 1, 96, 500, 3, 0.1),
+    # the d = 96 one-plane dK / dV kernel keeps TWO 16-key groups per wave (256 keys a work-group): a second key chunk of four
+    # keys, a single chunk two thirds empty with two heads, no dropout
+    (2, 2, 3, 1, 96, 260, 2, 0.1),
+    (2, 1, 2, 2, 96, 132, 1, 0.0),
 ]
 
 
