@@ -219,6 +219,17 @@ def test_recomputed_scores_equal_the_kept_ones(L, mode, S, E, H, d, T, nb, p_dro
         ref_v = torch.zeros(S, D, N, dtype=torch.float64).index_add_(0, ki64, rv)
         used = torch.from_numpy(np.unique(kv_idx)).long()
         assert _err(gk[used], ref_k[used]) < bound and _err(gv[used], ref_v[used]) < bound
+        # the same sums colour by colour (accumulate = 1: the epilogue's read-modify-write): every slot written once by the first
+        # colour, added to by the others — equal to the grouped call up to the association of the fp32 sums
+        ck, cv = (torch.full((S, D, N), float("nan"), device="cuda") for _ in range(2))
+        for ci, ids in enumerate(plan.dkv_colors):
+            L.check(lib.csn_block_attn_bwd_dkv_flash_f32(dctx.data_ptr(), D * N, q.data_ptr(), D * N, qi.data_ptr(), k_ptr, v_ptr,
+                                                         kv_stride, ki.data_ptr(), ldp, 0, N, lse.data_ptr(), delta2.data_ptr(),
+                                                         ck.data_ptr(), cv.data_ptr(), D * N, ki.data_ptr(), ki.data_ptr(),
+                                                         0 if ci == 0 else 1, ids.data_ptr(), ids.numel(), H, d, T, nb, Tp, p_drop,
+                                                         seed, None, 0, _stream()), "dkv flash, one colour")
+        torch.cuda.synchronize()
+        assert _err(ck[used], gk[used].cpu()) < 1e-5 and _err(cv[used], gv[used].cpu()) < 1e-5
 
 
 @pytest.mark.parametrize("d,T,nb", [(96, 500, 2), (256, 100, 3)])
