@@ -310,6 +310,26 @@ def knn_graph(f1: torch.Tensor, f2: torch.Tensor, K: int) -> torch.Tensor:
     return retrieval_measure(f1, f2).topk(K + 1, dim=-1)[1]
 
 
+def center_shape_indices(shapes, p: Params, n_head: int):
+    """k-means centre shapes of a collection (csa_models.py:302-332): max-pool every shape's SSA features over its points, cluster
+    into len // 10 groups (sklearn KMeans, random_state 0, n_init 10 — version-dependent: golden set G11 pins it for THIS image),
+    return for every centroid the index of the nearest shape.  ``shapes``: iterable of (1, C, N, 1) maps."""
+    import numpy as np
+    from sklearn.cluster import KMeans
+    glob = torch.cat([ssa_feats(x, p, n_head).squeeze(-1).amax(dim=2) for x in shapes], dim=0).numpy()      # (S, C)
+    km = KMeans(n_clusters=len(glob) // 10, random_state=0, n_init=10).fit(glob)
+    return np.argmin(((km.cluster_centers_[:, None, :] - glob) ** 2).sum(-1), axis=-1)
+
+
+def knn_graph_big(queries, candidates, centres, K: int, p: Params, n_head: int):
+    """The candidate-relative kNN table of get_knn_graph_big (csa_models.py:334-404): every query shape scored against the
+    candidate shapes ``sorted(centres)`` only.  Returns (measure (S_q, S_c) fp32, graph (S_q, K+1) int64)."""
+    pm = lambda x: ssa_feats(x, p, n_head).squeeze(-1).permute(0, 2, 1)                                       # (1, N, C)
+    cand = torch.cat([pm(candidates[int(i)]) for i in sorted(int(c) for c in centres)], dim=0)
+    meas = torch.cat([retrieval_measure(pm(x), cand) for x in queries], dim=0)
+    return meas, meas.topk(K + 1, dim=-1)[1]
+
+
 # ------------------------------------------------------------------------------------------------
 # parameter helpers (shapes as the reference's state_dict, csa_models.py:49-57,147-161)
 # ------------------------------------------------------------------------------------------------
@@ -379,3 +399,18 @@ def synth_clustered_feats(rng, S: int, N: int, C: int = 256, n_centers: int = 4)
     centers = rng.standard_normal(size=(n_centers, 1, C)).astype(np.float32)
     pick = rng.integers(0, n_centers, size=S)
     return torch.from_numpy((centers[pick] * 0.7 + rng.standard_normal(size=(S, N, C))).astype(np.float32))
+
+
+def synth_clustered_shapes(rng, S: int, n_centers: int = 3, n_points: int = 10000, C: int = 256):
+    """S feature maps (1, C, n_points, 1) — what FeaturesDataset yields per shape (features_data_loader.py:45-48) — drawn around
+    ``n_centers`` shared channel offsets (shape s belongs to centre s % n_centers), so that the max-pooled SSA descriptors fall
+    into well-separated clusters and neither the k-means seeding of csa_models.py:302-332 nor the ranking of
+    get_knn_graph_big (:360-404) is decided by rounding noise (golden set G11)."""
+    import numpy as np
+    centers = rng.standard_normal(size=(n_centers, C, 1, 1)).astype(np.float32)
+    out = []
+    for s in range(S):
+        x = 1.5 * centers[s % n_centers] + 0.2 * rng.standard_normal(size=(C, 1, 1)).astype(np.float32) \
+            + rng.standard_normal(size=(C, n_points, 1)).astype(np.float32)
+        out.append(torch.from_numpy(x[None]))
+    return out

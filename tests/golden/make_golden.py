@@ -300,13 +300,40 @@ def g10_after_fc_false(out):
         out[f"g10_{i}_grad_logit.weight"] = grads["logit.weight"].detach().numpy().astype(np.float32)
 
 
+def g11_big_category_graph(out):
+    """The big-category branch of update_knn_graphs (csa_training.py:138-155) run on the REFERENCE: k-means centre shapes
+    (`get_center_shape_indices`, csa_models.py:302-332 — sklearn KMeans, whatever version this image carries: the GPU box is the same
+    image) and the candidate-relative kNN tables of `get_knn_graph_big` (:334-404) for the train and the test loader."""
+    S_train, S_test, n_centers, K, seed = 30, 3, 3, 2, 1100
+    rng = np.random.default_rng(seed)
+    p = orc.make_params(rng, 1, n_cls=4, csa=False)
+    train = orc.synth_clustered_shapes(rng, S_train, n_centers)
+    test = orc.synth_clustered_shapes(rng, S_test, n_centers)
+    model = load_into(ref.get_model("ssa", 4, 1), {k: v for k, v in p.items() if not k.startswith("compat")}).eval()
+    model.device = torch.device("cpu")                                         # (csa_training.py:283)
+    lab = torch.zeros((1, 10000), dtype=torch.int64)
+    loader = lambda shapes: [(x[None], lab) for x in shapes]                   # batches of one: (1, 1, 256, N, 1), like DataLoader(FeaturesDataset, 1)
+    with torch.no_grad():
+        centres = model.get_center_shape_indices(loader(train))
+    assert len(centres) == S_train // 10
+    tr = model.get_knn_graph_big(loader(train), loader(train), centres.copy(), K)
+    te = model.get_knn_graph_big(loader(test), loader(train), centres.copy(), K)
+    meas = model.get_retrieval_measure_big(loader(test), loader(train), centres.copy())
+    out["g11_cfg"] = np.array([S_train, S_test, n_centers, K, seed])
+    out["g11_centres"] = np.sort(np.asarray(centres)).astype(np.int64)
+    out["g11_train_graph"] = tr.numpy().astype(np.int64)
+    out["g11_test_graph"] = te.numpy().astype(np.int64)
+    out["g11_test_measure"] = meas.numpy().astype(np.float32)
+
+
 def main():
     only = set(sys.argv[1:])
     for name, fn in [("g1_sdpa", g1_sdpa), ("g2_self_attention", g2_self_attention),
                      ("g3_mha_forward", g3_mha_forward), ("g4_csa", g4_csa), ("g5_ssa", g5_ssa),
                      ("g6_retrieval", g6_retrieval),
                      ("g7_csa_conditioned", g7_csa_conditioned), ("g8_mha_unequal_head_widths", g8_mha_unequal_head_widths),
-                     ("g9_data_path", g9_data_path), ("g10_after_fc_false", g10_after_fc_false)]:
+                     ("g9_data_path", g9_data_path), ("g10_after_fc_false", g10_after_fc_false),
+                     ("g11_big_category_graph", g11_big_category_graph)]:
         if only and name not in only:
             continue
         out = {}

@@ -494,6 +494,33 @@ def test_g10_after_fc_false_against_reference_goldens(golden_dir):
         assert np.abs(grads["logit.weight"].cpu().numpy() - ref).max() <= 1e-4 * np.abs(ref).max()
 
 
+def test_g11_big_category_graph_against_the_reference(golden_dir):
+    """golden set G11 (the reference's own big-category branch, csa_training.py:138-155): `get_center_shape_indices` picks the
+    reference's centre shapes (k-means over max-pooled HIP SSA features; sklearn of this image) and `get_knn_graph_big` returns
+    the reference's candidate-relative index tables bit for bit, for the train and the test loader."""
+    from csn_amd.csa_models import get_model
+    g = _load(golden_dir, "g11_big_category_graph")
+    S_train, S_test, n_centers, K, seed = (int(v) for v in g["g11_cfg"])
+    rng = np.random.default_rng(seed)
+    p = orc.make_params(rng, 1, n_cls=4, csa=False)
+    train = orc.synth_clustered_shapes(rng, S_train, n_centers)
+    test = orc.synth_clustered_shapes(rng, S_test, n_centers)
+    model = get_model("ssa", 4, 1)
+    missing, unexpected = model.load_state_dict(p, strict=False)
+    assert not unexpected and all(k.startswith("fc_1.") for k in missing)
+    model = model.cuda().eval()
+    lab = torch.zeros((1, 10000), dtype=torch.int64)
+    loader = lambda shapes: [(x[None].cuda(), lab) for x in shapes]            # batches of one, like DataLoader(FeaturesDataset, 1)
+    centres = np.asarray(model.get_center_shape_indices(loader(train)))
+    assert np.array_equal(np.sort(centres), g["g11_centres"])
+    tr = model.get_knn_graph_big(loader(train), loader(train), centres.copy(), K).cpu()
+    te = model.get_knn_graph_big(loader(test), loader(train), centres.copy(), K).cpu()
+    assert tr.dtype == torch.int64 and np.array_equal(tr.numpy(), g["g11_train_graph"])
+    assert np.array_equal(te.numpy(), g["g11_test_graph"])
+    meas = model.get_retrieval_measure_big(loader(test), loader(train), centres.copy()).cpu().numpy()
+    assert np.abs(meas - g["g11_test_measure"]).max() < 1e-5
+
+
 def test_g6_knn_graph_indices_bit_exact(golden_dir):
     g = _load(golden_dir, "g6_retrieval")
     from csn_amd.csa_models import get_model

@@ -204,6 +204,24 @@ def test_g6_retrieval_and_knn_indices_bit_exact(golden_dir):
         assert np.array_equal(graph.numpy(), g[f"g6_{i}_graph"])          # bit-exact index table
 
 
+def test_g11_big_category_graph(golden_dir):
+    """golden set G11: the big-category branch (csa_training.py:138-155) on the reference — k-means centre shapes
+    (csa_models.py:302-332) and the candidate-relative kNN tables of get_knn_graph_big (:334-404): the oracle's restatement gives
+    the same centres and the same index tables (the test loader's rows; the train table is checked on the GPU)."""
+    g = _load(golden_dir, "g11_big_category_graph")
+    S_train, S_test, n_centers, K, seed = (int(v) for v in g["g11_cfg"])
+    rng = np.random.default_rng(seed)
+    p = orc.make_params(rng, 1, n_cls=4, csa=False)
+    train = orc.synth_clustered_shapes(rng, S_train, n_centers)
+    test = orc.synth_clustered_shapes(rng, S_test, n_centers)
+    with torch.no_grad():
+        centres = orc.center_shape_indices(train, p, 1)
+        assert np.array_equal(np.sort(centres), g["g11_centres"])
+        meas, graph = orc.knn_graph_big(test, train, centres, K, p, 1)
+    _close(meas.numpy(), g["g11_test_measure"], 1e-6)
+    assert graph.dtype == torch.int64 and np.array_equal(graph.numpy(), g["g11_test_graph"])
+
+
 def test_compat_layout_is_the_reference_one_for_batches():
     """B > 1: the reference scores shape b against rows b*(K+1).. of the neighbour-major stack
     (csa_models.py:220,227).  For B == 1 both layouts agree."""
