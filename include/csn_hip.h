@@ -247,7 +247,8 @@ CSN_API int csn_block_attn_bwd_dkv_f32(const float* dctx, long long ctx_eval_str
                                int n_groups, void* stream);
 
 /* csn_block_attn_bwd_dkv_flash_f32 — dK and dV WITHOUT P / dS tensors (bit 3 of csn_attn_bwd_grouping: math modes 1 and 2,
- * d_head <= 128, block mode): a work-group keeps 128 keys of one (key/value slot, head, block) in registers, streams the
+ * d_head <= 128, block mode): a work-group keeps 128 keys (256 at d_head = 96 in math mode 2) of one (key/value slot, head, block)
+ * in registers, streams the
  * pre-scaled queries q and the output gradient dctx of every evaluation of its group through LDS, and rebuilds P (from lse,
  * with the dropout mask of (dropout_p, seed)) and dS (with delta, as the dq call wrote it) tile by tile:
  *   dv[dv_index[e]] (+)= P_drop^T dctx,   dk[dk_index[e]] (+)= dS^T Qs
