@@ -53,6 +53,7 @@ DTYPE_TEXT = {"fp32": "f32", "bf16x3": "bf16x3 (fp32 operands split into 2 bf16,
 N_CLS = 39
 INIT_TIMEOUT_S = 180                 # process-group timeout: rendezvous and every collective of the run (a step is milliseconds)
 LAUNCH_GRACE_S = 5.0                 # self-launch: seconds a rank gets between SIGTERM and SIGKILL when another rank has failed
+RENDEZVOUS_RETRY_S = 20.0            # self-launch: rank 0 failing this soon after the launch = rendezvous (port taken): one retry
 CONFIGS = {
     2: dict(B=4, K=2, N=10000, C=256, d=256, T=500, nb=20, name="BASELINE configs[1]"),
     3: dict(B=32, K=3, N=10000, C=256, d=256, T=500, nb=20, name="BASELINE configs[2]"),
@@ -138,18 +139,18 @@ def self_launch(args):
     collective's own timeout): the parent POLLS all ranks; on the first non-zero exit — or when the parent itself is told to
     stop (SIGTERM / SIGINT, e.g. from `timeout`), or raises — the remaining ranks get SIGTERM, then SIGKILL after
     `LAUNCH_GRACE_S`, each in its own session so that the signal reaches whatever the rank started; the parent then exits
-    non-zero within seconds.  Ranks are only ever fresh children: nothing that touched a GPU is re-executed.  (The rendezvous
-    port is picked by bind-and-close: another process can take it in between; the run then fails at rendezvous — loudly, through
-    this same path — and is simply started again.)"""
+    non-zero within seconds.  Ranks are only ever fresh children: nothing that touched a GPU is re-executed.  The rendezvous port is
+    picked by bind-and-close: another process can take it in between; rank 0 then fails within seconds — that one case gets ONE
+    more attempt with another port."""
     import signal
     import socket
     import subprocess
     import threading
-    port = os.environ.get("MASTER_PORT")
-    if port is None:
+    def free_port():
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
-            port = str(sk.getsockname()[1])
+            return str(sk.getsockname()[1])
+    given_port = os.environ.get("MASTER_PORT")
     procs, out_lines = [], []
 
     def stop_ranks(why):
@@ -174,30 +175,41 @@ def self_launch(args):
 
     old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
     deadline = float(os.environ.get("CSN_BENCH_LAUNCH_TIMEOUT_S", "0")) or None
-    t0 = time.monotonic()
+    bad = []
     try:
-        for r in range(args.gpus):
-            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                       MASTER_ADDR="127.0.0.1", MASTER_PORT=port, CSN_BENCH_CHILD="1")
-            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True,
-                                          start_new_session=True))
-        reader = threading.Thread(target=lambda: out_lines.extend(procs[0].stdout), daemon=True)   # rank 0's pipe never fills
-        reader.start()
-        bad = []
-        while True:
-            codes = [p.poll() for p in procs]
-            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
-            if bad or all(c == 0 for c in codes):
+        # A self-picked port can be taken between the probe and rank 0's bind: the ranks then fail at rendezvous, within seconds and
+        # before any of them has done work — ONE more attempt with another port (fresh processes again).
+        for attempt in range(1 if given_port else 2):
+            port = given_port or (os.environ.get("CSN_BENCH_FIRST_PORT") if attempt == 0 else None) or free_port()   # (FIRST_PORT: the test's taken port)
+            del procs[:], out_lines[:]
+            t0 = time.monotonic()
+            for r in range(args.gpus):
+                env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                           MASTER_ADDR="127.0.0.1", MASTER_PORT=port, CSN_BENCH_CHILD="1")
+                env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                              stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True,
+                                              start_new_session=True))
+            reader = threading.Thread(target=lambda: out_lines.extend(procs[0].stdout), daemon=True)   # rank 0's pipe never fills
+            reader.start()
+            while True:
+                codes = [p.poll() for p in procs]
+                bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+                if bad or all(c == 0 for c in codes):
+                    break
+                if deadline is not None and time.monotonic() - t0 > deadline:
+                    bad = [("launcher", f"no result after CSN_BENCH_LAUNCH_TIMEOUT_S={deadline:g} s")]
+                    break
+                time.sleep(0.1)
+            if bad:
+                stop_ranks(f"ranks failed (rank, exit code): {bad}")
+            reader.join(timeout=5)
+            rendezvous_failure = bad and bad[0][0] == 0 and time.monotonic() - t0 < RENDEZVOUS_RETRY_S and not any(l.startswith("{") for l in out_lines)
+            if not rendezvous_failure:
                 break
-            if deadline is not None and time.monotonic() - t0 > deadline:
-                bad = [("launcher", f"no result after CSN_BENCH_LAUNCH_TIMEOUT_S={deadline:g} s")]
-                break
-            time.sleep(0.1)
-        if bad:
-            stop_ranks(f"ranks failed (rank, exit code): {bad}")
-        reader.join(timeout=5)
+            if attempt == 0 and not given_port:
+                print(f"bench: rank 0 failed {time.monotonic() - t0:.1f} s after the launch (port {port} taken?): one more attempt "
+                      "with another port", file=sys.stderr, flush=True)
     finally:
         stop_ranks("launcher leaving")
         for sg, h in old.items():

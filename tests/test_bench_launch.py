@@ -99,3 +99,17 @@ def test_launch_deadline():
     t0 = time.monotonic()
     res = _run({"CSN_BENCH_LAUNCH_CHECK": "sleep", "CSN_BENCH_LAUNCH_TIMEOUT_S": "25"}, "--gpus", "2")
     assert res.returncode != 0 and "CSN_BENCH_LAUNCH_TIMEOUT_S" in res.stderr and time.monotonic() - t0 < 90
+
+
+def test_a_taken_rendezvous_port_gets_one_more_attempt():
+    """The launcher picks its port by bind-and-close; if somebody takes it before rank 0 binds, the ranks fail at rendezvous within
+    seconds: one more attempt with another port (here the first port is one this test holds)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        sk.listen(1)
+        res = _run({"CSN_BENCH_LAUNCH_CHECK": "1", "CSN_BENCH_FIRST_PORT": str(sk.getsockname()[1])}, "--gpus", "2")
+    assert res.returncode == 0, res.stderr[-2000:]
+    assert "one more attempt" in res.stderr
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0])["n_ranks_seen"] == 2
